@@ -1,0 +1,29 @@
+# Builds libstarkhip.so (HIP kernels for gfx950 + host C++) and the CPU oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := starky_bls12_381_amd/csrc
+OUT := starky_bls12_381_amd/libstarkhip.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude
+SRCS := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
+OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
+HDRS := $(wildcard $(CSRC)/*.h) include/starkhip.h
+
+all: $(OUT) oracle
+
+build/%.hip.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+build/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(OUT): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(OUT)
+	$(MAKE) -C oracle clean
+.PHONY: all oracle clean

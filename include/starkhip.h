@@ -1,0 +1,151 @@
+/* libstarkhip -- C ABI of the MI355X-native STARK prover for the four BLS12-381 AIRs of
+ * Electron-Labs/starky_bls12_381.
+ *
+ * Drop-in boundary: each entry point replaces one call the reference makes into the
+ * (un-vendored) starky / plonky2 crates or into its own AIR modules:
+ *
+ *   starkhip_prove            <- starky::prover::prove::<F, C, S, D>(stark, &config, trace_poly_values,
+ *                                &public_inputs, &mut timing)         src/aggregate_proof.rs:59-65,
+ *                                                                     :105-111, :138-144, :169-175
+ *   starkhip_verify           <- starky::verifier::verify_stark_proof src/aggregate_proof.rs:67,113,146,177
+ *   starkhip_config_standard_fast <- StarkConfig::standard_fast_config()  src/aggregate_proof.rs:32,76,122,155
+ *   starkhip_air_*            <- the associated consts S::COLUMNS / S::PUBLIC_INPUTS / constraint_degree()
+ *                                src/fp12_mul.rs:21-27,142-144; src/final_exponentiate.rs:1362-1364 ...
+ *   starkhip_trace_*          <- S::generate_trace(..) + trace_rows_to_poly_values
+ *                                src/fp12_mul.rs:44-48, src/final_exponentiate.rs:240-279,
+ *                                src/miller_loop.rs, src/calc_pairing_precomp.rs:150-348;
+ *                                src/aggregate_proof.rs:57,104,137,168
+ *   starkhip_native_*         <- crate::native (Fp12 mul, final_exponentiate, miller_loop,
+ *                                calc_pairing_precomp)               src/native.rs:1201-1468
+ *
+ * Because `S: Stark` is a compile-time generic in the reference, the AIR is selected by id.
+ * All field elements are canonical Goldilocks values (< 2^64 - 2^32 + 1) in little-endian
+ * uint64_t.  Fp elements are 12 little-endian u32 limbs (src/fp.rs:1).
+ *
+ * Threading: one in-flight prove per context; different contexts (GPUs) may run concurrently.
+ * Ownership: the caller owns every input for the duration of the call; buffers returned through
+ * `uint64_t** out` are owned by the library until starkhip_free().
+ */
+#ifndef STARKHIP_H
+#define STARKHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    uint32_t security_bits;      /* 100 */
+    uint32_t num_challenges;     /* 2   */
+    uint32_t rate_bits;          /* 1 (2 for PairingPrecomp / FinalExp) */
+    uint32_t cap_height;         /* 4   */
+    uint32_t proof_of_work_bits; /* 16  */
+    uint32_t arity_bits;         /* ConstantArityBits(4, 5) */
+    uint32_t final_poly_bits;
+    uint32_t num_query_rounds;   /* 84  */
+} starkhip_config_t;
+
+typedef enum {
+    STARKHIP_AIR_FP12_MUL = 0,
+    STARKHIP_AIR_PAIRING_PRECOMP = 1,
+    STARKHIP_AIR_MILLER_LOOP = 2,
+    STARKHIP_AIR_FINAL_EXP = 3,
+    STARKHIP_AIR_TEST_FIBONACCI = 100 /* 2-column toy AIR used by the unit tests */
+} starkhip_air_t;
+
+enum {
+    STARKHIP_OK = 0,
+    STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE = -1, /* "Quotient has failed, the vanishing polynomial is not divisible by Z_H" */
+    STARKHIP_ERR_ZETA_IN_SUBGROUP = -2,
+    STARKHIP_ERR_BAD_SHAPE = -3,
+    STARKHIP_ERR_HIP = -4,
+    STARKHIP_ERR_OOM = -5,
+    STARKHIP_ERR_NO_DEVICE = -6,
+    STARKHIP_ERR_VERIFY = -7,
+    STARKHIP_ERR_BAD_AIR = -8
+};
+
+#define STARKHIP_POW_SEARCH UINT64_MAX
+
+/* --- configuration ------------------------------------------------------------------- */
+void starkhip_config_standard_fast(starkhip_config_t* cfg);
+/* the per-AIR config the reference builds (rate_bits override for PairingPrecomp / FinalExp) */
+int starkhip_config_for_air(starkhip_air_t air, starkhip_config_t* cfg);
+
+/* --- AIR metadata -------------------------------------------------------------------- */
+int starkhip_air_columns(starkhip_air_t air);
+int starkhip_air_public_inputs(starkhip_air_t air);
+int starkhip_air_constraint_degree(starkhip_air_t air);
+int starkhip_air_num_constraints(starkhip_air_t air);
+int starkhip_air_default_rows(starkhip_air_t air);
+/* serialised constraint program (format: starky_bls12_381_amd/csrc/air_ir.h); library-owned */
+int starkhip_air_program(starkhip_air_t air, const uint64_t** blob, size_t* words);
+
+/* --- natives + trace generation (host) ----------------------------------------------- */
+/* inputs are u32 limb arrays: Fp = 12, Fp2 = 24, Fp12 = 144 limbs.
+ * trace is written row-major [n_rows][columns]; public_inputs has starkhip_air_public_inputs() entries. */
+int starkhip_trace_fp12_mul(const uint32_t x[144], const uint32_t y[144], uint64_t* trace, size_t n_rows, uint64_t* public_inputs);
+int starkhip_trace_final_exp(const uint32_t x[144], uint64_t* trace, size_t n_rows, uint64_t* public_inputs);
+int starkhip_trace_miller_loop(const uint32_t px[12], const uint32_t py[12], const uint32_t qx[24], const uint32_t qy[24],
+                               const uint32_t qz[24], uint64_t* trace, size_t n_rows, uint64_t* public_inputs);
+int starkhip_trace_pairing_precomp(const uint32_t qx[24], const uint32_t qy[24], const uint32_t qz[24], uint64_t* trace,
+                                   size_t n_rows, uint64_t* public_inputs);
+int starkhip_trace_fibonacci(uint64_t x0, uint64_t x1, uint64_t* trace, size_t n_rows, uint64_t* public_inputs);
+int starkhip_native_fp12_mul(const uint32_t x[144], const uint32_t y[144], uint32_t out[144]);
+int starkhip_native_final_exponentiate(const uint32_t x[144], uint32_t out[144]);
+int starkhip_native_miller_loop(const uint32_t px[12], const uint32_t py[12], const uint32_t qx[24], const uint32_t qy[24],
+                                const uint32_t qz[24], uint32_t out[144]);
+int starkhip_native_pairing_precomp(const uint32_t qx[24], const uint32_t qy[24], const uint32_t qz[24], uint32_t out[68 * 72]);
+
+/* --- prover (GPU) -------------------------------------------------------------------- */
+int starkhip_init(int device_ordinal, void** ctx);
+void starkhip_shutdown(void* ctx);
+
+/* trace_layout: 0 = row-major [n_rows][C] (what generate_trace returns), 1 = column-major [C][n_rows]
+ * (what trace_rows_to_poly_values returns).  trace_on_device != 0: `trace` is a device pointer
+ * (already resident in HBM; the benchmark path).  pow_witness: STARKHIP_POW_SEARCH = smallest valid
+ * nonce, otherwise use the given one.  *proof is a blob in the layout below. */
+int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows,
+                   int trace_layout, int trace_on_device, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness,
+                   uint64_t** proof, size_t* proof_words);
+
+/* per-phase device timings of the last prove on this ctx, milliseconds (HIP events):
+ * [0] upload/transpose [1] ifft+lde [2] trace leaf hash + merkle [3] quotient [4] quotient commit
+ * [5] openings [6] fri combine [7] fri commit [8] pow [9] queries [10] total */
+#define STARKHIP_N_PHASES 11
+int starkhip_last_timings(void* ctx, float ms[STARKHIP_N_PHASES]);
+
+/* --- kernel-level entry points (parity tests / micro-benchmarks) ---------------------- */
+/* values column-major [C][n] (host) -> coeffs [C][n] and LDE [C][N] in NATURAL point order i <-> 7*w_N^i */
+int starkhip_lde_batch(void* ctx, const uint64_t* values, size_t n_cols, unsigned log_n, unsigned rate_bits, uint64_t* coeffs_out,
+                       uint64_t* lde_out);
+/* Merkle cap of the matrix whose leaf j is the row bitrev(j) of an LDE given column-major natural order [C][N] */
+int starkhip_merkle_cap(void* ctx, const uint64_t* lde_colmajor, size_t n_cols, unsigned log_N, unsigned cap_height, uint64_t* cap_out);
+int starkhip_poseidon_permute_batch(void* ctx, uint64_t* states, size_t n_states);
+/* host-side permutation (the one the Fiat-Shamir challenger uses) */
+void starkhip_poseidon_permute_host(uint64_t state[12]);
+
+/* --- verifier (CPU) ------------------------------------------------------------------- */
+int starkhip_verify(starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* proof, size_t proof_words);
+
+void starkhip_free(void* p);
+const char* starkhip_error_string(int code);
+
+/* Proof blob, uint64 words (canonical field order of StarkProofWithPublicInputs):
+ *   [0..16)  header: magic "SSPRF001", C, Q, degree_bits, rate_bits, cap_height, L (FRI layers),
+ *            num_query_rounds, final_poly_len, n_pis, arity_bits, num_challenges, 0,0,0,0
+ *   trace_cap[2^cap_h][4]; quotient_polys_cap[2^cap_h][4]
+ *   openings.local_values[C][2]; openings.next_values[C][2]; openings.quotient_polys[Q][2]
+ *   commit_phase_merkle_caps[L][2^cap_h][4]
+ *   query_round_proofs[num_query_rounds]:
+ *       trace leaf[C], trace siblings[log N - cap_h][4], quotient leaf[Q], quotient siblings[log N - cap_h][4],
+ *       steps[L]: evals[2^arity][2], siblings[log(N / arity^(l+1)) - cap_h][4]
+ *   final_poly[final_poly_len][2]; pow_witness; public_inputs[n_pis]
+ */
+#define STARKHIP_PROOF_MAGIC 0x3130304652505353ULL
+
+#ifdef __cplusplus
+}
+#endif
+#endif

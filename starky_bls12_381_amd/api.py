@@ -1,0 +1,305 @@
+"""ctypes binding of libstarkhip.so (C ABI in include/starkhip.h).
+
+Host-side mirror of the reference's call surface for the starky prove() path
+(/root/reference/src/aggregate_proof.rs:23-179): `StarkConfig`, `prove`, `verify_stark_proof`,
+per-AIR `generate_trace`.  Python is only the harness here; all work happens behind the C ABI.
+There is NO CPU fallback: if the shared library is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstarkhip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()); "
+        "starky_bls12_381_amd has no CPU fallback for the prover")
+
+lib = C.CDLL(LIB_PATH)
+
+P = 0xFFFFFFFF00000001
+POW_SEARCH = 0xFFFFFFFFFFFFFFFF
+N_PHASES = 11
+PHASE_NAMES = ["upload", "ifft_lde", "trace_merkle", "quotient", "quotient_commit", "openings", "fri_combine",
+               "fri_commit", "pow", "queries", "total"]
+
+AIR_FP12_MUL, AIR_PAIRING_PRECOMP, AIR_MILLER_LOOP, AIR_FINAL_EXP, AIR_TEST_FIBONACCI = 0, 1, 2, 3, 100
+AIR_NAMES = {AIR_FP12_MUL: "FP12MulStark", AIR_PAIRING_PRECOMP: "PairingPrecompStark", AIR_MILLER_LOOP: "MillerLoopStark",
+             AIR_FINAL_EXP: "FinalExponentiateStark", AIR_TEST_FIBONACCI: "TestFibonacci"}
+
+ERR_QUOTIENT_NOT_DIVISIBLE, ERR_ZETA_IN_SUBGROUP, ERR_BAD_SHAPE, ERR_HIP, ERR_OOM, ERR_NO_DEVICE, ERR_VERIFY, ERR_BAD_AIR = range(-1, -9, -1)
+
+
+class StarkConfig(C.Structure):
+    """Mirror of starky::config::StarkConfig + FriConfig (flattened)."""
+    _fields_ = [(n, C.c_uint32) for n in ("security_bits", "num_challenges", "rate_bits", "cap_height", "proof_of_work_bits",
+                                          "arity_bits", "final_poly_bits", "num_query_rounds")]
+
+    @staticmethod
+    def standard_fast_config():
+        cfg = StarkConfig()
+        lib.starkhip_config_standard_fast(C.byref(cfg))
+        return cfg
+
+    @staticmethod
+    def for_air(air):
+        cfg = StarkConfig()
+        _chk(lib.starkhip_config_for_air(air, C.byref(cfg)))
+        return cfg
+
+
+class StarkhipError(RuntimeError):
+    def __init__(self, code):
+        self.code = code
+        super().__init__(f"starkhip error {code}: {lib.starkhip_error_string(code).decode()}")
+
+
+def _chk(rc):
+    if rc != 0:
+        raise StarkhipError(rc)
+
+
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+lib.starkhip_error_string.restype = C.c_char_p
+lib.starkhip_error_string.argtypes = [C.c_int]
+lib.starkhip_config_standard_fast.argtypes = [C.POINTER(StarkConfig)]
+lib.starkhip_config_for_air.argtypes = [C.c_int, C.POINTER(StarkConfig)]
+for _f in ("columns", "public_inputs", "constraint_degree", "num_constraints", "default_rows"):
+    getattr(lib, "starkhip_air_" + _f).argtypes = [C.c_int]
+lib.starkhip_air_program.argtypes = [C.c_int, C.POINTER(_u64p), C.POINTER(C.c_size_t)]
+lib.starkhip_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+lib.starkhip_shutdown.argtypes = [C.c_void_p]
+lib.starkhip_shutdown.restype = None
+lib.starkhip_prove.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), C.c_void_p, C.c_size_t, C.c_int, C.c_int, _u64p, C.c_size_t,
+                               C.c_uint64, C.POINTER(_u64p), C.POINTER(C.c_size_t)]
+lib.starkhip_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+lib.starkhip_lde_batch.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_uint, C.c_uint, _u64p, _u64p]
+lib.starkhip_merkle_cap.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_uint, C.c_uint, _u64p]
+lib.starkhip_poseidon_permute_batch.argtypes = [C.c_void_p, _u64p, C.c_size_t]
+lib.starkhip_poseidon_permute_host.argtypes = [_u64p]
+lib.starkhip_poseidon_permute_host.restype = None
+lib.starkhip_verify.argtypes = [C.c_int, C.POINTER(StarkConfig), _u64p, C.c_size_t]
+lib.starkhip_free.argtypes = [C.c_void_p]
+lib.starkhip_free.restype = None
+lib.starkhip_trace_fibonacci.argtypes = [C.c_uint64, C.c_uint64, _u64p, C.c_size_t, _u64p]
+lib.starkhip_trace_fp12_mul.argtypes = [_u32p, _u32p, _u64p, C.c_size_t, _u64p]
+lib.starkhip_trace_final_exp.argtypes = [_u32p, _u64p, C.c_size_t, _u64p]
+lib.starkhip_trace_miller_loop.argtypes = [_u32p, _u32p, _u32p, _u32p, _u32p, _u64p, C.c_size_t, _u64p]
+lib.starkhip_trace_pairing_precomp.argtypes = [_u32p, _u32p, _u32p, _u64p, C.c_size_t, _u64p]
+lib.starkhip_native_fp12_mul.argtypes = [_u32p, _u32p, _u32p]
+lib.starkhip_native_final_exponentiate.argtypes = [_u32p, _u32p]
+lib.starkhip_native_miller_loop.argtypes = [_u32p, _u32p, _u32p, _u32p, _u32p, _u32p]
+lib.starkhip_native_pairing_precomp.argtypes = [_u32p, _u32p, _u32p, _u32p]
+
+
+def _p64(a):
+    return a.ctypes.data_as(_u64p)
+
+
+def _p32(a):
+    return a.ctypes.data_as(_u32p)
+
+
+def _limbs(x, n):
+    a = np.ascontiguousarray(x, dtype=np.uint32).reshape(-1)
+    assert a.size == n, (a.size, n)
+    return a
+
+
+# ----------------------------------------------------------------------------- AIR metadata
+def air_columns(air):
+    r = lib.starkhip_air_columns(air)
+    if r < 0:
+        raise StarkhipError(r)
+    return r
+
+
+def air_public_inputs(air):
+    r = lib.starkhip_air_public_inputs(air)
+    if r < 0:
+        raise StarkhipError(r)
+    return r
+
+
+def air_constraint_degree(air):
+    r = lib.starkhip_air_constraint_degree(air)
+    if r < 0:
+        raise StarkhipError(r)
+    return r
+
+
+def air_num_constraints(air):
+    r = lib.starkhip_air_num_constraints(air)
+    if r < 0:
+        raise StarkhipError(r)
+    return r
+
+
+def air_default_rows(air):
+    r = lib.starkhip_air_default_rows(air)
+    if r < 0:
+        raise StarkhipError(r)
+    return r
+
+
+def air_program(air):
+    """Serialised constraint program (numpy uint64 copy)."""
+    blob = _u64p()
+    words = C.c_size_t()
+    _chk(lib.starkhip_air_program(air, C.byref(blob), C.byref(words)))
+    return np.ctypeslib.as_array(blob, shape=(words.value,)).copy()
+
+
+# ----------------------------------------------------------------------------- traces (generate_trace)
+def _trace_alloc(air, n_rows):
+    n_rows = n_rows or air_default_rows(air)
+    return np.zeros((n_rows, air_columns(air)), dtype=np.uint64), np.zeros(air_public_inputs(air), dtype=np.uint64), n_rows
+
+
+def trace_fibonacci(x0, x1, n_rows=None):
+    t, pis, n = _trace_alloc(AIR_TEST_FIBONACCI, n_rows)
+    _chk(lib.starkhip_trace_fibonacci(x0, x1, _p64(t), n, _p64(pis)))
+    return t, pis
+
+
+def trace_fp12_mul(x, y, n_rows=None):
+    """FP12MulStark::generate_trace + the public inputs of fp12_mul_main (src/aggregate_proof.rs:117-148)."""
+    t, pis, n = _trace_alloc(AIR_FP12_MUL, n_rows)
+    _chk(lib.starkhip_trace_fp12_mul(_p32(_limbs(x, 144)), _p32(_limbs(y, 144)), _p64(t), n, _p64(pis)))
+    return t, pis
+
+
+def trace_final_exp(x, n_rows=None):
+    t, pis, n = _trace_alloc(AIR_FINAL_EXP, n_rows)
+    _chk(lib.starkhip_trace_final_exp(_p32(_limbs(x, 144)), _p64(t), n, _p64(pis)))
+    return t, pis
+
+
+def trace_miller_loop(px, py, qx, qy, qz, n_rows=None):
+    t, pis, n = _trace_alloc(AIR_MILLER_LOOP, n_rows)
+    _chk(lib.starkhip_trace_miller_loop(_p32(_limbs(px, 12)), _p32(_limbs(py, 12)), _p32(_limbs(qx, 24)), _p32(_limbs(qy, 24)),
+                                        _p32(_limbs(qz, 24)), _p64(t), n, _p64(pis)))
+    return t, pis
+
+
+def trace_pairing_precomp(qx, qy, qz, n_rows=None):
+    t, pis, n = _trace_alloc(AIR_PAIRING_PRECOMP, n_rows)
+    _chk(lib.starkhip_trace_pairing_precomp(_p32(_limbs(qx, 24)), _p32(_limbs(qy, 24)), _p32(_limbs(qz, 24)), _p64(t), n, _p64(pis)))
+    return t, pis
+
+
+def native_fp12_mul(x, y):
+    out = np.zeros(144, dtype=np.uint32)
+    _chk(lib.starkhip_native_fp12_mul(_p32(_limbs(x, 144)), _p32(_limbs(y, 144)), _p32(out)))
+    return out
+
+
+def native_final_exponentiate(x):
+    out = np.zeros(144, dtype=np.uint32)
+    _chk(lib.starkhip_native_final_exponentiate(_p32(_limbs(x, 144)), _p32(out)))
+    return out
+
+
+def native_miller_loop(px, py, qx, qy, qz):
+    out = np.zeros(144, dtype=np.uint32)
+    _chk(lib.starkhip_native_miller_loop(_p32(_limbs(px, 12)), _p32(_limbs(py, 12)), _p32(_limbs(qx, 24)), _p32(_limbs(qy, 24)),
+                                         _p32(_limbs(qz, 24)), _p32(out)))
+    return out
+
+
+def native_pairing_precomp(qx, qy, qz):
+    out = np.zeros(68 * 72, dtype=np.uint32)
+    _chk(lib.starkhip_native_pairing_precomp(_p32(_limbs(qx, 24)), _p32(_limbs(qy, 24)), _p32(_limbs(qz, 24)), _p32(out)))
+    return out
+
+
+def poseidon_permute_host(state):
+    s = np.ascontiguousarray(state, dtype=np.uint64).copy()
+    assert s.size == 12
+    lib.starkhip_poseidon_permute_host(_p64(s))
+    return s
+
+
+# ----------------------------------------------------------------------------- prover / verifier
+class Prover:
+    """One context per GPU (starkhip_init).  `prove` mirrors starky::prover::prove."""
+
+    def __init__(self, device=0):
+        self._ctx = C.c_void_p()
+        _chk(lib.starkhip_init(device, C.byref(self._ctx)))
+
+    def close(self):
+        if self._ctx:
+            lib.starkhip_shutdown(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prove(self, air, config, trace, public_inputs, pow_witness=POW_SEARCH, layout=0):
+        """trace: numpy uint64, row-major [n][C] (layout 0) or column-major [C][n] (layout 1)."""
+        trace = np.ascontiguousarray(trace, dtype=np.uint64)
+        n_rows = trace.shape[0] if layout == 0 else trace.shape[1]
+        pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        out = _u64p()
+        words = C.c_size_t()
+        _chk(lib.starkhip_prove(self._ctx, air, C.byref(config), trace.ctypes.data_as(C.c_void_p), n_rows, layout, 0, _p64(pis), pis.size,
+                                pow_witness, C.byref(out), C.byref(words)))
+        proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy()
+        lib.starkhip_free(out)
+        return proof
+
+    def prove_device(self, air, config, trace_ptr, n_rows, public_inputs, pow_witness=POW_SEARCH, layout=1, keep=True):
+        """trace_ptr: integer device address of a uint64 trace already resident in HBM (benchmark path)."""
+        pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        out = _u64p()
+        words = C.c_size_t()
+        _chk(lib.starkhip_prove(self._ctx, air, C.byref(config), C.c_void_p(trace_ptr), n_rows, layout, 1, _p64(pis), pis.size, pow_witness,
+                                C.byref(out), C.byref(words)))
+        proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy() if keep else None
+        lib.starkhip_free(out)
+        return proof
+
+    def last_timings(self):
+        ms = (C.c_float * N_PHASES)()
+        _chk(lib.starkhip_last_timings(self._ctx, ms))
+        return dict(zip(PHASE_NAMES, [float(x) for x in ms]))
+
+    def lde_batch(self, values_colmajor, rate_bits):
+        v = np.ascontiguousarray(values_colmajor, dtype=np.uint64)
+        ncols, n = v.shape
+        log_n = n.bit_length() - 1
+        coeffs = np.zeros_like(v)
+        lde = np.zeros((ncols, n << rate_bits), dtype=np.uint64)
+        _chk(lib.starkhip_lde_batch(self._ctx, _p64(v), ncols, log_n, rate_bits, _p64(coeffs), _p64(lde)))
+        return coeffs, lde
+
+    def merkle_cap(self, lde_colmajor, cap_height):
+        v = np.ascontiguousarray(lde_colmajor, dtype=np.uint64)
+        ncols, N = v.shape
+        cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+        _chk(lib.starkhip_merkle_cap(self._ctx, _p64(v), ncols, N.bit_length() - 1, cap_height, _p64(cap)))
+        return cap
+
+    def poseidon_permute_batch(self, states):
+        s = np.ascontiguousarray(states, dtype=np.uint64).copy()
+        _chk(lib.starkhip_poseidon_permute_batch(self._ctx, _p64(s), s.shape[0]))
+        return s
+
+
+def verify_stark_proof(air, config, proof):
+    """Mirror of starky::verifier::verify_stark_proof; raises StarkhipError on rejection."""
+    p = np.ascontiguousarray(proof, dtype=np.uint64)
+    _chk(lib.starkhip_verify(air, C.byref(config), _p64(p), p.size))
+
+
+def trace_rows_to_poly_values(trace_rows):
+    """starky::util::trace_rows_to_poly_values: row-major [n][C] -> column-major [C][n]."""
+    return np.ascontiguousarray(np.asarray(trace_rows, dtype=np.uint64).T)

@@ -1,0 +1,116 @@
+// extern "C" surface of libstarkhip.so (declared in include/starkhip.h).
+#include <stdlib.h>
+#include <string.h>
+
+#include "airs.h"
+#include "poseidon.h"
+#include "prover.h"
+
+using namespace starkhip;
+
+extern "C" {
+
+void starkhip_config_standard_fast(starkhip_config_t* cfg) {
+    // starky StarkConfig::standard_fast_config(): security 100, 2 challenges, FRI rate_bits 1, cap_height 4,
+    // proof_of_work_bits 16, ConstantArityBits(4, 5), 84 query rounds
+    cfg->security_bits = 100;
+    cfg->num_challenges = 2;
+    cfg->rate_bits = 1;
+    cfg->cap_height = 4;
+    cfg->proof_of_work_bits = 16;
+    cfg->arity_bits = 4;
+    cfg->final_poly_bits = 5;
+    cfg->num_query_rounds = 84;
+}
+
+int starkhip_config_for_air(starkhip_air_t air, starkhip_config_t* cfg) {
+    starkhip_config_standard_fast(cfg);
+    switch (air) {
+        case STARKHIP_AIR_PAIRING_PRECOMP:  // src/aggregate_proof.rs:32-33
+        case STARKHIP_AIR_FINAL_EXP:        // src/aggregate_proof.rs:155-156
+            cfg->rate_bits = 2;
+            return STARKHIP_OK;
+        case STARKHIP_AIR_MILLER_LOOP:  // :76
+        case STARKHIP_AIR_FP12_MUL:     // :122
+        case STARKHIP_AIR_TEST_FIBONACCI:
+            return STARKHIP_OK;
+        default:
+            return STARKHIP_ERR_BAD_AIR;
+    }
+}
+
+int starkhip_air_columns(starkhip_air_t air) { const AirInfo* a = air_get(air); return a ? (int)a->cols : STARKHIP_ERR_BAD_AIR; }
+int starkhip_air_public_inputs(starkhip_air_t air) { const AirInfo* a = air_get(air); return a ? (int)a->pis : STARKHIP_ERR_BAD_AIR; }
+int starkhip_air_constraint_degree(starkhip_air_t air) { const AirInfo* a = air_get(air); return a ? (int)a->degree : STARKHIP_ERR_BAD_AIR; }
+int starkhip_air_num_constraints(starkhip_air_t air) { const AirInfo* a = air_get(air); return a ? (int)a->prog.n_constraints : STARKHIP_ERR_BAD_AIR; }
+int starkhip_air_default_rows(starkhip_air_t air) { const AirInfo* a = air_get(air); return a ? (int)a->default_rows : STARKHIP_ERR_BAD_AIR; }
+int starkhip_air_program(starkhip_air_t air, const uint64_t** blob, size_t* words) {
+    const AirInfo* a = air_get(air);
+    if (!a) return STARKHIP_ERR_BAD_AIR;
+    *blob = a->blob.data();
+    *words = a->blob.size();
+    return STARKHIP_OK;
+}
+
+int starkhip_init(int device_ordinal, void** ctx) {
+    Ctx* c = nullptr;
+    int rc = ctx_create(device_ordinal, &c);
+    *ctx = c;
+    return rc;
+}
+void starkhip_shutdown(void* ctx) { ctx_destroy((Ctx*)ctx); }
+
+int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows, int trace_layout,
+                   int trace_on_device, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness, uint64_t** proof,
+                   size_t* proof_words) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    const AirInfo* a = air_get(air);
+    if (!a) return STARKHIP_ERR_BAD_AIR;
+    return prove((Ctx*)ctx, *a, *cfg, trace, n_rows, trace_layout, trace_on_device, public_inputs, n_pis, pow_witness, proof, proof_words);
+}
+
+int starkhip_last_timings(void* ctx, float ms[STARKHIP_N_PHASES]) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    memcpy(ms, ctx_timings((Ctx*)ctx), sizeof(float) * STARKHIP_N_PHASES);
+    return STARKHIP_OK;
+}
+
+int starkhip_lde_batch(void* ctx, const uint64_t* values, size_t n_cols, unsigned log_n, unsigned rate_bits, uint64_t* coeffs_out,
+                       uint64_t* lde_out) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    return lde_batch((Ctx*)ctx, values, n_cols, log_n, rate_bits, coeffs_out, lde_out);
+}
+int starkhip_merkle_cap(void* ctx, const uint64_t* lde_colmajor, size_t n_cols, unsigned log_N, unsigned cap_height, uint64_t* cap_out) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    return merkle_cap((Ctx*)ctx, lde_colmajor, n_cols, log_N, cap_height, cap_out);
+}
+int starkhip_poseidon_permute_batch(void* ctx, uint64_t* states, size_t n_states) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    return permute_batch((Ctx*)ctx, states, n_states);
+}
+void starkhip_poseidon_permute_host(uint64_t state[12]) { poseidon_permute(state); }
+
+int starkhip_verify(starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* proof, size_t proof_words) {
+    const AirInfo* a = air_get(air);
+    if (!a) return STARKHIP_ERR_BAD_AIR;
+    return verify_proof(*a, *cfg, proof, proof_words);
+}
+
+void starkhip_free(void* p) { free(p); }
+
+const char* starkhip_error_string(int code) {
+    switch (code) {
+        case STARKHIP_OK: return "ok";
+        case STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE: return "Quotient has failed, the vanishing polynomial is not divisible by Z_H";
+        case STARKHIP_ERR_ZETA_IN_SUBGROUP: return "Opening point is in the subgroup";
+        case STARKHIP_ERR_BAD_SHAPE: return "bad shape (columns / public inputs / rows / config do not match the AIR)";
+        case STARKHIP_ERR_HIP: return "HIP runtime error";
+        case STARKHIP_ERR_OOM: return "out of device memory";
+        case STARKHIP_ERR_NO_DEVICE: return "no such HIP device / context";
+        case STARKHIP_ERR_VERIFY: return "proof rejected";
+        case STARKHIP_ERR_BAD_AIR: return "unknown or unbuildable AIR id";
+        default: return "unknown error";
+    }
+}
+
+}  // extern "C"

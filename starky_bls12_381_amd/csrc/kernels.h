@@ -1,0 +1,50 @@
+// Launchers of the gfx950 kernels (definitions in kernels_*.hip).  All launches are asynchronous on `st`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gl.h"
+
+namespace starkhip {
+
+// kernels_ntt.hip
+hipError_t launch_fill_powers(gl_t* out, gl_t base, gl_t mult, size_t count, hipStream_t st);  // out[i] = base * mult^i
+hipError_t launch_fill_coset_scale(gl_t* out, unsigned log_n, unsigned rate_bits, hipStream_t st);
+hipError_t launch_transpose(const gl_t* in, gl_t* out, size_t rows, size_t cols, hipStream_t st);
+// from_coeffs == 0: `values` holds evaluations on the subgroup (PolynomialBatch::from_values);
+// from_coeffs != 0: `values` already holds coefficients (PolynomialBatch::from_coeffs), coeffs_out unused.
+hipError_t launch_lde_columns(const gl_t* values, gl_t* coeffs, gl_t* lde, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                              const gl_t* tw_fwd, const gl_t* tw_inv, unsigned tw_log, const gl_t* coset_scale, int from_coeffs,
+                              hipStream_t st);
+hipError_t launch_ntt_global(gl_t* data, size_t n_vecs, size_t vec_stride, unsigned log_n, const gl_t* tw, unsigned tw_log,
+                             const gl_t* pre_scale, const gl_t* post_scale, gl_t final_mul, hipStream_t st);
+
+// kernels_hash.hip
+hipError_t launch_leaf_hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st);
+hipError_t launch_leaf_hash_rows(const gl_t* rows, size_t width, size_t n_leaves, gl_t* digests, hipStream_t st);
+hipError_t launch_merkle_levels(gl_t* digests, unsigned log_leaves, unsigned cap_h, hipStream_t st);
+hipError_t launch_permute_batch(gl_t* states, size_t n, hipStream_t st);
+hipError_t launch_pow_grind(const gl_t* base_state, int pos, unsigned pow_bits, uint64_t start, uint64_t count, unsigned long long* best,
+                            hipStream_t st);
+
+// kernels_quotient.hip
+hipError_t launch_quotient_tables(gl_t* tab, unsigned log_n, unsigned qdb, hipStream_t st);
+hipError_t launch_quotient_eval(const uint32_t* code, const gl_t* consts, const gl_t* pis, const gl_t* lde, const gl_t* tab,
+                                const uint32_t* chunk_off, unsigned n_chunks, const gl_t* apow, gl_t alpha0, gl_t alpha1, gl_t* partial,
+                                unsigned log_n, unsigned rate_bits, unsigned qdb, hipStream_t st);
+hipError_t launch_quotient_combine(const gl_t* partial, const gl_t* chunk_scale, unsigned n_chunks, const gl_t* tab, unsigned log_n,
+                                   unsigned qdb, gl_t* out, hipStream_t st);
+
+// kernels_fri.hip
+hipError_t launch_ext_powers(gl2_t* out, gl2_t base, size_t count, hipStream_t st);
+hipError_t launch_openings(const gl_t* coeffs, size_t n_polys, size_t n, const gl2_t* zpow, const gl2_t* gzpow, gl2_t* out_z, gl2_t* out_gz,
+                           hipStream_t st);
+hipError_t launch_fri_combine(const gl_t* coeffs, size_t n_polys, size_t n, const gl2_t* apow, size_t polys_per_chunk, size_t n_chunks,
+                              gl2_t* partial, hipStream_t st);
+hipError_t launch_ext_reduce(const gl2_t* partial, size_t n_chunks, size_t n, gl2_t* out, hipStream_t st);
+hipError_t launch_fri_leaves(const gl_t* vals, unsigned log_len, unsigned arity_bits, gl_t* rows, hipStream_t st);
+hipError_t launch_fri_fold(const gl_t* in, size_t len, unsigned arity_bits, gl2_t beta, gl_t* out, hipStream_t st);
+hipError_t launch_gather_rows(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, const uint32_t* nat_idx, size_t n_queries,
+                              gl_t* out, hipStream_t st);
+
+}  // namespace starkhip

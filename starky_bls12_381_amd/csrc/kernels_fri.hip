@@ -1,0 +1,142 @@
+// Openings, FRI batch combination, FRI commit-phase helpers and query gathers for gfx950.
+// Restates StarkOpeningSet::new, PolynomialBatch::prove_openings and fri_committed_trees of
+// starky 0.1.2 / plonky2 0.1.4, reached from the reference through prove()
+// at /root/reference/src/aggregate_proof.rs:59.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace starkhip {
+
+// out[i] = base^i in the extension, i < count (SoA-free: array of gl2_t)
+__global__ void ext_powers_kernel(gl2_t* out, gl2_t base, size_t count) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < count) out[i] = gl2_pow(base, i);
+}
+
+// ---------------------------------------------------------------- openings (App. A.7)
+// One workgroup per polynomial: out_z[c] = sum_k coeffs[c][k] * zpow[k], out_gz[c] likewise with gzpow.
+// coeffs is read exactly once; zpow / gzpow (n extension elements each) stay in L2.
+__global__ __launch_bounds__(256) void openings_kernel(const gl_t* __restrict__ coeffs, size_t n, const gl2_t* __restrict__ zpow,
+                                                       const gl2_t* __restrict__ gzpow, gl2_t* __restrict__ out_z,
+                                                       gl2_t* __restrict__ out_gz) {
+    const size_t c = blockIdx.x;
+    const gl_t* col = coeffs + c * n;
+    gl2_t a = gl2_zero(), b = gl2_zero();
+    for (size_t k = threadIdx.x; k < n; k += blockDim.x) {
+        gl_t v = col[k];
+        a = gl2_add(a, gl2_mul_base(zpow[k], v));
+        if (out_gz) b = gl2_add(b, gl2_mul_base(gzpow[k], v));
+    }
+    __shared__ gl2_t sa[256], sb[256];
+    sa[threadIdx.x] = a;
+    sb[threadIdx.x] = b;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            sa[threadIdx.x] = gl2_add(sa[threadIdx.x], sa[threadIdx.x + h]);
+            sb[threadIdx.x] = gl2_add(sb[threadIdx.x], sb[threadIdx.x + h]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out_z[c] = sa[0];
+        if (out_gz) out_gz[c] = sb[0];
+    }
+}
+
+// ---------------------------------------------------------------- FRI batch combine (App. A.8)
+// partial[jc][k] = sum_{j in chunk jc} apow[j0 + j] * coeffs[j][k]
+__global__ __launch_bounds__(256) void fri_combine_kernel(const gl_t* __restrict__ coeffs, size_t n_polys, size_t n,
+                                                          const gl2_t* __restrict__ apow, size_t polys_per_chunk,
+                                                          gl2_t* __restrict__ partial) {
+    size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    size_t j0 = (size_t)blockIdx.y * polys_per_chunk;
+    size_t j1 = j0 + polys_per_chunk < n_polys ? j0 + polys_per_chunk : n_polys;
+    gl2_t acc = gl2_zero();
+    for (size_t j = j0; j < j1; j++) acc = gl2_add(acc, gl2_mul_base(apow[j], coeffs[j * n + k]));
+    partial[(size_t)blockIdx.y * n + k] = acc;
+}
+// out[k] = sum_jc partial[jc][k]
+__global__ void ext_reduce_kernel(const gl2_t* __restrict__ partial, size_t n_chunks, size_t n, gl2_t* __restrict__ out) {
+    size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    gl2_t acc = gl2_zero();
+    for (size_t c = 0; c < n_chunks; c++) acc = gl2_add(acc, partial[c * n + k]);
+    out[k] = acc;
+}
+
+// ---------------------------------------------------------------- FRI commit phase
+// values SoA [2][len] natural order  ->  leaf rows [len / arity][2 * arity]: row r, slot e = value at bitrev(r * arity + e)
+__global__ void fri_leaves_kernel(const gl_t* __restrict__ vals, unsigned log_len, unsigned arity_bits, gl_t* __restrict__ rows) {
+    size_t len = (size_t)1 << log_len;
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= len) return;
+    size_t src = gl_bitrev((uint32_t)j, log_len);
+    rows[2 * j] = vals[src];
+    rows[2 * j + 1] = vals[len + src];
+}
+// coefficient fold: out[k] = sum_{i < arity} beta^i * in[k * arity + i]; in SoA [2][len], out SoA [2][len / arity]
+__global__ void fri_fold_kernel(const gl_t* __restrict__ in, size_t len, unsigned arity_bits, gl2_t beta, gl_t* __restrict__ out) {
+    size_t arity = (size_t)1 << arity_bits, olen = len >> arity_bits;
+    size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (k >= olen) return;
+    gl2_t acc = gl2_zero();
+    for (size_t i = arity; i-- > 0;) acc = gl2_add(gl2_mul(acc, beta), gl2_make(in[k * arity + i], in[len + k * arity + i]));
+    out[k] = acc.a0;
+    out[olen + k] = acc.a1;
+}
+
+// ---------------------------------------------------------------- query gathers
+// out[q][c] = mat[c * N + phys(idx[q])] where idx[q] is a NATURAL point index and the matrix is coset-major
+__global__ void gather_rows_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                                   const uint32_t* __restrict__ nat_idx, gl_t* __restrict__ out) {
+    size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (c >= n_cols) return;
+    size_t q = blockIdx.y;
+    size_t N = (size_t)1 << (log_n + rate_bits);
+    size_t i = nat_idx[q];
+    size_t phys = ((i & (((size_t)1 << rate_bits) - 1)) << log_n) + (i >> rate_bits);
+    out[q * n_cols + c] = mat[c * N + phys];
+}
+
+static inline unsigned nb(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+hipError_t launch_ext_powers(gl2_t* out, gl2_t base, size_t count, hipStream_t st) {
+    hipLaunchKernelGGL(ext_powers_kernel, dim3(nb(count, 256)), dim3(256), 0, st, out, base, count);
+    return hipGetLastError();
+}
+hipError_t launch_openings(const gl_t* coeffs, size_t n_polys, size_t n, const gl2_t* zpow, const gl2_t* gzpow, gl2_t* out_z, gl2_t* out_gz,
+                           hipStream_t st) {
+    if (!n_polys) return hipSuccess;
+    hipLaunchKernelGGL(openings_kernel, dim3((unsigned)n_polys), dim3(256), 0, st, coeffs, n, zpow, gzpow, out_z, out_gz);
+    return hipGetLastError();
+}
+hipError_t launch_fri_combine(const gl_t* coeffs, size_t n_polys, size_t n, const gl2_t* apow, size_t polys_per_chunk, size_t n_chunks,
+                              gl2_t* partial, hipStream_t st) {
+    hipLaunchKernelGGL(fri_combine_kernel, dim3(nb(n, 256), (unsigned)n_chunks), dim3(256), 0, st, coeffs, n_polys, n, apow, polys_per_chunk,
+                       partial);
+    return hipGetLastError();
+}
+hipError_t launch_ext_reduce(const gl2_t* partial, size_t n_chunks, size_t n, gl2_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(ext_reduce_kernel, dim3(nb(n, 256)), dim3(256), 0, st, partial, n_chunks, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_fri_leaves(const gl_t* vals, unsigned log_len, unsigned arity_bits, gl_t* rows, hipStream_t st) {
+    size_t len = (size_t)1 << log_len;
+    hipLaunchKernelGGL(fri_leaves_kernel, dim3(nb(len, 256)), dim3(256), 0, st, vals, log_len, arity_bits, rows);
+    return hipGetLastError();
+}
+hipError_t launch_fri_fold(const gl_t* in, size_t len, unsigned arity_bits, gl2_t beta, gl_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(fri_fold_kernel, dim3(nb(len >> arity_bits, 256)), dim3(256), 0, st, in, len, arity_bits, beta, out);
+    return hipGetLastError();
+}
+hipError_t launch_gather_rows(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, const uint32_t* nat_idx, size_t n_queries,
+                              gl_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb(n_cols, 256), (unsigned)n_queries), dim3(256), 0, st, mat, n_cols, log_n, rate_bits,
+                       nat_idx, out);
+    return hipGetLastError();
+}
+
+}  // namespace starkhip

@@ -1,0 +1,113 @@
+// Poseidon-Goldilocks hashing kernels for gfx950: Merkle leaf digests over the coset-major LDE,
+// 2-to-1 compression levels, proof-of-work grinding and a raw permutation batch for tests.
+// Restates plonky2 MerkleTree::new / hash_or_noop / two_to_one, which the
+// reference reaches through prove() at /root/reference/src/aggregate_proof.rs:59.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "poseidon.h"
+
+namespace starkhip {
+
+// Leaf digests of a column-major matrix laid out coset-major (see kernels_ntt.hip):
+//   element (column c, physical point q) at mat[c * N + q], q = s * n + k  <->  natural index i = k * R + s.
+// Leaf position j in the tree holds natural row bitrev_logN(j) (plonky2 reverse_index_bits_in_place),
+// so the thread that owns physical point q writes digest slot j = bitrev(i).
+// One lane walks one row; adjacent lanes read adjacent k => every load is a coalesced 512 B line.
+__global__ __launch_bounds__(64) void leaf_hash_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                                                        gl_t* __restrict__ digests) {
+    const unsigned log_N = log_n + rate_bits;
+    const size_t N = (size_t)1 << log_N;
+    size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    size_t s = q >> log_n, k = q & (((size_t)1 << log_n) - 1);
+    size_t i = (k << rate_bits) + s;
+    size_t j = gl_bitrev((uint32_t)i, log_N);
+    gl_t out[4];
+    poseidon_hash_or_noop(mat + q, n_cols, N, out);
+#pragma unroll
+    for (int e = 0; e < 4; e++) digests[4 * j + e] = out[e];
+}
+
+// Leaves stored row-major and already in tree order: leaf j = rows[j][0..width)
+__global__ __launch_bounds__(64) void leaf_hash_rows_kernel(const gl_t* __restrict__ rows, size_t width, size_t n_leaves,
+                                                             gl_t* __restrict__ digests) {
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= n_leaves) return;
+    gl_t out[4];
+    poseidon_hash_or_noop(rows + j * width, width, 1, out);
+#pragma unroll
+    for (int e = 0; e < 4; e++) digests[4 * j + e] = out[e];
+}
+
+__global__ __launch_bounds__(64) void merkle_level_kernel(const gl_t* __restrict__ child, gl_t* __restrict__ parent, size_t n_parent) {
+    size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= n_parent) return;
+    gl_t out[4];
+    poseidon_two_to_one(child + 8 * j, child + 8 * j + 4, out);
+#pragma unroll
+    for (int e = 0; e < 4; e++) parent[4 * j + e] = out[e];
+}
+
+__global__ void permute_batch_kernel(gl_t* states, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gl_t s[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) s[e] = states[12 * i + e];
+    poseidon_permute(s);
+#pragma unroll
+    for (int e = 0; e < 12; e++) states[12 * i + e] = s[e];
+}
+
+// Proof-of-work grinding (plonky2 fri_proof_of_work, App. A.8): the challenger's sponge state with its
+// pending inputs already written in; candidate nonce goes to lane `pos`; the response is state[7]
+// after one permutation.  Keeps the MINIMUM valid nonce in *best (initialised to UINT64_MAX).
+__global__ void pow_grind_kernel(const gl_t* __restrict__ base_state, int pos, unsigned pow_bits, uint64_t start, uint64_t count,
+                                 unsigned long long* best) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    uint64_t w = start + t;
+    gl_t s[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) s[e] = base_state[e];
+    s[pos] = w;
+    poseidon_permute(s);
+    if ((s[7] >> (64 - pow_bits)) == 0) atomicMin(best, (unsigned long long)w);
+}
+
+static inline unsigned nblocks(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+hipError_t launch_leaf_hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st) {
+    size_t N = (size_t)1 << (log_n + rate_bits);
+    hipLaunchKernelGGL(leaf_hash_kernel, dim3(nblocks(N, 64)), dim3(64), 0, st, mat, n_cols, log_n, rate_bits, digests);
+    return hipGetLastError();
+}
+hipError_t launch_leaf_hash_rows(const gl_t* rows, size_t width, size_t n_leaves, gl_t* digests, hipStream_t st) {
+    hipLaunchKernelGGL(leaf_hash_rows_kernel, dim3(nblocks(n_leaves, 64)), dim3(64), 0, st, rows, width, n_leaves, digests);
+    return hipGetLastError();
+}
+// levels: digests buffer holds level 0 (n_leaves * 4) followed by level 1 (n_leaves/2 * 4) ... down to the cap level.
+hipError_t launch_merkle_levels(gl_t* digests, unsigned log_leaves, unsigned cap_h, hipStream_t st) {
+    gl_t* child = digests;
+    for (unsigned lv = log_leaves; lv > cap_h; lv--) {
+        size_t n_parent = (size_t)1 << (lv - 1);
+        gl_t* parent = child + ((size_t)4 << lv);
+        hipLaunchKernelGGL(merkle_level_kernel, dim3(nblocks(n_parent, 64)), dim3(64), 0, st, child, parent, n_parent);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        child = parent;
+    }
+    return hipSuccess;
+}
+hipError_t launch_permute_batch(gl_t* states, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(permute_batch_kernel, dim3(nblocks(n, 64)), dim3(64), 0, st, states, n);
+    return hipGetLastError();
+}
+hipError_t launch_pow_grind(const gl_t* base_state, int pos, unsigned pow_bits, uint64_t start, uint64_t count, unsigned long long* best,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(pow_grind_kernel, dim3(nblocks(count, 256)), dim3(256), 0, st, base_state, pos, pow_bits, start, count, best);
+    return hipGetLastError();
+}
+
+}  // namespace starkhip

@@ -1,0 +1,23 @@
+// Internal interface between the C ABI (capi.cpp) and the GPU prover driver (prover.hip).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "airs.h"
+
+namespace starkhip {
+
+struct Ctx;
+int ctx_create(int device, Ctx** out);
+void ctx_destroy(Ctx* c);
+const float* ctx_timings(Ctx* c);
+
+int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64_t* trace, size_t n_rows, int layout, int on_device,
+          const uint64_t* pis, size_t n_pis, uint64_t pow_witness, uint64_t** proof_out, size_t* proof_words);
+int lde_batch(Ctx* c, const uint64_t* values, size_t n_cols, unsigned log_n, unsigned rate_bits, uint64_t* coeffs_out, uint64_t* lde_out);
+int merkle_cap(Ctx* c, const uint64_t* lde_natural, size_t n_cols, unsigned log_N, unsigned cap_h, uint64_t* cap_out);
+int permute_batch(Ctx* c, uint64_t* states, size_t n);
+
+int verify_proof(const AirInfo& air, const starkhip_config_t& cfg, const uint64_t* proof, size_t words);
+
+}  // namespace starkhip

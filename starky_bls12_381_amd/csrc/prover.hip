@@ -1,0 +1,570 @@
+// Host driver of the GPU prover: the MI355X-native replacement of starky::prover::prove as called at
+// /root/reference/src/aggregate_proof.rs:59-65 (and :105, :138, :169).  Follows the transcript of
+// SURVEY.md App. A.5 step by step; every heavy step is one of the kernels in kernels_*.hip, the host
+// only runs the Fiat-Shamir challenger, two length-n synthetic divisions and the proof assembly.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "airs.h"
+#include "kernels.h"
+#include "poseidon.h"
+#include "proof.h"
+#include "prover.h"
+
+namespace starkhip {
+
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) {                                                                            \
+            fprintf(stderr, "starkhip: HIP error %s at %s:%d (%s)\n", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+            return _e == hipErrorOutOfMemory ? STARKHIP_ERR_OOM : STARKHIP_ERR_HIP;                        \
+        }                                                                                                  \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[STARKHIP_N_PHASES + 1];
+    float timings[STARKHIP_N_PHASES] = {0};
+    // shape-dependent tables
+    int tab_log_n = -1, tab_rate = -1, tab_qdb = -1;
+    DevBuf tw_fwd, tw_inv, coset_scale, qtab, qshift_inv;
+    // program
+    int prog_air = -1;
+    unsigned prog_chunks = 0;
+    DevBuf d_code, d_consts, d_chunk_off;
+    std::vector<uint32_t> chunk_off, chunk_k_after;
+    // work buffers
+    DevBuf staging, values, coeffs, lde, digests, pis, apow, chunk_scale, partial, qvals, qcoef, qlde, qdigests, zpow, gzpow, open_local,
+        open_next, open_q, ext_apow, comb_partial, comb_out, fri_coef, fri_vals, fri_rows[16], fri_digests[16], scale_tab, pow_state,
+        pow_best, qidx, gather_t, gather_q;
+};
+
+static int ensure_tables(Ctx* c, unsigned log_n, unsigned rate, unsigned qdb) {
+    if (c->tab_log_n == (int)log_n && c->tab_rate == (int)rate && c->tab_qdb == (int)qdb) return 0;
+    const unsigned log_N = log_n + rate;
+    const size_t N = (size_t)1 << log_N, size = (size_t)1 << (log_n + qdb);
+    HIPCHK(c->tw_fwd.ensure(N / 2 * 8 + 8));
+    HIPCHK(c->tw_inv.ensure(N / 2 * 8 + 8));
+    HIPCHK(c->coset_scale.ensure(N * 8));
+    HIPCHK(c->qtab.ensure(4 * size * 8));
+    HIPCHK(c->qshift_inv.ensure(size * 8));
+    gl_t w = gl_root_of_unity(log_N);
+    HIPCHK(launch_fill_powers(c->tw_fwd.as<gl_t>(), 1, w, N / 2, c->st));
+    HIPCHK(launch_fill_powers(c->tw_inv.as<gl_t>(), 1, gl_inv(w), N / 2, c->st));
+    HIPCHK(launch_fill_coset_scale(c->coset_scale.as<gl_t>(), log_n, rate, c->st));
+    HIPCHK(launch_quotient_tables(c->qtab.as<gl_t>(), log_n, qdb, c->st));
+    HIPCHK(launch_fill_powers(c->qshift_inv.as<gl_t>(), 1, gl_inv(GL_GENERATOR), size, c->st));
+    c->tab_log_n = log_n;
+    c->tab_rate = rate;
+    c->tab_qdb = qdb;
+    return 0;
+}
+
+static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
+    // enough (point-block x chunk) waves to fill 256 CUs several times over
+    size_t blocks = (quotient_points + 63) / 64;
+    unsigned want = (unsigned)std::min<size_t>(256, std::max<size_t>(1, (16384 + blocks - 1) / blocks));
+    want = (unsigned)std::min<size_t>(want, air.prog.group_off.size());
+    if (c->prog_air == air.id && c->prog_chunks == want) return 0;
+    const AirProgram& P = air.prog;
+    HIPCHK(c->d_code.ensure(P.code.size() * 4));
+    HIPCHK(c->d_consts.ensure(std::max<size_t>(1, P.consts.size()) * 8));
+    HIPCHK(hipMemcpyAsync(c->d_code.p, P.code.data(), P.code.size() * 4, hipMemcpyHostToDevice, c->st));
+    if (!P.consts.empty()) HIPCHK(hipMemcpyAsync(c->d_consts.p, P.consts.data(), P.consts.size() * 8, hipMemcpyHostToDevice, c->st));
+    // cut at group boundaries into `want` pieces of about equal code length
+    c->chunk_off.clear();
+    c->chunk_k_after.clear();
+    const size_t total_words = P.code.size() - 1;  // END word excluded
+    size_t g = 0;
+    const size_t n_groups = P.group_off.size();
+    for (unsigned p = 0; p < want; p++) {
+        c->chunk_off.push_back(P.group_off[g]);
+        size_t target = total_words * (p + 1) / want;
+        size_t g_end = g + 1;
+        while (g_end < n_groups && P.group_off[g_end] < target && (n_groups - g_end) > (want - 1 - p)) g_end++;
+        if (p + 1 == want) g_end = n_groups;
+        uint32_t k_end = g_end < n_groups ? P.group_k0[g_end] : P.n_constraints;
+        c->chunk_k_after.push_back(P.n_constraints - k_end);
+        g = g_end;
+    }
+    c->chunk_off.push_back((uint32_t)total_words);
+    HIPCHK(c->d_chunk_off.ensure(c->chunk_off.size() * 4));
+    HIPCHK(hipMemcpyAsync(c->d_chunk_off.p, c->chunk_off.data(), c->chunk_off.size() * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    c->prog_air = air.id;
+    c->prog_chunks = want;
+    return 0;
+}
+
+// digest buffer: level 0 (n_leaves nodes) followed by level 1, ... ; offset of level l in nodes
+static inline size_t level_off(size_t n_leaves, unsigned l) { return 2 * n_leaves - (2 * n_leaves >> l); }
+static inline size_t digest_words(size_t n_leaves) { return 8 * n_leaves; }
+
+static void merkle_path(const gl_t* digests, size_t n_leaves, unsigned depth, size_t idx, gl_t* out) {
+    for (unsigned l = 0; l < depth; l++) {
+        memcpy(out + 4 * l, digests + 4 * (level_off(n_leaves, l) + (idx ^ 1)), 32);
+        idx >>= 1;
+    }
+}
+
+int ctx_create(int device, Ctx** out) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return STARKHIP_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return STARKHIP_ERR_NO_DEVICE;
+    HIPCHK(hipSetDevice(device));
+    Ctx* c = new Ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreate(&c->st));
+    for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+    *out = c;
+    return 0;
+}
+
+void ctx_destroy(Ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->st);
+    DevBuf* bufs[] = {&c->tw_fwd, &c->tw_inv, &c->coset_scale, &c->qtab, &c->qshift_inv, &c->d_code, &c->d_consts, &c->d_chunk_off, &c->staging,
+                      &c->values, &c->coeffs, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial, &c->qvals, &c->qcoef,
+                      &c->qlde, &c->qdigests, &c->zpow, &c->gzpow, &c->open_local, &c->open_next, &c->open_q, &c->ext_apow, &c->comb_partial,
+                      &c->comb_out, &c->fri_coef, &c->fri_vals, &c->scale_tab, &c->pow_state, &c->pow_best, &c->qidx, &c->gather_t,
+                      &c->gather_q};
+    for (auto b : bufs) b->release();
+    for (auto& b : c->fri_rows) b.release();
+    for (auto& b : c->fri_digests) b.release();
+    for (auto& e : c->ev) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->st);
+    delete c;
+}
+
+hipStream_t ctx_stream(Ctx* c) { return c->st; }
+const float* ctx_timings(Ctx* c) { return c->timings; }
+
+// (F(X) - F(z)) / (X - z), padded with one zero coefficient back to length n (plonky2 divide_by_linear + push(0))
+static void divide_by_linear(const gl2_t* F, size_t n, gl2_t z, gl2_t* q) {
+    gl2_t carry = gl2_zero();
+    q[n - 1] = gl2_zero();
+    for (size_t k = n; k-- > 1;) {
+        carry = gl2_add(F[k], gl2_mul(carry, z));
+        q[k - 1] = carry;
+    }
+}
+
+int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64_t* trace, size_t n_rows, int layout, int on_device,
+          const uint64_t* pis_host, size_t n_pis, uint64_t pow_witness, uint64_t** proof_out, size_t* proof_words) {
+    const AirProgram& P = air.prog;
+    unsigned log_n = 0;
+    while (((size_t)1 << log_n) < n_rows) log_n++;
+    if (n_rows < 2 || ((size_t)1 << log_n) != n_rows || n_pis != P.n_pis || cfg.num_challenges != 2 || log_n > 13) return STARKHIP_ERR_BAD_SHAPE;
+    FriGeometry geo;
+    if (!FriGeometry::make(cfg, log_n, &geo)) return STARKHIP_ERR_BAD_SHAPE;
+    const unsigned r = cfg.rate_bits, cap_h = cfg.cap_height, log_N = log_n + r;
+    const unsigned factor = P.degree > 1 ? P.degree - 1 : 1;
+    unsigned qdb = 0;
+    while ((1u << qdb) < factor) qdb++;
+    if (qdb > r) return STARKHIP_ERR_BAD_SHAPE;
+    for (size_t i = 0; i < n_pis; i++)
+        if (pis_host[i] >= GL_P) return STARKHIP_ERR_BAD_SHAPE;
+    const size_t n = n_rows, N = n << r, C = P.n_cols, Q = (size_t)factor * 2, size = n << qdb, ncap = (size_t)1 << cap_h;
+    const size_t L = geo.arities.size();
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->st;
+    int rc;
+    if ((rc = ensure_tables(c, log_n, r, qdb))) return rc;
+    if ((rc = ensure_program(c, air, size))) return rc;
+    const unsigned n_chunks = c->prog_chunks;
+
+    // ---- buffers
+    HIPCHK(c->coeffs.ensure(C * n * 8));
+    HIPCHK(c->lde.ensure(C * N * 8));
+    HIPCHK(c->digests.ensure(digest_words(N) * 8));
+    HIPCHK(c->pis.ensure(std::max<size_t>(1, n_pis) * 8));
+    HIPCHK(c->apow.ensure(2 * (AIR_MAX_GROUP + 1) * 8));
+    HIPCHK(c->chunk_scale.ensure(2 * n_chunks * 8));
+    HIPCHK(c->partial.ensure((size_t)n_chunks * 2 * size * 8));
+    HIPCHK(c->qvals.ensure(2 * size * 8));
+    HIPCHK(c->qcoef.ensure(Q * n * 8));
+    HIPCHK(c->qlde.ensure(Q * N * 8));
+    HIPCHK(c->qdigests.ensure(digest_words(N) * 8));
+    HIPCHK(c->zpow.ensure(n * 16));
+    HIPCHK(c->gzpow.ensure(n * 16));
+    HIPCHK(c->open_local.ensure(C * 16));
+    HIPCHK(c->open_next.ensure(C * 16));
+    HIPCHK(c->open_q.ensure(Q * 16));
+    HIPCHK(c->ext_apow.ensure((C + Q) * 16));
+    const size_t comb_ppc = 256, comb_chunks = (C + comb_ppc - 1) / comb_ppc;
+    HIPCHK(c->comb_partial.ensure(comb_chunks * n * 16));
+    HIPCHK(c->comb_out.ensure(2 * n * 16));
+    HIPCHK(c->fri_coef.ensure(2 * N * 8));
+    HIPCHK(c->fri_vals.ensure(2 * N * 8));
+    HIPCHK(c->scale_tab.ensure(N * 8));
+    HIPCHK(c->pow_state.ensure(12 * 8));
+    HIPCHK(c->pow_best.ensure(8));
+    HIPCHK(c->qidx.ensure(cfg.num_query_rounds * 4));
+    HIPCHK(c->gather_t.ensure((size_t)cfg.num_query_rounds * C * 8));
+    HIPCHK(c->gather_q.ensure((size_t)cfg.num_query_rounds * Q * 8));
+
+    int evi = 0;
+    HIPCHK(hipEventRecord(c->ev[evi++], st));
+
+    // ---- phase 0: trace into column-major device memory (trace_rows_to_poly_values)
+    const gl_t* d_values;
+    if (on_device && layout == 1) {
+        d_values = trace;
+    } else if (on_device) {
+        HIPCHK(c->values.ensure(C * n * 8));
+        HIPCHK(launch_transpose(trace, c->values.as<gl_t>(), n, C, st));
+        d_values = c->values.as<gl_t>();
+    } else if (layout == 1) {
+        HIPCHK(c->values.ensure(C * n * 8));
+        HIPCHK(hipMemcpyAsync(c->values.p, trace, C * n * 8, hipMemcpyHostToDevice, st));
+        d_values = c->values.as<gl_t>();
+    } else {
+        HIPCHK(c->values.ensure(C * n * 8));
+        HIPCHK(c->staging.ensure(C * n * 8));
+        HIPCHK(hipMemcpyAsync(c->staging.p, trace, C * n * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(launch_transpose(c->staging.as<gl_t>(), c->values.as<gl_t>(), n, C, st));
+        d_values = c->values.as<gl_t>();
+    }
+    HIPCHK(hipEventRecord(c->ev[evi++], st));
+
+    // ---- phase 1: IFFT + LDE (PolynomialBatch::from_values, App. A.3)
+    HIPCHK(launch_lde_columns(d_values, c->coeffs.as<gl_t>(), c->lde.as<gl_t>(), C, log_n, r, c->tw_fwd.as<gl_t>(), c->tw_inv.as<gl_t>(), log_N,
+                              c->coset_scale.as<gl_t>(), 0, st));
+    HIPCHK(hipEventRecord(c->ev[evi++], st));
+
+    // ---- phase 2: Merkle tree over bit-reversed LDE rows
+    HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
+    HIPCHK(launch_merkle_levels(c->digests.as<gl_t>(), log_N, cap_h, st));
+    std::vector<gl_t> trace_cap(4 * ncap), quot_cap(4 * ncap);
+    HIPCHK(hipMemcpyAsync(trace_cap.data(), c->digests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), 4 * ncap * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(c->ev[evi++], st));
+    HIPCHK(hipStreamSynchronize(st));
+
+    Challenger ch;
+    ch.observe_many(trace_cap.data(), trace_cap.size());  // public inputs are NOT observed (App. A.5)
+    gl_t alphas[2] = {ch.get(), ch.get()};
+
+    // ---- phase 3: quotient polynomials (App. A.6)
+    {
+        std::vector<gl_t> apow(2 * (AIR_MAX_GROUP + 1)), cscale(2 * n_chunks);
+        for (int j = 0; j < 2; j++) {
+            apow[j * (AIR_MAX_GROUP + 1)] = 1;
+            for (unsigned m = 1; m <= AIR_MAX_GROUP; m++) apow[j * (AIR_MAX_GROUP + 1) + m] = gl_mul(apow[j * (AIR_MAX_GROUP + 1) + m - 1], alphas[j]);
+            for (unsigned p = 0; p < n_chunks; p++) cscale[p * 2 + j] = gl_pow(alphas[j], c->chunk_k_after[p]);
+        }
+        HIPCHK(hipMemcpyAsync(c->apow.p, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->chunk_scale.p, cscale.data(), cscale.size() * 8, hipMemcpyHostToDevice, st));
+        if (n_pis) HIPCHK(hipMemcpyAsync(c->pis.p, pis_host, n_pis * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(launch_quotient_eval(c->d_code.as<uint32_t>(), c->d_consts.as<gl_t>(), c->pis.as<gl_t>(), c->lde.as<gl_t>(), c->qtab.as<gl_t>(),
+                                    c->d_chunk_off.as<uint32_t>(), n_chunks, c->apow.as<gl_t>(), alphas[0], alphas[1], c->partial.as<gl_t>(),
+                                    log_n, r, qdb, st));
+        HIPCHK(launch_quotient_combine(c->partial.as<gl_t>(), c->chunk_scale.as<gl_t>(), n_chunks, c->qtab.as<gl_t>(), log_n, qdb,
+                                       c->qvals.as<gl_t>(), st));
+        // coset_ifft(7): inverse transform, scale by size^-1 and by 7^-i
+        HIPCHK(launch_ntt_global(c->qvals.as<gl_t>(), 2, size, log_n + qdb, c->tw_inv.as<gl_t>(), log_N, nullptr, c->qshift_inv.as<gl_t>(),
+                                 gl_inv((gl_t)size), st));
+        // trim_to_len(n * factor) must succeed, then chunks of n: [alpha0: c0..cf-1, alpha1: c0..cf-1]
+        std::vector<gl_t> tail;
+        if (size > (size_t)factor * n) {
+            tail.resize(2 * (size - factor * n));
+            for (int j = 0; j < 2; j++)
+                HIPCHK(hipMemcpyAsync(tail.data() + j * (size - factor * n), c->qvals.as<gl_t>() + j * size + factor * n,
+                                      (size - factor * n) * 8, hipMemcpyDeviceToHost, st));
+        }
+        for (int j = 0; j < 2; j++)
+            HIPCHK(hipMemcpyAsync(c->qcoef.as<gl_t>() + (size_t)j * factor * n, c->qvals.as<gl_t>() + j * size, (size_t)factor * n * 8,
+                                  hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipEventRecord(c->ev[evi++], st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (gl_t v : tail)
+            if (v != 0) return STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE;
+    }
+
+    // ---- phase 4: quotient commit (PolynomialBatch::from_coeffs)
+    HIPCHK(launch_lde_columns(c->qcoef.as<gl_t>(), nullptr, c->qlde.as<gl_t>(), Q, log_n, r, c->tw_fwd.as<gl_t>(), c->tw_inv.as<gl_t>(), log_N,
+                              c->coset_scale.as<gl_t>(), 1, st));
+    HIPCHK(launch_leaf_hash(c->qlde.as<gl_t>(), Q, log_n, r, c->qdigests.as<gl_t>(), st));
+    HIPCHK(launch_merkle_levels(c->qdigests.as<gl_t>(), log_N, cap_h, st));
+    HIPCHK(hipMemcpyAsync(quot_cap.data(), c->qdigests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), 4 * ncap * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(c->ev[evi++], st));
+    HIPCHK(hipStreamSynchronize(st));
+    ch.observe_many(quot_cap.data(), quot_cap.size());
+    gl2_t zeta = ch.get_ext();
+    if (gl2_eq(gl2_pow(zeta, n), gl2_one())) return STARKHIP_ERR_ZETA_IN_SUBGROUP;
+    gl2_t gzeta = gl2_mul_base(zeta, gl_root_of_unity(log_n));
+
+    // ---- phase 5: openings (App. A.7)
+    std::vector<gl2_t> op_local(C), op_next(C), op_q(Q);
+    HIPCHK(launch_ext_powers(c->zpow.as<gl2_t>(), zeta, n, st));
+    HIPCHK(launch_ext_powers(c->gzpow.as<gl2_t>(), gzeta, n, st));
+    HIPCHK(launch_openings(c->coeffs.as<gl_t>(), C, n, c->zpow.as<gl2_t>(), c->gzpow.as<gl2_t>(), c->open_local.as<gl2_t>(),
+                           c->open_next.as<gl2_t>(), st));
+    HIPCHK(launch_openings(c->qcoef.as<gl_t>(), Q, n, c->zpow.as<gl2_t>(), nullptr, c->open_q.as<gl2_t>(), nullptr, st));
+    HIPCHK(hipMemcpyAsync(op_local.data(), c->open_local.p, C * 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(op_next.data(), c->open_next.p, C * 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(op_q.data(), c->open_q.p, Q * 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(c->ev[evi++], st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t i = 0; i < C; i++) ch.observe_ext(op_local[i]);
+    for (size_t i = 0; i < Q; i++) ch.observe_ext(op_q[i]);
+    for (size_t i = 0; i < C; i++) ch.observe_ext(op_next[i]);
+
+    // ---- phase 6: FRI batch combination (prove_openings, App. A.8)
+    gl2_t fri_alpha = ch.get_ext();
+    std::vector<gl2_t> fin(n);
+    {
+        HIPCHK(launch_ext_powers(c->ext_apow.as<gl2_t>(), fri_alpha, C + Q, st));
+        gl2_t* comb = c->comb_out.as<gl2_t>();
+        HIPCHK(launch_fri_combine(c->coeffs.as<gl_t>(), C, n, c->ext_apow.as<gl2_t>(), comb_ppc, comb_chunks, c->comb_partial.as<gl2_t>(), st));
+        HIPCHK(launch_ext_reduce(c->comb_partial.as<gl2_t>(), comb_chunks, n, comb, st));  // sum_j alpha^j trace_j
+        HIPCHK(launch_fri_combine(c->qcoef.as<gl_t>(), Q, n, c->ext_apow.as<gl2_t>() + C, Q, 1, comb + n, st));  // alpha^(C+q) quotient_q
+        std::vector<gl2_t> F1(n), tailq(n), F0(n), q0(n), q1(n);
+        HIPCHK(hipMemcpyAsync(F1.data(), comb, n * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(tailq.data(), comb + n, n * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (size_t k = 0; k < n; k++) F0[k] = gl2_add(F1[k], tailq[k]);
+        divide_by_linear(F0.data(), n, zeta, q0.data());   // batch 0: trace ++ quotient at zeta
+        divide_by_linear(F1.data(), n, gzeta, q1.data());  // batch 1: trace at g*zeta
+        gl2_t shift = gl2_pow(fri_alpha, C);               // alpha^{|batch 1|}
+        for (size_t k = 0; k < n; k++) fin[k] = gl2_add(gl2_mul(q0[k], shift), q1[k]);
+        // upload as SoA, zero padded to N (lde(rate_bits))
+        std::vector<gl_t> soa(2 * N, 0);
+        for (size_t k = 0; k < n; k++) {
+            soa[k] = fin[k].a0;
+            soa[N + k] = fin[k].a1;
+        }
+        HIPCHK(hipMemcpyAsync(c->fri_coef.p, soa.data(), 2 * N * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    HIPCHK(hipEventRecord(c->ev[evi++], st));
+
+    // ---- phase 7: FRI commit phase (fri_committed_trees)
+    std::vector<std::vector<gl_t>> fri_rows_h(L), fri_dig_h(L);
+    std::vector<gl_t> fri_caps(L * 4 * ncap);
+    std::vector<gl2_t> final_poly(geo.final_poly_len);
+    {
+        size_t len = N;
+        unsigned log_len = log_N;
+        gl_t shift = GL_GENERATOR;
+        gl_t* coef = c->fri_coef.as<gl_t>();
+        gl_t* vals = c->fri_vals.as<gl_t>();
+        for (size_t l = 0; l <= L; l++) {
+            if (l == L) break;
+            // values on shift * <w_len>
+            HIPCHK(hipMemcpyAsync(vals, coef, len * 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(vals + len, coef + len, len * 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(launch_fill_powers(c->scale_tab.as<gl_t>(), 1, shift, len, st));
+            HIPCHK(launch_ntt_global(vals, 2, len, log_len, c->tw_fwd.as<gl_t>(), log_N, c->scale_tab.as<gl_t>(), nullptr, 1, st));
+            const unsigned ab = geo.arities[l];
+            const size_t n_leaves = len >> ab, width = 2 << ab;
+            HIPCHK(c->fri_rows[l].ensure(len * 2 * 8));
+            HIPCHK(c->fri_digests[l].ensure(digest_words(n_leaves) * 8));
+            HIPCHK(launch_fri_leaves(vals, log_len, ab, c->fri_rows[l].as<gl_t>(), st));
+            HIPCHK(launch_leaf_hash_rows(c->fri_rows[l].as<gl_t>(), width, n_leaves, c->fri_digests[l].as<gl_t>(), st));
+            HIPCHK(launch_merkle_levels(c->fri_digests[l].as<gl_t>(), log_len - ab, cap_h, st));
+            fri_rows_h[l].resize(len * 2);
+            fri_dig_h[l].resize(digest_words(n_leaves));
+            HIPCHK(hipMemcpyAsync(fri_rows_h[l].data(), c->fri_rows[l].p, len * 2 * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(fri_dig_h[l].data(), c->fri_digests[l].p, digest_words(n_leaves) * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            const gl_t* cap = fri_dig_h[l].data() + 4 * level_off(n_leaves, log_len - ab - cap_h);
+            memcpy(fri_caps.data() + l * 4 * ncap, cap, 4 * ncap * 8);
+            ch.observe_many(cap, 4 * ncap);
+            gl2_t beta = ch.get_ext();
+            // fold coefficients; output goes to the other half of fri_vals' sibling buffer: reuse coef in place via temp
+            HIPCHK(launch_fri_fold(coef, len, ab, beta, vals, st));  // vals now holds folded coefficients SoA [2][len >> ab]
+            std::swap(coef, vals);
+            len >>= ab;
+            log_len -= ab;
+            for (unsigned b = 0; b < ab; b++) shift = gl_sqr(shift);
+        }
+        // final polynomial: truncate to len >> rate_bits; the dropped coefficients must be zero
+        std::vector<gl_t> fc(2 * len);
+        HIPCHK(hipMemcpyAsync(fc.data(), coef, len * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(fc.data() + len, coef + len, len * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if ((len >> r) != geo.final_poly_len) return STARKHIP_ERR_BAD_SHAPE;
+        for (size_t k = 0; k < len; k++) {
+            if (k < geo.final_poly_len) final_poly[k] = gl2_make(fc[k], fc[len + k]);
+            else if (fc[k] || fc[len + k]) return STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE;
+        }
+        for (auto& e : final_poly) ch.observe_ext(e);
+    }
+    HIPCHK(hipEventRecord(c->ev[evi++], st));
+
+    // ---- phase 8: proof of work (fri_proof_of_work): smallest nonce unless one is supplied
+    if (pow_witness == STARKHIP_POW_SEARCH) {
+        if (cfg.proof_of_work_bits == 0) {
+            pow_witness = 0;
+        } else {
+            gl_t base[12];
+            memcpy(base, ch.state, sizeof base);
+            for (int i = 0; i < ch.n_in; i++) base[i] = ch.in[i];
+            HIPCHK(hipMemcpyAsync(c->pow_state.p, base, sizeof base, hipMemcpyHostToDevice, st));
+            unsigned long long best = ~0ULL;
+            const uint64_t batch = 1ULL << 20;
+            for (uint64_t start = 0; best == ~0ULL; start += batch) {
+                if (start >= GL_P - batch) return STARKHIP_ERR_HIP;
+                HIPCHK(hipMemcpyAsync(c->pow_best.p, &best, 8, hipMemcpyHostToDevice, st));
+                HIPCHK(launch_pow_grind(c->pow_state.as<gl_t>(), ch.n_in, cfg.proof_of_work_bits, start, batch, c->pow_best.as<unsigned long long>(), st));
+                HIPCHK(hipMemcpyAsync(&best, c->pow_best.p, 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+            }
+            pow_witness = best;
+        }
+    }
+    ch.observe(pow_witness);
+    (void)ch.get();  // pow_response
+    HIPCHK(hipEventRecord(c->ev[evi++], st));
+
+    // ---- phase 9: query rounds (fri_prover_query_rounds)
+    ProofLayout pl;
+    pl.C = C; pl.Q = Q; pl.log_n = log_n; pl.rate_bits = r; pl.cap_h = cap_h; pl.L = L; pl.n_queries = cfg.num_query_rounds;
+    pl.final_len = geo.final_poly_len; pl.n_pis = n_pis; pl.arity_bits = cfg.arity_bits; pl.n_challenges = 2;
+    pl.compute();
+    uint64_t* out = (uint64_t*)malloc(pl.total * 8);
+    if (!out) return STARKHIP_ERR_OOM;
+    {
+        const size_t nq = cfg.num_query_rounds;
+        std::vector<size_t> xs(nq);
+        std::vector<uint32_t> nat(nq);
+        for (size_t q = 0; q < nq; q++) {
+            xs[q] = (size_t)(ch.get() % N);
+            nat[q] = gl_bitrev((uint32_t)xs[q], log_N);
+        }
+        std::vector<gl_t> dig_t(digest_words(N)), dig_q(digest_words(N)), rows_t(nq * C), rows_q(nq * Q);
+        int err = 0;
+#define HIPCHK_FREE(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fprintf(stderr, "starkhip: HIP error %s (%s)\n", hipGetErrorString(_e), #expr); err = 1; } } while (0)
+        HIPCHK_FREE(hipMemcpyAsync(c->qidx.p, nat.data(), nq * 4, hipMemcpyHostToDevice, st));
+        HIPCHK_FREE(launch_gather_rows(c->lde.as<gl_t>(), C, log_n, r, c->qidx.as<uint32_t>(), nq, c->gather_t.as<gl_t>(), st));
+        HIPCHK_FREE(launch_gather_rows(c->qlde.as<gl_t>(), Q, log_n, r, c->qidx.as<uint32_t>(), nq, c->gather_q.as<gl_t>(), st));
+        HIPCHK_FREE(hipMemcpyAsync(rows_t.data(), c->gather_t.p, nq * C * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK_FREE(hipMemcpyAsync(rows_q.data(), c->gather_q.p, nq * Q * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK_FREE(hipMemcpyAsync(dig_t.data(), c->digests.p, dig_t.size() * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK_FREE(hipMemcpyAsync(dig_q.data(), c->qdigests.p, dig_q.size() * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK_FREE(hipStreamSynchronize(st));
+#undef HIPCHK_FREE
+        if (err) {
+            free(out);
+            return STARKHIP_ERR_HIP;
+        }
+        pl.write_header(out);
+        memcpy(out + pl.off_trace_cap, trace_cap.data(), 4 * ncap * 8);
+        memcpy(out + pl.off_quot_cap, quot_cap.data(), 4 * ncap * 8);
+        memcpy(out + pl.off_local, op_local.data(), C * 16);
+        memcpy(out + pl.off_next, op_next.data(), C * 16);
+        memcpy(out + pl.off_quot_open, op_q.data(), Q * 16);
+        if (L) memcpy(out + pl.off_fri_caps, fri_caps.data(), L * 4 * ncap * 8);
+        const unsigned d0 = log_N - cap_h;
+        for (size_t q = 0; q < nq; q++) {
+            uint64_t* w = out + pl.off_queries + q * pl.query_words;
+            size_t x = xs[q];
+            memcpy(w, rows_t.data() + q * C, C * 8); w += C;
+            merkle_path(dig_t.data(), N, d0, x, w); w += 4 * d0;
+            memcpy(w, rows_q.data() + q * Q, Q * 8); w += Q;
+            merkle_path(dig_q.data(), N, d0, x, w); w += 4 * d0;
+            size_t len = N;
+            for (size_t l = 0; l < L; l++) {
+                const unsigned ab = geo.arities[l];
+                const size_t width = 2 << ab, n_leaves = len >> ab;
+                x >>= ab;
+                memcpy(w, fri_rows_h[l].data() + x * width, width * 8); w += width;
+                merkle_path(fri_dig_h[l].data(), n_leaves, (unsigned)pl.layer_depth[l], x, w); w += 4 * pl.layer_depth[l];
+                len = n_leaves;
+            }
+        }
+        memcpy(out + pl.off_final, final_poly.data(), geo.final_poly_len * 16);
+        out[pl.off_pow] = pow_witness;
+        if (n_pis) memcpy(out + pl.off_pis, pis_host, n_pis * 8);
+    }
+    HIPCHK(hipEventRecord(c->ev[evi++], st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < STARKHIP_N_PHASES - 1; i++) (void)hipEventElapsedTime(&c->timings[i], c->ev[i], c->ev[i + 1]);
+    (void)hipEventElapsedTime(&c->timings[STARKHIP_N_PHASES - 1], c->ev[0], c->ev[STARKHIP_N_PHASES - 1]);
+    *proof_out = out;
+    *proof_words = pl.total;
+    return STARKHIP_OK;
+}
+
+// ---------------------------------------------------------------- kernel-level entry points (tests)
+int lde_batch(Ctx* c, const uint64_t* values, size_t n_cols, unsigned log_n, unsigned rate_bits, uint64_t* coeffs_out, uint64_t* lde_out) {
+    if (log_n < 1 || log_n > 13) return STARKHIP_ERR_BAD_SHAPE;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_tables(c, log_n, rate_bits, 0))) return rc;
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    HIPCHK(c->values.ensure(n_cols * n * 8));
+    HIPCHK(c->coeffs.ensure(n_cols * n * 8));
+    HIPCHK(c->lde.ensure(n_cols * N * 8));
+    HIPCHK(hipMemcpyAsync(c->values.p, values, n_cols * n * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(launch_lde_columns(c->values.as<gl_t>(), c->coeffs.as<gl_t>(), c->lde.as<gl_t>(), n_cols, log_n, rate_bits, c->tw_fwd.as<gl_t>(),
+                              c->tw_inv.as<gl_t>(), log_n + rate_bits, c->coset_scale.as<gl_t>(), 0, c->st));
+    if (coeffs_out) HIPCHK(hipMemcpyAsync(coeffs_out, c->coeffs.p, n_cols * n * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    if (lde_out) {
+        // device layout is coset-major; hand back NATURAL point order i = k * R + s
+        std::vector<gl_t> tmp(n_cols * N);
+        HIPCHK(hipMemcpy(tmp.data(), c->lde.p, n_cols * N * 8, hipMemcpyDeviceToHost));
+        const size_t R = (size_t)1 << rate_bits;
+        for (size_t col = 0; col < n_cols; col++)
+            for (size_t s = 0; s < R; s++)
+                for (size_t k = 0; k < n; k++) lde_out[col * N + k * R + s] = tmp[col * N + s * n + k];
+    }
+    return STARKHIP_OK;
+}
+
+int merkle_cap(Ctx* c, const uint64_t* lde_natural, size_t n_cols, unsigned log_N, unsigned cap_h, uint64_t* cap_out) {
+    if (log_N < cap_h) return STARKHIP_ERR_BAD_SHAPE;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t N = (size_t)1 << log_N;
+    // treat the input as rate_bits = 0 (coset-major == natural)
+    HIPCHK(c->lde.ensure(n_cols * N * 8));
+    HIPCHK(c->digests.ensure(digest_words(N) * 8));
+    HIPCHK(hipMemcpyAsync(c->lde.p, lde_natural, n_cols * N * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
+    HIPCHK(launch_merkle_levels(c->digests.as<gl_t>(), log_N, cap_h, c->st));
+    HIPCHK(hipMemcpyAsync(cap_out, c->digests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), ((size_t)4 << cap_h) * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return STARKHIP_OK;
+}
+
+int permute_batch(Ctx* c, uint64_t* states, size_t n) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(c->staging.ensure(n * 12 * 8));
+    HIPCHK(hipMemcpyAsync(c->staging.p, states, n * 96, hipMemcpyHostToDevice, c->st));
+    HIPCHK(launch_permute_batch(c->staging.as<gl_t>(), n, c->st));
+    HIPCHK(hipMemcpyAsync(states, c->staging.p, n * 96, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return STARKHIP_OK;
+}
+
+}  // namespace starkhip

@@ -1,0 +1,86 @@
+"""CPU tests: oracle vs known-answer vectors, product host code vs oracle, C-ABI exports."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+import oracle_lib as O
+import starky_bls12_381_amd as S
+
+P = S.P
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_oracle_round_constants_spot_values():
+    # constants quoted from plonky2's poseidon_goldilocks.rs
+    rc = O.round_constants()
+    assert [hex(int(x)) for x in rc[:4]] == ["0xb585f766f2144405", "0x7746a55f43921ad7", "0xb2fb0d31cee799b4", "0xf6760a4803427d7"]
+    assert int(rc[12]) == 0x86287821F722C881 and int(rc[15]) == 0xA484C4C5EF6A0781
+    assert int(rc[359]) == 0xBC8DFB627FE558FC
+    assert all(int(x) < P for x in rc)
+
+
+KAT_ZERO = [0x3C18A9786CB0B359, 0xC4055E3364A246C3, 0x7953DB0AB48808F4, 0xC71603F33A1144CA, 0xD7709673896996DC, 0x46A84E87642F44ED,
+            0xD032648251EE0B3C, 0x1C687363B207DF62, 0xDF8565563E8045FE, 0x40F5B37FF4254DAE, 0xD070F637B431067C, 0x1792B1C4342109D7]
+KAT_IOTA = [0xD64E1E3EFC5B8E9E, 0x53666633020AAA47, 0xD40285597C6A8825, 0x613A4F81E81231D2, 0x414754BFEBD051F0, 0xCB1F8980294A023F,
+            0x6EB2A9E4D54A9D0F, 0x1902BC3AF467E056, 0xF045D5EAFDC6021F, 0xE4150F77CAAA3BE5, 0xC9BFD01D39B50CCE, 0x5C0A27FCB0E1459B]
+KAT_NEG1_HEAD = [0xBE0085CFC57A8357, 0xD95AF71847D05C09, 0xCF55A13D33C1C953, 0x95803A74F4530E82]
+
+
+def test_poseidon_known_answers_oracle_and_host():
+    for perm in (O.poseidon_permute, S.poseidon_permute_host):
+        assert [int(x) for x in perm(np.zeros(12, dtype=np.uint64))] == KAT_ZERO
+        assert [int(x) for x in perm(np.arange(12, dtype=np.uint64))] == KAT_IOTA
+        assert [int(x) for x in perm(np.full(12, P - 1, dtype=np.uint64))[:4]] == KAT_NEG1_HEAD
+
+
+def test_host_permutation_matches_oracle_on_random_states():
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        s = rng.integers(0, P, size=12, dtype=np.uint64)
+        assert np.array_equal(O.poseidon_permute(s), S.poseidon_permute_host(s))
+    # extreme limbs
+    for v in (0, 1, P - 1, 0xFFFFFFFF, 0xFFFFFFFF00000000, 1 << 63):
+        s = np.full(12, v, dtype=np.uint64)
+        assert np.array_equal(O.poseidon_permute(s), S.poseidon_permute_host(s))
+
+
+def test_oracle_fast_reduction_matches_plain_modulo():
+    rng = np.random.default_rng(11)
+    vals = [0, 1, P - 1, P - 2, 0xFFFFFFFF, 0xFFFFFFFF00000000, 1 << 32, (1 << 32) - 1] + [int(x) for x in rng.integers(0, P, size=64, dtype=np.uint64)]
+    for a in vals:
+        for b in vals[:16]:
+            assert O.lib.oracle_mul(a, b) == O.lib.oracle_mul_slow(a, b) == (a * b) % P
+
+
+def test_oracle_ntt_round_trip_and_definition():
+    rng = np.random.default_rng(3)
+    n, logn = 64, 6
+    coeffs = rng.integers(0, P, size=n, dtype=np.uint64)
+    v = coeffs.copy()
+    O.lib.oracle_fft(v.ctypes.data_as(O._u64p), logn)
+    w = pow(1753635133440165772, 1 << (32 - logn), P)
+    for i in (0, 1, 5, 63):
+        assert int(v[i]) == sum(int(c) * pow(w, i * k, P) for k, c in enumerate(coeffs)) % P
+    O.lib.oracle_ifft(v.ctypes.data_as(O._u64p), logn)
+    assert np.array_equal(v, coeffs)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "starkhip.h")).read()
+    names = set(re.findall(r"\b(starkhip_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 25
+    lib = ctypes.CDLL(S.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_config_mirrors_standard_fast_config():
+    cfg = S.StarkConfig.standard_fast_config()
+    assert (cfg.security_bits, cfg.num_challenges, cfg.rate_bits, cfg.cap_height, cfg.proof_of_work_bits, cfg.arity_bits,
+            cfg.final_poly_bits, cfg.num_query_rounds) == (100, 2, 1, 4, 16, 4, 5, 84)
+    assert S.StarkConfig.for_air(S.AIR_FINAL_EXP).rate_bits == 2
+    assert S.StarkConfig.for_air(S.AIR_PAIRING_PRECOMP).rate_bits == 2
+    assert S.StarkConfig.for_air(S.AIR_MILLER_LOOP).rate_bits == 1
+    assert S.StarkConfig.for_air(S.AIR_FP12_MUL).rate_bits == 1
