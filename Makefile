@@ -15,7 +15,7 @@ build/%.hip.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 build/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+	$(HIPCC) -O2 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude -c $< -o $@
 
 $(OUT): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
