@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Benchmark: starky proofs/s for FinalExponentiateStark (73527 columns x 8192 rows) on N MI355X.
+
+A "step" is one full prove() of one FinalExp trace whose column-major u64[C][n] values are already
+resident in HBM (BASELINE.json configs[2]).  Each rank proves its own independent proof (the six proofs
+of a signature verification shard at proof granularity): weak scaling, no data-path
+collective; torch.distributed is used only for the barrier and the max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def synthetic_final_exp_input(seed):
+    """12 Fp coordinates below p from splitmix64(seed); any invertible Fp12 is provable."""
+    from bls_util import random_fp12
+    return random_fp12(seed)
+
+
+def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=1024, budget_points=256):
+    """Time the CPU oracle on a bounded slice of the same workload and scale to one whole proof.
+
+    LDE + Merkle leaf hashing run on `budget_cols` of the C columns (cost linear in C); the constraint
+    evaluation runs on `budget_points` of the N coset points with all C columns (cost linear in points).
+    Openings / FRI are < 5 % of the CPU time and are left out, which flatters the CPU."""
+    import numpy as np
+    import oracle_lib as O
+    rng = np.random.default_rng(1)
+    n = 1 << log_n
+    N = n << rate_bits
+    cols = rng.integers(0, S.P, size=(budget_cols, n), dtype=np.uint64)
+    t0 = time.time()
+    _, lde_rows = O.lde_rows(cols, rate_bits)
+    t_lde = time.time() - t0
+    t0 = time.time()
+    O.merkle_cap(lde_rows, 4)
+    t_hash = time.time() - t0
+    rows = rng.integers(0, S.P, size=(budget_points + 1, n_cols), dtype=np.uint64)
+    pis = np.zeros(S.air_public_inputs(S.AIR_FINAL_EXP), dtype=np.uint64)
+    t0 = time.time()
+    O.bench_quotient(blob, rows, pis)  # every constraint, both alphas, at budget_points points
+    t_q = time.time() - t0
+    scale_c = n_cols / budget_cols
+    total = t_lde * scale_c + t_hash * scale_c + t_q * (N / budget_points)
+    return {
+        "value": 1.0 / total, "unit": "proofs/s", "cores": int(O.lib.oracle_num_threads()), "kind": "port",
+        "sample": (f"CPU oracle (OpenMP C restatement, not the reference's Rust): LDE+leaf-hash on {budget_cols}/{n_cols} columns x {n} rows, "
+                   f"constraint evaluation on {budget_points}/{N} coset points; scaled linearly to one proof "
+                   f"(lde {t_lde * scale_c:.1f}s + hash {t_hash * scale_c:.1f}s + quotient {t_q * N / budget_points:.1f}s); openings/FRI omitted"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import starky_bls12_381_amd as S
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    air = S.AIR_FINAL_EXP
+    cfg = S.StarkConfig.for_air(air)
+    C, n = S.air_columns(air), S.air_default_rows(air)
+    log_n = n.bit_length() - 1
+    N = n << cfg.rate_bits
+
+    # synthetic input, different per rank; trace generated on the host (the reference's generate_trace side),
+    # moved to HBM as column-major u64 (as int64 bit patterns) before the timed region
+    x = synthetic_final_exp_input(0x5EED0000 + 1 + rank)
+    trace, pis = S.trace_final_exp(x)
+    d_rows = torch.from_numpy(trace.view(np.int64)).to(f"cuda:{local_rank}")
+    del trace
+    d_cols = d_rows.t().contiguous()  # trace_rows_to_poly_values
+    del d_rows
+    torch.cuda.synchronize()
+    prover = S.Prover(local_rank)
+
+    def step(keep=False):
+        return prover.prove_device(air, cfg, d_cols.data_ptr(), n, pis, layout=1, keep=keep)
+
+    proof = None
+    for w in range(args.warmup):
+        proof = step(keep=(w == 0))
+    if proof is not None and rank == 0:
+        S.verify_stark_proof(air, cfg, proof)  # untimed: the product's CPU verifier accepts what we time
+    phase_ms = {k: 0.0 for k in S.PHASE_NAMES}
+    kern_ms = {"lde_columns": 0.0, "leaf_hash": 0.0, "quotient_eval": 0.0}
+
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for k, v in prover.last_timings().items():
+            phase_ms[k] += v
+        for k, v in prover.last_kernel_timings().items():
+            kern_ms[k] += v
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        phase_ms = {k: v / steps for k, v in phase_ms.items()}
+        kern_ms = {k: v / steps for k, v in kern_ms.items()}
+        # algorithmic bytes per launch: u64 cells, dense, minimum traffic of the decomposition
+        alg = {"lde_columns": 8.0 * C * (n + n + N),  # read values, write coeffs + LDE (IFFT and LDE fused in one kernel)
+               "leaf_hash": 8.0 * C * N,              # read the LDE once
+               "quotient_eval": 8.0 * C * N}          # read the LDE on the quotient coset once
+        dominant = max(kern_ms, key=kern_ms.get)
+        gbs = {k: alg[k] / (kern_ms[k] * 1e-3) / 1e9 if kern_ms[k] > 0 else 0.0 for k in alg}
+        out = {
+            "metric": "starky proofs/sec (FinalExponentiateStark 73527x8192)",
+            "value": world * args.steps / elapsed,
+            "unit": "proofs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 (Goldilocks field)", "data": "synthetic",
+            "config": {"workload": "FinalExponentiateStark 73527 cols x 8192 rows, rate_bits 2, 360800 constraints, "
+                                   "standard_fast_config (84 queries, 16 pow bits); one independent proof per GPU",
+                       "parallelism": f"proof-parallel x{world}"},
+            "roofline": {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": gbs[dominant], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs[dominant] / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": kern_ms[dominant]},
+            "kernels": {k: {"avg_ms": kern_ms[k], "algorithmic_GBps": gbs[k], "hbm_frac": gbs[k] / HBM_PEAK_GBS} for k in alg},
+            "phase_ms": phase_ms,
+            "reference_published": {"value": 1 / 92.0, "unit": "proofs/s", "hardware": "AWS r6a.8xlarge, 32-core EPYC 7R13 (reference README.md:39)"},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline_sample(S, S.air_program(air), C, log_n, cfg.rate_bits)
+            except Exception as e:  # the oracle is a checker, never a dependency of the measured path
+                out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    prover.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,6 +115,9 @@ int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, 
  * [5] openings [6] fri combine [7] fri commit [8] pow [9] queries [10] total */
 #define STARKHIP_N_PHASES 11
 int starkhip_last_timings(void* ctx, float ms[STARKHIP_N_PHASES]);
+/* durations (ms, HIP events on the launch stream) of the three heavy kernels of the last prove:
+ * [0] lde_columns_kernel (trace) [1] leaf_hash_kernel (trace) [2] quotient_eval_kernel */
+int starkhip_last_kernel_timings(void* ctx, float ms[3]);
 
 /* --- kernel-level entry points (parity tests / micro-benchmarks) ---------------------- */
 /* values column-major [C][n] (host) -> coeffs [C][n] and LDE [C][N] in NATURAL point order i <-> 7*w_N^i */

@@ -604,6 +604,29 @@ EXPORT int oracle_prove(const uint64_t* air_blob, size_t air_words, const oracle
     return rc;
 }
 
+/* cpu_baseline helper for bench.py: the quotient phase's inner loop (every constraint, both alphas) at
+ * n_points points taken from `rows` (row-major [n_points + 1][C]; point i uses rows i and i + 1).
+ * Returns a checksum so the work cannot be optimised away. */
+EXPORT fe oracle_bench_quotient(const uint64_t* air_blob, size_t air_words, const fe* rows, size_t n_points, const fe* pis) {
+    air_prog p;
+    if (air_parse(air_blob, air_words, &p)) return 0;
+    fe sum = 0;
+#pragma omp parallel
+    {
+        fe local = 0;
+#pragma omp for schedule(dynamic, 4)
+        for (size_t i = 0; i < n_points; i++) {
+            fe masks[4] = {1, 3, 5, 7}, alphas[2] = {0x1234567, 0x7654321}, acc[2];
+            air_eval(&p, rows + i * p.n_cols, rows + (i + 1) * p.n_cols, pis, masks, alphas, 2, acc, NULL);
+            local = f_add(local, f_add(acc[0], acc[1]));
+        }
+#pragma omp critical(oracle_bench)
+        sum = f_add(sum, local);
+    }
+    free(p.code);
+    return sum;
+}
+
 EXPORT void oracle_free(void* p) { free(p); }
 EXPORT fe oracle_mul(fe a, fe b) { return f_mul(a, b); }
 EXPORT fe oracle_mul_slow(fe a, fe b) { return f_mul_slow(a, b); }

@@ -77,6 +77,7 @@ lib.starkhip_shutdown.restype = None
 lib.starkhip_prove.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), C.c_void_p, C.c_size_t, C.c_int, C.c_int, _u64p, C.c_size_t,
                                C.c_uint64, C.POINTER(_u64p), C.POINTER(C.c_size_t)]
 lib.starkhip_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+lib.starkhip_last_kernel_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
 lib.starkhip_lde_batch.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_uint, C.c_uint, _u64p, _u64p]
 lib.starkhip_merkle_cap.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_uint, C.c_uint, _u64p]
 lib.starkhip_poseidon_permute_batch.argtypes = [C.c_void_p, _u64p, C.c_size_t]
@@ -271,6 +272,11 @@ class Prover:
         ms = (C.c_float * N_PHASES)()
         _chk(lib.starkhip_last_timings(self._ctx, ms))
         return dict(zip(PHASE_NAMES, [float(x) for x in ms]))
+
+    def last_kernel_timings(self):
+        ms = (C.c_float * 3)()
+        _chk(lib.starkhip_last_kernel_timings(self._ctx, ms))
+        return {"lde_columns": float(ms[0]), "leaf_hash": float(ms[1]), "quotient_eval": float(ms[2])}
 
     def lde_batch(self, values_colmajor, rate_bits):
         v = np.ascontiguousarray(values_colmajor, dtype=np.uint64)

@@ -75,6 +75,12 @@ int starkhip_last_timings(void* ctx, float ms[STARKHIP_N_PHASES]) {
     return STARKHIP_OK;
 }
 
+int starkhip_last_kernel_timings(void* ctx, float ms[3]) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    memcpy(ms, ctx_kernel_timings((Ctx*)ctx), sizeof(float) * 3);
+    return STARKHIP_OK;
+}
+
 int starkhip_lde_batch(void* ctx, const uint64_t* values, size_t n_cols, unsigned log_n, unsigned rate_bits, uint64_t* coeffs_out,
                        uint64_t* lde_out) {
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;

@@ -53,6 +53,8 @@ struct Ctx {
     hipStream_t st = nullptr;
     hipEvent_t ev[STARKHIP_N_PHASES + 1];
     float timings[STARKHIP_N_PHASES] = {0};
+    hipEvent_t kev[4];            // leaf-hash and quotient-eval kernels bracketed on their own
+    float ktimings[3] = {0};      // lde_columns, leaf_hash (trace), quotient_eval
     // shape-dependent tables
     int tab_log_n = -1, tab_rate = -1, tab_qdb = -1;
     DevBuf tw_fwd, tw_inv, coset_scale, qtab, qshift_inv;
@@ -144,6 +146,7 @@ int ctx_create(int device, Ctx** out) {
     c->device = device;
     HIPCHK(hipStreamCreate(&c->st));
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+    for (auto& e : c->kev) HIPCHK(hipEventCreate(&e));
     *out = c;
     return 0;
 }
@@ -161,12 +164,14 @@ void ctx_destroy(Ctx* c) {
     for (auto& b : c->fri_rows) b.release();
     for (auto& b : c->fri_digests) b.release();
     for (auto& e : c->ev) (void)hipEventDestroy(e);
+    for (auto& e : c->kev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->st);
     delete c;
 }
 
 hipStream_t ctx_stream(Ctx* c) { return c->st; }
 const float* ctx_timings(Ctx* c) { return c->timings; }
+const float* ctx_kernel_timings(Ctx* c) { return c->ktimings; }
 
 // (F(X) - F(z)) / (X - z), padded with one zero coefficient back to length n (plonky2 divide_by_linear + push(0))
 static void divide_by_linear(const gl2_t* F, size_t n, gl2_t z, gl2_t* q) {
@@ -262,7 +267,9 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(hipEventRecord(c->ev[evi++], st));
 
     // ---- phase 2: Merkle tree over bit-reversed LDE rows
+    HIPCHK(hipEventRecord(c->kev[0], st));
     HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
+    HIPCHK(hipEventRecord(c->kev[1], st));
     HIPCHK(launch_merkle_levels(c->digests.as<gl_t>(), log_N, cap_h, st));
     std::vector<gl_t> trace_cap(4 * ncap), quot_cap(4 * ncap);
     HIPCHK(hipMemcpyAsync(trace_cap.data(), c->digests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), 4 * ncap * 8, hipMemcpyDeviceToHost, st));
@@ -284,9 +291,11 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         HIPCHK(hipMemcpyAsync(c->apow.p, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(c->chunk_scale.p, cscale.data(), cscale.size() * 8, hipMemcpyHostToDevice, st));
         if (n_pis) HIPCHK(hipMemcpyAsync(c->pis.p, pis_host, n_pis * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(c->kev[2], st));
         HIPCHK(launch_quotient_eval(c->d_code.as<uint32_t>(), c->d_consts.as<gl_t>(), c->pis.as<gl_t>(), c->lde.as<gl_t>(), c->qtab.as<gl_t>(),
                                     c->d_chunk_off.as<uint32_t>(), n_chunks, c->apow.as<gl_t>(), alphas[0], alphas[1], c->partial.as<gl_t>(),
                                     log_n, r, qdb, st));
+        HIPCHK(hipEventRecord(c->kev[3], st));
         HIPCHK(launch_quotient_combine(c->partial.as<gl_t>(), c->chunk_scale.as<gl_t>(), n_chunks, c->qtab.as<gl_t>(), log_n, qdb,
                                        c->qvals.as<gl_t>(), st));
         // coset_ifft(7): inverse transform, scale by size^-1 and by 7^-i
@@ -510,6 +519,9 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < STARKHIP_N_PHASES - 1; i++) (void)hipEventElapsedTime(&c->timings[i], c->ev[i], c->ev[i + 1]);
     (void)hipEventElapsedTime(&c->timings[STARKHIP_N_PHASES - 1], c->ev[0], c->ev[STARKHIP_N_PHASES - 1]);
+    c->ktimings[0] = c->timings[1];
+    (void)hipEventElapsedTime(&c->ktimings[1], c->kev[0], c->kev[1]);
+    (void)hipEventElapsedTime(&c->ktimings[2], c->kev[2], c->kev[3]);
     *proof_out = out;
     *proof_words = pl.total;
     return STARKHIP_OK;

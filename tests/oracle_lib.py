@@ -110,3 +110,15 @@ def prove(air_blob, config, trace_cols, pis, pow_witness=0xFFFFFFFFFFFFFFFF):
     proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy()
     lib.oracle_free(out)
     return proof
+
+
+lib.oracle_bench_quotient.argtypes = [_u64p, C.c_size_t, _u64p, C.c_size_t, _u64p]
+lib.oracle_bench_quotient.restype = C.c_uint64
+
+
+def bench_quotient(air_blob, rows, pis):
+    """Evaluate every constraint (two alphas) at rows.shape[0] - 1 points; returns a checksum."""
+    blob = np.ascontiguousarray(air_blob, dtype=np.uint64)
+    r = np.ascontiguousarray(rows, dtype=np.uint64)
+    p = np.ascontiguousarray(pis, dtype=np.uint64)
+    return lib.oracle_bench_quotient(_p(blob), blob.size, _p(r), r.shape[0] - 1, _p(p))

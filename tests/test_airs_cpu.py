@@ -78,3 +78,22 @@ def test_fp12_mul_oracle_proof_verifies():
     bad[16 + 64 + 64 + 5] = (int(bad[16 + 64 + 64 + 5]) + 1) % S.P  # an opening
     with pytest.raises(S.StarkhipError):
         S.verify_stark_proof(air, cfg, bad)
+
+
+def test_final_exp_trace_satisfies_all_constraints_on_the_reference_vector():
+    """src/native.rs:1546-1563 (`aa`, final exponentiation == 1) through generate_trace: every one of the
+    360800 constraints vanishes on every one of the 8192 rows, and the public output is Fp12::one()."""
+    if not _available(S.AIR_FINAL_EXP):
+        pytest.skip("FinalExponentiateStark not restated yet")
+    aa = fp_arr(*[int(s) for s in native_vectors()["final_exp_input_aa"]])
+    t, pis = S.trace_final_exp(aa)
+    assert t.shape == (8192, 73527)
+    assert np.array_equal(pis[:144], aa)
+    assert np.array_equal(pis[144:], fp_arr(1, *([0] * 11)))
+    blob = S.air_program(S.AIR_FINAL_EXP)
+    assert O.check_trace(blob, t, pis)[0] == 0
+    # 4441 rows carry operations (TOTAL_ROW), the rest of the op window is zero
+    assert not t[4441:, 12949:].any()
+    t[100, 20000] = (int(t[100, 20000]) + 1) % S.P
+    bad, first = O.check_trace(blob, t, pis)
+    assert bad > 0 and first[1] in (99, 100)

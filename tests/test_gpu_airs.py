@@ -27,3 +27,32 @@ def test_fp12_mul_proof_is_bit_identical_to_oracle(prover, seed):
     S.verify_stark_proof(air, cfg, proof)
     ref = O.prove(S.air_program(air), cfg, S.trace_rows_to_poly_values(t), pis)
     assert proof.size == ref.size and np.array_equal(proof, ref)
+
+
+def test_final_exp_proof_verifies_and_matches_golden_digest(prover):
+    """Full-size FinalExponentiateStark (73527 x 8192): the product verifier accepts the GPU proof; the proof bytes
+    hash to the digest of the CPU oracle's proof for the same input when that fixture exists
+    (tests/golden/final_exp_aa_proof.sha256, made by tools/make_final_exp_golden.py on a 64+ GB host)."""
+    import hashlib
+    import os
+    from bls_util import GOLDEN, fp_arr, native_vectors
+    air = S.AIR_FINAL_EXP
+    if not _available(air):
+        pytest.skip("FinalExponentiateStark not restated yet")
+    aa = fp_arr(*[int(s) for s in native_vectors()["final_exp_input_aa"]])
+    t, pis = S.trace_final_exp(aa)
+    cfg = S.StarkConfig.for_air(air)
+    proof = prover.prove(air, cfg, t, pis)
+    del t
+    S.verify_stark_proof(air, cfg, proof)
+    tm = prover.last_timings()
+    assert tm["total"] > 0
+    digest = hashlib.sha256(proof.tobytes()).hexdigest()
+    path = os.path.join(GOLDEN, "final_exp_aa_proof.sha256")
+    if os.path.exists(path):
+        assert digest == open(path).read().split()[0]
+    # tampering with an opening or the public output is rejected
+    bad = proof.copy()
+    bad[-1] = (int(bad[-1]) + 1) % S.P
+    with pytest.raises(S.StarkhipError):
+        S.verify_stark_proof(air, cfg, bad)
