@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
-#include "poseidon.h"
+#include "poseidon_dev.h"
 
 namespace starkhip {
 
@@ -14,19 +14,47 @@ namespace starkhip {
 // Leaf position j in the tree holds natural row bitrev_logN(j) (plonky2 reverse_index_bits_in_place),
 // so the thread that owns physical point q writes digest slot j = bitrev(i).
 // One lane walks one row; adjacent lanes read adjacent k => every load is a coalesced 512 B line.
-__global__ __launch_bounds__(64) void leaf_hash_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
-                                                        gl_t* __restrict__ digests) {
+__global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                                                         gl_t* __restrict__ digests) {
+    // 4 lanes (one DPP quad) per leaf: lane l owns sponge state elements l, l + 4, l + 8
+    __shared__ gl_t rcs[4][96];  // per-lane view of the round constants + 3 zeros ("next round" of the last round)
+    for (unsigned idx = threadIdx.x; idx < 4 * 96; idx += blockDim.x) {
+        const unsigned ll = idx / 96, w = idx % 96;
+        rcs[ll][w] = w < 90 ? POSEIDON_RC_DEV[12 * (w / 3) + ll + 4 * (w % 3)] : 0;
+    }
+    __syncthreads();
     const unsigned log_N = log_n + rate_bits;
     const size_t N = (size_t)1 << log_N;
-    size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (q >= N) return;
-    size_t s = q >> log_n, k = q & (((size_t)1 << log_n) - 1);
-    size_t i = (k << rate_bits) + s;
-    size_t j = gl_bitrev((uint32_t)i, log_N);
-    gl_t out[4];
-    poseidon_hash_or_noop(mat + q, n_cols, N, out);
-#pragma unroll
-    for (int e = 0; e < 4; e++) digests[4 * j + e] = out[e];
+    const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const unsigned l = (unsigned)tid & 3u;
+    const size_t q = tid >> 2;
+    if (q >= N) return;  // whole quads drop out together
+    const size_t s = q >> log_n, k = q & (((size_t)1 << log_n) - 1);
+    const size_t i = (k << rate_bits) + s;
+    const size_t j = gl_bitrev((uint32_t)i, log_N);
+    const gl_t* col = mat + q;
+    if (n_cols <= 4) {  // hash_or_noop: short leaves are copied, zero padded
+        digests[4 * j + l] = l < n_cols ? col[(size_t)l * N] : 0;
+        return;
+    }
+    QuadConsts qc;
+    quad_consts_init(qc, l);
+    const gl_t* rc = rcs[l];
+    gl_t s0 = 0, s1 = 0, s2 = 0;
+    size_t off = 0;
+    // full 8-element blocks: lane l absorbs columns off + l and off + 4 + l (overwrite mode)
+    for (; off + 8 <= n_cols; off += 8) {
+        s0 = col[(off + l) * N];
+        s1 = col[(off + 4 + l) * N];
+        poseidon_permute_quad(s0, s1, s2, qc, rc, l == 0);
+    }
+    if (off < n_cols) {
+        const size_t rem = n_cols - off;
+        if (l < rem) s0 = col[(off + l) * N];
+        if (4 + l < rem) s1 = col[(off + 4 + l) * N];
+        poseidon_permute_quad(s0, s1, s2, qc, rc, l == 0);
+    }
+    digests[4 * j + l] = gl_canon(s0);  // elements 0..3 live in slot 0 of lanes 0..3
 }
 
 // Leaves stored row-major and already in tree order: leaf j = rows[j][0..width)
@@ -35,7 +63,7 @@ __global__ __launch_bounds__(64) void leaf_hash_rows_kernel(const gl_t* __restri
     size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (j >= n_leaves) return;
     gl_t out[4];
-    poseidon_hash_or_noop(rows + j * width, width, 1, out);
+    poseidon_hash_or_noop_dev(rows + j * width, width, 1, out);
 #pragma unroll
     for (int e = 0; e < 4; e++) digests[4 * j + e] = out[e];
 }
@@ -44,7 +72,7 @@ __global__ __launch_bounds__(64) void merkle_level_kernel(const gl_t* __restrict
     size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (j >= n_parent) return;
     gl_t out[4];
-    poseidon_two_to_one(child + 8 * j, child + 8 * j + 4, out);
+    poseidon_two_to_one_dev(child + 8 * j, child + 8 * j + 4, out);
 #pragma unroll
     for (int e = 0; e < 4; e++) parent[4 * j + e] = out[e];
 }
@@ -55,7 +83,7 @@ __global__ void permute_batch_kernel(gl_t* states, size_t n) {
     gl_t s[12];
 #pragma unroll
     for (int e = 0; e < 12; e++) s[e] = states[12 * i + e];
-    poseidon_permute(s);
+    poseidon_permute_dev(s);
 #pragma unroll
     for (int e = 0; e < 12; e++) states[12 * i + e] = s[e];
 }
@@ -72,7 +100,7 @@ __global__ void pow_grind_kernel(const gl_t* __restrict__ base_state, int pos, u
 #pragma unroll
     for (int e = 0; e < 12; e++) s[e] = base_state[e];
     s[pos] = w;
-    poseidon_permute(s);
+    poseidon_permute_dev(s);
     if ((s[7] >> (64 - pow_bits)) == 0) atomicMin(best, (unsigned long long)w);
 }
 
@@ -80,7 +108,7 @@ static inline unsigned nblocks(size_t n, unsigned bs) { return (unsigned)((n + b
 
 hipError_t launch_leaf_hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st) {
     size_t N = (size_t)1 << (log_n + rate_bits);
-    hipLaunchKernelGGL(leaf_hash_kernel, dim3(nblocks(N, 64)), dim3(64), 0, st, mat, n_cols, log_n, rate_bits, digests);
+    hipLaunchKernelGGL(leaf_hash_kernel, dim3(nblocks(4 * N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
     return hipGetLastError();
 }
 hipError_t launch_leaf_hash_rows(const gl_t* rows, size_t width, size_t n_leaves, gl_t* digests, hipStream_t st) {

@@ -97,3 +97,44 @@ def test_final_exp_trace_satisfies_all_constraints_on_the_reference_vector():
     t[100, 20000] = (int(t[100, 20000]) + 1) % S.P
     bad, first = O.check_trace(blob, t, pis)
     assert bad > 0 and first[1] in (99, 100)
+
+
+def _bls():
+    return {k: int(s) for k, s in native_vectors()["bls_signature"].items()}
+
+
+def test_miller_loop_trace_satisfies_all_constraints_on_the_reference_signature():
+    """G1 generator x signature point of src/native.rs:1490-1498: 68 steps x 12 rows, result == native miller_loop."""
+    if not _available(S.AIR_MILLER_LOOP):
+        pytest.skip("MillerLoopStark not restated yet")
+    b = _bls()
+    args = (fp_arr(b["gx"]), fp_arr(b["gy"]), fp_arr(b["s_x1"], b["s_x2"]), fp_arr(b["s_y1"], b["s_y2"]), fp_arr(b["s_z1"], b["s_z2"]))
+    t, pis = S.trace_miller_loop(*args)
+    assert t.shape == (1024, 97330)
+    assert np.array_equal(pis[-144:], S.native_miller_loop(*args))
+    assert np.array_equal(pis[24:24 + 68 * 72], S.native_pairing_precomp(*args[2:]))
+    blob = S.air_program(S.AIR_MILLER_LOOP)
+    assert O.check_trace(blob, t, pis)[0] == 0
+    t[30, 50000] = (int(t[30, 50000]) + 1) % S.P
+    assert O.check_trace(blob, t, pis)[0] > 0
+
+
+def test_pairing_precomp_trace_satisfies_all_constraints_on_the_reference_signature():
+    if not _available(S.AIR_PAIRING_PRECOMP):
+        pytest.skip("PairingPrecompStark not restated yet")
+    b = _bls()
+    q = (fp_arr(b["hm_x1"], b["hm_x2"]), fp_arr(b["hm_y1"], b["hm_y2"]), fp_arr(b["hm_z1"], b["hm_z2"]))
+    t, pis = S.trace_pairing_precomp(*q)
+    assert t.shape == (1024, 29376)
+    assert np.array_equal(pis[:24], q[0]) and np.array_equal(pis[48:72], q[2])
+    assert np.array_equal(pis[72:], S.native_pairing_precomp(*q))
+    blob = S.air_program(S.AIR_PAIRING_PRECOMP)
+    assert O.check_trace(blob, t, pis)[0] == 0
+    # a point with z != 1 exercises the z * z^-1 multiplications
+    g = __import__("bls_util").splitmix64(0x5EED1000)
+    from bls_util import random_fp
+    q2 = tuple(fp_arr(random_fp(g), random_fp(g)) for _ in range(3))
+    t2, pis2 = S.trace_pairing_precomp(*q2)
+    assert O.check_trace(blob, t2, pis2)[0] == 0
+    t2[200, 15000] = (int(t2[200, 15000]) + 1) % S.P
+    assert O.check_trace(blob, t2, pis2)[0] > 0

@@ -56,3 +56,37 @@ def test_final_exp_proof_verifies_and_matches_golden_digest(prover):
     bad[-1] = (int(bad[-1]) + 1) % S.P
     with pytest.raises(S.StarkhipError):
         S.verify_stark_proof(air, cfg, bad)
+
+
+def _bls():
+    from bls_util import native_vectors
+    return {k: int(s) for k, s in native_vectors()["bls_signature"].items()}
+
+
+def test_pairing_precomp_proof_is_bit_identical_to_oracle(prover):
+    from bls_util import fp_arr
+    air = S.AIR_PAIRING_PRECOMP
+    if not _available(air):
+        pytest.skip("PairingPrecompStark not restated yet")
+    b = _bls()
+    t, pis = S.trace_pairing_precomp(fp_arr(b["hm_x1"], b["hm_x2"]), fp_arr(b["hm_y1"], b["hm_y2"]), fp_arr(b["hm_z1"], b["hm_z2"]))
+    cfg = S.StarkConfig.for_air(air)
+    proof = prover.prove(air, cfg, t, pis)
+    S.verify_stark_proof(air, cfg, proof)
+    ref = O.prove(S.air_program(air), cfg, S.trace_rows_to_poly_values(t), pis)
+    assert proof.size == ref.size and np.array_equal(proof, ref)
+
+
+def test_miller_loop_proof_is_bit_identical_to_oracle(prover):
+    from bls_util import fp_arr
+    air = S.AIR_MILLER_LOOP
+    if not _available(air):
+        pytest.skip("MillerLoopStark not restated yet")
+    b = _bls()
+    t, pis = S.trace_miller_loop(fp_arr(b["gx"]), fp_arr(b["gy"]), fp_arr(b["s_x1"], b["s_x2"]), fp_arr(b["s_y1"], b["s_y2"]),
+                                 fp_arr(b["s_z1"], b["s_z2"]))
+    cfg = S.StarkConfig.for_air(air)
+    proof = prover.prove(air, cfg, t, pis)
+    S.verify_stark_proof(air, cfg, proof)
+    ref = O.prove(S.air_program(air), cfg, S.trace_rows_to_poly_values(t), pis)
+    assert proof.size == ref.size and np.array_equal(proof, ref)
