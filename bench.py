@@ -78,10 +78,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from starky_bls12_381_amd import parallel
+    dist = parallel.init_distributed("nccl") if world > 1 else None
 
     air = S.AIR_FINAL_EXP
     cfg = S.StarkConfig.for_air(air)
@@ -125,10 +123,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = parallel.max_over_ranks(dist, elapsed, device=f"cuda:{local_rank}")
 
     if rank == 0:
         steps = max(1, args.steps)

@@ -1,0 +1,80 @@
+"""N > 1 path on CPU: two gloo ranks run the job assignment, the public-input broadcast, the barrier/max-reduce that
+bench.py uses around the timed region, and (host side only) trace generation for their share of the proofs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import starky_bls12_381_amd as S
+    from starky_bls12_381_amd import parallel as P
+    from bls_util import random_fp12
+    dist = P.init_distributed("gloo")
+    assert dist is not None and dist.get_world_size() == world
+    # the six proofs of one signature verification: 2 x precomp, 2 x miller, fp12_mul, final_exp
+    airs = [S.AIR_PAIRING_PRECOMP, S.AIR_MILLER_LOOP, S.AIR_PAIRING_PRECOMP, S.AIR_MILLER_LOOP, S.AIR_FP12_MUL, S.AIR_FINAL_EXP]
+    plan = P.assign_jobs([P.AIR_COST[a] for a in airs], world)
+    mine = plan[rank]
+    # rank 0 owns the input; everybody needs the FP12Mul public inputs of job 4
+    x, y = random_fp12(0x5EED2000), random_fp12(0x5EED2001)
+    if rank == 0:
+        _, pis = S.trace_fp12_mul(x, y)
+    else:
+        pis = np.zeros(S.air_public_inputs(S.AIR_FP12_MUL), dtype=np.uint64)
+    pis = P.broadcast_u64(dist, pis, src=0)
+    digest = int(np.bitwise_xor.reduce(pis))
+    dist.barrier()
+    elapsed = 1.0 + rank  # pretend rank 1 is slower
+    slowest = P.max_over_ranks(dist, elapsed)
+    done = P.sum_over_ranks(dist, len(mine))
+    q.put((rank, mine, digest, slowest, done))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_share_six_proofs():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results.sort()
+    jobs = sorted(j for _, mine, _, _, _ in results for j in mine)
+    assert jobs == list(range(6))                       # every proof exactly once
+    assert [5] == results[0][1]                          # LPT: FinalExp alone on one rank, everything else on the other
+    assert results[0][2] == results[1][2] != 0           # broadcast public inputs identical on both ranks
+    assert all(r[3] == 2.0 for r in results)             # max over ranks
+    assert all(r[4] == 6.0 for r in results)
+
+
+def test_lpt_assignment_for_a_batch_of_eight_signatures():
+    from starky_bls12_381_amd import parallel as P
+    airs = [1, 2, 1, 2, 0, 3] * 8
+    plan = P.assign_jobs([P.AIR_COST[a] for a in airs], 8)
+    assert sorted(j for r in plan for j in r) == list(range(48))
+    loads = [sum(P.AIR_COST[airs[j]] for j in r) for r in plan]
+    assert max(loads) - min(loads) < 13.0                # within one MillerLoop of each other
+    assert all(sum(1 for j in r if airs[j] == 3) == 1 for r in plan)  # one FinalExp per GPU
