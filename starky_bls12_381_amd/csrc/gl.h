@@ -5,6 +5,7 @@
 // by the reference at /root/reference/src/aggregate_proof.rs:235-237 (F, D = 2);
 // SURVEY.md App. A.1.  All values stored by this library are canonical (< p).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -27,16 +28,16 @@ typedef uint64_t gl_t;
 GL_HD gl_t gl_add(gl_t a, gl_t b) {
     // a, b < p  =>  a + b < 2p < 2^65
     gl_t s = a + b;
-    bool carry = s < a;
-    // if carry: true sum = s + 2^64 = s + eps (mod p), and s < p - 1 so no second wrap
-    if (carry) s += GL_EPS;
-    if (s >= GL_P) s -= GL_P;
+    // if carry: true sum = s + 2^64 = s + eps (mod p), and s < p - 1 so no second wrap.
+    // Written with masks: on the host these are data-dependent and a branch would mispredict half the time.
+    s += (gl_t)(0 - (gl_t)(s < a)) & GL_EPS;
+    s -= (gl_t)(0 - (gl_t)(s >= GL_P)) & GL_P;
     return s;
 }
 
 GL_HD gl_t gl_sub(gl_t a, gl_t b) {
     gl_t d = a - b;
-    if (a < b) d += GL_P;  // wraps mod 2^64 to the right residue
+    d += (gl_t)(0 - (gl_t)(a < b)) & GL_P;  // wraps mod 2^64 to the right residue
     return d;
 }
 
@@ -50,11 +51,11 @@ GL_HD gl_t gl_reduce128(uint64_t hi, uint64_t lo) {
     uint64_t hi_lo = hi & GL_EPS;
     // 2^96 = -1, 2^64 = eps (mod p)
     uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GL_EPS;  // borrow: add p == subtract eps mod 2^64
-    uint64_t t1 = hi_lo * GL_EPS;  // < 2^64
+    t0 -= (uint64_t)(0 - (uint64_t)(lo < hi_hi)) & GL_EPS;  // borrow: add p == subtract eps mod 2^64
+    uint64_t t1 = (hi_lo << 32) - hi_lo;                    // hi_lo * eps, < 2^64
     uint64_t r = t0 + t1;
-    if (r < t1) r += GL_EPS;  // carry: 2^64 = eps
-    if (r >= GL_P) r -= GL_P;
+    r += (uint64_t)(0 - (uint64_t)(r < t1)) & GL_EPS;       // carry: 2^64 = eps
+    r -= (uint64_t)(0 - (uint64_t)(r >= GL_P)) & GL_P;
     return r;
 }
 

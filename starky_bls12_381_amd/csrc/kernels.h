@@ -47,4 +47,12 @@ hipError_t launch_fri_fold(const gl_t* in, size_t len, unsigned arity_bits, gl2_
 hipError_t launch_gather_rows(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, const uint32_t* nat_idx, size_t n_queries,
                               gl_t* out, hipStream_t st);
 
+// kernels_query.hip: query-round leaves and Merkle paths written in proof-blob layout (stride = words per query round)
+hipError_t launch_query_leaf_colmajor(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, const uint32_t* xs, size_t n_queries,
+                                      gl_t* out, size_t stride, size_t off, hipStream_t st);
+hipError_t launch_query_leaf_rows(const gl_t* rows, size_t width, const uint32_t* xs, unsigned shift, size_t n_queries, gl_t* out, size_t stride,
+                                  size_t off, hipStream_t st);
+hipError_t launch_query_path(const gl_t* digests, size_t n_leaves, unsigned depth, const uint32_t* xs, unsigned shift, size_t n_queries, gl_t* out,
+                             size_t stride, size_t off, hipStream_t st);
+
 }  // namespace starkhip

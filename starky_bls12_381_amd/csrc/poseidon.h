@@ -43,11 +43,12 @@ GL_HD void acc_mad(acc128& a, uint64_t s, uint32_t k) {
 GL_HD void poseidon_mds(gl_t* s) {
     const uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     // split into 32-bit halves: sums stay below 2^32 * 12 * 41 < 2^42, no carries needed
-    uint64_t lo[12], hi[12];
+    // duplicated (lo[i + 12] == lo[i]) so the circulant index i + r needs no modulo (host compilers do not unroll this)
+    uint64_t lo[24], hi[24];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        lo[i] = s[i] & 0xFFFFFFFFULL;
-        hi[i] = s[i] >> 32;
+        lo[i] = lo[i + 12] = s[i] & 0xFFFFFFFFULL;
+        hi[i] = hi[i + 12] = s[i] >> 32;
     }
     gl_t out[12];
 #pragma unroll
@@ -55,9 +56,8 @@ GL_HD void poseidon_mds(gl_t* s) {
         uint64_t al = 0, ah = 0;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
-            int j = (i + r) % 12;
-            al += lo[j] * CIRC[i];
-            ah += hi[j] * CIRC[i];
+            al += lo[i + r] * CIRC[i];
+            ah += hi[i + r] * CIRC[i];
         }
         if (r == 0) {
             al += lo[0] * 8;
@@ -137,6 +137,9 @@ GL_HD void poseidon_hash_or_noop(const gl_t* in, size_t len, size_t stride, gl_t
     }
 }
 
+// host permutation tuned for the challenger's long sequential absorbs (poseidon_host.cpp)
+void poseidon_permute_host(gl_t* s);
+
 // ---------------------------------------------------------------- Challenger (host only)
 struct Challenger {
     gl_t state[12];
@@ -150,7 +153,11 @@ struct Challenger {
     void duplex() {
         for (int i = 0; i < n_in; i++) state[i] = in[i];
         n_in = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
         poseidon_permute(state);
+#else
+        poseidon_permute_host(state);
+#endif
         for (int i = 0; i < 8; i++) out[i] = state[i];
         n_out = 8;
     }

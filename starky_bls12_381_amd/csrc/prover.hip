@@ -234,8 +234,6 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(c->pow_state.ensure(12 * 8));
     HIPCHK(c->pow_best.ensure(8));
     HIPCHK(c->qidx.ensure(cfg.num_query_rounds * 4));
-    HIPCHK(c->gather_t.ensure((size_t)cfg.num_query_rounds * C * 8));
-    HIPCHK(c->gather_q.ensure((size_t)cfg.num_query_rounds * Q * 8));
 
     int evi = 0;
     HIPCHK(hipEventRecord(c->ev[evi++], st));
@@ -377,7 +375,6 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(hipEventRecord(c->ev[evi++], st));
 
     // ---- phase 7: FRI commit phase (fri_committed_trees)
-    std::vector<std::vector<gl_t>> fri_rows_h(L), fri_dig_h(L);
     std::vector<gl_t> fri_caps(L * 4 * ncap);
     std::vector<gl2_t> final_poly(geo.final_poly_len);
     {
@@ -400,13 +397,11 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             HIPCHK(launch_fri_leaves(vals, log_len, ab, c->fri_rows[l].as<gl_t>(), st));
             HIPCHK(launch_leaf_hash_rows(c->fri_rows[l].as<gl_t>(), width, n_leaves, c->fri_digests[l].as<gl_t>(), st));
             HIPCHK(launch_merkle_levels(c->fri_digests[l].as<gl_t>(), log_len - ab, cap_h, st));
-            fri_rows_h[l].resize(len * 2);
-            fri_dig_h[l].resize(digest_words(n_leaves));
-            HIPCHK(hipMemcpyAsync(fri_rows_h[l].data(), c->fri_rows[l].p, len * 2 * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(fri_dig_h[l].data(), c->fri_digests[l].p, digest_words(n_leaves) * 8, hipMemcpyDeviceToHost, st));
+            // leaves and digests stay on the device (the query phase gathers from them); only the cap feeds the transcript
+            gl_t* cap = fri_caps.data() + l * 4 * ncap;
+            HIPCHK(hipMemcpyAsync(cap, c->fri_digests[l].as<gl_t>() + 4 * level_off(n_leaves, log_len - ab - cap_h), 4 * ncap * 8,
+                                  hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            const gl_t* cap = fri_dig_h[l].data() + 4 * level_off(n_leaves, log_len - ab - cap_h);
-            memcpy(fri_caps.data() + l * 4 * ncap, cap, 4 * ncap * 8);
             ch.observe_many(cap, 4 * ncap);
             gl2_t beta = ch.get_ext();
             // fold coefficients; output goes to the other half of fri_vals' sibling buffer: reuse coef in place via temp
@@ -464,27 +459,35 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     if (!out) return STARKHIP_ERR_OOM;
     {
         const size_t nq = cfg.num_query_rounds;
-        std::vector<size_t> xs(nq);
-        std::vector<uint32_t> nat(nq);
-        for (size_t q = 0; q < nq; q++) {
-            xs[q] = (size_t)(ch.get() % N);
-            nat[q] = gl_bitrev((uint32_t)xs[q], log_N);
-        }
-        std::vector<gl_t> dig_t(digest_words(N)), dig_q(digest_words(N)), rows_t(nq * C), rows_q(nq * Q);
+        std::vector<uint32_t> xs(nq);
+        for (size_t q = 0; q < nq; q++) xs[q] = (uint32_t)(ch.get() % N);
+        // every round's leaves and Merkle paths are gathered on the device, already in proof layout
+        const size_t stride = pl.query_words;
+        const unsigned d0 = log_N - cap_h;
         int err = 0;
 #define HIPCHK_FREE(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fprintf(stderr, "starkhip: HIP error %s (%s)\n", hipGetErrorString(_e), #expr); err = 1; } } while (0)
-        HIPCHK_FREE(hipMemcpyAsync(c->qidx.p, nat.data(), nq * 4, hipMemcpyHostToDevice, st));
-        HIPCHK_FREE(launch_gather_rows(c->lde.as<gl_t>(), C, log_n, r, c->qidx.as<uint32_t>(), nq, c->gather_t.as<gl_t>(), st));
-        HIPCHK_FREE(launch_gather_rows(c->qlde.as<gl_t>(), Q, log_n, r, c->qidx.as<uint32_t>(), nq, c->gather_q.as<gl_t>(), st));
-        HIPCHK_FREE(hipMemcpyAsync(rows_t.data(), c->gather_t.p, nq * C * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK_FREE(hipMemcpyAsync(rows_q.data(), c->gather_q.p, nq * Q * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK_FREE(hipMemcpyAsync(dig_t.data(), c->digests.p, dig_t.size() * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK_FREE(hipMemcpyAsync(dig_q.data(), c->qdigests.p, dig_q.size() * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK_FREE(hipStreamSynchronize(st));
-#undef HIPCHK_FREE
-        if (err) {
-            free(out);
-            return STARKHIP_ERR_HIP;
+        HIPCHK_FREE(c->gather_t.ensure(nq * stride * 8));
+        gl_t* dq = c->gather_t.as<gl_t>();
+        HIPCHK_FREE(hipMemcpyAsync(c->qidx.p, xs.data(), nq * 4, hipMemcpyHostToDevice, st));
+        const uint32_t* dxs = c->qidx.as<uint32_t>();
+        size_t off = 0;
+        if (!err) {
+            HIPCHK_FREE(launch_query_leaf_colmajor(c->lde.as<gl_t>(), C, log_n, r, dxs, nq, dq, stride, off, st)); off += C;
+            HIPCHK_FREE(launch_query_path(c->digests.as<gl_t>(), N, d0, dxs, 0, nq, dq, stride, off, st)); off += 4 * d0;
+            HIPCHK_FREE(launch_query_leaf_colmajor(c->qlde.as<gl_t>(), Q, log_n, r, dxs, nq, dq, stride, off, st)); off += Q;
+            HIPCHK_FREE(launch_query_path(c->qdigests.as<gl_t>(), N, d0, dxs, 0, nq, dq, stride, off, st)); off += 4 * d0;
+            size_t len = N;
+            unsigned shift_bits = 0;
+            for (size_t l = 0; l < L; l++) {
+                const unsigned ab = geo.arities[l];
+                const size_t width = 2 << ab, n_leaves = len >> ab;
+                shift_bits += ab;
+                HIPCHK_FREE(launch_query_leaf_rows(c->fri_rows[l].as<gl_t>(), width, dxs, shift_bits, nq, dq, stride, off, st)); off += width;
+                HIPCHK_FREE(launch_query_path(c->fri_digests[l].as<gl_t>(), n_leaves, (unsigned)pl.layer_depth[l], dxs, shift_bits, nq, dq, stride, off, st));
+                off += 4 * pl.layer_depth[l];
+                len = n_leaves;
+            }
+            HIPCHK_FREE(hipMemcpyAsync(out + pl.off_queries, dq, nq * stride * 8, hipMemcpyDeviceToHost, st));
         }
         pl.write_header(out);
         memcpy(out + pl.off_trace_cap, trace_cap.data(), 4 * ncap * 8);
@@ -493,23 +496,11 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         memcpy(out + pl.off_next, op_next.data(), C * 16);
         memcpy(out + pl.off_quot_open, op_q.data(), Q * 16);
         if (L) memcpy(out + pl.off_fri_caps, fri_caps.data(), L * 4 * ncap * 8);
-        const unsigned d0 = log_N - cap_h;
-        for (size_t q = 0; q < nq; q++) {
-            uint64_t* w = out + pl.off_queries + q * pl.query_words;
-            size_t x = xs[q];
-            memcpy(w, rows_t.data() + q * C, C * 8); w += C;
-            merkle_path(dig_t.data(), N, d0, x, w); w += 4 * d0;
-            memcpy(w, rows_q.data() + q * Q, Q * 8); w += Q;
-            merkle_path(dig_q.data(), N, d0, x, w); w += 4 * d0;
-            size_t len = N;
-            for (size_t l = 0; l < L; l++) {
-                const unsigned ab = geo.arities[l];
-                const size_t width = 2 << ab, n_leaves = len >> ab;
-                x >>= ab;
-                memcpy(w, fri_rows_h[l].data() + x * width, width * 8); w += width;
-                merkle_path(fri_dig_h[l].data(), n_leaves, (unsigned)pl.layer_depth[l], x, w); w += 4 * pl.layer_depth[l];
-                len = n_leaves;
-            }
+        HIPCHK_FREE(hipStreamSynchronize(st));
+#undef HIPCHK_FREE
+        if (err || off != stride) {
+            free(out);
+            return STARKHIP_ERR_HIP;
         }
         memcpy(out + pl.off_final, final_poly.data(), geo.final_poly_len * 16);
         out[pl.off_pow] = pow_witness;
