@@ -128,6 +128,8 @@ int starkhip_merkle_cap(void* ctx, const uint64_t* lde_colmajor, size_t n_cols, 
 int starkhip_poseidon_permute_batch(void* ctx, uint64_t* states, size_t n_states);
 /* host-side permutation (the one the Fiat-Shamir challenger uses) */
 void starkhip_poseidon_permute_host(uint64_t state[12]);
+/* n chained host permutations; which = 0: the challenger's tuned permutation, 1: the portable loop */
+void starkhip_poseidon_permute_host_many(uint64_t state[12], size_t n, int which);
 
 /* --- verifier (CPU) ------------------------------------------------------------------- */
 int starkhip_verify(starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* proof, size_t proof_words);

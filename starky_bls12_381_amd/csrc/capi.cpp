@@ -94,7 +94,15 @@ int starkhip_poseidon_permute_batch(void* ctx, uint64_t* states, size_t n_states
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;
     return permute_batch((Ctx*)ctx, states, n_states);
 }
-void starkhip_poseidon_permute_host(uint64_t state[12]) { poseidon_permute(state); }
+void starkhip_poseidon_permute_host(uint64_t state[12]) { poseidon_permute_host(state); }
+/* n chained permutations with the challenger's host permutation (which = 0) or the portable reference loop (which = 1);
+ * lets the tests compare the two and the benchmark report the host hashing rate */
+void starkhip_poseidon_permute_host_many(uint64_t state[12], size_t n, int which) {
+    for (size_t i = 0; i < n; i++) {
+        if (which == 0) poseidon_permute_host(state);
+        else poseidon_permute(state);
+    }
+}
 
 int starkhip_verify(starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* proof, size_t proof_words) {
     const AirInfo* a = air_get(air);

@@ -128,7 +128,13 @@ __device__ __forceinline__ gl_t gl_canon(gl_t x) { return x >= GL_P ? x - GL_P :
 
 // a * b mod p, any representative in [0, 2^64); a, b arbitrary 64-bit
 __device__ __forceinline__ gl_t gl_mul_nc(gl_t a, gl_t b) {
-    const uint64_t lo = a * b, hi = __umul64hi(a, b);
+    // 64 x 64 -> 128 as exactly four v_mad_u64_u32 (32 x 32 + 64): each partial sum below fits 64 bits
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t p00 = (uint64_t)a0 * b0;
+    const uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
+    const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
+    const uint64_t hi = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    const uint64_t lo = (p10 << 32) | (uint32_t)p00;
     const uint32_t hi_lo = (uint32_t)hi, hi_hi = (uint32_t)(hi >> 32);
     uint64_t t0 = lo - hi_hi;
     if (lo < hi_hi) t0 -= GL_EPS;
