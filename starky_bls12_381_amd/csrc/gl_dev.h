@@ -1,0 +1,67 @@
+// gfx950 device-only Goldilocks arithmetic with lazy ("non-canonical") reduction.
+//
+// A value is any 64-bit representative of its class mod p = 2^64 - 2^32 + 1 (so p..2^64-1 are allowed
+// aliases of 0..2^32-2).  Each routine states which operands may be arbitrary and which must be canonical;
+// every step is exact mod p, so a kernel canonicalises once (gl_canon) where results leave it.
+// The 64 x 64 multiply is written as exactly four v_mad_u64_u32 (quarter-rate on CDNA4, the dominant cost)
+// and the reduction uses 2^64 = 2^32 - 1 and 2^96 = -1 (mod p) with two conditional corrections.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gl.h"
+
+namespace starkhip {
+
+__device__ __forceinline__ gl_t gl_canon(gl_t x) { return x >= GL_P ? x - GL_P : x; }
+
+// (hi * 2^64 + lo) mod p, any representative; hi, lo arbitrary
+__device__ __forceinline__ gl_t gl_reduce128_nc(uint64_t hi, uint64_t lo) {
+    const uint32_t hi_lo = (uint32_t)hi, hi_hi = (uint32_t)(hi >> 32);
+    uint64_t t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= GL_EPS;
+    const uint64_t t1 = ((uint64_t)hi_lo << 32) - hi_lo;
+    uint64_t r = t0 + t1;
+    if (r < t1) r += GL_EPS;
+    return r;
+}
+
+// a * b mod p, any representative in [0, 2^64); a, b arbitrary 64-bit
+__device__ __forceinline__ gl_t gl_mul_nc(gl_t a, gl_t b) {
+    // 64 x 64 -> 128 as exactly four v_mad_u64_u32 (32 x 32 + 64): each partial sum below fits 64 bits
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t p00 = (uint64_t)a0 * b0;
+    const uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
+    const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
+    const uint64_t hi = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    const uint64_t lo = (p10 << 32) | (uint32_t)p00;
+    return gl_reduce128_nc(hi, lo);
+}
+
+// a * b + c mod p, any representative; a, b, c arbitrary 64-bit (a*b + c < 2^128)
+__device__ __forceinline__ gl_t gl_mad_nc(gl_t a, gl_t b, gl_t c) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t p00 = (uint64_t)a0 * b0;
+    const uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
+    const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
+    uint64_t hi = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);  // <= 2^64 - 2
+    const uint64_t lo0 = (p10 << 32) | (uint32_t)p00;
+    const uint64_t lo = lo0 + c;
+    hi += lo < lo0;
+    return gl_reduce128_nc(hi, lo);
+}
+
+// a arbitrary, b canonical (< p)
+__device__ __forceinline__ gl_t gl_add_nc(gl_t a, gl_t b) {
+    uint64_t s = a + b;
+    if (s < a) s += GL_EPS;  // wrapped: s <= p - 2, so + eps cannot wrap again
+    return s;
+}
+
+// a - b; a arbitrary, b canonical (< p)
+__device__ __forceinline__ gl_t gl_sub_nc(gl_t a, gl_t b) {
+    uint64_t d = a - b;
+    if (a < b) d -= GL_EPS;  // wrapped: d >= 2^64 - p + 1 > eps, so - eps cannot wrap again
+    return d;
+}
+
+}  // namespace starkhip

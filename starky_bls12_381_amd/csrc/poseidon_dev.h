@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "gl_dev.h"
 #include "poseidon.h"
 
 namespace starkhip {
@@ -124,34 +125,9 @@ struct QuadConsts {
     uint32_t k[3][12];  // k[m][e] = MDS coefficient of state element e in output row l + 4 m
 };
 
-__device__ __forceinline__ gl_t gl_canon(gl_t x) { return x >= GL_P ? x - GL_P : x; }
-
-// a * b mod p, any representative in [0, 2^64); a, b arbitrary 64-bit
-__device__ __forceinline__ gl_t gl_mul_nc(gl_t a, gl_t b) {
-    // 64 x 64 -> 128 as exactly four v_mad_u64_u32 (32 x 32 + 64): each partial sum below fits 64 bits
-    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
-    const uint64_t p00 = (uint64_t)a0 * b0;
-    const uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
-    const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
-    const uint64_t hi = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);
-    const uint64_t lo = (p10 << 32) | (uint32_t)p00;
-    const uint32_t hi_lo = (uint32_t)hi, hi_hi = (uint32_t)(hi >> 32);
-    uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GL_EPS;
-    const uint64_t t1 = ((uint64_t)hi_lo << 32) - hi_lo;
-    uint64_t r = t0 + t1;
-    if (r < t1) r += GL_EPS;
-    return r;
-}
 __device__ __forceinline__ gl_t sbox_nc(gl_t x) {
     const gl_t x2 = gl_mul_nc(x, x), x4 = gl_mul_nc(x2, x2), x3 = gl_mul_nc(x2, x);
     return gl_mul_nc(x3, x4);
-}
-// a arbitrary, b < p
-__device__ __forceinline__ gl_t gl_add_nc(gl_t a, gl_t b) {
-    uint64_t s = a + b;
-    if (s < a) s += GL_EPS;
-    return s;
 }
 // S0 + S1 * 2^22 + S2 * 2^44 + c  (S < 2^31, c < 2^64) mod p, any representative
 __device__ __forceinline__ gl_t combine22_add_nc(uint32_t S0, uint32_t S1, uint32_t S2, gl_t c) {

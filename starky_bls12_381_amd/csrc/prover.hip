@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "poseidon.h"
 #include "proof.h"
+#include "quotient_ops.h"
 #include "prover.h"
 
 namespace starkhip {
@@ -61,8 +62,8 @@ struct Ctx {
     // program
     int prog_air = -1;
     unsigned prog_chunks = 0;
-    DevBuf d_code, d_consts, d_chunk_off;
-    std::vector<uint32_t> chunk_off, chunk_k_after;
+    DevBuf d_ops, d_chunk_off;  // compile_quotient_ops() output for prog_air
+    std::vector<uint32_t> chunk_k_after;
     // work buffers
     DevBuf staging, values, coeffs, lde, digests, pis, apow, chunk_scale, partial, qvals, qcoef, qlde, qdigests, zpow, gzpow, open_local,
         open_next, open_q, ext_apow, comb_partial, comb_out, fri_coef, fri_vals, fri_rows[16], fri_digests[16], scale_tab, pow_state,
@@ -96,31 +97,14 @@ static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
     unsigned want = (unsigned)std::min<size_t>(256, std::max<size_t>(1, (16384 + blocks - 1) / blocks));
     want = (unsigned)std::min<size_t>(want, air.prog.group_off.size());
     if (c->prog_air == air.id && c->prog_chunks == want) return 0;
-    const AirProgram& P = air.prog;
-    HIPCHK(c->d_code.ensure(P.code.size() * 4));
-    HIPCHK(c->d_consts.ensure(std::max<size_t>(1, P.consts.size()) * 8));
-    HIPCHK(hipMemcpyAsync(c->d_code.p, P.code.data(), P.code.size() * 4, hipMemcpyHostToDevice, c->st));
-    if (!P.consts.empty()) HIPCHK(hipMemcpyAsync(c->d_consts.p, P.consts.data(), P.consts.size() * 8, hipMemcpyHostToDevice, c->st));
-    // cut at group boundaries into `want` pieces of about equal code length
-    c->chunk_off.clear();
-    c->chunk_k_after.clear();
-    const size_t total_words = P.code.size() - 1;  // END word excluded
-    size_t g = 0;
-    const size_t n_groups = P.group_off.size();
-    for (unsigned p = 0; p < want; p++) {
-        c->chunk_off.push_back(P.group_off[g]);
-        size_t target = total_words * (p + 1) / want;
-        size_t g_end = g + 1;
-        while (g_end < n_groups && P.group_off[g_end] < target && (n_groups - g_end) > (want - 1 - p)) g_end++;
-        if (p + 1 == want) g_end = n_groups;
-        uint32_t k_end = g_end < n_groups ? P.group_k0[g_end] : P.n_constraints;
-        c->chunk_k_after.push_back(P.n_constraints - k_end);
-        g = g_end;
-    }
-    c->chunk_off.push_back((uint32_t)total_words);
-    HIPCHK(c->d_chunk_off.ensure(c->chunk_off.size() * 4));
-    HIPCHK(hipMemcpyAsync(c->d_chunk_off.p, c->chunk_off.data(), c->chunk_off.size() * 4, hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    const QProgram Q = compile_quotient_ops(air.prog, want);
+    want = (unsigned)Q.chunk_k_after.size();
+    c->chunk_k_after = Q.chunk_k_after;
+    HIPCHK(c->d_ops.ensure(Q.ops.size() * sizeof(QOp)));
+    HIPCHK(hipMemcpyAsync(c->d_ops.p, Q.ops.data(), Q.ops.size() * sizeof(QOp), hipMemcpyHostToDevice, c->st));
+    HIPCHK(c->d_chunk_off.ensure(Q.chunk_batch.size() * 4));
+    HIPCHK(hipMemcpyAsync(c->d_chunk_off.p, Q.chunk_batch.data(), Q.chunk_batch.size() * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));  // Q goes out of scope
     c->prog_air = air.id;
     c->prog_chunks = want;
     return 0;
@@ -155,7 +139,7 @@ void ctx_destroy(Ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
-    DevBuf* bufs[] = {&c->tw_fwd, &c->tw_inv, &c->coset_scale, &c->qtab, &c->qshift_inv, &c->d_code, &c->d_consts, &c->d_chunk_off, &c->staging,
+    DevBuf* bufs[] = {&c->tw_fwd, &c->tw_inv, &c->coset_scale, &c->qtab, &c->qshift_inv, &c->d_ops, &c->d_chunk_off, &c->staging,
                       &c->values, &c->coeffs, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial, &c->qvals, &c->qcoef,
                       &c->qlde, &c->qdigests, &c->zpow, &c->gzpow, &c->open_local, &c->open_next, &c->open_q, &c->ext_apow, &c->comb_partial,
                       &c->comb_out, &c->fri_coef, &c->fri_vals, &c->scale_tab, &c->pow_state, &c->pow_best, &c->qidx, &c->gather_t,
@@ -290,9 +274,8 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         HIPCHK(hipMemcpyAsync(c->chunk_scale.p, cscale.data(), cscale.size() * 8, hipMemcpyHostToDevice, st));
         if (n_pis) HIPCHK(hipMemcpyAsync(c->pis.p, pis_host, n_pis * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipEventRecord(c->kev[2], st));
-        HIPCHK(launch_quotient_eval(c->d_code.as<uint32_t>(), c->d_consts.as<gl_t>(), c->pis.as<gl_t>(), c->lde.as<gl_t>(), c->qtab.as<gl_t>(),
-                                    c->d_chunk_off.as<uint32_t>(), n_chunks, c->apow.as<gl_t>(), alphas[0], alphas[1], c->partial.as<gl_t>(),
-                                    log_n, r, qdb, st));
+        HIPCHK(launch_quotient_eval(c->d_ops.as<QOp>(), c->d_chunk_off.as<uint32_t>(), n_chunks, c->pis.as<gl_t>(), c->lde.as<gl_t>(),
+                                    c->qtab.as<gl_t>(), c->apow.as<gl_t>(), alphas[0], alphas[1], c->partial.as<gl_t>(), log_n, r, qdb, st));
         HIPCHK(hipEventRecord(c->kev[3], st));
         HIPCHK(launch_quotient_combine(c->partial.as<gl_t>(), c->chunk_scale.as<gl_t>(), n_chunks, c->qtab.as<gl_t>(), log_n, qdb,
                                        c->qvals.as<gl_t>(), st));
