@@ -1,0 +1,351 @@
+// Trace-column IFFT + coset LDE for 2^8 .. 2^13 rows: the device twin of plonky2's
+// PolynomialBatch::from_values (values -> ifft -> lde onto the coset 7 * <w_N>), which the
+// reference reaches through starky::prover::prove (/root/reference/src/aggregate_proof.rs:59-65).
+//
+// One workgroup owns whole columns (n / 16 threads per column, 16 elements per thread) and runs every
+// transform of that column back to back: 1 inverse NTT, then 2^rate_bits forward NTTs whose inputs are the
+// coefficients, still in registers, times the coset powers.  HBM sees each value once in, each coefficient and
+// LDE point once out: 8 * (n + n + N) bytes per column.
+//
+// Each transform is a Stockham auto-sort NTT in radix-16 passes (plus one radix-2/4/8 pass when log n is not a
+// multiple of 4).  Inside a pass the 16-point sub-transform runs in registers and all of its twiddles are
+// powers of two -- in Goldilocks 2 has order 192 and plonky2's 64th root of unity is 2^39 -- so they cost
+// shifts and adds, not 64x64 multiplies; only the n * 15/16 inter-pass twiddles per pass are generic
+// multiplies, read from tables laid out [i][j mod Ns] so that a wave reads them as whole lines.  Passes
+// exchange data through one padded LDS image of the column (row of 16 elements + 1 pad => the stride-16
+// scatter of the first pass and the unit-stride gathers of the next are both conflict-free).
+// Arithmetic is the lazy-reduction form of gl_dev.h; values are canonicalised when stored to HBM.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "gl_dev.h"
+#include "kernels.h"
+
+namespace starkhip {
+
+// ---------------------------------------------------------------- arithmetic on arbitrary representatives
+__device__ __forceinline__ gl_t gl_add_nn(gl_t a, gl_t b) {
+    uint64_t s = a + b;
+    const bool c1 = s < a;
+    uint64_t s2 = s + (c1 ? GL_EPS : 0);
+    const bool c2 = c1 && (s2 < GL_EPS);
+    return s2 + (c2 ? GL_EPS : 0);
+}
+__device__ __forceinline__ gl_t gl_sub_nn(gl_t a, gl_t b) {
+    uint64_t d = a - b;
+    const bool b1 = a < b;
+    uint64_t d2 = d - (b1 ? GL_EPS : 0);
+    const bool b2 = b1 && (d < GL_EPS);
+    return d2 - (b2 ? GL_EPS : 0);
+}
+
+// x * 2^e mod p for a compile-time-foldable 0 <= e < 96; x arbitrary, result any representative.
+// 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32 (mod p).
+__device__ __forceinline__ gl_t gl_mul_pow2_nn(gl_t x, int e) {
+    if (e == 0) return x;
+    const int a = e >> 5, b = e & 31;
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
+    uint32_t y0, y1, y2;  // x << b as three words, y2 < 2^31
+    if (b == 0) {
+        y0 = x0; y1 = x1; y2 = 0;
+    } else {
+        y0 = x0 << b;
+        y1 = (x1 << b) | (x0 >> (32 - b));
+        y2 = x1 >> (32 - b);
+    }
+    if (a == 0) {  // (y1:y0) + y2 * eps
+        const uint64_t lo = ((uint64_t)y1 << 32) | y0;
+        const uint64_t t = ((uint64_t)y2 << 32) - y2;  // < p
+        return gl_add_nc(lo, t);
+    }
+    if (a == 1) {  // y0 * 2^32 + y1 * eps - y2
+        const uint64_t A = (uint64_t)y0 << 32;             // < p
+        const uint64_t B = ((uint64_t)y1 << 32) - y1;      // < p
+        return gl_sub_nc(gl_add_nc(A, B), (gl_t)y2);
+    }
+    // a == 2: y0 * eps - y1 - y2 * 2^32
+    const uint64_t A = ((uint64_t)y0 << 32) - y0;          // < p
+    const uint64_t B = ((uint64_t)y2 << 32) + y1;          // < 2^63 + 2^32 < p
+    return gl_sub_nc(A, B);
+}
+
+// ---------------------------------------------------------------- register sub-transforms
+constexpr int bitrev_c(int k, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((k >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x >> 1); }
+
+// Decimation-in-frequency radix-2 network of size R on v[BASE + STRIDE * i], root w_R = 2^(39 * 64 / R) (or its
+// inverse).  Leaves X[k] at i = bitrev(k).
+template <int R, bool INV, int BASE, int STRIDE>
+struct Dif {
+    static __device__ __forceinline__ void run(gl_t (&v)[16]) {
+        constexpr int H = R / 2;
+        constexpr int E_FWD = (39 * (64 / R)) % 192;
+        constexpr int E = INV ? (192 - E_FWD) % 192 : E_FWD;
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            const int e = (E * i) % 192;
+            const gl_t a = v[BASE + STRIDE * i], b = v[BASE + STRIDE * (i + H)];
+            v[BASE + STRIDE * i] = gl_add_nn(a, b);
+            v[BASE + STRIDE * (i + H)] = e < 96 ? gl_mul_pow2_nn(gl_sub_nn(a, b), e) : gl_mul_pow2_nn(gl_sub_nn(b, a), e - 96);
+        }
+        Dif<H, INV, BASE, STRIDE>::run(v);
+        Dif<H, INV, BASE + STRIDE * H, STRIDE>::run(v);
+    }
+};
+template <bool INV, int BASE, int STRIDE>
+struct Dif<1, INV, BASE, STRIDE> {
+    static __device__ __forceinline__ void run(gl_t (&)[16]) {}
+};
+
+// S = 16 / R independent size-R transforms: transform m lives in v[m + S * i]; natural order in and out.
+template <int R, bool INV, int M>
+struct SubNtts {
+    static __device__ __forceinline__ void run(gl_t (&v)[16]) {
+        constexpr int S = 16 / R;
+        Dif<R, INV, M, S>::run(v);
+        if constexpr (M + 1 < S) SubNtts<R, INV, M + 1>::run(v);
+    }
+};
+template <int R>
+__device__ __forceinline__ void unscramble(gl_t (&v)[16]) {
+    constexpr int S = 16 / R, LOGR = ilog2_c(R);
+    gl_t w[16];
+#pragma unroll
+    for (int m = 0; m < S; m++)
+#pragma unroll
+        for (int k = 0; k < R; k++) w[m + S * k] = v[m + S * bitrev_c(k, LOGR)];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = w[i];
+}
+
+// ---------------------------------------------------------------- pass structure
+template <int LOGN>
+struct LdePlan {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int T = N / 16;                       // threads per column
+    static constexpr int FULL = LOGN / 4;                  // radix-16 passes
+    static constexpr int TAIL = LOGN % 4;                  // log2 of the last pass's radix (0: none)
+    static constexpr int NP = FULL + (TAIL ? 1 : 0);
+    static constexpr int radix(int p) { return p < FULL ? 16 : (1 << TAIL); }
+    static constexpr int ns(int p) { return p == 0 ? 1 : ns(p - 1) * radix(p - 1); }
+    // twiddle table: passes 1 .. NP-1, each radix(p) rows of ns(p) entries
+    static constexpr int tw_off(int p) { return p <= 1 ? 0 : tw_off(p - 1) + radix(p - 1) * ns(p - 1); }
+    static constexpr int tw_words() { return tw_off(NP); }
+    static constexpr int THREADS = T < 256 ? 256 : T;
+    static constexpr int CPB = THREADS / T;                // columns per workgroup
+    static constexpr int LDS_COL = N + N / 16;             // padded elements per column
+};
+
+__device__ __forceinline__ int lds_pad(int a) { return a + (a >> 4); }
+
+// One Stockham pass on the 16 values a thread holds (element i' = column index t + i' * T).
+// P > 0: inputs come from the LDS image written by pass P-1.  Last pass: results stay in registers (natural index
+// t + i' * T); otherwise they are scattered to the LDS image for pass P+1.
+template <int LOGN, int P, bool INV>
+__device__ __forceinline__ void lde_pass(gl_t (&v)[16], gl_t* __restrict__ lds, const gl_t* __restrict__ tw, int t) {
+    using PL = LdePlan<LOGN>;
+    constexpr int R = PL::radix(P), S = 16 / R, NS = PL::ns(P), T = PL::T;
+    constexpr bool LAST = P == PL::NP - 1;
+    if constexpr (P > 0) {
+        // T is a multiple of 16, so pad(t + i T) = pad(t) + i * (T + T/16): one address register, immediate offsets
+        const int tpad = lds_pad(t);
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = lds[tpad + i * (T + T / 16)];
+        // twiddles w_{NS*R}^{i * (j mod NS)}, j = t + m * T; the inverse transform's last pass also carries n^-1 (row 0).
+        // Uniform row base + 32-bit lane offset => scalar-base loads, no per-load address registers.
+        const gl_t* twp = tw + PL::tw_off(P);
+#pragma unroll
+        for (int m = 0; m < S; m++) {
+            const uint32_t jj8 = (uint32_t)((t + m * T) % NS) * 8u;
+#pragma unroll
+            for (int i = (INV && LAST) ? 0 : 1; i < R; i++) {
+                const gl_t w = *(const gl_t*)((const char*)(twp + i * NS) + jj8);
+                v[m + S * i] = gl_mul_nc(v[m + S * i], w);
+            }
+        }
+    }
+    SubNtts<R, INV, 0>::run(v);
+    unscramble<R>(v);
+    if constexpr (!LAST) {
+        __syncthreads();  // every thread of the column has read its inputs
+#pragma unroll
+        for (int m = 0; m < S; m++) {
+            const int j = t + m * T;
+            if constexpr (NS == 1) {  // first pass (radix 16): element 16 j + k -> padded 17 j + k
+#pragma unroll
+                for (int k = 0; k < R; k++) lds[17 * j + k] = v[m + S * k];
+            } else {  // NS is a multiple of 16: pad(base + k NS) = pad(base) + k * (NS + NS/16)
+                const int pbase = lds_pad((j / NS) * NS * R + (j % NS));
+#pragma unroll
+                for (int k = 0; k < R; k++) lds[pbase + k * (NS + NS / 16)] = v[m + S * k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int LOGN, int P, bool INV>
+struct LdePasses {
+    static __device__ __forceinline__ void run(gl_t (&v)[16], gl_t* lds, const gl_t* tw, int t) {
+        lde_pass<LOGN, P, INV>(v, lds, tw, t);
+        if constexpr (P + 1 < LdePlan<LOGN>::NP) LdePasses<LOGN, P + 1, INV>::run(v, lds, tw, t);
+    }
+};
+
+// values [C][n] (or coefficients when from_coeffs) -> coeffs [C][n] (nullable) and lde [C][2^rate][n], coset-major.
+template <int LOGN>
+__global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kernel(const gl_t* __restrict__ values, gl_t* __restrict__ coeffs,
+                                                                                    gl_t* __restrict__ lde, unsigned n_cols, unsigned rate_bits,
+                                                                                    const gl_t* __restrict__ tw_fwd,
+                                                                                    const gl_t* __restrict__ tw_inv, const gl_t* __restrict__ cs,
+                                                                                    int from_coeffs) {
+    using PL = LdePlan<LOGN>;
+    constexpr int T = PL::T, n = PL::N;
+    extern __shared__ gl_t lds_all[];
+    const int cib_raw = threadIdx.x / T, t = threadIdx.x % T;
+    const unsigned col0 = blockIdx.x * PL::CPB;           // first column of this workgroup (always < n_cols)
+    const bool live = col0 + cib_raw < n_cols;            // idle columns of the last workgroup shadow col0 and store nothing
+    const int cib = live ? cib_raw : 0;
+    gl_t* lds = lds_all + (size_t)cib_raw * PL::LDS_COL;
+    // every HBM access below is (uniform workgroup base) + (32-bit lane byte offset) + (compile-time i * T * 8)
+    const char* in_base = (const char*)(values + (size_t)col0 * n);
+    const uint32_t in_off = (uint32_t)(cib * n + t) * 8u;
+    gl_t v[16];
+    // The coefficients are not held in registers across the coset transforms (16 x 64-bit more per lane would halve
+    // the occupancy): each thread re-reads exactly the 16 words it stored itself, which are still in L2 / MALL.
+    const char* cf_base = in_base;
+    if (!from_coeffs) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = *(const gl_t*)(in_base + in_off + (uint32_t)(i * T * 8));
+        LdePasses<LOGN, 0, true>::run(v, lds, tw_inv, t);
+        char* cf_out = (char*)(coeffs + (size_t)col0 * n);
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) *(gl_t*)(cf_out + in_off + (uint32_t)(i * T * 8)) = gl_canon(v[i]);
+        }
+        cf_base = cf_out;
+    }
+    const unsigned n_cosets = 1u << rate_bits;
+    char* out_base = (char*)(lde + (size_t)col0 * n_cosets * n);
+    for (unsigned s = 0; s < n_cosets; s++) {
+        // (no barrier needed here: pass 0 synchronises before it overwrites the LDS image the previous transform read)
+        const char* cs_base = (const char*)(cs + (size_t)s * n);
+        const uint32_t t8 = (uint32_t)t * 8u;
+        const char* cfb = cf_base;
+        asm volatile("" : "+s"(cfb));  // opaque: keeps the re-read a load (no forwarding from the stores above, no hoisting out of the loop)
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            v[i] = gl_mul_nc(*(const gl_t*)(cfb + in_off + (uint32_t)(i * T * 8)), *(const gl_t*)(cs_base + t8 + (uint32_t)(i * T * 8)));
+        LdePasses<LOGN, 0, false>::run(v, lds, tw_fwd, t);
+        if (live) {
+            const uint32_t out_off = (uint32_t)((cib * n_cosets + s) * n + t) * 8u;  // < CPB * 2^rate * n * 8 <= 2^22
+#pragma unroll
+            for (int i = 0; i < 16; i++) *(gl_t*)(out_base + out_off + (uint32_t)(i * T * 8)) = gl_canon(v[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+template <int LOGN>
+static void fill_tw(std::vector<gl_t>& out, bool inv) {
+    using PL = LdePlan<LOGN>;
+    out.assign(PL::tw_words() ? PL::tw_words() : 1, 1);
+    const gl_t ninv = gl_inv((gl_t)PL::N);
+    if (PL::NP == 1) out[0] = inv ? ninv : 1;
+    for (int p = 1; p < PL::NP; p++) {
+        const int R = PL::radix(p), NS = PL::ns(p);
+        gl_t w = gl_root_of_unity(ilog2_c(NS * R));
+        if (inv) w = gl_inv(w);
+        const gl_t scale = (inv && p == PL::NP - 1) ? ninv : 1;
+        for (int i = 0; i < R; i++) {
+            const gl_t wi = gl_pow(w, i);
+            gl_t acc = scale;
+            for (int jj = 0; jj < NS; jj++) {
+                out[PL::tw_off(p) + i * NS + jj] = acc;
+                acc = gl_mul(acc, wi);
+            }
+        }
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, size_t n_cols, unsigned rate_bits, const gl_t* tw_fwd,
+                            const gl_t* tw_inv, const gl_t* cs, int from_coeffs, hipStream_t st) {
+    using PL = LdePlan<LOGN>;
+    const size_t lds_bytes = (size_t)PL::CPB * PL::LDS_COL * sizeof(gl_t);
+    if (lds_bytes > 64 * 1024) {  // per device, so not cached in a static
+        hipError_t e = hipFuncSetAttribute((const void*)lde_columns_v2_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const unsigned blocks = (unsigned)((n_cols + PL::CPB - 1) / PL::CPB);
+    hipLaunchKernelGGL(lde_columns_v2_kernel<LOGN>, dim3(blocks), dim3(PL::THREADS), lds_bytes, st, values, coeffs, lde, (unsigned)n_cols,
+                       rate_bits, tw_fwd, tw_inv, cs, from_coeffs);
+    return hipGetLastError();
+}
+
+bool lde_v2_supported(unsigned log_n) { return log_n >= 8 && log_n <= 13; }
+
+size_t lde_v2_tw_words(unsigned log_n) {
+    switch (log_n) {
+        case 8: return LdePlan<8>::tw_words();
+        case 9: return LdePlan<9>::tw_words();
+        case 10: return LdePlan<10>::tw_words();
+        case 11: return LdePlan<11>::tw_words();
+        case 12: return LdePlan<12>::tw_words();
+        case 13: return LdePlan<13>::tw_words();
+        default: return 0;
+    }
+}
+
+// Host-built tables: forward / inverse inter-pass twiddles, and cs[s][k] = (7 * w_N^s)^k (the coset shift of
+// coset s; N = n * 2^rate_bits).  The three device buffers must hold lde_v2_tw_words(log_n) (x2) and N words.
+hipError_t lde_v2_upload_tables(unsigned log_n, unsigned rate_bits, gl_t* d_tw_fwd, gl_t* d_tw_inv, gl_t* d_cs, hipStream_t st) {
+    std::vector<gl_t> fwd, inv;
+    switch (log_n) {
+        case 8: fill_tw<8>(fwd, false); fill_tw<8>(inv, true); break;
+        case 9: fill_tw<9>(fwd, false); fill_tw<9>(inv, true); break;
+        case 10: fill_tw<10>(fwd, false); fill_tw<10>(inv, true); break;
+        case 11: fill_tw<11>(fwd, false); fill_tw<11>(inv, true); break;
+        case 12: fill_tw<12>(fwd, false); fill_tw<12>(inv, true); break;
+        case 13: fill_tw<13>(fwd, false); fill_tw<13>(inv, true); break;
+        default: return hipErrorInvalidValue;
+    }
+    const size_t n = (size_t)1 << log_n, n_cosets = (size_t)1 << rate_bits;
+    std::vector<gl_t> cs(n * n_cosets);
+    const gl_t wN = gl_root_of_unity(log_n + rate_bits);
+    for (size_t s = 0; s < n_cosets; s++) {
+        const gl_t shift = gl_mul(GL_GENERATOR, gl_pow(wN, s));
+        gl_t acc = 1;
+        for (size_t k = 0; k < n; k++) {
+            cs[s * n + k] = acc;
+            acc = gl_mul(acc, shift);
+        }
+    }
+    hipError_t e;
+    if ((e = hipMemcpyAsync(d_tw_fwd, fwd.data(), fwd.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(d_tw_inv, inv.data(), inv.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(d_cs, cs.data(), cs.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    return hipStreamSynchronize(st);  // the host vectors go out of scope
+}
+
+hipError_t launch_lde_columns_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                                 const gl_t* tw_fwd, const gl_t* tw_inv, const gl_t* cs, int from_coeffs, hipStream_t st) {
+    if (!from_coeffs && !coeffs) return hipErrorInvalidValue;  // the coset transforms read the coefficients back from `coeffs`
+    if (n_cols == 0) return hipSuccess;
+    switch (log_n) {
+        case 8: return launch_v2<8>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, from_coeffs, st);
+        case 9: return launch_v2<9>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, from_coeffs, st);
+        case 10: return launch_v2<10>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, from_coeffs, st);
+        case 11: return launch_v2<11>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, from_coeffs, st);
+        case 12: return launch_v2<12>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, from_coeffs, st);
+        case 13: return launch_v2<13>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, from_coeffs, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace starkhip

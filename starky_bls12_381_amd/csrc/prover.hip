@@ -59,6 +59,7 @@ struct Ctx {
     // shape-dependent tables
     int tab_log_n = -1, tab_rate = -1, tab_qdb = -1;
     DevBuf tw_fwd, tw_inv, coset_scale, qtab, qshift_inv;
+    DevBuf lde2_fwd, lde2_inv, lde2_cs;  // kernels_lde.hip tables (log_n >= 8)
     // program
     int prog_air = -1;
     unsigned prog_chunks = 0;
@@ -85,10 +86,25 @@ static int ensure_tables(Ctx* c, unsigned log_n, unsigned rate, unsigned qdb) {
     HIPCHK(launch_fill_coset_scale(c->coset_scale.as<gl_t>(), log_n, rate, c->st));
     HIPCHK(launch_quotient_tables(c->qtab.as<gl_t>(), log_n, qdb, c->st));
     HIPCHK(launch_fill_powers(c->qshift_inv.as<gl_t>(), 1, gl_inv(GL_GENERATOR), size, c->st));
+    if (lde_v2_supported(log_n)) {
+        HIPCHK(c->lde2_fwd.ensure(lde_v2_tw_words(log_n) * 8));
+        HIPCHK(c->lde2_inv.ensure(lde_v2_tw_words(log_n) * 8));
+        HIPCHK(c->lde2_cs.ensure(N * 8));
+        HIPCHK(lde_v2_upload_tables(log_n, rate, c->lde2_fwd.as<gl_t>(), c->lde2_inv.as<gl_t>(), c->lde2_cs.as<gl_t>(), c->st));
+    }
     c->tab_log_n = log_n;
     c->tab_rate = rate;
     c->tab_qdb = qdb;
     return 0;
+}
+
+// IFFT + coset LDE of `cols` columns with the tables of ensure_tables(log_n, rate, .)
+static hipError_t run_lde(Ctx* c, const gl_t* values, gl_t* coeffs, gl_t* lde, size_t cols, unsigned log_n, unsigned rate, int from_coeffs) {
+    if (lde_v2_supported(log_n))
+        return launch_lde_columns_v2(values, coeffs, lde, cols, log_n, rate, c->lde2_fwd.as<gl_t>(), c->lde2_inv.as<gl_t>(),
+                                     c->lde2_cs.as<gl_t>(), from_coeffs, c->st);
+    return launch_lde_columns(values, coeffs, lde, cols, log_n, rate, c->tw_fwd.as<gl_t>(), c->tw_inv.as<gl_t>(), log_n + rate,
+                              c->coset_scale.as<gl_t>(), from_coeffs, c->st);
 }
 
 static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
@@ -139,7 +155,7 @@ void ctx_destroy(Ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
-    DevBuf* bufs[] = {&c->tw_fwd, &c->tw_inv, &c->coset_scale, &c->qtab, &c->qshift_inv, &c->d_ops, &c->d_chunk_off, &c->staging,
+    DevBuf* bufs[] = {&c->tw_fwd, &c->tw_inv, &c->coset_scale, &c->qtab, &c->qshift_inv, &c->lde2_fwd, &c->lde2_inv, &c->lde2_cs, &c->d_ops, &c->d_chunk_off, &c->staging,
                       &c->values, &c->coeffs, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial, &c->qvals, &c->qcoef,
                       &c->qlde, &c->qdigests, &c->zpow, &c->gzpow, &c->open_local, &c->open_next, &c->open_q, &c->ext_apow, &c->comb_partial,
                       &c->comb_out, &c->fri_coef, &c->fri_vals, &c->scale_tab, &c->pow_state, &c->pow_best, &c->qidx, &c->gather_t,
@@ -244,8 +260,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(hipEventRecord(c->ev[evi++], st));
 
     // ---- phase 1: IFFT + LDE (PolynomialBatch::from_values, App. A.3)
-    HIPCHK(launch_lde_columns(d_values, c->coeffs.as<gl_t>(), c->lde.as<gl_t>(), C, log_n, r, c->tw_fwd.as<gl_t>(), c->tw_inv.as<gl_t>(), log_N,
-                              c->coset_scale.as<gl_t>(), 0, st));
+    HIPCHK(run_lde(c, d_values, c->coeffs.as<gl_t>(), c->lde.as<gl_t>(), C, log_n, r, 0));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
 
     // ---- phase 2: Merkle tree over bit-reversed LDE rows
@@ -300,8 +315,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     }
 
     // ---- phase 4: quotient commit (PolynomialBatch::from_coeffs)
-    HIPCHK(launch_lde_columns(c->qcoef.as<gl_t>(), nullptr, c->qlde.as<gl_t>(), Q, log_n, r, c->tw_fwd.as<gl_t>(), c->tw_inv.as<gl_t>(), log_N,
-                              c->coset_scale.as<gl_t>(), 1, st));
+    HIPCHK(run_lde(c, c->qcoef.as<gl_t>(), nullptr, c->qlde.as<gl_t>(), Q, log_n, r, 1));
     HIPCHK(launch_leaf_hash(c->qlde.as<gl_t>(), Q, log_n, r, c->qdigests.as<gl_t>(), st));
     HIPCHK(launch_merkle_levels(c->qdigests.as<gl_t>(), log_N, cap_h, st));
     HIPCHK(hipMemcpyAsync(quot_cap.data(), c->qdigests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), 4 * ncap * 8, hipMemcpyDeviceToHost, st));
@@ -512,8 +526,7 @@ int lde_batch(Ctx* c, const uint64_t* values, size_t n_cols, unsigned log_n, uns
     HIPCHK(c->coeffs.ensure(n_cols * n * 8));
     HIPCHK(c->lde.ensure(n_cols * N * 8));
     HIPCHK(hipMemcpyAsync(c->values.p, values, n_cols * n * 8, hipMemcpyHostToDevice, c->st));
-    HIPCHK(launch_lde_columns(c->values.as<gl_t>(), c->coeffs.as<gl_t>(), c->lde.as<gl_t>(), n_cols, log_n, rate_bits, c->tw_fwd.as<gl_t>(),
-                              c->tw_inv.as<gl_t>(), log_n + rate_bits, c->coset_scale.as<gl_t>(), 0, c->st));
+    HIPCHK(run_lde(c, c->values.as<gl_t>(), c->coeffs.as<gl_t>(), c->lde.as<gl_t>(), n_cols, log_n, rate_bits, 0));
     if (coeffs_out) HIPCHK(hipMemcpyAsync(coeffs_out, c->coeffs.p, n_cols * n * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
     if (lde_out) {

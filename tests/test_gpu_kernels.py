@@ -25,7 +25,8 @@ def test_poseidon_permutation_batch(prover):
     assert np.array_equal(out[2], O.poseidon_permute(states[2]))
 
 
-@pytest.mark.parametrize("log_n,rate_bits,ncols", [(1, 1, 5), (4, 1, 301), (6, 2, 130), (10, 2, 257), (10, 1, 64), (13, 2, 9), (12, 3, 3)])
+@pytest.mark.parametrize("log_n,rate_bits,ncols", [(1, 1, 5), (4, 1, 301), (6, 2, 130), (7, 1, 33), (8, 1, 37), (8, 2, 16), (9, 2, 21), (10, 2, 257),
+                                                    (10, 1, 64), (11, 1, 10), (13, 2, 9), (12, 3, 3), (13, 1, 2)])
 def test_lde_matches_oracle(prover, log_n, rate_bits, ncols):
     rng = np.random.default_rng(log_n * 10 + rate_bits)
     vals = _rand(rng, (ncols, 1 << log_n))
