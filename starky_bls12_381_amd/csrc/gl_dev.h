@@ -19,9 +19,8 @@ __device__ __forceinline__ gl_t gl_reduce128_nc(uint64_t hi, uint64_t lo) {
     const uint32_t hi_lo = (uint32_t)hi, hi_hi = (uint32_t)(hi >> 32);
     uint64_t t0 = lo - hi_hi;
     if (lo < hi_hi) t0 -= GL_EPS;
-    const uint64_t t1 = ((uint64_t)hi_lo << 32) - hi_lo;
-    uint64_t r = t0 + t1;
-    if (r < t1) r += GL_EPS;
+    uint64_t r = t0 + (uint64_t)hi_lo * 0xFFFFFFFFu;  // + hi_lo * eps as one v_mad_u64_u32; hi_lo * eps < p
+    if (r < t0) r += GL_EPS;
     return r;
 }
 

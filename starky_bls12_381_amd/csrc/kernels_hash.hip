@@ -13,14 +13,16 @@ namespace starkhip {
 //   element (column c, physical point q) at mat[c * N + q], q = s * n + k  <->  natural index i = k * R + s.
 // Leaf position j in the tree holds natural row bitrev_logN(j) (plonky2 reverse_index_bits_in_place),
 // so the thread that owns physical point q writes digest slot j = bitrev(i).
-// One lane walks one row; adjacent lanes read adjacent k => every load is a coalesced 512 B line.
+// Four lanes (one DPP quad) walk one row; adjacent quads read adjacent k => each load touches whole 128-byte runs.
 __global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
                                                          gl_t* __restrict__ digests) {
-    // 4 lanes (one DPP quad) per leaf: lane l owns sponge state elements l, l + 4, l + 8
-    __shared__ gl_t rcs[4][96];  // per-lane view of the round constants + 3 zeros ("next round" of the last round)
+    // lane l of the quad owns sponge state elements 3l, 3l+1, 3l+2 (poseidon_dev.h)
+    __shared__ RcPair rcs[4][96];  // per-lane view of the round constants, split in halves, + 3 zeros ("next round" of the last round)
     for (unsigned idx = threadIdx.x; idx < 4 * 96; idx += blockDim.x) {
         const unsigned ll = idx / 96, w = idx % 96;
-        rcs[ll][w] = w < 90 ? POSEIDON_RC_DEV[12 * (w / 3) + ll + 4 * (w % 3)] : 0;
+        const gl_t c = w < 90 ? POSEIDON_RC_DEV[12 * (w / 3) + 3 * ll + (w % 3)] : 0;
+        rcs[ll][w].lo = c & 0xFFFFFFFFull;
+        rcs[ll][w].hi = c >> 32;
     }
     __syncthreads();
     const unsigned log_N = log_n + rate_bits;
@@ -34,27 +36,43 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__
     const size_t j = gl_bitrev((uint32_t)i, log_N);
     const gl_t* col = mat + q;
     if (n_cols <= 4) {  // hash_or_noop: short leaves are copied, zero padded
-        digests[4 * j + l] = l < n_cols ? col[(size_t)l * N] : 0;
+        if (l == 0) {
+#pragma unroll
+            for (unsigned e = 0; e < 3; e++) digests[4 * j + e] = e < n_cols ? col[(size_t)e * N] : 0;
+        } else if (l == 1) {
+            digests[4 * j + 3] = 3 < n_cols ? col[(size_t)3 * N] : 0;
+        }
         return;
     }
-    QuadConsts qc;
-    quad_consts_init(qc, l);
-    const gl_t* rc = rcs[l];
+    const uint32_t diag0 = l == 0 ? 8u : 0u;
+    const RcPair* rc = rcs[l];
     gl_t s0 = 0, s1 = 0, s2 = 0;
     size_t off = 0;
-    // full 8-element blocks: lane l absorbs columns off + l and off + 4 + l (overwrite mode)
+    // full 8-element blocks (overwrite mode): lanes 0, 1 absorb three columns, lane 2 two, lane 3 holds capacity only
+    const gl_t* mine = col + (size_t)(3 * l) * N;
     for (; off + 8 <= n_cols; off += 8) {
-        s0 = col[(off + l) * N];
-        s1 = col[(off + 4 + l) * N];
-        poseidon_permute_quad(s0, s1, s2, qc, rc, l == 0);
+        if (l <= 2) {
+            s0 = mine[off * N];
+            s1 = mine[(off + 1) * N];
+        }
+        if (l <= 1) s2 = mine[(off + 2) * N];
+        poseidon_permute_quad(s0, s1, s2, diag0, rc, l == 0);
     }
     if (off < n_cols) {
         const size_t rem = n_cols - off;
-        if (l < rem) s0 = col[(off + l) * N];
-        if (4 + l < rem) s1 = col[(off + 4 + l) * N];
-        poseidon_permute_quad(s0, s1, s2, qc, rc, l == 0);
+        if (3 * l + 0 < rem) s0 = mine[off * N];
+        if (3 * l + 1 < rem) s1 = mine[(off + 1) * N];
+        if (3 * l + 2 < rem) s2 = mine[(off + 2) * N];
+        poseidon_permute_quad(s0, s1, s2, diag0, rc, l == 0);
     }
-    digests[4 * j + l] = gl_canon(s0);  // elements 0..3 live in slot 0 of lanes 0..3
+    // digest = state elements 0..3: lane 0's three and lane 1's first
+    if (l == 0) {
+        digests[4 * j + 0] = gl_canon(s0);
+        digests[4 * j + 1] = gl_canon(s1);
+        digests[4 * j + 2] = gl_canon(s2);
+    } else if (l == 1) {
+        digests[4 * j + 3] = gl_canon(s0);
+    }
 }
 
 // Leaves stored row-major and already in tree order: leaf j = rows[j][0..width)

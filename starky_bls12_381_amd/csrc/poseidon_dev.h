@@ -117,115 +117,115 @@ __device__ __forceinline__ void poseidon_hash_or_noop_dev(const gl_t* in, size_t
 }
 
 // ---------------------------------------------------------------- one permutation per DPP quad
-// Lane l (= lane id & 3) owns state elements l, l + 4, l + 8 in (s0, s1, s2).
-// Inside the quad permutation values are kept as ANY 64-bit representative of their residue (no canonical
-// "subtract p" after each operation): limbs22 / the 128-bit product treat the register as a plain integer,
-// so every step stays exact mod p; the caller canonicalises what leaves the permutation (gl_canon).
-struct QuadConsts {
-    uint32_t k[3][12];  // k[m][e] = MDS coefficient of state element e in output row l + 4 m
-};
+// Lane l (= lane id & 3) owns the three CONSECUTIVE state elements 3l, 3l+1, 3l+2 in (s0, s1, s2).  Because
+// 3 * 4 = 12, rotating the quad by r lanes shifts every element index by 3r (mod 12) in all four lanes alike, so
+// the circulant MDS coefficient of a rotated operand, CIRC[(3r + m - m') mod 12], is the same compile-time
+// constant in every lane: it is an inline operand of v_mad_u64_u32, not a register.
+//
+// Cost model (measured on MI355X, tools/valu_rate_bench.hip): every integer VALU instruction other than a plain
+// 32-bit add/logic op issues in 4 cycles per wave -- v_mad_u64_u32 (32 x 32 + 64) included -- so the MDS layer is
+// written to minimise instruction COUNT: the 64-bit state words are multiplied as two 32-bit halves into two
+// 64-bit accumulators (2 mads per coefficient, 74 per lane and round) after 18 quad-rotation moves, instead of
+// 22-bit limbs with 24-bit multiplies (108 multiplies + 54 three-operand adds + limb split and merge).
+// Values are kept as ANY 64-bit representative of their residue; the caller canonicalises what leaves the
+// permutation (gl_canon).
+template <int ROT>
+__device__ __forceinline__ uint32_t quad_rot(uint32_t v) {
+    // lane i of the quad reads lane (i + ROT) & 3
+    constexpr int sel = ((0 + ROT) & 3) | (((1 + ROT) & 3) << 2) | (((2 + ROT) & 3) << 4) | (((3 + ROT) & 3) << 6);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, sel, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ uint64_t mad32(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }  // one v_mad_u64_u32
 
 __device__ __forceinline__ gl_t sbox_nc(gl_t x) {
     const gl_t x2 = gl_mul_nc(x, x), x4 = gl_mul_nc(x2, x2), x3 = gl_mul_nc(x2, x);
     return gl_mul_nc(x3, x4);
 }
-// S0 + S1 * 2^22 + S2 * 2^44 + c  (S < 2^31, c < 2^64) mod p, any representative
-__device__ __forceinline__ gl_t combine22_add_nc(uint32_t S0, uint32_t S1, uint32_t S2, gl_t c) {
-    const uint64_t t = (uint64_t)S0 + ((uint64_t)S1 << 22);
-    const uint64_t u = (uint64_t)(S2 & 0xFFFFFu) << 44;
-    uint64_t hi = S2 >> 20;
-    uint64_t lo = t + u;
-    hi += lo < t;
-    const uint64_t lo2 = lo + c;
-    hi += lo2 < lo;
-    uint64_t r = lo2 + ((hi << 32) - hi);  // hi <= 2^11 + 1
-    if (r < lo2) r += GL_EPS;
+
+// A + B * 2^32 mod p for A, B < 2^44, any representative
+__device__ __forceinline__ gl_t combine_lohi_nc(uint64_t A, uint64_t B) {
+    const uint32_t a0 = (uint32_t)A, a1 = (uint32_t)(A >> 32), b0 = (uint32_t)B, b1 = (uint32_t)(B >> 32);
+    const uint64_t t = (uint64_t)a1 + b0;                 // < 2^33
+    const uint64_t X = (t << 32) | a0;                    // words (a0, low word of t)
+    const uint32_t k = b1 + (uint32_t)(t >> 32);          // weight-2^64 part, < 2^13
+    uint64_t r = X + (uint64_t)k * 0xFFFFFFFFu;           // 2^64 = eps (mod p)
+    if (r < X) r += GL_EPS;                               // after a wrap r < 2^45: cannot wrap again
     return r;
 }
 
-template <int J>
-__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
-    // every lane of the quad reads lane J's value
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xF, 0xF, true);
-}
+// Round constants as the kernels stage them in LDS: per constant two 64-bit words (low half, high half), so each
+// is directly the 64-bit addend of the first multiply-add of its accumulator.
+struct RcPair {
+    uint64_t lo, hi;
+};
 
-__device__ __forceinline__ void quad_consts_init(QuadConsts& q, unsigned l) {
-    const uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+// MDS layer; the accumulators start from this lane's three round constants of the NEXT round.
+// diag0 = 8 on lane 0, 0 elsewhere (MDS_MATRIX_DIAG has a single non-zero entry, at element 0).
+__device__ __forceinline__ void poseidon_mds_quad(gl_t& s0, gl_t& s1, gl_t& s2, uint32_t diag0, const RcPair& c0, const RcPair& c1,
+                                                  const RcPair& c2) {
+    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    uint32_t lo[4][3], hi[4][3];  // [r][m]: halves of element 3((l + r) & 3) + m
+    lo[0][0] = (uint32_t)s0; hi[0][0] = (uint32_t)(s0 >> 32);
+    lo[0][1] = (uint32_t)s1; hi[0][1] = (uint32_t)(s1 >> 32);
+    lo[0][2] = (uint32_t)s2; hi[0][2] = (uint32_t)(s2 >> 32);
 #pragma unroll
-    for (int m = 0; m < 3; m++)
+    for (int m = 0; m < 3; m++) {
+        lo[1][m] = quad_rot<1>(lo[0][m]); hi[1][m] = quad_rot<1>(hi[0][m]);
+        lo[2][m] = quad_rot<2>(lo[0][m]); hi[2][m] = quad_rot<2>(hi[0][m]);
+        lo[3][m] = quad_rot<3>(lo[0][m]); hi[3][m] = quad_rot<3>(hi[0][m]);
+    }
+    gl_t out[3];
 #pragma unroll
-        for (int e = 0; e < 12; e++) {
-            // out[r] = sum_i s[(i + r) % 12] * CIRC[i]  =>  coefficient of s[e] in row r is CIRC[(e - r) mod 12]
-            uint32_t c = 0;
+    for (int mo = 0; mo < 3; mo++) {
+        const RcPair& c = mo == 0 ? c0 : mo == 1 ? c1 : c2;
+        uint64_t A = c.lo, B = c.hi;
+        // out[3l + mo] = sum_j CIRC[(j - (3l + mo)) mod 12] * x[j],  j = 3(l + r) + m
 #pragma unroll
-            for (int ll = 0; ll < 4; ll++) {
-                const int r = ll + 4 * m;
-                const uint32_t v = CIRC[(e - r + 24) % 12] + ((r == 0 && e == 0) ? 8u : 0u);
-                c = (l == (unsigned)ll) ? v : c;
-            }
-            // keep the 36 coefficients resident in VGPRs (do not rematerialise them from the lane id every round)
-            asm volatile("" : "+v"(c));
-            q.k[m][e] = c;
-        }
-}
-
-// MDS layer; also adds this lane's three round constants of the NEXT round (c0, c1, c2) before reducing
-__device__ __forceinline__ void poseidon_mds_quad(gl_t& s0, gl_t& s1, gl_t& s2, const QuadConsts& q, gl_t c0, gl_t c1, gl_t c2) {
-    uint32_t own[3][3];
-    limbs22(s0, own[0][0], own[0][1], own[0][2]);
-    limbs22(s1, own[1][0], own[1][1], own[1][2]);
-    limbs22(s2, own[2][0], own[2][1], own[2][2]);
-    uint32_t S[3][3];
-#pragma unroll
-    for (int m = 0; m < 3; m++) S[m][0] = S[m][1] = S[m][2] = 0;
-#pragma unroll
-    for (int slot = 0; slot < 3; slot++) {
-#pragma unroll
-        for (int limb = 0; limb < 3; limb++) {
-            const uint32_t v = own[slot][limb];
-            const uint32_t e0 = quad_bcast<0>(v), e1 = quad_bcast<1>(v), e2 = quad_bcast<2>(v), e3 = quad_bcast<3>(v);
+        for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int m = 0; m < 3; m++) {
-                uint32_t acc = S[m][limb];
-                acc = mad24(e0, q.k[m][4 * slot + 0], acc);
-                acc = mad24(e1, q.k[m][4 * slot + 1], acc);
-                acc = mad24(e2, q.k[m][4 * slot + 2], acc);
-                acc = mad24(e3, q.k[m][4 * slot + 3], acc);
-                S[m][limb] = acc;
+                const uint32_t k = CIRC[(3 * r + m - mo + 12) % 12];
+                A = mad32(lo[r][m], k, A);
+                B = mad32(hi[r][m], k, B);
             }
+        if (mo == 0) {
+            A = mad32(lo[0][0], diag0, A);
+            B = mad32(hi[0][0], diag0, B);
         }
+        out[mo] = combine_lohi_nc(A, B);  // A, B <= 2^32 + (276 + 8) * 2^32 < 2^41
     }
-    s0 = combine22_add_nc(S[0][0], S[0][1], S[0][2], c0);
-    s1 = combine22_add_nc(S[1][0], S[1][1], S[1][2], c1);
-    s2 = combine22_add_nc(S[2][0], S[2][1], S[2][2], c2);
+    s0 = out[0];
+    s1 = out[1];
+    s2 = out[2];
 }
 
-// rc: this lane's view of the round constants, rc[r * 3 + m] = RC[12 r + l + 4 m], r < 30, followed by three zeros.
+// rc: this lane's view of the round constants, rc[3 r + m] = split(RC[12 r + 3 l + m]), r < 30, followed by three zeros.
 // In: canonical or not; out: any representative (canonicalise with gl_canon before it leaves the kernel).
-__device__ __forceinline__ void poseidon_permute_quad(gl_t& s0, gl_t& s1, gl_t& s2, const QuadConsts& q, const gl_t* __restrict__ rc, bool lane0) {
-    s0 = gl_add_nc(s0, rc[0]);
-    s1 = gl_add_nc(s1, rc[1]);
-    s2 = gl_add_nc(s2, rc[2]);
+__device__ __forceinline__ void poseidon_permute_quad(gl_t& s0, gl_t& s1, gl_t& s2, uint32_t diag0, const RcPair* __restrict__ rc, bool lane0) {
+    s0 = gl_add_nc(s0, rc[0].lo | (rc[0].hi << 32));
+    s1 = gl_add_nc(s1, rc[1].lo | (rc[1].hi << 32));
+    s2 = gl_add_nc(s2, rc[2].lo | (rc[2].hi << 32));
     int r = 0;
 #pragma unroll 1
     for (; r < 4; r++) {
         s0 = sbox_nc(s0);
         s1 = sbox_nc(s1);
         s2 = sbox_nc(s2);
-        poseidon_mds_quad(s0, s1, s2, q, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
+        poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
     }
 #pragma unroll 1
     for (; r < 26; r++) {
         const gl_t t = sbox_nc(s0);
         s0 = lane0 ? t : s0;
-        poseidon_mds_quad(s0, s1, s2, q, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
+        poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
     }
 #pragma unroll 1
     for (; r < 30; r++) {
         s0 = sbox_nc(s0);
         s1 = sbox_nc(s1);
         s2 = sbox_nc(s2);
-        poseidon_mds_quad(s0, s1, s2, q, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
+        poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
     }
 }
 

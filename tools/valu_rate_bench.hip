@@ -1,0 +1,87 @@
+// Issue-rate microbenchmark for the integer VALU instructions the Goldilocks kernels are built from (gfx950).
+// Each kernel runs ITER iterations of 32 independent instructions of one kind in every wave; the host reports
+// cycles per wave-instruction per SIMD at W waves per SIMD.  Build: hipcc --offload-arch=gfx950 -O2 -o build/valu_rate_bench tools/valu_rate_bench.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define ITER 20000
+
+#define REP8(x) x x x x x x x x
+#define REP32(x) REP8(x) REP8(x) REP8(x) REP8(x)
+
+#define KERNEL(name, body)                                                                  \
+    __global__ __launch_bounds__(256) void name(unsigned* out, unsigned seed) {            \
+        unsigned a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 7, a3 = a0 ^ 0x55; \
+        unsigned long long q0 = a0 * 77ull + 1, q1 = a1 * 99ull + 3, q2 = 5;                \
+        for (int it = 0; it < ITER; it++) {                                                 \
+            asm volatile(REP32(body) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(q0), "+v"(q1), "+v"(q2)::"vcc", "s10", "s11"); \
+        }                                                                                   \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + (unsigned)q0 + (unsigned)q1 + (unsigned)q2; \
+    }
+
+KERNEL(k_add_u32, "v_add_u32 %0, %1, %2\n")
+KERNEL(k_add3_u32, "v_add3_u32 %0, %1, %2, %3\n")
+KERNEL(k_mul_u24, "v_mul_u32_u24 %0, %1, %2\n")
+KERNEL(k_mul_u24_dpp, "v_mul_u32_u24_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n")
+KERNEL(k_mad_u24, "v_mad_u32_u24 %0, %1, %2, %3\n")
+KERNEL(k_mad_u64_u32, "v_mad_u64_u32 %4, s[10:11], %1, %2, %5\n")
+KERNEL(k_mul_lo_u32, "v_mul_lo_u32 %0, %1, %2\n")
+KERNEL(k_mul_hi_u32, "v_mul_hi_u32 %0, %1, %2\n")
+KERNEL(k_lshl_add_u64, "v_lshl_add_u64 %4, %5, 0, %6\n")
+KERNEL(k_cmp_lt_u64, "v_cmp_lt_u64 vcc, %4, %5\n")
+KERNEL(k_cmp_lt_u32, "v_cmp_lt_u32 vcc, %1, %2\n")
+KERNEL(k_cndmask, "v_cndmask_b32 %0, %1, %2, vcc\n")
+KERNEL(k_add_co_pair, "v_add_co_u32 %0, vcc, %1, %2\n v_addc_co_u32 %3, vcc, %1, %2, vcc\n")
+KERNEL(k_lshlrev_b64, "v_lshlrev_b64 %4, 3, %5\n")
+KERNEL(k_alignbit, "v_alignbit_b32 %0, %1, %2, 7\n")
+KERNEL(k_mov_dpp, "v_mov_b32_dpp %0, %1 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n")
+KERNEL(k_cmp_cnd_chain, "v_cmp_lt_u64 vcc, %4, %5\n v_cndmask_b32 %0, %1, %2, vcc\n")
+KERNEL(k_dot4_u8, "v_dot4_u32_u8 %0, %1, %2, %3\n")
+KERNEL(k_pk_add_u16, "v_pk_add_u16 %0, %1, %2\n")
+
+typedef void (*kern_t)(unsigned*, unsigned);
+struct Entry {
+    const char* name;
+    kern_t k;
+    int per_rep;  // instructions per asm repetition
+};
+
+int main() {
+    Entry tab[] = {{"v_add_u32", k_add_u32, 1},          {"v_add3_u32", k_add3_u32, 1},        {"v_mul_u32_u24", k_mul_u24, 1},
+                   {"v_mul_u32_u24_dpp", k_mul_u24_dpp, 1}, {"v_mad_u32_u24", k_mad_u24, 1},     {"v_mad_u64_u32", k_mad_u64_u32, 1},
+                   {"v_mul_lo_u32", k_mul_lo_u32, 1},    {"v_mul_hi_u32", k_mul_hi_u32, 1},    {"v_lshl_add_u64", k_lshl_add_u64, 1},
+                   {"v_cmp_lt_u64", k_cmp_lt_u64, 1},    {"v_cmp_lt_u32", k_cmp_lt_u32, 1},    {"v_cndmask_b32", k_cndmask, 1},
+                   {"v_add_co+v_addc_co", k_add_co_pair, 2}, {"v_lshlrev_b64", k_lshlrev_b64, 1}, {"v_alignbit_b32", k_alignbit, 1},
+                   {"v_mov_b32_dpp", k_mov_dpp, 1},      {"v_cmp_lt_u64+v_cndmask", k_cmp_cnd_chain, 2}, {"v_dot4_u32_u8", k_dot4_u8, 1},
+                   {"v_pk_add_u16", k_pk_add_u16, 1}};
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    const double ghz = prop.clockRate / 1e6;
+    printf("device %s, %d CUs, %.2f GHz\n", prop.name, cus, ghz);
+    unsigned* out;
+    hipMalloc(&out, (size_t)cus * 16 * 256 * 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    printf("%-26s %10s %10s %10s   (cycles per wave-instruction per SIMD)\n", "instruction", "1 wave", "2 waves", "4 waves");
+    for (auto& en : tab) {
+        printf("%-26s", en.name);
+        for (int wps : {1, 2, 4}) {
+            const int blocks = cus * wps;  // 256 threads = 4 waves, one per SIMD
+            en.k<<<blocks, 256>>>(out, 1);
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            en.k<<<blocks, 256>>>(out, 2);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double instr_per_simd = (double)ITER * 32 * en.per_rep * wps;
+            printf(" %10.2f", ms * 1e-3 * ghz * 1e9 / instr_per_simd);
+        }
+        printf("\n");
+    }
+    return 0;
+}
