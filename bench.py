@@ -19,6 +19,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4  # wave-instructions/ns: one 4-cycle integer VALU instruction per SIMD (measured, tools/valu_rate_bench.hip)
+POSEIDON_QUAD_INSTRS = 22 * 254 + 8 * 451  # ISA instruction count of one permutation in the 4-lane form (poseidon_dev.h)
 
 
 def synthetic_final_exp_input(seed):
@@ -63,12 +65,13 @@ def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=1024, bud
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1,
+    ap.add_argument("--inflight", type=int, default=2,
                     help="proofs in flight per GPU (independent contexts on separate host threads and HIP streams); "
-                         "1 = one proof at a time (latency), 2 hides the host-side Fiat-Shamir hashing of one proof behind the kernels of another")
+                         "1 = one proof at a time (latency), 2 (default) hides the host-side Fiat-Shamir hashing and the launch gaps of one "
+                         "proof behind the kernels of another")
     args = ap.parse_args()
 
     import numpy as np
@@ -151,6 +154,17 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = parallel.max_over_ranks(dist, elapsed, device=f"cuda:{local_rank}")
 
+    # untimed: the same kernels with the GPU to themselves (one proof in flight), for the uncontended roofline numbers
+    solo_ms = {"lde_columns": 0.0, "leaf_hash": 0.0, "quotient_eval": 0.0}
+    solo_phase = {k: 0.0 for k in S.PHASE_NAMES}
+    n_solo = 2 if (rank == 0 and inflight > 1) else 0
+    for _ in range(n_solo):
+        step(prover)
+        for k, v in prover.last_kernel_timings().items():
+            solo_ms[k] += v / n_solo
+        for k, v in prover.last_timings().items():
+            solo_phase[k] += v / n_solo
+
     if rank == 0:
         steps = max(1, args.steps)
         phase_ms = {k: v / steps for k, v in phase_ms.items()}
@@ -160,6 +174,14 @@ def main():
                "leaf_hash": 8.0 * C * N,              # read the LDE once
                "quotient_eval": 8.0 * C * N}          # read the LDE on the quotient coset once
         dominant = max(kern_ms, key=kern_ms.get)
+        # HBM-side bytes per launch from the committed PMC passes (bench.py cannot collect counters itself)
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+            key = {"lde_columns": "lde_columns_v2_kernel", "leaf_hash": "leaf_hash_kernel", "quotient_eval": "quotient_eval_kernel"}[dominant]
+            traffic, traffic_src = pmc[key]["traffic_bytes"], pmc["_source"]
+        except Exception:
+            pass
         gbs = {k: alg[k] / (kern_ms[k] * 1e-3) / 1e9 if kern_ms[k] > 0 else 0.0 for k in alg}
         out = {
             "metric": "starky proofs/sec (FinalExponentiateStark 73527x8192)",
@@ -173,12 +195,27 @@ def main():
                                    "standard_fast_config (84 queries, 16 pow bits); one independent proof per GPU",
                        "parallelism": f"proof-parallel x{world}", "proofs_in_flight_per_gpu": inflight},
             "roofline": {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": gbs[dominant], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs[dominant] / HBM_PEAK_GBS, "traffic": None,
+                         "frac": gbs[dominant] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": kern_ms[dominant]},
             "kernels": {k: {"avg_ms": kern_ms[k], "algorithmic_GBps": gbs[k], "hbm_frac": gbs[k] / HBM_PEAK_GBS} for k in alg},
             "phase_ms": phase_ms,
+            "note": ("kernel and phase times above are HIP-event durations inside the timed region; with more than one proof in flight "
+                     "they include the time a kernel shares the CUs with the other proof's kernels. 'solo' repeats them with one proof in flight."),
             "reference_published": {"value": 1 / 92.0, "unit": "proofs/s", "hardware": "AWS r6a.8xlarge, 32-core EPYC 7R13 (reference README.md:39)"},
         }
+        if n_solo:
+            out["solo"] = {"kernels": {k: {"avg_ms": solo_ms[k], "algorithmic_GBps": alg[k] / (solo_ms[k] * 1e-3) / 1e9,
+                                           "hbm_frac": alg[k] / (solo_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS} for k in alg if solo_ms[k] > 0},
+                           "phase_ms": solo_phase}
+        # the leaf hash is VALU-issue bound, not HBM bound: static instruction count of one quad permutation x permutations / 16 quads per wave
+        perms = (C + 7) // 8 * N
+        wave_instr = perms * POSEIDON_QUAD_INSTRS / 16.0
+        lh_ms = (solo_ms["leaf_hash"] if n_solo else kern_ms["leaf_hash"])
+        if lh_ms > 0:
+            out["leaf_hash_valu"] = {"wave_instructions": wave_instr, "achieved_Ginstr_per_s": wave_instr / (lh_ms * 1e-3) / 1e9,
+                                     "peak_Ginstr_per_s": VALU_PEAK_GINSTR, "frac": wave_instr / (lh_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR,
+                                     "basis": "22 partial rounds x 254 + 8 full rounds x 451 instructions per 4-lane permutation (ISA count); "
+                                              "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per integer VALU instruction (tools/valu_rate_bench.hip)"}
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline_sample(S, S.air_program(air), C, log_n, cfg.rate_bits)

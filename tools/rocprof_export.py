@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3's sqlite output (ROCm 7.2 default format) into the small CSV summaries kept under profiles/.
+
+  rocprof_export.py stats  <results.db> <out.csv>          # what --kernel-trace --stats prints: per-kernel calls / total / average ns
+  rocprof_export.py pmc    <results.db> <out.csv>          # per kernel: launches, average counter value, average duration
+"""
+import csv
+import sqlite3
+import sys
+
+
+def short(name):
+    name = name.replace("starkhip::", "")
+    cut = name.find("(")
+    name = name if cut < 0 else name[:cut]
+    return name[:90]
+
+
+def main():
+    mode, db, out = sys.argv[1:4]
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        if mode == "stats":
+            w.writerow(["kernel", "calls", "total_ns", "average_ns", "percent"])
+            for name, calls, total, avg, pct in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+                w.writerow([short(name), calls, f"{total:.0f}", f"{avg:.0f}", f"{pct:.3f}"])
+        else:
+            w.writerow(["kernel", "counter", "launches", "average_value", "average_duration_ns"])
+            q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
+                 "group by kernel_name, counter_name order by sum(duration) desc")
+            for name, ctr, n, val, dur in cur.execute(q):
+                w.writerow([short(name), ctr, n, f"{val:.1f}", f"{dur:.0f}"])
+
+
+if __name__ == "__main__":
+    main()
