@@ -17,10 +17,13 @@ __device__ __forceinline__ gl_t gl_canon(gl_t x) { return x >= GL_P ? x - GL_P :
 // (hi * 2^64 + lo) mod p, any representative; hi, lo arbitrary
 __device__ __forceinline__ gl_t gl_reduce128_nc(uint64_t hi, uint64_t lo) {
     const uint32_t hi_lo = (uint32_t)hi, hi_hi = (uint32_t)(hi >> 32);
-    uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GL_EPS;
-    uint64_t r = t0 + (uint64_t)hi_lo * 0xFFFFFFFFu;  // + hi_lo * eps as one v_mad_u64_u32; hi_lo * eps < p
-    if (r < t0) r += GL_EPS;
+    // carries are taken from the add / subtract themselves (__builtin_*_overflow), which costs fewer instructions than
+    // comparing afterwards; the corrections are adds of a selected constant, not selects between two 64-bit candidates
+    uint64_t t0, r;
+    const bool borrow = __builtin_sub_overflow(lo, (uint64_t)hi_hi, &t0);
+    t0 -= borrow ? GL_EPS : 0;
+    const bool carry = __builtin_add_overflow(t0, (uint64_t)hi_lo * 0xFFFFFFFFu, &r);  // hi_lo * eps < p
+    r += carry ? GL_EPS : 0;
     return r;
 }
 
@@ -44,23 +47,23 @@ __device__ __forceinline__ gl_t gl_mad_nc(gl_t a, gl_t b, gl_t c) {
     const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
     uint64_t hi = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);  // <= 2^64 - 2
     const uint64_t lo0 = (p10 << 32) | (uint32_t)p00;
-    const uint64_t lo = lo0 + c;
-    hi += lo < lo0;
+    uint64_t lo;
+    hi += __builtin_add_overflow(lo0, c, &lo) ? 1 : 0;
     return gl_reduce128_nc(hi, lo);
 }
 
 // a arbitrary, b canonical (< p)
 __device__ __forceinline__ gl_t gl_add_nc(gl_t a, gl_t b) {
-    uint64_t s = a + b;
-    if (s < a) s += GL_EPS;  // wrapped: s <= p - 2, so + eps cannot wrap again
-    return s;
+    uint64_t s;
+    const bool c = __builtin_add_overflow(a, b, &s);
+    return s + (c ? GL_EPS : 0);  // wrapped: s <= p - 2, so + eps cannot wrap again
 }
 
 // a - b; a arbitrary, b canonical (< p)
 __device__ __forceinline__ gl_t gl_sub_nc(gl_t a, gl_t b) {
-    uint64_t d = a - b;
-    if (a < b) d -= GL_EPS;  // wrapped: d >= 2^64 - p + 1 > eps, so - eps cannot wrap again
-    return d;
+    uint64_t d;
+    const bool c = __builtin_sub_overflow(a, b, &d);
+    return d - (c ? GL_EPS : 0);  // wrapped: d >= 2^64 - p + 1 > eps, so - eps cannot wrap again
 }
 
 }  // namespace starkhip

@@ -26,17 +26,15 @@ namespace starkhip {
 
 // ---------------------------------------------------------------- arithmetic on arbitrary representatives
 __device__ __forceinline__ gl_t gl_add_nn(gl_t a, gl_t b) {
-    uint64_t s = a + b;
-    const bool c1 = s < a;
-    uint64_t s2 = s + (c1 ? GL_EPS : 0);
-    const bool c2 = c1 && (s2 < GL_EPS);
+    uint64_t s, s2;
+    const bool c1 = __builtin_add_overflow(a, b, &s);
+    const bool c2 = __builtin_add_overflow(s, c1 ? GL_EPS : 0, &s2);  // second wrap only when both were >= p - 1
     return s2 + (c2 ? GL_EPS : 0);
 }
 __device__ __forceinline__ gl_t gl_sub_nn(gl_t a, gl_t b) {
-    uint64_t d = a - b;
-    const bool b1 = a < b;
-    uint64_t d2 = d - (b1 ? GL_EPS : 0);
-    const bool b2 = b1 && (d < GL_EPS);
+    uint64_t d, d2;
+    const bool b1 = __builtin_sub_overflow(a, b, &d);
+    const bool b2 = __builtin_sub_overflow(d, b1 ? GL_EPS : 0, &d2);
     return d2 - (b2 ? GL_EPS : 0);
 }
 

@@ -143,15 +143,36 @@ __device__ __forceinline__ gl_t sbox_nc(gl_t x) {
     return gl_mul_nc(x3, x4);
 }
 
+template <int ROT>
+__device__ __forceinline__ gl_t quad_rot64(gl_t v) {
+    return (gl_t)quad_rot<ROT>((uint32_t)v) | ((gl_t)quad_rot<ROT>((uint32_t)(v >> 32)) << 32);
+}
+__device__ __forceinline__ gl_t quad_lane0_64(gl_t v) {  // every lane of the quad reads lane 0's value
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)v, 0x00, 0xF, 0xF, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), 0x00, 0xF, 0xF, true);
+    return (gl_t)lo | ((gl_t)hi << 32);
+}
+
+// Partial rounds: x^7 of lane 0's element only.  The quad's other lanes would repeat lane 0's four multiplies for
+// nothing, so lane 1 is put to work instead: after x^2, lane 0 forms x^3 = x^2 * x while lane 1 forms x^4 = x^2 * x^2 in
+// the SAME multiply, then lane 0 fetches x^4 from lane 1 for x^7 = x^3 * x^4: three multiplies deep instead of four.
+__device__ __forceinline__ gl_t sbox_lane0_nc(gl_t s0, bool lane0) {
+    const gl_t x2 = quad_lane0_64(gl_mul_nc(s0, s0));          // lane 0's x^2 in every lane
+    const gl_t y = gl_mul_nc(x2, lane0 ? s0 : x2);              // lane 0: x^3, lanes 1..3: x^4
+    const gl_t x7 = gl_mul_nc(y, quad_rot64<1>(y));             // lane 0: x^3 * (lane 1's x^4)
+    return lane0 ? x7 : s0;
+}
+
 // A + B * 2^32 mod p for A, B < 2^44, any representative
 __device__ __forceinline__ gl_t combine_lohi_nc(uint64_t A, uint64_t B) {
     const uint32_t a0 = (uint32_t)A, a1 = (uint32_t)(A >> 32), b0 = (uint32_t)B, b1 = (uint32_t)(B >> 32);
-    const uint64_t t = (uint64_t)a1 + b0;                 // < 2^33
-    const uint64_t X = (t << 32) | a0;                    // words (a0, low word of t)
-    const uint32_t k = b1 + (uint32_t)(t >> 32);          // weight-2^64 part, < 2^13
-    uint64_t r = X + (uint64_t)k * 0xFFFFFFFFu;           // 2^64 = eps (mod p)
-    if (r < X) r += GL_EPS;                               // after a wrap r < 2^45: cannot wrap again
-    return r;
+    uint32_t t;
+    const bool c = __builtin_add_overflow(a1, b0, &t);    // a1 + b0 < 2^33
+    const uint64_t X = ((uint64_t)t << 32) | a0;          // words (a0, t)
+    const uint32_t k = b1 + (c ? 1u : 0u);                // weight-2^64 part, < 2^13
+    uint64_t r;
+    const bool c2 = __builtin_add_overflow(X, (uint64_t)k * 0xFFFFFFFFu, &r);  // 2^64 = eps (mod p)
+    return r + (c2 ? GL_EPS : 0);                         // after a wrap r < 2^45: cannot wrap again
 }
 
 // Round constants as the kernels stage them in LDS: per constant two 64-bit words (low half, high half), so each
@@ -216,8 +237,7 @@ __device__ __forceinline__ void poseidon_permute_quad(gl_t& s0, gl_t& s1, gl_t& 
     }
 #pragma unroll 1
     for (; r < 26; r++) {
-        const gl_t t = sbox_nc(s0);
-        s0 = lane0 ? t : s0;
+        s0 = sbox_lane0_nc(s0, lane0);
         poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
     }
 #pragma unroll 1
