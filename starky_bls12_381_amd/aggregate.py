@@ -1,0 +1,139 @@
+"""Host drivers around the hot path: the STARK half of the reference's `generate_aggregate_proof`.
+
+Mirrors /root/reference/src/aggregate_proof.rs:
+  calc_pairing_precomp    :23-72    PairingPrecompStark(1024), rate_bits 2
+  miller_loop_main        :74-118   MillerLoopStark(1024)
+  fp12_mul_main           :120-151  FP12MulStark(16)
+  final_exponentiate_main :153-179  FinalExponentiateStark(8192), rate_bits 2
+each = build config, generate trace + public inputs, prove, verify_stark_proof, return (air, proof, config);
+and the six-proof plan of one BLS signature check (:304-370): pp1, ml1 on (aggregate pk, H(m)), pp2, ml2 on
+(-G1 generator, signature), fp12_mul on the two Miller-loop values, final_exponentiate on their product.
+Out of scope here (SURVEY.md §8f / DESIGN.md §8): the EC aggregation AIR, hash-to-curve, the plonky2 recursion.
+
+Points are passed as u32 limb arrays (Fp = 12 limbs, Fp2 = 24: c0 then c1), exactly what the reference's
+`get_u32_slice()` yields.  `prover` is an `api.Prover` bound to one GPU; nothing here touches the oracle.
+"""
+import numpy as np
+
+from . import api as S
+from . import parallel
+
+# -G1 generator, the fixed first argument of the second pairing (src/aggregate_proof.rs:336-337)
+NEG_G1_X = 3685416753713387016781088315183077757961620795782546409894578378688607592378376318836054947676345821548104185464507
+NEG_G1_Y = 2662903010277190920397318445793982934971948944000658264905514399707520226534504357969962973775649129045502516118218
+
+JOB_ORDER = ("pp1", "ml1", "pp2", "ml2", "fp12_mul", "final_exp")  # the order the reference proves them in
+JOB_AIR = {"pp1": S.AIR_PAIRING_PRECOMP, "pp2": S.AIR_PAIRING_PRECOMP, "ml1": S.AIR_MILLER_LOOP, "ml2": S.AIR_MILLER_LOOP,
+           "fp12_mul": S.AIR_FP12_MUL, "final_exp": S.AIR_FINAL_EXP}
+
+
+def fp_limbs(v):
+    """One Fp as 12 little-endian u32 limbs (src/native.rs Fp([u32; 12]))."""
+    v = int(v)
+    return np.array([(v >> (32 * i)) & 0xFFFFFFFF for i in range(12)], dtype=np.uint32)
+
+
+def fp2_limbs(c0, c1):
+    return np.concatenate([fp_limbs(c0), fp_limbs(c1)])
+
+
+def _prove_and_verify(prover, air, trace, pis):
+    cfg = S.StarkConfig.for_air(air)
+    proof = prover.prove(air, cfg, trace, pis)
+    S.verify_stark_proof(air, cfg, proof)  # src/aggregate_proof.rs:67,113,146,177
+    return air, proof, cfg
+
+
+def calc_pairing_precomp(prover, x, y, z):
+    """src/aggregate_proof.rs:23-72.  x, y, z: Fp2 limb arrays of the G2 point."""
+    trace, pis = S.trace_pairing_precomp(x, y, z)
+    return _prove_and_verify(prover, S.AIR_PAIRING_PRECOMP, trace, pis)
+
+
+def miller_loop_main(prover, x, y, q_x, q_y, q_z):
+    """src/aggregate_proof.rs:74-118.  (x, y): G1 point (Fp limbs); (q_x, q_y, q_z): G2 point (Fp2 limbs)."""
+    trace, pis = S.trace_miller_loop(x, y, q_x, q_y, q_z)
+    return _prove_and_verify(prover, S.AIR_MILLER_LOOP, trace, pis)
+
+
+def fp12_mul_main(prover, x, y):
+    """src/aggregate_proof.rs:120-151."""
+    trace, pis = S.trace_fp12_mul(x, y)
+    return _prove_and_verify(prover, S.AIR_FP12_MUL, trace, pis)
+
+
+def final_exponentiate_main(prover, x):
+    """src/aggregate_proof.rs:153-179."""
+    trace, pis = S.trace_final_exp(x)
+    return _prove_and_verify(prover, S.AIR_FINAL_EXP, trace, pis)
+
+
+def signature_jobs(pk, hm, sig):
+    """The six proof jobs of one signature check, in the reference's order, with the natives that link them.
+
+    pk = (x, y) Fp limbs of the aggregate public key; hm, sig = (x, y, z) Fp2 limbs of H(m) and the signature.
+    Returns (jobs, natives): jobs[name] = (driver function, args); natives = {"ml1", "ml2", "product", "final"} Fp12 limbs.
+    The Miller-loop values are computed natively first, as the reference does at :352-353, so that all six jobs are
+    independent and can be proven on different GPUs."""
+    neg_g = (fp_limbs(NEG_G1_X), fp_limbs(NEG_G1_Y))
+    ml1 = S.native_miller_loop(pk[0], pk[1], hm[0], hm[1], hm[2])
+    ml2 = S.native_miller_loop(neg_g[0], neg_g[1], sig[0], sig[1], sig[2])
+    product = S.native_fp12_mul(ml1, ml2)
+    jobs = {
+        "pp1": (calc_pairing_precomp, (hm[0], hm[1], hm[2])),
+        "ml1": (miller_loop_main, (pk[0], pk[1], hm[0], hm[1], hm[2])),
+        "pp2": (calc_pairing_precomp, (sig[0], sig[1], sig[2])),
+        "ml2": (miller_loop_main, (neg_g[0], neg_g[1], sig[0], sig[1], sig[2])),
+        "fp12_mul": (fp12_mul_main, (ml1, ml2)),
+        "final_exp": (final_exponentiate_main, (product,)),
+    }
+    natives = {"ml1": ml1, "ml2": ml2, "product": product, "final": S.native_final_exponentiate(product)}
+    return jobs, natives
+
+
+def signature_is_valid(natives):
+    """e(pk, H(m)) * e(-G, sig) == 1  <=>  final_exponentiate(ml1 * ml2) == 1 (src/native.rs:1522-1526)."""
+    one = np.zeros(144, dtype=np.uint32)
+    one[0] = 1
+    return bool(np.array_equal(np.asarray(natives["final"], dtype=np.uint32), one))
+
+
+def check_links(proofs):
+    """The cross-proof equalities the reference's recursive aggregation enforces on public inputs:
+    ell_coeffs produced by pp_i are the ones ml_i consumed; ml outputs are the fp12_mul inputs; its output is the
+    final_exp input.  `proofs[name]` = (air, proof, cfg); public inputs are the tail of each proof blob."""
+    def pis(name):
+        air, proof, _ = proofs[name]
+        n = S.air_public_inputs(air)
+        return np.asarray(proof[-n:], dtype=np.uint64)
+    ok = True
+    for i in ("1", "2"):
+        pp, ml = pis("pp" + i), pis("ml" + i)
+        ell = pp[72:]                 # after x, y, z (3 Fp2 = 72 limbs): 68 x 3 Fp2 coefficients
+        ok &= bool(np.array_equal(ell, ml[24:24 + ell.size]))   # after px, py (2 Fp = 24 limbs)
+    mul = pis("fp12_mul")
+    ok &= bool(np.array_equal(pis("ml1")[-144:], mul[0:144]))
+    ok &= bool(np.array_equal(pis("ml2")[-144:], mul[144:288]))
+    ok &= bool(np.array_equal(mul[288:432], pis("final_exp")[0:144]))
+    return ok
+
+
+def signature_plan(world, names=JOB_ORDER):
+    """Per-rank job names: longest-processing-time-first on the per-AIR cost weights (parallel.AIR_COST)."""
+    plan = parallel.assign_jobs([parallel.AIR_COST[JOB_AIR[n]] for n in names], world)
+    return [[names[i] for i in idxs] for idxs in plan]
+
+
+def prove_signature(prover, pk, hm, sig, dist=None, names=JOB_ORDER):
+    """Prove this rank's share of the six proofs of one signature check.
+
+    Jobs are assigned with longest-processing-time scheduling on the per-AIR cost weights (parallel.AIR_COST):
+    one process per GPU, no collective on the data path; every rank derives the same plan from the same inputs.
+    Returns {name: (air, proof, cfg)} for the jobs this rank ran, and the natives."""
+    rank, _, world = parallel.rank_info() if dist is not None else (0, 0, 1)
+    jobs, natives = signature_jobs(pk, hm, sig)
+    out = {}
+    for name in signature_plan(world, names)[rank]:
+        fn, args = jobs[name]
+        out[name] = fn(prover, *args)
+    return out, natives
