@@ -40,9 +40,9 @@ hipError_t launch_pow_grind(const gl_t* base_state, int pos, unsigned pow_bits, 
 
 // kernels_quotient.hip
 hipError_t launch_quotient_tables(gl_t* tab, unsigned log_n, unsigned qdb, hipStream_t st);
-hipError_t launch_quotient_eval(const QOp* ops, const uint32_t* chunk_batch, unsigned n_chunks, const gl_t* pis, const gl_t* lde, const gl_t* tab,
-                                const gl_t* apow, gl_t alpha0, gl_t alpha1, gl_t* partial, unsigned log_n, unsigned rate_bits, unsigned qdb,
-                                hipStream_t st);
+hipError_t launch_quotient_eval(const QOp* ops, const uint32_t* loads, unsigned n_slots, const uint32_t* chunk_batch, unsigned n_chunks,
+                                const gl_t* pis, const gl_t* lde, const gl_t* tab, const gl_t* apow, gl_t alpha0, gl_t alpha1, gl_t* partial,
+                                unsigned log_n, unsigned rate_bits, unsigned qdb, hipStream_t st);
 hipError_t launch_quotient_combine(const gl_t* partial, const gl_t* chunk_scale, unsigned n_chunks, const gl_t* tab, unsigned log_n,
                                    unsigned qdb, gl_t* out, hipStream_t st);
 

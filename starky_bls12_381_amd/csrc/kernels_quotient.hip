@@ -4,12 +4,19 @@
 //  src/calc_pairing_precomp.rs:376, src/fp12_mul.rs:58).
 //
 // The AIR arrives as the op stream of quotient_ops.h (the flat program of air_ir.h in 16-byte ops).
-// One lane owns one coset point; ops are wave-uniform and are fetched four at a time with one scalar
-// load, two batches ahead; their four trace-cell loads (scalar column base + per-lane 32-bit offset,
-// each a coalesced 512-byte line of the coset-major LDE) are issued one batch ahead of the arithmetic,
-// so neither the scalar nor the vector memory latency sits on the dependent chain.  Field arithmetic is
-// the lazy-reduction form of gl_dev.h.  The program is cut into `n_chunks` pieces at group boundaries so
-// that (points / 64) x n_chunks waves fill the chip; a chunk's partial fold is scaled by
+// One lane owns one coset point; ops are wave-uniform and are fetched four at a time with one scalar load.
+//
+// Memory: a chunk of the FinalExp program touches each trace column ~15 times, a few hundred ops apart --
+// too far for L1/L2 with thousands of waves in flight (the first version fetched 249 GB per launch, 12.9x the
+// LDE's 19.3 GB).  So every wave (= workgroup) keeps a cell cache in LDS, `n_slots` x 64 lanes x 8 B, whose
+// slot assignment the host computed with Belady's rule (attach_cell_cache).  An op either reads its cell from a
+// slot, or takes it from its global load and, if told so, writes it to a slot for later ops.  EVERY op issues
+// exactly one global load (ops that need none load column 0, an L1 hit), four batches ahead of its use, so the
+// s_waitcnt counts are compile-time constants and the HBM / MALL latency sits behind three batches of work; LDS
+// reads are issued one batch ahead.  The batch loop is unrolled four times so both staging rings are registers.
+//
+// Field arithmetic is the lazy-reduction form of gl_dev.h.  The program is cut into `n_chunks` pieces at group
+// boundaries so that (points / 64) x n_chunks waves fill the chip; a chunk's partial fold is scaled by
 // alpha^(constraints after the chunk) in the combine kernel, which is exact in the field.
 #include <hip/hip_runtime.h>
 
@@ -22,6 +29,9 @@ namespace starkhip {
 
 struct alignas(64) QBatch {
     QOp op[QOP_BATCH];
+};
+struct alignas(16) QLoads {
+    uint32_t ref[QOP_BATCH];
 };
 
 // Per-point tables in the quotient domain's physical order t = s' * n + k  <->  i = k * 2^qdb + s',
@@ -43,29 +53,106 @@ __global__ void quotient_tables_kernel(gl_t* tab, unsigned log_n, unsigned qdb) 
 }
 
 struct QuotientParams {
-    const QBatch* ops;          // compile_quotient_ops() output, batches of QOP_BATCH ops
-    const uint32_t* chunk_batch;// [n_chunks + 1] first batch of each chunk
+    const QBatch* ops;           // compile_quotient_ops() + attach_cell_cache() output, batches of QOP_BATCH ops
+    const QLoads* loads;         // per batch, the four cellrefs to load
+    const uint32_t* chunk_batch; // [n_chunks + 1] first batch of each chunk
     const gl_t* pis;
-    const gl_t* lde;            // [C][N] coset-major
-    const gl_t* tab;            // quotient_tables_kernel output
-    const gl_t* apow;           // [2][AIR_MAX_GROUP + 1] powers of alpha_0 / alpha_1
-    gl_t* partial;              // [n_chunks][2][size]
+    const gl_t* lde;             // [C][N] coset-major
+    const gl_t* tab;             // quotient_tables_kernel output
+    const gl_t* apow;            // [2][AIR_MAX_GROUP + 1] powers of alpha_0 / alpha_1
+    gl_t* partial;               // [n_chunks][2][size]
     gl_t alpha0, alpha1;
     unsigned log_n, rate_bits, qdb;
 };
 
-// The four cell loads of one batch: scalar base (lde + col * N * 8, SALU) + 32-bit per-lane byte offset.
-__device__ __forceinline__ void quotient_issue_loads(const QBatch& b, const char* __restrict__ lde, unsigned col_shift, uint32_t boff_local,
-                                                     uint32_t boff_next, gl_t (&x)[QOP_BATCH]) {
+// per-lane evaluation state
+struct QState {
+    gl_t acc0, acc1, t0, t1, G, body, v;
+};
+struct QLane {
+    const char* lde;
+    const gl_t* pis;
+    const gl_t* apow;
+    gl_t a0, a1, mask_tr, mask_first, mask_last;
+    uint32_t boff_local, boff_next;
+    unsigned col_shift;
+};
+
+// The four (always issued) cell loads of one batch: scalar base (lde + col * N * 8, SALU) + 32-bit per-lane byte offset.
+__device__ __forceinline__ void quotient_issue_loads(const QLoads& r, const QLane& L, gl_t (&x)[QOP_BATCH]) {
+#pragma unroll
+    for (unsigned i = 0; i < QOP_BATCH; i++) {
+        const uint32_t ref = r.ref[i];
+        const char* base = L.lde + ((uint64_t)(ref & REF_COL_MASK) << L.col_shift);
+        x[i] = *(const gl_t*)(base + ((ref & REF_NEXT) ? L.boff_next : L.boff_local));
+    }
+}
+
+// LDS reads of the ops of one batch that take their cell from the cache
+__device__ __forceinline__ void quotient_cache_reads(const QBatch& b, const gl_t* cache_lane, gl_t (&x)[QOP_BATCH]) {
 #pragma unroll
     for (unsigned i = 0; i < QOP_BATCH; i++) {
         const uint32_t ref = b.op[i].ref;
-        const char* base = lde + ((uint64_t)(ref & REF_COL_MASK) << col_shift);
-        x[i] = *(const gl_t*)(base + ((ref & REF_NEXT) ? boff_next : boff_local));
+        if (ref & QREF_FROM_LDS) x[i] = cache_lane[(ref & QREF_SLOT_MASK) << 6];
+    }
+}
+
+__device__ __forceinline__ void quotient_eval_batch(const QBatch& cur, const gl_t (&xg)[QOP_BATCH], const gl_t (&xl)[QOP_BATCH], gl_t* cache_lane,
+                                                    const QLane& L, QState& S) {
+#pragma unroll
+    for (unsigned i = 0; i < QOP_BATCH; i++) {
+        const uint32_t hdr = cur.op[i].hdr, ref = cur.op[i].ref;
+        const gl_t x = (ref & QREF_FROM_LDS) ? xl[i] : xg[i];  // canonical (LDE output)
+        if (ref & QREF_STORE) cache_lane[(ref & QREF_SLOT_MASK) << 6] = x;
+        switch (hdr & 7u) {
+            case QOP_TERM: {
+                gl_t u = (hdr & QOP_NOCELL) ? (gl_t)1 : x;
+                if (hdr & QOP_PREV) u = gl_canon(gl_mul_nc(S.v, x));
+                const uint32_t ck = (hdr >> QOP_CK_SHIFT) & 7u;
+                if (ck == CK_PLUS) S.body = gl_add_nc(S.body, u);
+                else if (ck == CK_MINUS) S.body = gl_sub_nc(S.body, u);
+                else {
+                    gl_t kk = cur.op[i].k;
+                    if (ck != CK_CONST) {
+                        kk = L.pis[hdr >> QOP_IDX_SHIFT];
+                        if (ck == CK_NEG_PI) kk = kk ? GL_P - kk : 0;
+                    }
+                    S.body = gl_mad_nc(u, kk, S.body);
+                }
+                if (hdr & QOP_FOLD) {
+                    S.t0 = gl_mad_nc(S.t0, L.a0, S.body);
+                    S.t1 = gl_mad_nc(S.t1, L.a1, S.body);
+                    S.body = 0;
+                }
+                break;
+            }
+            case QOP_FACTOR:
+                S.v = (hdr & QOP_PREV) ? gl_mul_nc(S.v, x) : x;
+                break;
+            case QOP_GATE:
+                S.G = gl_mul_nc(S.G, (ref & REF_COMPL) ? gl_sub_nc(1, x) : x);
+                break;
+            case QOP_GROUP: {
+                const uint32_t kind = (hdr >> QOP_KIND_SHIFT) & 3u;
+                S.G = kind == KIND_PLAIN ? (gl_t)1 : kind == KIND_TRANSITION ? L.mask_tr : kind == KIND_FIRST ? L.mask_first : L.mask_last;
+                S.t0 = 0;
+                S.t1 = 0;
+                break;
+            }
+            case QOP_ENDGROUP: {
+                const uint32_t m = hdr >> QOP_IDX_SHIFT;
+                S.acc0 = gl_mad_nc(S.acc0, L.apow[m], gl_mul_nc(S.G, S.t0));
+                S.acc1 = gl_mad_nc(S.acc1, L.apow[(AIR_MAX_GROUP + 1) + m], gl_mul_nc(S.G, S.t1));
+                break;
+            }
+            default:
+                break;
+        }
     }
 }
 
 __global__ __launch_bounds__(64) void quotient_eval_kernel(QuotientParams P) {
+    extern __shared__ gl_t cell_cache[];  // [n_slots][64]
     const size_t n = (size_t)1 << P.log_n, size = n << P.qdb;
     const unsigned t_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t_raw < size;  // domains smaller than a wave (FP12Mul: 32 points): idle lanes shadow point 0
@@ -73,86 +160,57 @@ __global__ __launch_bounds__(64) void quotient_eval_kernel(QuotientParams P) {
     const unsigned chunk = blockIdx.y;
     const unsigned sp = t >> P.log_n, k = t & (unsigned)(n - 1);
     const unsigned s = sp << (P.rate_bits - P.qdb);  // LDE coset of this quotient point
-    const uint32_t boff_local = (s * (unsigned)n + k) * 8u;                           // < 2^32: N * 8 <= 2^(13+3+3)
-    const uint32_t boff_next = (s * (unsigned)n + ((k + 1) & (unsigned)(n - 1))) * 8u;
-    const unsigned col_shift = P.log_n + P.rate_bits + 3;
-    const gl_t mask_tr = P.tab[t], mask_first = P.tab[size + t], mask_last = P.tab[2 * size + t];
+    QLane L;
+    L.lde = (const char*)P.lde;
+    L.pis = P.pis;
+    L.apow = P.apow;
+    L.a0 = P.alpha0;
+    L.a1 = P.alpha1;
+    L.mask_tr = P.tab[t];
+    L.mask_first = P.tab[size + t];
+    L.mask_last = P.tab[2 * size + t];
+    L.boff_local = (s * (unsigned)n + k) * 8u;  // < 2^32: N * 8 <= 2^(13+3+3)
+    L.boff_next = (s * (unsigned)n + ((k + 1) & (unsigned)(n - 1))) * 8u;
+    L.col_shift = P.log_n + P.rate_bits + 3;
+    gl_t* cache_lane = cell_cache + threadIdx.x;
 
     const QBatch* __restrict__ ops = P.ops;
-    const gl_t* __restrict__ pis = P.pis;
-    const gl_t* __restrict__ apow = P.apow;
-    const char* __restrict__ lde = (const char*)P.lde;
-    const gl_t a0 = P.alpha0, a1 = P.alpha1;
+    const QLoads* __restrict__ loads = P.loads;
     unsigned b = P.chunk_batch[chunk];
-    const unsigned b_end = P.chunk_batch[chunk + 1];
+    const unsigned b_end = P.chunk_batch[chunk + 1];  // b_end - b is a multiple of QOP_UNROLL
 
-    gl_t acc0 = 0, acc1 = 0, t0 = 0, t1 = 0, G = 1, body = 0, v = 1;
-    // software pipeline: ops of batch b+2 and cells of batch b+1 are in flight while batch b is evaluated
-    QBatch cur = ops[b];
-    gl_t x_cur[QOP_BATCH];
-    quotient_issue_loads(cur, lde, col_shift, boff_local, boff_next, x_cur);
-    QBatch nxt = ops[b + 1];
-    for (; b < b_end; b++) {
-        gl_t x_nxt[QOP_BATCH];
-        quotient_issue_loads(nxt, lde, col_shift, boff_local, boff_next, x_nxt);
-        const QBatch nn = ops[b + 2];
+    QState S = {0, 0, 0, 0, 1, 0, 1};
+    // the two staging rings as separately named arrays, so that every index is a constant and they stay in registers
+    static_assert(QOP_UNROLL == 4, "the step sequence below is written out for a ring of four");
+    gl_t xg0[QOP_BATCH], xg1[QOP_BATCH], xg2[QOP_BATCH], xg3[QOP_BATCH], xl0[QOP_BATCH], xl1[QOP_BATCH];
+    quotient_issue_loads(loads[b + 0], L, xg0);
+    quotient_issue_loads(loads[b + 1], L, xg1);
+    quotient_issue_loads(loads[b + 2], L, xg2);
+    quotient_issue_loads(loads[b + 3], L, xg3);
+    QLoads rn = loads[b + QOP_UNROLL];
+    QBatch cur = ops[b], nxt = ops[b + 1];
 #pragma unroll
-        for (unsigned i = 0; i < QOP_BATCH; i++) {
-            const uint32_t hdr = cur.op[i].hdr;
-            const gl_t x = x_cur[i];  // canonical (LDE output)
-            switch (hdr & 7u) {
-                case QOP_TERM: {
-                    gl_t u = (hdr & QOP_NOCELL) ? (gl_t)1 : x;
-                    if (hdr & QOP_PREV) u = gl_canon(gl_mul_nc(v, x));
-                    const uint32_t ck = (hdr >> QOP_CK_SHIFT) & 7u;
-                    if (ck == CK_PLUS) body = gl_add_nc(body, u);
-                    else if (ck == CK_MINUS) body = gl_sub_nc(body, u);
-                    else {
-                        gl_t kk = cur.op[i].k;
-                        if (ck != CK_CONST) {
-                            kk = pis[hdr >> QOP_IDX_SHIFT];
-                            if (ck == CK_NEG_PI) kk = kk ? GL_P - kk : 0;
-                        }
-                        body = gl_mad_nc(u, kk, body);
-                    }
-                    if (hdr & QOP_FOLD) {
-                        t0 = gl_mad_nc(t0, a0, body);
-                        t1 = gl_mad_nc(t1, a1, body);
-                        body = 0;
-                    }
-                    break;
-                }
-                case QOP_FACTOR:
-                    v = (hdr & QOP_PREV) ? gl_mul_nc(v, x) : x;
-                    break;
-                case QOP_GATE:
-                    G = gl_mul_nc(G, (cur.op[i].ref & REF_COMPL) ? gl_sub_nc(1, x) : x);
-                    break;
-                case QOP_GROUP: {
-                    const uint32_t kind = (hdr >> QOP_KIND_SHIFT) & 3u;
-                    G = kind == KIND_PLAIN ? (gl_t)1 : kind == KIND_TRANSITION ? mask_tr : kind == KIND_FIRST ? mask_first : mask_last;
-                    t0 = 0;
-                    t1 = 0;
-                    break;
-                }
-                case QOP_ENDGROUP: {
-                    const uint32_t m = hdr >> QOP_IDX_SHIFT;
-                    acc0 = gl_mad_nc(acc0, apow[m], gl_mul_nc(G, t0));
-                    acc1 = gl_mad_nc(acc1, apow[(AIR_MAX_GROUP + 1) + m], gl_mul_nc(G, t1));
-                    break;
-                }
-                default:
-                    break;
-            }
-        }
-        cur = nxt;
-        nxt = nn;
-#pragma unroll
-        for (unsigned i = 0; i < QOP_BATCH; i++) x_cur[i] = x_nxt[i];
+    for (unsigned i = 0; i < QOP_BATCH; i++) xl0[i] = xl1[i] = 0;
+#define QSTEP(U, XG, XL_CUR, XL_NXT)                                                                         \
+    {                                                                                                        \
+        quotient_cache_reads(nxt, cache_lane, XL_NXT); /* batch b+U+1, before this batch's slot writes */   \
+        const QBatch nn = ops[b + (U) + 2];                                                                  \
+        quotient_eval_batch(cur, XG, XL_CUR, cache_lane, L, S);                                              \
+        quotient_issue_loads(rn, L, XG); /* batch b+U+4 takes over this ring entry */                        \
+        rn = loads[b + (U) + QOP_UNROLL + 1];                                                                \
+        cur = nxt;                                                                                           \
+        nxt = nn;                                                                                            \
     }
+    for (; b < b_end; b += QOP_UNROLL) {
+        QSTEP(0, xg0, xl0, xl1)
+        QSTEP(1, xg1, xl1, xl0)
+        QSTEP(2, xg2, xl0, xl1)
+        QSTEP(3, xg3, xl1, xl0)
+    }
+#undef QSTEP
     if (live) {
-        P.partial[((size_t)chunk * 2 + 0) * size + t] = gl_canon(acc0);
-        P.partial[((size_t)chunk * 2 + 1) * size + t] = gl_canon(acc1);
+        P.partial[((size_t)chunk * 2 + 0) * size + t] = gl_canon(S.acc0);
+        P.partial[((size_t)chunk * 2 + 1) * size + t] = gl_canon(S.acc1);
     }
 }
 
@@ -178,14 +236,16 @@ hipError_t launch_quotient_tables(gl_t* tab, unsigned log_n, unsigned qdb, hipSt
     return hipGetLastError();
 }
 
-hipError_t launch_quotient_eval(const QOp* ops, const uint32_t* chunk_batch, unsigned n_chunks, const gl_t* pis, const gl_t* lde, const gl_t* tab,
-                                const gl_t* apow, gl_t alpha0, gl_t alpha1, gl_t* partial, unsigned log_n, unsigned rate_bits, unsigned qdb,
-                                hipStream_t st) {
+hipError_t launch_quotient_eval(const QOp* ops, const uint32_t* loads, unsigned n_slots, const uint32_t* chunk_batch, unsigned n_chunks,
+                                const gl_t* pis, const gl_t* lde, const gl_t* tab, const gl_t* apow, gl_t alpha0, gl_t alpha1, gl_t* partial,
+                                unsigned log_n, unsigned rate_bits, unsigned qdb, hipStream_t st) {
     QuotientParams P;
-    P.ops = (const QBatch*)ops; P.chunk_batch = chunk_batch; P.pis = pis; P.lde = lde; P.tab = tab; P.apow = apow; P.partial = partial;
+    P.ops = (const QBatch*)ops; P.loads = (const QLoads*)loads; P.chunk_batch = chunk_batch; P.pis = pis; P.lde = lde; P.tab = tab;
+    P.apow = apow; P.partial = partial;
     P.alpha0 = alpha0; P.alpha1 = alpha1; P.log_n = log_n; P.rate_bits = rate_bits; P.qdb = qdb;
     size_t size = (size_t)1 << (log_n + qdb);
-    hipLaunchKernelGGL(quotient_eval_kernel, dim3((unsigned)((size + 63) / 64), n_chunks), dim3(64), 0, st, P);
+    const size_t lds_bytes = (size_t)(n_slots ? n_slots : 1) * 64 * sizeof(gl_t);
+    hipLaunchKernelGGL(quotient_eval_kernel, dim3((unsigned)((size + 63) / 64), n_chunks), dim3(64), lds_bytes, st, P);
     return hipGetLastError();
 }
 

@@ -63,7 +63,8 @@ struct Ctx {
     // program
     int prog_air = -1;
     unsigned prog_chunks = 0;
-    DevBuf d_ops, d_chunk_off;  // compile_quotient_ops() output for prog_air
+    DevBuf d_ops, d_loads, d_chunk_off;  // compile_quotient_ops() + attach_cell_cache() output for prog_air
+    unsigned prog_slots = 0;
     std::vector<uint32_t> chunk_k_after;
     // work buffers
     DevBuf staging, values, coeffs, lde, digests, pis, apow, chunk_scale, partial, qvals, qcoef, qlde, qdigests, zpow, gzpow, open_local,
@@ -113,8 +114,17 @@ static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
     unsigned want = (unsigned)std::min<size_t>(256, std::max<size_t>(1, (16384 + blocks - 1) / blocks));
     want = (unsigned)std::min<size_t>(want, air.prog.group_off.size());
     if (c->prog_air == air.id && c->prog_chunks == want) return 0;
-    const QProgram Q = compile_quotient_ops(air.prog, want);
+    QProgram Q = compile_quotient_ops(air.prog, want);
     want = (unsigned)Q.chunk_k_after.size();
+    // per-wave LDS cell cache, OFF by default: measured on FinalExp (MI355X) 0 slots 64 ms, 16: 72, 24: 88, 32: 106, 40: 115 ms.
+    // The kernel is VALU-issue bound (PMC: 3.1e10 VALU wave-instructions per launch = 50 ms at the 4-cycle issue rate); the
+    // column re-reads it saves are served by MALL/L2 behind the arithmetic, while the LDS footprint costs occupancy.
+    // STARKHIP_QUOTIENT_SLOTS (0..64) keeps the path testable.
+    c->prog_slots = 0;
+    if (const char* e = getenv("STARKHIP_QUOTIENT_SLOTS")) c->prog_slots = (unsigned)std::min(64, std::max(0, atoi(e)));
+    attach_cell_cache(Q, c->prog_slots);
+    HIPCHK(c->d_loads.ensure(Q.loads.size() * 4));
+    HIPCHK(hipMemcpyAsync(c->d_loads.p, Q.loads.data(), Q.loads.size() * 4, hipMemcpyHostToDevice, c->st));
     c->chunk_k_after = Q.chunk_k_after;
     HIPCHK(c->d_ops.ensure(Q.ops.size() * sizeof(QOp)));
     HIPCHK(hipMemcpyAsync(c->d_ops.p, Q.ops.data(), Q.ops.size() * sizeof(QOp), hipMemcpyHostToDevice, c->st));
@@ -155,7 +165,7 @@ void ctx_destroy(Ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
-    DevBuf* bufs[] = {&c->tw_fwd, &c->tw_inv, &c->coset_scale, &c->qtab, &c->qshift_inv, &c->lde2_fwd, &c->lde2_inv, &c->lde2_cs, &c->d_ops, &c->d_chunk_off, &c->staging,
+    DevBuf* bufs[] = {&c->tw_fwd, &c->tw_inv, &c->coset_scale, &c->qtab, &c->qshift_inv, &c->lde2_fwd, &c->lde2_inv, &c->lde2_cs, &c->d_ops, &c->d_loads, &c->d_chunk_off, &c->staging,
                       &c->values, &c->coeffs, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial, &c->qvals, &c->qcoef,
                       &c->qlde, &c->qdigests, &c->zpow, &c->gzpow, &c->open_local, &c->open_next, &c->open_q, &c->ext_apow, &c->comb_partial,
                       &c->comb_out, &c->fri_coef, &c->fri_vals, &c->scale_tab, &c->pow_state, &c->pow_best, &c->qidx, &c->gather_t,
@@ -289,8 +299,9 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         HIPCHK(hipMemcpyAsync(c->chunk_scale.p, cscale.data(), cscale.size() * 8, hipMemcpyHostToDevice, st));
         if (n_pis) HIPCHK(hipMemcpyAsync(c->pis.p, pis_host, n_pis * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipEventRecord(c->kev[2], st));
-        HIPCHK(launch_quotient_eval(c->d_ops.as<QOp>(), c->d_chunk_off.as<uint32_t>(), n_chunks, c->pis.as<gl_t>(), c->lde.as<gl_t>(),
-                                    c->qtab.as<gl_t>(), c->apow.as<gl_t>(), alphas[0], alphas[1], c->partial.as<gl_t>(), log_n, r, qdb, st));
+        HIPCHK(launch_quotient_eval(c->d_ops.as<QOp>(), c->d_loads.as<uint32_t>(), c->prog_slots, c->d_chunk_off.as<uint32_t>(), n_chunks,
+                                    c->pis.as<gl_t>(), c->lde.as<gl_t>(), c->qtab.as<gl_t>(), c->apow.as<gl_t>(), alphas[0], alphas[1],
+                                    c->partial.as<gl_t>(), log_n, r, qdb, st));
         HIPCHK(hipEventRecord(c->kev[3], st));
         HIPCHK(launch_quotient_combine(c->partial.as<gl_t>(), c->chunk_scale.as<gl_t>(), n_chunks, c->qtab.as<gl_t>(), log_n, qdb,
                                        c->qvals.as<gl_t>(), st));

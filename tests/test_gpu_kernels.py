@@ -80,3 +80,22 @@ def test_bad_shapes_are_refused(prover):
     assert e.value.code == S.ERR_BAD_SHAPE
     with pytest.raises(S.StarkhipError):
         prover.prove(S.AIR_TEST_FIBONACCI, cfg, t, pis[:2])
+
+
+@pytest.mark.parametrize("slots", [0, 7, 24])
+def test_quotient_cell_cache_does_not_change_the_proof(slots, monkeypatch):
+    """The optional per-wave LDS cell cache of the quotient kernel (STARKHIP_QUOTIENT_SLOTS, off by default) is a pure
+    re-scheduling of cell loads: FP12Mul proofs are identical to the oracle's for every slot count."""
+    import oracle_lib as O
+    from bls_util import random_fp12
+    monkeypatch.setenv("STARKHIP_QUOTIENT_SLOTS", str(slots))
+    pv = S.Prover(0)  # the slot count is read when a context compiles an AIR's op stream
+    try:
+        air = S.AIR_FP12_MUL
+        t, pis = S.trace_fp12_mul(random_fp12(0x5EED3000), random_fp12(0x5EED3001))
+        cfg = S.StarkConfig.for_air(air)
+        proof = pv.prove(air, cfg, t, pis)
+        ref = O.prove(S.air_program(air), cfg, S.trace_rows_to_poly_values(t), pis)
+        assert np.array_equal(proof, ref)
+    finally:
+        pv.close()
