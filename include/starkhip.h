@@ -15,6 +15,8 @@
  *                                src/fp12_mul.rs:44-48, src/final_exponentiate.rs:240-279,
  *                                src/miller_loop.rs, src/calc_pairing_precomp.rs:150-348;
  *                                src/aggregate_proof.rs:57,104,137,168
+ *   starkhip_trace_ecc_aggregate <- ECCAggStark::generate_trace + the public inputs of ec_aggregate_main
+ *                                src/ecc_aggregate.rs:39-84, src/aggregate_proof.rs:181-221
  *   starkhip_native_*         <- crate::native (Fp12 mul, final_exponentiate, miller_loop,
  *                                calc_pairing_precomp)               src/native.rs:1201-1468
  *
@@ -51,6 +53,7 @@ typedef enum {
     STARKHIP_AIR_PAIRING_PRECOMP = 1,
     STARKHIP_AIR_MILLER_LOOP = 2,
     STARKHIP_AIR_FINAL_EXP = 3,
+    STARKHIP_AIR_ECC_AGGREGATE = 4, /* ECCAggStark: sum of the 512 sync-committee keys whose bit is set (src/ecc_aggregate.rs) */
     STARKHIP_AIR_TEST_FIBONACCI = 100 /* 2-column toy AIR used by the unit tests */
 } starkhip_air_t;
 
@@ -91,6 +94,10 @@ int starkhip_trace_miller_loop(const uint32_t px[12], const uint32_t py[12], con
                                const uint32_t qz[24], uint64_t* trace, size_t n_rows, uint64_t* public_inputs);
 int starkhip_trace_pairing_precomp(const uint32_t qx[24], const uint32_t qy[24], const uint32_t qz[24], uint64_t* trace,
                                    size_t n_rows, uint64_t* public_inputs);
+/* points: 512 affine G1 points as [x(12 limbs), y(12 limbs)]; bits: 512 bytes (0 / 1).  The aggregate is computed here and
+ * written to the last 24 public inputs.  At least one of the first two bits must be set; consecutive operands must differ in x. */
+int starkhip_trace_ecc_aggregate(const uint32_t* points, const uint8_t* bits, uint64_t* trace, size_t n_rows, uint64_t* public_inputs);
+int starkhip_native_g1_aggregate(const uint32_t* points, const uint8_t* bits, uint32_t out[24]);
 int starkhip_trace_fibonacci(uint64_t x0, uint64_t x1, uint64_t* trace, size_t n_rows, uint64_t* public_inputs);
 int starkhip_native_fp12_mul(const uint32_t x[144], const uint32_t y[144], uint32_t out[144]);
 int starkhip_native_final_exponentiate(const uint32_t x[144], uint32_t out[144]);

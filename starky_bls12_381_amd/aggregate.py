@@ -8,7 +8,8 @@ Mirrors /root/reference/src/aggregate_proof.rs:
 each = build config, generate trace + public inputs, prove, verify_stark_proof, return (air, proof, config);
 and the six-proof plan of one BLS signature check (:304-370): pp1, ml1 on (aggregate pk, H(m)), pp2, ml2 on
 (-G1 generator, signature), fp12_mul on the two Miller-loop values, final_exponentiate on their product.
-Out of scope here (SURVEY.md §8f / DESIGN.md §8): the EC aggregation AIR, hash-to-curve, the plonky2 recursion.
+  ec_aggregate_main       :181-221  ECCAggStark(8192), rate_bits 2 (the aggregate public key the pairing proofs take as pk)
+Out of scope here (SURVEY.md §8f / DESIGN.md §8): hash-to-curve, key decompression, the plonky2 recursion.
 
 Points are passed as u32 limb arrays (Fp = 12 limbs, Fp2 = 24: c0 then c1), exactly what the reference's
 `get_u32_slice()` yields.  `prover` is an `api.Prover` bound to one GPU; nothing here touches the oracle.
@@ -66,6 +67,13 @@ def final_exponentiate_main(prover, x):
     """src/aggregate_proof.rs:153-179."""
     trace, pis = S.trace_final_exp(x)
     return _prove_and_verify(prover, S.AIR_FINAL_EXP, trace, pis)
+
+
+def ec_aggregate_main(prover, points, bits):
+    """src/aggregate_proof.rs:181-221: ECCAggStark over the 512 sync-committee keys and their participation bits.
+    points: [512][24] u32 limbs (x, y); the aggregate (the `pk` of the pairing proofs) is the last 24 public inputs."""
+    trace, pis = S.trace_ecc_aggregate(points, bits)
+    return _prove_and_verify(prover, S.AIR_ECC_AGGREGATE, trace, pis)
 
 
 def signature_jobs(pk, hm, sig):

@@ -26,9 +26,10 @@ N_PHASES = 11
 PHASE_NAMES = ["upload", "ifft_lde", "trace_merkle", "quotient", "quotient_commit", "openings", "fri_combine",
                "fri_commit", "pow", "queries", "total"]
 
-AIR_FP12_MUL, AIR_PAIRING_PRECOMP, AIR_MILLER_LOOP, AIR_FINAL_EXP, AIR_TEST_FIBONACCI = 0, 1, 2, 3, 100
+AIR_FP12_MUL, AIR_PAIRING_PRECOMP, AIR_MILLER_LOOP, AIR_FINAL_EXP, AIR_ECC_AGGREGATE, AIR_TEST_FIBONACCI = 0, 1, 2, 3, 4, 100
 AIR_NAMES = {AIR_FP12_MUL: "FP12MulStark", AIR_PAIRING_PRECOMP: "PairingPrecompStark", AIR_MILLER_LOOP: "MillerLoopStark",
-             AIR_FINAL_EXP: "FinalExponentiateStark", AIR_TEST_FIBONACCI: "TestFibonacci"}
+             AIR_FINAL_EXP: "FinalExponentiateStark", AIR_ECC_AGGREGATE: "ECCAggStark", AIR_TEST_FIBONACCI: "TestFibonacci"}
+ECC_NUM_POINTS = 512  # src/ecc_aggregate.rs:7
 
 ERR_QUOTIENT_NOT_DIVISIBLE, ERR_ZETA_IN_SUBGROUP, ERR_BAD_SHAPE, ERR_HIP, ERR_OOM, ERR_NO_DEVICE, ERR_VERIFY, ERR_BAD_AIR = range(-1, -9, -1)
 
@@ -95,6 +96,9 @@ lib.starkhip_native_fp12_mul.argtypes = [_u32p, _u32p, _u32p]
 lib.starkhip_native_final_exponentiate.argtypes = [_u32p, _u32p]
 lib.starkhip_native_miller_loop.argtypes = [_u32p, _u32p, _u32p, _u32p, _u32p, _u32p]
 lib.starkhip_native_pairing_precomp.argtypes = [_u32p, _u32p, _u32p, _u32p]
+_u8p = C.POINTER(C.c_uint8)
+lib.starkhip_trace_ecc_aggregate.argtypes = [_u32p, _u8p, _u64p, C.c_size_t, _u64p]
+lib.starkhip_native_g1_aggregate.argtypes = [_u32p, _u8p, _u32p]
 
 
 def _p64(a):
@@ -178,6 +182,30 @@ def trace_final_exp(x, n_rows=None):
     t, pis, n = _trace_alloc(AIR_FINAL_EXP, n_rows)
     _chk(lib.starkhip_trace_final_exp(_p32(_limbs(x, 144)), _p64(t), n, _p64(pis)))
     return t, pis
+
+
+def _ecc_inputs(points, bits):
+    pts = np.ascontiguousarray(points, dtype=np.uint32).reshape(-1)
+    b = np.ascontiguousarray(np.asarray(bits).astype(bool), dtype=np.uint8).reshape(-1)
+    assert pts.size == 24 * ECC_NUM_POINTS and b.size == ECC_NUM_POINTS, (pts.size, b.size)
+    return pts, b
+
+
+def trace_ecc_aggregate(points, bits, n_rows=None):
+    """ECCAggStark::generate_trace + ec_aggregate_main's public inputs (src/ecc_aggregate.rs:39-84, src/aggregate_proof.rs:191-209).
+    points: [512][24] u32 limbs (x then y); bits: 512 booleans.  The aggregate lands in the last 24 public inputs."""
+    t, pis, n = _trace_alloc(AIR_ECC_AGGREGATE, n_rows)
+    pts, b = _ecc_inputs(points, bits)
+    _chk(lib.starkhip_trace_ecc_aggregate(_p32(pts), b.ctypes.data_as(_u8p), _p64(t), n, _p64(pis)))
+    return t, pis
+
+
+def native_g1_aggregate(points, bits):
+    """Sum of the points whose bit is set, in the reference's order of operations; 24 limbs (x, y)."""
+    pts, b = _ecc_inputs(points, bits)
+    out = np.zeros(24, dtype=np.uint32)
+    _chk(lib.starkhip_native_g1_aggregate(_p32(pts), b.ctypes.data_as(_u8p), _p32(out)))
+    return out
 
 
 def trace_miller_loop(px, py, qx, qy, qz, n_rows=None):

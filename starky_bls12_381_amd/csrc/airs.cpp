@@ -22,6 +22,7 @@ Slot g_slots[] = {
     {STARKHIP_AIR_PAIRING_PRECOMP, "PairingPrecompStark", 1024, build_air_pairing_precomp},
     {STARKHIP_AIR_MILLER_LOOP, "MillerLoopStark", 1024, build_air_miller_loop},
     {STARKHIP_AIR_FINAL_EXP, "FinalExponentiateStark", 8192, build_air_final_exp},
+    {STARKHIP_AIR_ECC_AGGREGATE, "ECCAggStark", 8192, build_air_ecc_aggregate},  // src/aggregate_proof.rs:188-189
     {STARKHIP_AIR_TEST_FIBONACCI, "TestFibonacci", 64, build_air_fibonacci},
 };
 }  // namespace

@@ -24,5 +24,6 @@ AirProgram build_air_fp12_mul();
 AirProgram build_air_final_exp();
 AirProgram build_air_miller_loop();
 AirProgram build_air_pairing_precomp();
+AirProgram build_air_ecc_aggregate();
 
 }  // namespace starkhip

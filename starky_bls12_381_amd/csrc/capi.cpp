@@ -27,6 +27,7 @@ int starkhip_config_for_air(starkhip_air_t air, starkhip_config_t* cfg) {
     starkhip_config_standard_fast(cfg);
     switch (air) {
         case STARKHIP_AIR_PAIRING_PRECOMP:  // src/aggregate_proof.rs:32-33
+        case STARKHIP_AIR_ECC_AGGREGATE:    // src/aggregate_proof.rs:186-187
         case STARKHIP_AIR_FINAL_EXP:        // src/aggregate_proof.rs:155-156
             cfg->rate_bits = 2;
             return STARKHIP_OK;

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 # relative single-GPU proving cost per AIR (FinalExp dominates; README.md:36-39 of the reference has the same ordering)
-AIR_COST = {3: 92.0, 2: 12.5, 1: 4.5, 0: 0.22}
+AIR_COST = {3: 92.0, 2: 12.5, 1: 4.5, 0: 0.22, 4: 3.0}
 
 
 def rank_info():

@@ -90,3 +90,24 @@ def test_miller_loop_proof_is_bit_identical_to_oracle(prover):
     S.verify_stark_proof(air, cfg, proof)
     ref = O.prove(S.air_program(air), cfg, S.trace_rows_to_poly_values(t), pis)
     assert proof.size == ref.size and np.array_equal(proof, ref)
+
+
+def test_ecc_aggregate_proof_is_bit_identical_to_oracle(prover):
+    """ECCAggStark (3339 x 8192, constraint degree 4 => three quotient chunks per challenge) on the reference's own
+    aggregation vector (src/ecc_aggregate.rs:489-523, padded to the AIR's 512 operands)."""
+    from test_ecc_aggregate_cpu import pack, reference_vector
+    from bls_util import limbs
+    air = S.AIR_ECC_AGGREGATE
+    pts, bits, res = reference_vector()
+    arr, b = pack(pts, bits)
+    t, pis = S.trace_ecc_aggregate(arr, b)
+    assert [int(x) for x in pis[-24:]] == limbs(res[0]) + limbs(res[1])
+    cfg = S.StarkConfig.for_air(air)
+    proof = prover.prove(air, cfg, t, pis)
+    S.verify_stark_proof(air, cfg, proof)
+    ref = O.prove(S.air_program(air), cfg, S.trace_rows_to_poly_values(t), pis)
+    assert proof.size == ref.size and np.array_equal(proof, ref)
+    bad = proof.copy()
+    bad[-30] = (int(bad[-30]) + 1) % S.P  # a limb of the published aggregate
+    with pytest.raises(S.StarkhipError):
+        S.verify_stark_proof(air, cfg, bad)
