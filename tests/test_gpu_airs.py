@@ -111,3 +111,44 @@ def test_ecc_aggregate_proof_is_bit_identical_to_oracle(prover):
     bad[-30] = (int(bad[-30]) + 1) % S.P  # a limb of the published aggregate
     with pytest.raises(S.StarkhipError):
         S.verify_stark_proof(air, cfg, bad)
+
+
+def test_ecc_aggregate_invalid_witness_fails_like_the_reference(prover):
+    """Degree 4 at blow-up 4 leaves one zero chunk in the quotient: a witness that breaks a constraint makes
+    `quotient_poly.trim_to_len` fail -- starky's "Quotient has failed" error -- instead of yielding a proof."""
+    from test_ecc_aggregate_cpu import pack, reference_vector
+    air = S.AIR_ECC_AGGREGATE
+    pts, bits, _ = reference_vector()
+    t, pis = S.trace_ecc_aggregate(*pack(pts, bits))
+    t[100, 526 + 50] = (int(t[100, 526 + 50]) + 1) % S.P
+    with pytest.raises(S.StarkhipError) as e:
+        prover.prove(air, S.StarkConfig.for_air(air), t, pis)
+    assert e.value.code == S.ERR_QUOTIENT_NOT_DIVISIBLE
+
+
+def test_two_contexts_prove_concurrently_and_agree_with_sequential(prover):
+    """The bench keeps two proofs in flight on one GPU (two contexts, two host threads): results must not depend on it."""
+    import threading
+    from bls_util import fp_arr
+    b = _bls()
+    args = [(fp_arr(b["hm_x1"], b["hm_x2"]), fp_arr(b["hm_y1"], b["hm_y2"]), fp_arr(b["hm_z1"], b["hm_z2"])),
+            (fp_arr(b["s_x1"], b["s_x2"]), fp_arr(b["s_y1"], b["s_y2"]), fp_arr(b["s_z1"], b["s_z2"]))]
+    air = S.AIR_PAIRING_PRECOMP
+    cfg = S.StarkConfig.for_air(air)
+    traces = [S.trace_pairing_precomp(*a) for a in args]
+    want = [prover.prove(air, cfg, t, pis) for t, pis in traces]
+    got = [None, None]
+    provers = [S.Prover(0), S.Prover(0)]
+
+    def run(i):
+        for _ in range(3):
+            got[i] = provers[i].prove(air, cfg, traces[i][0], traces[i][1])
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for pv in provers:
+        pv.close()
+    for i in range(2):
+        assert np.array_equal(got[i], want[i])
