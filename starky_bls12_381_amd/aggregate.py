@@ -119,6 +119,8 @@ def check_links(proofs):
         pp, ml = pis("pp" + i), pis("ml" + i)
         ell = pp[72:]                 # after x, y, z (3 Fp2 = 72 limbs): 68 x 3 Fp2 coefficients
         ok &= bool(np.array_equal(ell, ml[24:24 + ell.size]))   # after px, py (2 Fp = 24 limbs)
+    if "ec" in proofs:  # the aggregate ECCAggStark publishes is the G1 operand of the first Miller loop
+        ok &= bool(np.array_equal(pis("ec")[-24:], pis("ml1")[0:24]))
     mul = pis("fp12_mul")
     ok &= bool(np.array_equal(pis("ml1")[-144:], mul[0:144]))
     ok &= bool(np.array_equal(pis("ml2")[-144:], mul[144:288]))

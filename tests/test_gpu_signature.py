@@ -1,5 +1,6 @@
 """All six STARK proofs of one BLS signature check on one GPU (BASELINE.json configs[3], single-GPU form):
 the reference's own test vector (src/native.rs:1480-1498), every proof accepted by the verifier, public inputs chained."""
+import numpy as np
 import pytest
 
 import starky_bls12_381_amd as S
@@ -19,3 +20,23 @@ def test_six_proofs_of_the_reference_signature(prover):
         assert air == A.JOB_AIR[name]
         S.verify_stark_proof(air, cfg, proof)
         assert int(proof[0]) == 0x3130304652505353  # blob magic
+
+
+def test_seven_proofs_of_the_mainnet_update(prover):
+    """The light-client update the reference's main.rs proves (period 1053, keys from period 1052): ECCAggStark over the 512
+    committee keys, then the six pairing proofs on its aggregate; every proof verifies and the public inputs chain."""
+    import os
+    from bls_util import GOLDEN
+    from starky_bls12_381_amd import eth_input as E
+    upd = E.load_update(os.path.join(GOLDEN, "light_client_update_period_1053.json"), os.path.join(GOLDEN, "light_client_update_period_1052.json"))
+    ec = A.ec_aggregate_main(prover, upd["points"], upd["bits"])
+    agg = np.asarray(ec[1][-24:], dtype=np.uint32)
+    proofs, natives = A.prove_signature(prover, (agg[:12], agg[12:]), upd["hm"], upd["sig"])
+    assert A.signature_is_valid(natives)
+    proofs["ec"] = ec
+    assert A.check_links(proofs)
+    bad = dict(proofs)
+    t = ec[1].copy()
+    t[-1] ^= 1
+    bad["ec"] = (ec[0], t, ec[2])
+    assert not A.check_links(bad)
