@@ -55,8 +55,6 @@ hipError_t launch_fri_combine(const gl_t* coeffs, size_t n_polys, size_t n, cons
 hipError_t launch_ext_reduce(const gl2_t* partial, size_t n_chunks, size_t n, gl2_t* out, hipStream_t st);
 hipError_t launch_fri_leaves(const gl_t* vals, unsigned log_len, unsigned arity_bits, gl_t* rows, hipStream_t st);
 hipError_t launch_fri_fold(const gl_t* in, size_t len, unsigned arity_bits, gl2_t beta, gl_t* out, hipStream_t st);
-hipError_t launch_gather_rows(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, const uint32_t* nat_idx, size_t n_queries,
-                              gl_t* out, hipStream_t st);
 
 // kernels_query.hip: query-round leaves and Merkle paths written in proof-blob layout (stride = words per query round)
 hipError_t launch_query_leaf_colmajor(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, const uint32_t* xs, size_t n_queries,

@@ -88,19 +88,6 @@ __global__ void fri_fold_kernel(const gl_t* __restrict__ in, size_t len, unsigne
     out[olen + k] = acc.a1;
 }
 
-// ---------------------------------------------------------------- query gathers
-// out[q][c] = mat[c * N + phys(idx[q])] where idx[q] is a NATURAL point index and the matrix is coset-major
-__global__ void gather_rows_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
-                                   const uint32_t* __restrict__ nat_idx, gl_t* __restrict__ out) {
-    size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (c >= n_cols) return;
-    size_t q = blockIdx.y;
-    size_t N = (size_t)1 << (log_n + rate_bits);
-    size_t i = nat_idx[q];
-    size_t phys = ((i & (((size_t)1 << rate_bits) - 1)) << log_n) + (i >> rate_bits);
-    out[q * n_cols + c] = mat[c * N + phys];
-}
-
 static inline unsigned nb(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 hipError_t launch_ext_powers(gl2_t* out, gl2_t base, size_t count, hipStream_t st) {
@@ -130,12 +117,6 @@ hipError_t launch_fri_leaves(const gl_t* vals, unsigned log_len, unsigned arity_
 }
 hipError_t launch_fri_fold(const gl_t* in, size_t len, unsigned arity_bits, gl2_t beta, gl_t* out, hipStream_t st) {
     hipLaunchKernelGGL(fri_fold_kernel, dim3(nb(len >> arity_bits, 256)), dim3(256), 0, st, in, len, arity_bits, beta, out);
-    return hipGetLastError();
-}
-hipError_t launch_gather_rows(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, const uint32_t* nat_idx, size_t n_queries,
-                              gl_t* out, hipStream_t st) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb(n_cols, 256), (unsigned)n_queries), dim3(256), 0, st, mat, n_cols, log_n, rate_bits,
-                       nat_idx, out);
     return hipGetLastError();
 }
 

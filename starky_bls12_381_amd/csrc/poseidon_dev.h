@@ -1,11 +1,12 @@
-// gfx950 device-side Poseidon-Goldilocks, tuned for the VALU mix of CDNA4:
-//  * the MDS layer (30 per permutation, 144 small-constant MACs each) is done on 22-bit limbs with
-//    v_mad_u32_u24 (full rate) instead of 64-bit multiplies (quarter rate): three limb sums per output stay
-//    below 2^31 (12 * 41 * 2^22), one cheap reduction per output;
-//  * "quad" form: one permutation spread over the 4 lanes of a DPP quad (lane l owns state elements
-//    l, l+4, l+8), so a Merkle-leaf kernel can field 4x as many lanes as there are leaves -- the trace
-//    commitment has only N = 32768 leaves of 9191 sequential permutations each, far too few lanes for
-//    256 CUs with one lane per leaf.  The other lanes' limbs arrive through v_mov_b32 quad_perm broadcasts.
+// gfx950 device-side Poseidon-Goldilocks, written for the integer VALU of CDNA4 (every instruction but a plain
+// 32-bit add issues in 4 cycles, v_mad_u64_u32 included -- so: as few instructions as possible):
+//  * the MDS layer (30 per permutation, 144 small-constant MACs each) multiplies the 32-bit halves of the state
+//    words into two 64-bit accumulators per output with v_mad_u64_u32 and folds them once (2^64 = 2^32 - 1);
+//  * "quad" form for the big Merkle-leaf kernel: one permutation spread over the 4 lanes of a DPP quad (lane l
+//    owns state elements 3l .. 3l+2), so the kernel fields 4x as many lanes as there are leaves -- a trace
+//    commitment has only N = 32768 leaves of 9191 sequential permutations each, far too few lanes for 256 CUs
+//    with one lane per leaf.  The other lanes' words arrive through v_mov_b32 quad_perm rotations;
+//  * values inside a permutation are lazily reduced 64-bit representatives (gl_dev.h).
 // Semantics are exactly those of poseidon.h (same permutation); tests compare both against the CPU oracle.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -15,75 +16,81 @@
 
 namespace starkhip {
 
-__device__ __forceinline__ void limbs22(gl_t x, uint32_t& a0, uint32_t& a1, uint32_t& a2) {
-    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    a0 = lo & 0x3FFFFFu;
-    a1 = __builtin_amdgcn_alignbit(hi, lo, 22) & 0x3FFFFFu;
-    a2 = hi >> 12;
+// ---------------------------------------------------------------- shared pieces (lazy reduction, gl_dev.h)
+// The MDS matrix is circulant with 6-bit entries: out[r] = sum_i CIRC[i] * s[(i + r) % 12] (+ 8 * s[0] for r = 0).  Every
+// product is taken on the 32-bit halves of the state words into two 64-bit accumulators, one v_mad_u64_u32 each
+// (that instruction issues at the same 4 cycles as a 24-bit multiply on this part, tools/valu_rate_bench.hip).
+__device__ __forceinline__ uint64_t mad32(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }  // one v_mad_u64_u32
+
+__device__ __forceinline__ gl_t sbox_nc(gl_t x) {
+    const gl_t x2 = gl_mul_nc(x, x), x4 = gl_mul_nc(x2, x2), x3 = gl_mul_nc(x2, x);
+    return gl_mul_nc(x3, x4);
 }
 
-// S0 + S1 * 2^22 + S2 * 2^44  (each S < 2^31)  mod p, canonical
-__device__ __forceinline__ gl_t combine22(uint32_t S0, uint32_t S1, uint32_t S2) {
-    uint64_t t = (uint64_t)S0 + ((uint64_t)S1 << 22);           // < 2^54
-    uint64_t u = (uint64_t)(S2 & 0xFFFFFu) << 44;               // low 64 bits of S2 << 44
-    uint64_t hi = S2 >> 20;                                       // < 2^11
-    uint64_t lo = t + u;
-    hi += lo < t;
-    // value = hi * 2^64 + lo,  2^64 = eps (mod p), hi * eps < 2^44
-    uint64_t r = lo + ((hi << 32) - hi);
-    if (r < lo) r += GL_EPS;
-    if (r >= GL_P) r -= GL_P;
-    return r;
+// A + B * 2^32 mod p for A, B < 2^44, any representative
+__device__ __forceinline__ gl_t combine_lohi_nc(uint64_t A, uint64_t B) {
+    const uint32_t a0 = (uint32_t)A, a1 = (uint32_t)(A >> 32), b0 = (uint32_t)B, b1 = (uint32_t)(B >> 32);
+    uint32_t t;
+    const bool c = __builtin_add_overflow(a1, b0, &t);    // a1 + b0 < 2^33
+    const uint64_t X = ((uint64_t)t << 32) | a0;          // words (a0, t)
+    const uint32_t k = b1 + (c ? 1u : 0u);                // weight-2^64 part, < 2^13
+    uint64_t r;
+    const bool c2 = __builtin_add_overflow(X, (uint64_t)k * 0xFFFFFFFFu, &r);  // 2^64 = eps (mod p)
+    return r + (c2 ? GL_EPS : 0);                         // after a wrap r < 2^45: cannot wrap again
 }
-
-__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
 
 // ---------------------------------------------------------------- one permutation per lane
+// (Merkle levels, proof-of-work grinding, FRI leaves: few, short launches.)  Any representative in and out.
 __device__ __forceinline__ void poseidon_mds_dev(gl_t* s) {
-    const uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    uint32_t a0[12], a1[12], a2[12];
+    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    uint32_t lo[12], hi[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) limbs22(s[i], a0[i], a1[i], a2[i]);
+    for (int i = 0; i < 12; i++) {
+        lo[i] = (uint32_t)s[i];
+        hi[i] = (uint32_t)(s[i] >> 32);
+    }
 #pragma unroll
     for (int r = 0; r < 12; r++) {
-        uint32_t S0 = 0, S1 = 0, S2 = 0;
+        uint64_t A = 0, B = 0;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             const int j = (i + r) % 12;
             const uint32_t k = CIRC[i] + ((r == 0 && i == 0) ? 8u : 0u);
-            S0 = mad24(a0[j], k, S0);
-            S1 = mad24(a1[j], k, S1);
-            S2 = mad24(a2[j], k, S2);
+            A = mad32(lo[j], k, A);
+            B = mad32(hi[j], k, B);
         }
-        s[r] = combine22(S0, S1, S2);
+        s[r] = combine_lohi_nc(A, B);  // A, B <= (276 + 8) * 2^32
     }
 }
 
+// In: canonical or not; out: canonical.
 __device__ __forceinline__ void poseidon_permute_dev(gl_t* s) {
     const uint64_t* RC = POSEIDON_RC_DEV;
     int rc = 0;
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(gl_add(s[i], RC[rc + i]));
+        for (int i = 0; i < 12; i++) s[i] = sbox_nc(gl_add_nc(s[i], RC[rc + i]));
         rc += 12;
         poseidon_mds_dev(s);
     }
 #pragma unroll 1
     for (int r = 0; r < 22; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], RC[rc + i]);
+        for (int i = 0; i < 12; i++) s[i] = gl_add_nc(s[i], RC[rc + i]);
         rc += 12;
-        s[0] = poseidon_sbox(s[0]);
+        s[0] = sbox_nc(s[0]);
         poseidon_mds_dev(s);
     }
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(gl_add(s[i], RC[rc + i]));
+        for (int i = 0; i < 12; i++) s[i] = sbox_nc(gl_add_nc(s[i], RC[rc + i]));
         rc += 12;
         poseidon_mds_dev(s);
     }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
 
 __device__ __forceinline__ void poseidon_two_to_one_dev(const gl_t* a, const gl_t* b, gl_t* out) {
@@ -136,13 +143,6 @@ __device__ __forceinline__ uint32_t quad_rot(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, sel, 0xF, 0xF, true);
 }
 
-__device__ __forceinline__ uint64_t mad32(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }  // one v_mad_u64_u32
-
-__device__ __forceinline__ gl_t sbox_nc(gl_t x) {
-    const gl_t x2 = gl_mul_nc(x, x), x4 = gl_mul_nc(x2, x2), x3 = gl_mul_nc(x2, x);
-    return gl_mul_nc(x3, x4);
-}
-
 template <int ROT>
 __device__ __forceinline__ gl_t quad_rot64(gl_t v) {
     return (gl_t)quad_rot<ROT>((uint32_t)v) | ((gl_t)quad_rot<ROT>((uint32_t)(v >> 32)) << 32);
@@ -161,18 +161,6 @@ __device__ __forceinline__ gl_t sbox_lane0_nc(gl_t s0, bool lane0) {
     const gl_t y = gl_mul_nc(x2, lane0 ? s0 : x2);              // lane 0: x^3, lanes 1..3: x^4
     const gl_t x7 = gl_mul_nc(y, quad_rot64<1>(y));             // lane 0: x^3 * (lane 1's x^4)
     return lane0 ? x7 : s0;
-}
-
-// A + B * 2^32 mod p for A, B < 2^44, any representative
-__device__ __forceinline__ gl_t combine_lohi_nc(uint64_t A, uint64_t B) {
-    const uint32_t a0 = (uint32_t)A, a1 = (uint32_t)(A >> 32), b0 = (uint32_t)B, b1 = (uint32_t)(B >> 32);
-    uint32_t t;
-    const bool c = __builtin_add_overflow(a1, b0, &t);    // a1 + b0 < 2^33
-    const uint64_t X = ((uint64_t)t << 32) | a0;          // words (a0, t)
-    const uint32_t k = b1 + (c ? 1u : 0u);                // weight-2^64 part, < 2^13
-    uint64_t r;
-    const bool c2 = __builtin_add_overflow(X, (uint64_t)k * 0xFFFFFFFFu, &r);  // 2^64 = eps (mod p)
-    return r + (c2 ? GL_EPS : 0);                         // after a wrap r < 2^45: cannot wrap again
 }
 
 // Round constants as the kernels stage them in LDS: per constant two 64-bit words (low half, high half), so each

@@ -140,13 +140,6 @@ static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
 static inline size_t level_off(size_t n_leaves, unsigned l) { return 2 * n_leaves - (2 * n_leaves >> l); }
 static inline size_t digest_words(size_t n_leaves) { return 8 * n_leaves; }
 
-static void merkle_path(const gl_t* digests, size_t n_leaves, unsigned depth, size_t idx, gl_t* out) {
-    for (unsigned l = 0; l < depth; l++) {
-        memcpy(out + 4 * l, digests + 4 * (level_off(n_leaves, l) + (idx ^ 1)), 32);
-        idx >>= 1;
-    }
-}
-
 int ctx_create(int device, Ctx** out) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return STARKHIP_ERR_NO_DEVICE;
