@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic_latest.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of
+`python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --inflight 1`): per-launch HBM-side bytes of the three heavy
+kernels, trace-commitment launches only.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.
+usage: pmc_traffic.py <fetch_results.db> <write_results.db> <out.json>"""
+import json
+import sqlite3
+import sys
+
+
+def main():
+    fdb, wdb, out_path = sys.argv[1:4]
+    res = {}
+    for f, ctr in ((fdb, "FETCH_SIZE"), (wdb, "WRITE_SIZE")):
+        cur = sqlite3.connect(f).cursor()
+        for k in ("leaf_hash_kernel", "quotient_eval_kernel", "lde_columns_v2_kernel"):
+            rows = list(cur.execute("select value, duration from counters_collection where kernel_name like ? and counter_name = ? order by duration desc",
+                                    ("%" + k + "%", ctr)))
+            big = [r for r in rows if r[1] > 0.5 * rows[0][1]]
+            res.setdefault(k, {})[ctr] = (sum(r[0] for r in big) / len(big), len(big), sum(r[1] for r in big) / len(big) / 1e6)
+    out = {}
+    for k, v in res.items():
+        fetch = v["FETCH_SIZE"][0] * 1024 * 2  # gfx950: 128-byte requests are tallied as 64 bytes
+        write = v["WRITE_SIZE"][0] * 1024
+        out[k] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "traffic_bytes": fetch + write, "fetch_size_raw_KB": v["FETCH_SIZE"][0],
+                  "write_size_raw_KB": v["WRITE_SIZE"][0], "launches_averaged": v["FETCH_SIZE"][1], "avg_ms_under_pmc": v["FETCH_SIZE"][2]}
+    out["_source"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "
+                      "--inflight 1`, trace-commitment launches only; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-byte requests "
+                      "as 64 bytes); Infinity-Cache hits are included in these memory-side counters")
+    json.dump(out, open(out_path, "w"), indent=1)
+    for k, v in out.items():
+        if k != "_source":
+            print(k, round(v["traffic_bytes"] / 1e9, 2), "GB", round(v["avg_ms_under_pmc"], 1), "ms")
+
+
+if __name__ == "__main__":
+    main()
