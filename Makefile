@@ -8,7 +8,7 @@ SRCS := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
 OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.h) include/starkhip.h
 
-all: $(OUT) oracle
+all: $(OUT) oracle demo
 
 build/%.hip.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build
@@ -23,7 +23,13 @@ $(OUT): $(OBJS)
 oracle:
 	$(MAKE) -C oracle
 
+# C++ drivers above the C ABI (include/starkhip_driver.hpp): the six proofs of one signature check
+demo: build/signature_demo
+build/signature_demo: tools/signature_demo.cpp include/starkhip_driver.hpp $(OUT)
+	@mkdir -p build
+	g++ -O2 -std=c++17 -Iinclude $< -o $@ -Lstarky_bls12_381_amd -lstarkhip -Wl,-rpath,'$$ORIGIN/../starky_bls12_381_amd'
+
 clean:
 	rm -rf build $(OUT)
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean
+.PHONY: all oracle clean demo

@@ -88,22 +88,29 @@ __device__ __forceinline__ void quotient_issue_loads(const QLoads& r, const QLan
     }
 }
 
-// LDS reads of the ops of one batch that take their cell from the cache
+// LDS reads of the ops of one batch that take their cell from the cache (CACHE = false: the program has no such ops)
+template <bool CACHE>
 __device__ __forceinline__ void quotient_cache_reads(const QBatch& b, const gl_t* cache_lane, gl_t (&x)[QOP_BATCH]) {
+    if constexpr (CACHE) {
 #pragma unroll
-    for (unsigned i = 0; i < QOP_BATCH; i++) {
-        const uint32_t ref = b.op[i].ref;
-        if (ref & QREF_FROM_LDS) x[i] = cache_lane[(ref & QREF_SLOT_MASK) << 6];
+        for (unsigned i = 0; i < QOP_BATCH; i++) {
+            const uint32_t ref = b.op[i].ref;
+            if (ref & QREF_FROM_LDS) x[i] = cache_lane[(ref & QREF_SLOT_MASK) << 6];
+        }
     }
 }
 
+template <bool CACHE>
 __device__ __forceinline__ void quotient_eval_batch(const QBatch& cur, const gl_t (&xg)[QOP_BATCH], const gl_t (&xl)[QOP_BATCH], gl_t* cache_lane,
                                                     const QLane& L, QState& S) {
 #pragma unroll
     for (unsigned i = 0; i < QOP_BATCH; i++) {
         const uint32_t hdr = cur.op[i].hdr, ref = cur.op[i].ref;
-        const gl_t x = (ref & QREF_FROM_LDS) ? xl[i] : xg[i];  // canonical (LDE output)
-        if (ref & QREF_STORE) cache_lane[(ref & QREF_SLOT_MASK) << 6] = x;
+        gl_t x = xg[i];  // canonical (LDE output)
+        if constexpr (CACHE) {
+            x = (ref & QREF_FROM_LDS) ? xl[i] : xg[i];
+            if (ref & QREF_STORE) cache_lane[(ref & QREF_SLOT_MASK) << 6] = x;
+        }
         switch (hdr & 7u) {
             case QOP_TERM: {
                 gl_t u = (hdr & QOP_NOCELL) ? (gl_t)1 : x;
@@ -151,6 +158,7 @@ __device__ __forceinline__ void quotient_eval_batch(const QBatch& cur, const gl_
     }
 }
 
+template <bool CACHE>
 __global__ __launch_bounds__(64) void quotient_eval_kernel(QuotientParams P) {
     extern __shared__ gl_t cell_cache[];  // [n_slots][64]
     const size_t n = (size_t)1 << P.log_n, size = n << P.qdb;
@@ -193,9 +201,9 @@ __global__ __launch_bounds__(64) void quotient_eval_kernel(QuotientParams P) {
     for (unsigned i = 0; i < QOP_BATCH; i++) xl0[i] = xl1[i] = 0;
 #define QSTEP(U, XG, XL_CUR, XL_NXT)                                                                         \
     {                                                                                                        \
-        quotient_cache_reads(nxt, cache_lane, XL_NXT); /* batch b+U+1, before this batch's slot writes */   \
+        quotient_cache_reads<CACHE>(nxt, cache_lane, XL_NXT); /* batch b+U+1, before this batch's slot writes */ \
         const QBatch nn = ops[b + (U) + 2];                                                                  \
-        quotient_eval_batch(cur, XG, XL_CUR, cache_lane, L, S);                                              \
+        quotient_eval_batch<CACHE>(cur, XG, XL_CUR, cache_lane, L, S);                                       \
         quotient_issue_loads(rn, L, XG); /* batch b+U+4 takes over this ring entry */                        \
         rn = loads[b + (U) + QOP_UNROLL + 1];                                                                \
         cur = nxt;                                                                                           \
@@ -245,7 +253,10 @@ hipError_t launch_quotient_eval(const QOp* ops, const uint32_t* loads, unsigned 
     P.alpha0 = alpha0; P.alpha1 = alpha1; P.log_n = log_n; P.rate_bits = rate_bits; P.qdb = qdb;
     size_t size = (size_t)1 << (log_n + qdb);
     const size_t lds_bytes = (size_t)(n_slots ? n_slots : 1) * 64 * sizeof(gl_t);
-    hipLaunchKernelGGL(quotient_eval_kernel, dim3((unsigned)((size + 63) / 64), n_chunks), dim3(64), lds_bytes, st, P);
+    if (n_slots)
+        hipLaunchKernelGGL(quotient_eval_kernel<true>, dim3((unsigned)((size + 63) / 64), n_chunks), dim3(64), lds_bytes, st, P);
+    else
+        hipLaunchKernelGGL(quotient_eval_kernel<false>, dim3((unsigned)((size + 63) / 64), n_chunks), dim3(64), 0, st, P);
     return hipGetLastError();
 }
 

@@ -40,3 +40,15 @@ def test_seven_proofs_of_the_mainnet_update(prover):
     t[-1] ^= 1
     bad["ec"] = (ec[0], t, ec[2])
     assert not A.check_links(bad)
+
+
+def test_cpp_driver_proves_the_reference_signature():
+    """include/starkhip_driver.hpp (the C++ mirror of src/aggregate_proof.rs's drivers) through tools/signature_demo.cpp."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build", "signature_demo")
+    if not os.path.exists(exe):
+        pytest.skip("build/signature_demo not built (make demo)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "valid=1 linked=1" in r.stdout
