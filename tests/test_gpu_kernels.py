@@ -38,7 +38,9 @@ def test_lde_matches_oracle(prover, log_n, rate_bits, ncols):
     assert np.array_equal(lde, olde_rows.T)
 
 
-@pytest.mark.parametrize("log_N,ncols,cap_h", [(5, 60285 // 16, 4), (4, 3, 4), (8, 4, 4), (8, 5, 2), (12, 200, 4), (6, 8, 0)])
+@pytest.mark.parametrize("log_N,ncols,cap_h", [(5, 60285 // 16, 4), (4, 3, 4), (8, 4, 4), (8, 5, 2), (12, 200, 4), (6, 8, 0),
+                                               # many leaves, widths around the 8-element sponge blocks
+                                               (14, 21, 4), (14, 8, 4), (14, 6, 4), (14, 15, 4), (15, 9, 4), (14, 3, 4)])
 def test_merkle_cap_matches_oracle(prover, log_N, ncols, cap_h):
     rng = np.random.default_rng(log_N + ncols)
     mat = _rand(rng, (ncols, 1 << log_N))
