@@ -216,7 +216,7 @@ def main():
                                      "peak_Ginstr_per_s": VALU_PEAK_GINSTR, "frac": wave_instr / (lh_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR,
                                      "basis": "22 partial rounds x 215 + 8 full rounds x 419 instructions per 4-lane permutation (ISA count; a few of them are 2-cycle moves, so the fraction can exceed 1); "
                                               "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per integer VALU instruction (tools/valu_rate_bench.hip)"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: other ranks would sit in the teardown barrier meanwhile
             try:
                 out["cpu_baseline"] = cpu_baseline_sample(S, S.air_program(air), C, log_n, cfg.rate_bits)
             except Exception as e:  # the oracle is a checker, never a dependency of the measured path

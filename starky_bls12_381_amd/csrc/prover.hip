@@ -147,9 +147,20 @@ int ctx_create(int device, Ctx** out) {
     HIPCHK(hipSetDevice(device));
     Ctx* c = new Ctx();
     c->device = device;
-    HIPCHK(hipStreamCreate(&c->st));
-    for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
-    for (auto& e : c->kev) HIPCHK(hipEventCreate(&e));
+    for (auto& e : c->ev) e = nullptr;
+    for (auto& e : c->kev) e = nullptr;
+    bool ok = hipStreamCreate(&c->st) == hipSuccess;
+    for (auto& e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    for (auto& e : c->kev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    if (!ok) {  // release whatever was created
+        for (auto& e : c->ev)
+            if (e) (void)hipEventDestroy(e);
+        for (auto& e : c->kev)
+            if (e) (void)hipEventDestroy(e);
+        if (c->st) (void)hipStreamDestroy(c->st);
+        delete c;
+        return STARKHIP_ERR_HIP;
+    }
     *out = c;
     return 0;
 }
