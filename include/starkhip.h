@@ -133,6 +133,9 @@ int starkhip_lde_batch(void* ctx, const uint64_t* values, size_t n_cols, unsigne
 /* Merkle cap of the matrix whose leaf j is the row bitrev(j) of an LDE given column-major natural order [C][N] */
 int starkhip_merkle_cap(void* ctx, const uint64_t* lde_colmajor, size_t n_cols, unsigned log_N, unsigned cap_height, uint64_t* cap_out);
 int starkhip_poseidon_permute_batch(void* ctx, uint64_t* states, size_t n_states);
+/* device field arithmetic under test: out[i] = canonical(op(a[i], b[i])) with the lazy-reduction helpers the kernels use
+ * (op codes: starky_bls12_381_amd/csrc/kernels_selftest.hip); lets the tests feed boundary operands */
+int starkhip_field_ops_batch(void* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* host-side permutation (the one the Fiat-Shamir challenger uses) */
 void starkhip_poseidon_permute_host(uint64_t state[12]);
 /* n chained host permutations; which = 0: the challenger's tuned permutation, 1: the portable loop */

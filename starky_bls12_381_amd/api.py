@@ -82,6 +82,7 @@ lib.starkhip_last_kernel_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
 lib.starkhip_lde_batch.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_uint, C.c_uint, _u64p, _u64p]
 lib.starkhip_merkle_cap.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_uint, C.c_uint, _u64p]
 lib.starkhip_poseidon_permute_batch.argtypes = [C.c_void_p, _u64p, C.c_size_t]
+lib.starkhip_field_ops_batch.argtypes = [C.c_void_p, C.c_int, _u64p, _u64p, _u64p, C.c_size_t]
 lib.starkhip_poseidon_permute_host.argtypes = [_u64p]
 lib.starkhip_poseidon_permute_host.restype = None
 lib.starkhip_verify.argtypes = [C.c_int, C.POINTER(StarkConfig), _u64p, C.c_size_t]
@@ -321,6 +322,15 @@ class Prover:
         cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
         _chk(lib.starkhip_merkle_cap(self._ctx, _p64(v), ncols, N.bit_length() - 1, cap_height, _p64(cap)))
         return cap
+
+    def field_ops(self, op, a, b):
+        """Device field arithmetic under test (kernels_selftest.hip): canonical(op(a[i], b[i]))."""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        assert a.shape == b.shape and a.ndim == 1
+        out = np.zeros_like(a)
+        _chk(lib.starkhip_field_ops_batch(self._ctx, op, _p64(a), _p64(b), _p64(out), a.size))
+        return out
 
     def poseidon_permute_batch(self, states):
         s = np.ascontiguousarray(states, dtype=np.uint64).copy()

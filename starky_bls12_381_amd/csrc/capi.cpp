@@ -95,6 +95,10 @@ int starkhip_poseidon_permute_batch(void* ctx, uint64_t* states, size_t n_states
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;
     return permute_batch((Ctx*)ctx, states, n_states);
 }
+int starkhip_field_ops_batch(void* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    return field_ops((Ctx*)ctx, op, a, b, out, n);
+}
 void starkhip_poseidon_permute_host(uint64_t state[12]) { poseidon_permute_host(state); }
 /* n chained permutations with the challenger's host permutation (which = 0) or the portable reference loop (which = 1);
  * lets the tests compare the two and the benchmark report the host hashing rate */

@@ -24,50 +24,6 @@
 
 namespace starkhip {
 
-// ---------------------------------------------------------------- arithmetic on arbitrary representatives
-__device__ __forceinline__ gl_t gl_add_nn(gl_t a, gl_t b) {
-    uint64_t s, s2;
-    const bool c1 = __builtin_add_overflow(a, b, &s);
-    const bool c2 = __builtin_add_overflow(s, c1 ? GL_EPS : 0, &s2);  // second wrap only when both were >= p - 1
-    return s2 + (c2 ? GL_EPS : 0);
-}
-__device__ __forceinline__ gl_t gl_sub_nn(gl_t a, gl_t b) {
-    uint64_t d, d2;
-    const bool b1 = __builtin_sub_overflow(a, b, &d);
-    const bool b2 = __builtin_sub_overflow(d, b1 ? GL_EPS : 0, &d2);
-    return d2 - (b2 ? GL_EPS : 0);
-}
-
-// x * 2^e mod p for a compile-time-foldable 0 <= e < 96; x arbitrary, result any representative.
-// 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32 (mod p).
-__device__ __forceinline__ gl_t gl_mul_pow2_nn(gl_t x, int e) {
-    if (e == 0) return x;
-    const int a = e >> 5, b = e & 31;
-    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
-    uint32_t y0, y1, y2;  // x << b as three words, y2 < 2^31
-    if (b == 0) {
-        y0 = x0; y1 = x1; y2 = 0;
-    } else {
-        y0 = x0 << b;
-        y1 = (x1 << b) | (x0 >> (32 - b));
-        y2 = x1 >> (32 - b);
-    }
-    if (a == 0) {  // (y1:y0) + y2 * eps
-        const uint64_t lo = ((uint64_t)y1 << 32) | y0;
-        const uint64_t t = ((uint64_t)y2 << 32) - y2;  // < p
-        return gl_add_nc(lo, t);
-    }
-    if (a == 1) {  // y0 * 2^32 + y1 * eps - y2
-        const uint64_t A = (uint64_t)y0 << 32;             // < p
-        const uint64_t B = ((uint64_t)y1 << 32) - y1;      // < p
-        return gl_sub_nc(gl_add_nc(A, B), (gl_t)y2);
-    }
-    // a == 2: y0 * eps - y1 - y2 * 2^32
-    const uint64_t A = ((uint64_t)y0 << 32) - y0;          // < p
-    const uint64_t B = ((uint64_t)y2 << 32) + y1;          // < 2^63 + 2^32 < p
-    return gl_sub_nc(A, B);
-}
-
 // ---------------------------------------------------------------- register sub-transforms
 constexpr int bitrev_c(int k, int bits) {
     int r = 0;

@@ -18,6 +18,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
 int lde_batch(Ctx* c, const uint64_t* values, size_t n_cols, unsigned log_n, unsigned rate_bits, uint64_t* coeffs_out, uint64_t* lde_out);
 int merkle_cap(Ctx* c, const uint64_t* lde_natural, size_t n_cols, unsigned log_N, unsigned cap_h, uint64_t* cap_out);
 int permute_batch(Ctx* c, uint64_t* states, size_t n);
+int field_ops(Ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 
 int verify_proof(const AirInfo& air, const starkhip_config_t& cfg, const uint64_t* proof, size_t words);
 

@@ -581,4 +581,16 @@ int permute_batch(Ctx* c, uint64_t* states, size_t n) {
     return STARKHIP_OK;
 }
 
+int field_ops(Ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(c->staging.ensure(3 * n * 8));
+    gl_t* d = c->staging.as<gl_t>();
+    HIPCHK(hipMemcpyAsync(d, a, n * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(d + n, b, n * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(launch_field_ops(op, d, d + n, d + 2 * n, n, c->st));
+    HIPCHK(hipMemcpyAsync(out, d + 2 * n, n * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return STARKHIP_OK;
+}
+
 }  // namespace starkhip

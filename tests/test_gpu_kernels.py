@@ -101,3 +101,34 @@ def test_quotient_cell_cache_does_not_change_the_proof(slots, monkeypatch):
         assert np.array_equal(proof, ref)
     finally:
         pv.close()
+
+
+def test_lazy_reduction_arithmetic_on_boundary_operands(prover):
+    """The kernels keep field values as arbitrary 64-bit representatives and correct wraps lazily; the wrap paths fire with
+    probability ~2^-32 per operation on proof data, so they are driven here with boundary operands, all pairs."""
+    EPS = (1 << 32) - 1
+    M = (1 << 64) - 1
+    edge = [0, 1, 2, EPS - 1, EPS, EPS + 1, 1 << 32, (1 << 63) - 1, 1 << 63, P - 2, P - 1, P, P + 1, M - EPS, M - 1, M, 0xFFFFFFFE00000001,
+            0x00000001FFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF00000000]
+    rng = np.random.default_rng(5)
+    vals = edge + [int(x) for x in rng.integers(0, 1 << 63, size=12, dtype=np.uint64) * 2 + rng.integers(0, 2, size=12, dtype=np.uint64)]
+    a = np.array([x for x in vals for _ in vals], dtype=np.uint64)
+    b = np.array([y for _ in vals for y in vals], dtype=np.uint64)
+    ai, bi = [int(x) for x in a], [int(y) for y in b]
+    m44 = (1 << 44) - 1
+    want = {
+        0: [x * y % P for x, y in zip(ai, bi)],
+        1: [(x * y + (x ^ y)) % P for x, y in zip(ai, bi)],
+        2: [(x + y) % P for x, y in zip(ai, bi)],
+        3: [(x - y) % P for x, y in zip(ai, bi)],
+        4: [(x + y) % P for x, y in zip(ai, bi)],
+        5: [(x - y) % P for x, y in zip(ai, bi)],
+        6: [((x & m44) + ((y & m44) << 32)) % P for x, y in zip(ai, bi)],
+        7: [((x << 64) + y) % P for x, y in zip(ai, bi)],
+        8: [x % P for x in ai],
+    }
+    for e in range(96):
+        want[100 + e] = [(x << e) % P for x in ai]
+    for op, w in want.items():
+        got = prover.field_ops(op, a, b)
+        assert [int(g) for g in got] == w, f"op {op}"
