@@ -1,12 +1,180 @@
 // Host-side Poseidon permutation used by the Fiat-Shamir challenger and the verifier.  The challenger absorbs
-// 2 * (2C + Q) field elements per proof (36.8 K sequential permutations for FinalExp), so this sits on the proof's
-// critical path between the openings and the FRI combination.  Measured on the GPU box's EPYC 9575F
-// (tools/host_perm_rate.py): the plain loop with branch-free field ops runs 2.08 us / permutation; an AVX2
-// auto-vectorised MDS variant was slower (2.74 us) and was dropped.
+// 2 * (2C + Q) field elements per proof (36.8 K sequential permutations for FinalExp, 48.7 K for MillerLoop), so this
+// sits on a proof's critical path between the openings and the FRI combination (19 % of FinalExp's latency, 33 % of
+// MillerLoop's with the plain loop at 2.08 us per permutation on the GPU box's EPYC 9575F, tools/host_perm_rate.py).
+//
+// AVX-512 form (used when the CPU has avx512f/dq/vl, otherwise the portable loop of poseidon.h): the 12 state words
+// live in one 8-lane and one 4-lane vector.
+//  * S-box: 64 x 64 -> 128 from four 32 x 32 vpmuludq per lane, Goldilocks reduction with mask compares; x^7 for all
+//    lanes in the full rounds, scalar for element 0 in the partial rounds.
+//  * MDS: the 32-bit halves are stored twice in a row (lo[24], hi[24]), so the circulant's input rotated by i is an
+//    UNALIGNED LOAD at offset i -- no shuffles; 12 x (vpmuludq by a broadcast coefficient + add) per half.
+// An earlier auto-vectorised AVX2 variant of the plain loop was slower than scalar (2.74 us) and was dropped.
+#include <immintrin.h>
+
 #include "poseidon.h"
 
 namespace starkhip {
 
-void poseidon_permute_host(gl_t* s) { poseidon_permute(s); }
+namespace {
+
+#define AVX512_TARGET __attribute__((target("avx512f,avx512dq,avx512vl")))
+
+struct V12 {  // 12 x u64: elements 0..7 and 8..11
+    __m512i a;
+    __m256i b;
+};
+
+const uint64_t EPS = 0xFFFFFFFFull;
+
+// ---- 8 lanes
+AVX512_TARGET inline __m512i reduce128_8(__m512i hi, __m512i lo) {  // canonical result
+    const __m512i eps = _mm512_set1_epi64((long long)EPS), p = _mm512_set1_epi64((long long)GL_P);
+    const __m512i hh = _mm512_srli_epi64(hi, 32), hl = _mm512_and_si512(hi, eps);
+    __m512i t0 = _mm512_sub_epi64(lo, hh);
+    t0 = _mm512_mask_sub_epi64(t0, _mm512_cmplt_epu64_mask(lo, hh), t0, eps);  // borrowed: - eps
+    const __m512i t1 = _mm512_sub_epi64(_mm512_slli_epi64(hl, 32), hl);          // hl * eps < p
+    __m512i r = _mm512_add_epi64(t0, t1);
+    r = _mm512_mask_add_epi64(r, _mm512_cmplt_epu64_mask(r, t1), r, eps);         // wrapped: + eps
+    return _mm512_mask_sub_epi64(r, _mm512_cmpge_epu64_mask(r, p), r, p);
+}
+AVX512_TARGET inline __m512i mul_8(__m512i x, __m512i y) {
+    const __m512i m32 = _mm512_set1_epi64((long long)EPS);
+    const __m512i x1 = _mm512_srli_epi64(x, 32), y1 = _mm512_srli_epi64(y, 32);
+    const __m512i p00 = _mm512_mul_epu32(x, y), p01 = _mm512_mul_epu32(x, y1), p10 = _mm512_mul_epu32(x1, y), p11 = _mm512_mul_epu32(x1, y1);
+    const __m512i mid = _mm512_add_epi64(p01, _mm512_srli_epi64(p00, 32));                       // < 2^64
+    const __m512i mid2 = _mm512_add_epi64(p10, _mm512_and_si512(mid, m32));                      // < 2^64
+    const __m512i lo = _mm512_or_si512(_mm512_slli_epi64(mid2, 32), _mm512_and_si512(p00, m32));
+    const __m512i hi = _mm512_add_epi64(p11, _mm512_add_epi64(_mm512_srli_epi64(mid, 32), _mm512_srli_epi64(mid2, 32)));
+    return reduce128_8(hi, lo);
+}
+AVX512_TARGET inline __m512i add_8(__m512i x, __m512i y) {  // canonical inputs, canonical result
+    const __m512i p = _mm512_set1_epi64((long long)GL_P);
+    const __m512i s = _mm512_add_epi64(x, y);
+    const __mmask8 wrap = _mm512_cmplt_epu64_mask(s, x);
+    const __mmask8 big = _mm512_cmpge_epu64_mask(s, p);
+    return _mm512_mask_sub_epi64(s, (__mmask8)(wrap | big), s, p);  // s - p == s + eps (mod 2^64) when wrapped
+}
+AVX512_TARGET inline __m512i sbox_8(__m512i x) {
+    const __m512i x2 = mul_8(x, x), x4 = mul_8(x2, x2), x3 = mul_8(x2, x);
+    return mul_8(x3, x4);
+}
+
+// ---- 4 lanes (same code on 256-bit vectors)
+AVX512_TARGET inline __m256i reduce128_4(__m256i hi, __m256i lo) {
+    const __m256i eps = _mm256_set1_epi64x((long long)EPS), p = _mm256_set1_epi64x((long long)GL_P);
+    const __m256i hh = _mm256_srli_epi64(hi, 32), hl = _mm256_and_si256(hi, eps);
+    __m256i t0 = _mm256_sub_epi64(lo, hh);
+    t0 = _mm256_mask_sub_epi64(t0, _mm256_cmplt_epu64_mask(lo, hh), t0, eps);
+    const __m256i t1 = _mm256_sub_epi64(_mm256_slli_epi64(hl, 32), hl);
+    __m256i r = _mm256_add_epi64(t0, t1);
+    r = _mm256_mask_add_epi64(r, _mm256_cmplt_epu64_mask(r, t1), r, eps);
+    return _mm256_mask_sub_epi64(r, _mm256_cmpge_epu64_mask(r, p), r, p);
+}
+AVX512_TARGET inline __m256i mul_4(__m256i x, __m256i y) {
+    const __m256i m32 = _mm256_set1_epi64x((long long)EPS);
+    const __m256i x1 = _mm256_srli_epi64(x, 32), y1 = _mm256_srli_epi64(y, 32);
+    const __m256i p00 = _mm256_mul_epu32(x, y), p01 = _mm256_mul_epu32(x, y1), p10 = _mm256_mul_epu32(x1, y), p11 = _mm256_mul_epu32(x1, y1);
+    const __m256i mid = _mm256_add_epi64(p01, _mm256_srli_epi64(p00, 32));
+    const __m256i mid2 = _mm256_add_epi64(p10, _mm256_and_si256(mid, m32));
+    const __m256i lo = _mm256_or_si256(_mm256_slli_epi64(mid2, 32), _mm256_and_si256(p00, m32));
+    const __m256i hi = _mm256_add_epi64(p11, _mm256_add_epi64(_mm256_srli_epi64(mid, 32), _mm256_srli_epi64(mid2, 32)));
+    return reduce128_4(hi, lo);
+}
+AVX512_TARGET inline __m256i add_4(__m256i x, __m256i y) {
+    const __m256i p = _mm256_set1_epi64x((long long)GL_P);
+    const __m256i s = _mm256_add_epi64(x, y);
+    const __mmask8 wrap = _mm256_cmplt_epu64_mask(s, x);
+    const __mmask8 big = _mm256_cmpge_epu64_mask(s, p);
+    return _mm256_mask_sub_epi64(s, (__mmask8)(wrap | big), s, p);
+}
+AVX512_TARGET inline __m256i sbox_4(__m256i x) {
+    const __m256i x2 = mul_4(x, x), x4 = mul_4(x2, x2), x3 = mul_4(x2, x);
+    return mul_4(x3, x4);
+}
+
+// MDS layer: out[r] = sum_i CIRC[i] * s[(i + r) % 12] + (r == 0) * 8 * s[0]
+AVX512_TARGET inline void mds(V12& s) {
+    static const uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    alignas(64) uint64_t lo[24], hi[24];
+    const __m512i m32 = _mm512_set1_epi64((long long)EPS);
+    const __m256i m32h = _mm256_set1_epi64x((long long)EPS);
+    const __m512i alo = _mm512_and_si512(s.a, m32), ahi = _mm512_srli_epi64(s.a, 32);
+    const __m256i blo = _mm256_and_si256(s.b, m32h), bhi = _mm256_srli_epi64(s.b, 32);
+    _mm512_store_si512((void*)lo, alo);
+    _mm256_store_si256((__m256i*)(lo + 8), blo);
+    _mm512_storeu_si512((void*)(lo + 12), alo);
+    _mm256_storeu_si256((__m256i*)(lo + 20), blo);
+    _mm512_store_si512((void*)hi, ahi);
+    _mm256_store_si256((__m256i*)(hi + 8), bhi);
+    _mm512_storeu_si512((void*)(hi + 12), ahi);
+    _mm256_storeu_si256((__m256i*)(hi + 20), bhi);
+    __m512i La = _mm512_setzero_si512(), Ha = _mm512_setzero_si512();
+    __m256i Lb = _mm256_setzero_si256(), Hb = _mm256_setzero_si256();
+    for (int i = 0; i < 12; i++) {  // fully unrolled by the compiler
+        const __m512i c = _mm512_set1_epi64((long long)CIRC[i]);
+        const __m256i ch = _mm256_set1_epi64x((long long)CIRC[i]);
+        La = _mm512_add_epi64(La, _mm512_mul_epu32(_mm512_loadu_si512((const void*)(lo + i)), c));      // outputs r = 0..7 see s[r + i]
+        Ha = _mm512_add_epi64(Ha, _mm512_mul_epu32(_mm512_loadu_si512((const void*)(hi + i)), c));
+        Lb = _mm256_add_epi64(Lb, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(lo + 8 + i)), ch));  // r = 8..11
+        Hb = _mm256_add_epi64(Hb, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(hi + 8 + i)), ch));
+    }
+    // + 8 * s[0] on output 0 only
+    La = _mm512_mask_add_epi64(La, 1, La, _mm512_slli_epi64(alo, 3));
+    Ha = _mm512_mask_add_epi64(Ha, 1, Ha, _mm512_slli_epi64(ahi, 3));
+    // value = L + H * 2^32 with L, H < 2^42
+    {
+        const __m512i l = _mm512_add_epi64(La, _mm512_slli_epi64(Ha, 32));
+        const __m512i h = _mm512_mask_add_epi64(_mm512_srli_epi64(Ha, 32), _mm512_cmplt_epu64_mask(l, La), _mm512_srli_epi64(Ha, 32),
+                                                _mm512_set1_epi64(1));
+        s.a = reduce128_8(h, l);
+    }
+    {
+        const __m256i l = _mm256_add_epi64(Lb, _mm256_slli_epi64(Hb, 32));
+        const __m256i h = _mm256_mask_add_epi64(_mm256_srli_epi64(Hb, 32), _mm256_cmplt_epu64_mask(l, Lb), _mm256_srli_epi64(Hb, 32),
+                                                _mm256_set1_epi64x(1));
+        s.b = reduce128_4(h, l);
+    }
+}
+
+AVX512_TARGET void permute_avx512(gl_t* st) {
+    const uint64_t* RC = POSEIDON_RC_HOST;
+    V12 s;
+    s.a = _mm512_loadu_si512((const void*)st);
+    s.b = _mm256_loadu_si256((const __m256i*)(st + 8));
+    int rc = 0;
+    for (int r = 0; r < 4; r++, rc += 12) {
+        s.a = sbox_8(add_8(s.a, _mm512_loadu_si512((const void*)(RC + rc))));
+        s.b = sbox_4(add_4(s.b, _mm256_loadu_si256((const __m256i*)(RC + rc + 8))));
+        mds(s);
+    }
+    for (int r = 0; r < 22; r++, rc += 12) {
+        s.a = add_8(s.a, _mm512_loadu_si512((const void*)(RC + rc)));
+        s.b = add_4(s.b, _mm256_loadu_si256((const __m256i*)(RC + rc + 8)));
+        const gl_t x0 = poseidon_sbox((gl_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(s.a)));  // element 0, scalar
+        s.a = _mm512_mask_set1_epi64(s.a, 1, (long long)x0);
+        mds(s);
+    }
+    for (int r = 0; r < 4; r++, rc += 12) {
+        s.a = sbox_8(add_8(s.a, _mm512_loadu_si512((const void*)(RC + rc))));
+        s.b = sbox_4(add_4(s.b, _mm256_loadu_si256((const __m256i*)(RC + rc + 8))));
+        mds(s);
+    }
+    _mm512_storeu_si512((void*)st, s.a);
+    _mm256_storeu_si256((__m256i*)(st + 8), s.b);
+}
+
+bool have_avx512() {
+    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl");
+    return ok;
+}
+
+}  // namespace
+
+// Inputs must be canonical (they are: the challenger absorbs proof data and its own canonical state).
+void poseidon_permute_host(gl_t* s) {
+    if (have_avx512()) permute_avx512(s);
+    else poseidon_permute(s);
+}
 
 }  // namespace starkhip
