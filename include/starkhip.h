@@ -112,7 +112,10 @@ void starkhip_shutdown(void* ctx);
 /* trace_layout: 0 = row-major [n_rows][C] (what generate_trace returns), 1 = column-major [C][n_rows]
  * (what trace_rows_to_poly_values returns).  trace_on_device != 0: `trace` is a device pointer
  * (already resident in HBM; the benchmark path).  pow_witness: STARKHIP_POW_SEARCH = smallest valid
- * nonce, otherwise use the given one.  *proof is a blob in the layout below. */
+ * nonce, otherwise use the given one.  *proof is a blob in the layout below.
+ * Shapes: n_rows a power of two, 2 <= n_rows <= 8192 (the reference's largest trace; one LDS image per column),
+ * n_pis and the column count as the AIR declares, num_challenges = 2, and rate_bits large enough for the AIR's
+ * constraint degree (2^rate_bits >= degree - 1); anything else is STARKHIP_ERR_BAD_SHAPE before any GPU work. */
 int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows,
                    int trace_layout, int trace_on_device, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness,
                    uint64_t** proof, size_t* proof_words);
