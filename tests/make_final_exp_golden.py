@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Run the CPU oracle on the full FinalExponentiateStark proof of the reference's `aa` vector
 (src/native.rs:1546-1557) and store the SHA-256 of the proof bytes as a golden fixture.
-Needs ~35 GB of host RAM and several minutes; run on the GPU box:  python tools/make_final_exp_golden.py"""
+Needs ~35 GB of host RAM and several minutes; run on the GPU box:  python tests/make_final_exp_golden.py
+(kept under tests/: it executes the CPU oracle, which only tests, smoke() and bench.py's cpu_baseline leg may do)"""
 import hashlib
 import os
 import sys

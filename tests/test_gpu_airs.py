@@ -32,7 +32,7 @@ def test_fp12_mul_proof_is_bit_identical_to_oracle(prover, seed):
 def test_final_exp_proof_verifies_and_matches_golden_digest(prover):
     """Full-size FinalExponentiateStark (73527 x 8192): the product verifier accepts the GPU proof; the proof bytes
     hash to the digest of the CPU oracle's proof for the same input when that fixture exists
-    (tests/golden/final_exp_aa_proof.sha256, made by tools/make_final_exp_golden.py on a 64+ GB host)."""
+    (tests/golden/final_exp_aa_proof.sha256, made by tests/make_final_exp_golden.py on a 64+ GB host)."""
     import hashlib
     import os
     from bls_util import GOLDEN, fp_arr, native_vectors
