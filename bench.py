@@ -65,7 +65,7 @@ def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=1024, bud
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=2,
