@@ -111,49 +111,45 @@ __device__ __forceinline__ void quotient_eval_batch(const QBatch& cur, const gl_
             x = (ref & QREF_FROM_LDS) ? xl[i] : xg[i];
             if (ref & QREF_STORE) cache_lane[(ref & QREF_SLOT_MASK) << 6] = x;
         }
-        switch (hdr & 7u) {
-            case QOP_TERM: {
-                gl_t u = x;  // the common case (92 % of the terms): one cell, no earlier factor
-                if (hdr & (QOP_NOCELL | QOP_PREV)) u = (hdr & QOP_NOCELL) ? (gl_t)1 : gl_canon(gl_mul_nc(S.v, x));
-                const uint32_t ck = (hdr >> QOP_CK_SHIFT) & 7u;
-                if (ck == CK_PLUS) S.body = gl_add_nc(S.body, u);
-                else if (ck == CK_MINUS) S.body = gl_sub_nc(S.body, u);
-                else {
-                    gl_t kk = cur.op[i].k;
-                    if (ck != CK_CONST) {
-                        kk = L.pis[hdr >> QOP_IDX_SHIFT];
-                        if (ck == CK_NEG_PI) kk = kk ? GL_P - kk : 0;
-                    }
-                    S.body = gl_mad_nc(u, kk, S.body);
+        // A sequence of independent `if`s, each updating its own part of the state in place, rather than one switch: the
+        // merge points then carry no register-to-register copies of the rest of the state.
+        const uint32_t op = hdr & 7u;
+        if (op == QOP_TERM) {
+            gl_t u = x;  // the common case (92 % of the terms): one cell, no earlier factor
+            if (hdr & (QOP_NOCELL | QOP_PREV)) u = (hdr & QOP_NOCELL) ? (gl_t)1 : gl_canon(gl_mul_nc(S.v, x));
+            const uint32_t ck = (hdr >> QOP_CK_SHIFT) & 7u;
+            if (ck == CK_PLUS) S.body = gl_add_nc(S.body, u);
+            else if (ck == CK_MINUS) S.body = gl_sub_nc(S.body, u);
+            else {
+                gl_t kk = cur.op[i].k;
+                if (ck != CK_CONST) {
+                    kk = L.pis[hdr >> QOP_IDX_SHIFT];
+                    if (ck == CK_NEG_PI) kk = kk ? GL_P - kk : 0;
                 }
-                if (hdr & QOP_FOLD) {
-                    S.t0 = gl_mad_nc(S.t0, L.a0, S.body);
-                    S.t1 = gl_mad_nc(S.t1, L.a1, S.body);
-                    S.body = 0;
-                }
-                break;
+                S.body = gl_mad_nc(u, kk, S.body);
             }
-            case QOP_FACTOR:
-                S.v = (hdr & QOP_PREV) ? gl_mul_nc(S.v, x) : x;
-                break;
-            case QOP_GATE:
-                S.G = gl_mul_nc(S.G, (ref & REF_COMPL) ? gl_sub_nc(1, x) : x);
-                break;
-            case QOP_GROUP: {
-                const uint32_t kind = (hdr >> QOP_KIND_SHIFT) & 3u;
-                S.G = kind == KIND_PLAIN ? (gl_t)1 : kind == KIND_TRANSITION ? L.mask_tr : kind == KIND_FIRST ? L.mask_first : L.mask_last;
-                S.t0 = 0;
-                S.t1 = 0;
-                break;
-            }
-            case QOP_ENDGROUP: {
-                const uint32_t m = hdr >> QOP_IDX_SHIFT;
-                S.acc0 = gl_mad_nc(S.acc0, L.apow[m], gl_mul_nc(S.G, S.t0));
-                S.acc1 = gl_mad_nc(S.acc1, L.apow[(AIR_MAX_GROUP + 1) + m], gl_mul_nc(S.G, S.t1));
-                break;
-            }
-            default:
-                break;
+        }
+        if (hdr & QOP_FOLD) {  // only ever set on a TERM: the constraint is complete
+            S.t0 = gl_mad_nc(S.t0, L.a0, S.body);
+            S.t1 = gl_mad_nc(S.t1, L.a1, S.body);
+            S.body = 0;
+        }
+        if (op == QOP_FACTOR) S.v = (hdr & QOP_PREV) ? gl_mul_nc(S.v, x) : x;
+        if (op == QOP_GATE) {
+            gl_t g = x;
+            if (ref & REF_COMPL) g = gl_sub_nc(1, x);
+            S.G = gl_mul_nc(S.G, g);
+        }
+        if (op == QOP_GROUP) {
+            const uint32_t kind = (hdr >> QOP_KIND_SHIFT) & 3u;
+            S.G = kind == KIND_PLAIN ? (gl_t)1 : kind == KIND_TRANSITION ? L.mask_tr : kind == KIND_FIRST ? L.mask_first : L.mask_last;
+            S.t0 = 0;
+            S.t1 = 0;
+        }
+        if (op == QOP_ENDGROUP) {
+            const uint32_t m = hdr >> QOP_IDX_SHIFT;
+            S.acc0 = gl_mad_nc(S.acc0, L.apow[m], gl_mul_nc(S.G, S.t0));
+            S.acc1 = gl_mad_nc(S.acc1, L.apow[(AIR_MAX_GROUP + 1) + m], gl_mul_nc(S.G, S.t1));
         }
     }
 }

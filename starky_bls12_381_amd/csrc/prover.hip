@@ -111,7 +111,9 @@ static hipError_t run_lde(Ctx* c, const gl_t* values, gl_t* coeffs, gl_t* lde, s
 static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
     // enough (point-block x chunk) waves to fill 256 CUs several times over
     size_t blocks = (quotient_points + 63) / 64;
-    unsigned want = (unsigned)std::min<size_t>(256, std::max<size_t>(1, (16384 + blocks - 1) / blocks));
+    size_t target_waves = 16384;
+    if (const char* e = getenv("STARKHIP_QUOTIENT_WAVES")) target_waves = (size_t)std::max(64, atoi(e));  // tuning knob
+    unsigned want = (unsigned)std::min<size_t>(256, std::max<size_t>(1, (target_waves + blocks - 1) / blocks));
     want = (unsigned)std::min<size_t>(want, air.prog.group_off.size());
     if (c->prog_air == air.id && c->prog_chunks == want) return 0;
     QProgram Q = compile_quotient_ops(air.prog, want);
