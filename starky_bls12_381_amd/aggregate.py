@@ -147,3 +147,22 @@ def prove_signature(prover, pk, hm, sig, dist=None, names=JOB_ORDER):
         fn, args = jobs[name]
         out[name] = fn(prover, *args)
     return out, natives
+
+
+def collect_proofs(dist, mine):
+    """Every rank's share {name: (air, proof, cfg)} merged into one dict on every rank, so that any of them can run
+    `check_links` and hand the six proofs to the recursion stage.  Proof blobs (0.2-0.7 MB each) travel as objects
+    after the timed data path has finished; this is result collection, not a data-path collective."""
+    if dist is None:
+        return dict(mine)
+    world = dist.get_world_size()
+    share = [(name, int(air), np.asarray(proof, dtype=np.uint64)) for name, (air, proof, _) in mine.items()]
+    shares = [None] * world
+    dist.all_gather_object(shares, share)
+    merged = {}
+    for part in shares:
+        for name, air, proof in part:
+            if name in merged:
+                raise ValueError(f"proof {name!r} was produced by more than one rank")
+            merged[name] = (air, proof, S.StarkConfig.for_air(air))
+    return merged

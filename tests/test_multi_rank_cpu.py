@@ -78,3 +78,60 @@ def test_lpt_assignment_for_a_batch_of_eight_signatures():
     loads = [sum(P.AIR_COST[airs[j]] for j in r) for r in plan]
     assert max(loads) - min(loads) < 13.0                # within one MillerLoop of each other
     assert all(sum(1 for j in r if airs[j] == 3) == 1 for r in plan)  # one FinalExp per GPU
+
+
+def _collect_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import starky_bls12_381_amd as S
+    from starky_bls12_381_amd import aggregate as A
+    from starky_bls12_381_amd import parallel as P
+    dist = P.init_distributed("gloo")
+    # stand-in blobs (no GPU here): what matters is who produced which proof and that the public-input tails survive
+    mine = {}
+    for name in A.signature_plan(world)[rank]:
+        air = A.JOB_AIR[name]
+        n_pis = S.air_public_inputs(air)
+        blob = np.arange(n_pis + 16, dtype=np.uint64) * np.uint64(1 + A.JOB_ORDER.index(name))
+        mine[name] = (air, blob, S.StarkConfig.for_air(air))
+    merged = A.collect_proofs(dist, mine)
+    summary = {name: (int(air), int(np.bitwise_xor.reduce(proof)), int(cfg.rate_bits)) for name, (air, proof, cfg) in merged.items()}
+    q.put((rank, sorted(mine), summary))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_collect_all_six_proofs_everywhere():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_collect_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from starky_bls12_381_amd import aggregate as A
+    assert sorted(results[0][1] + results[1][1]) == sorted(A.JOB_ORDER)   # shares are disjoint and cover the plan
+    assert results[0][2] == results[1][2]                                  # both ranks end up with the same six proofs
+    assert sorted(results[0][2]) == sorted(A.JOB_ORDER)
+    assert results[0][2]["final_exp"][2] == 2 and results[0][2]["fp12_mul"][2] == 1   # configs rebuilt per AIR
+
+
+def test_collect_rejects_a_proof_produced_twice():
+    import pytest
+    from starky_bls12_381_amd import aggregate as A
+
+    class TwoRanksBothRanFp12Mul:
+        def get_world_size(self):
+            return 2
+
+        def all_gather_object(self, out, obj):
+            out[0] = obj
+            out[1] = obj
+    with pytest.raises(ValueError):
+        A.collect_proofs(TwoRanksBothRanFp12Mul(), {"fp12_mul": (A.JOB_AIR["fp12_mul"], np.zeros(4, dtype=np.uint64), None)})
