@@ -129,6 +129,13 @@ int starkhip_last_timings(void* ctx, float ms[STARKHIP_N_PHASES]);
  * [0] lde_columns_kernel (trace) [1] leaf_hash_kernel (trace) [2] quotient_eval_kernel */
 int starkhip_last_kernel_timings(void* ctx, float ms[3]);
 
+/* Page-locked, reusable host memory for traces (starkhip_trace_* take any pointer).  Measured on FinalExp (4.8 GB of
+ * rows): the upload itself already runs at link speed from pageable memory (86 ms, 56 GB/s) and stays there; what a
+ * long-lived buffer saves is the first-touch page faulting of a fresh 4.8 GB allocation per trace (host generation
+ * 815 -> 315 ms).  Needs an initialised context; release with starkhip_host_free. */
+int starkhip_host_alloc(void* ctx, size_t bytes, void** out);
+void starkhip_host_free(void* p);
+
 /* --- kernel-level entry points (parity tests / micro-benchmarks) ---------------------- */
 /* values column-major [C][n] (host) -> coeffs [C][n] and LDE [C][N] in NATURAL point order i <-> 7*w_N^i */
 int starkhip_lde_batch(void* ctx, const uint64_t* values, size_t n_cols, unsigned log_n, unsigned rate_bits, uint64_t* coeffs_out,

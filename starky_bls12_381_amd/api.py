@@ -7,6 +7,7 @@ There is NO CPU fallback: if the shared library is missing, importing this modul
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -88,6 +89,9 @@ lib.starkhip_poseidon_permute_host.restype = None
 lib.starkhip_verify.argtypes = [C.c_int, C.POINTER(StarkConfig), _u64p, C.c_size_t]
 lib.starkhip_free.argtypes = [C.c_void_p]
 lib.starkhip_free.restype = None
+lib.starkhip_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+lib.starkhip_host_free.argtypes = [C.c_void_p]
+lib.starkhip_host_free.restype = None
 lib.starkhip_trace_fibonacci.argtypes = [C.c_uint64, C.c_uint64, _u64p, C.c_size_t, _u64p]
 lib.starkhip_trace_fp12_mul.argtypes = [_u32p, _u32p, _u64p, C.c_size_t, _u64p]
 lib.starkhip_trace_final_exp.argtypes = [_u32p, _u64p, C.c_size_t, _u64p]
@@ -161,26 +165,33 @@ def air_program(air):
 
 
 # ----------------------------------------------------------------------------- traces (generate_trace)
-def _trace_alloc(air, n_rows):
+def _trace_alloc(air, n_rows, out=None):
+    """`out`: optional C-contiguous uint64 [n_rows][columns] array to generate into (e.g. Prover.host_array); the
+    generators clear it themselves."""
     n_rows = n_rows or air_default_rows(air)
-    return np.zeros((n_rows, air_columns(air)), dtype=np.uint64), np.zeros(air_public_inputs(air), dtype=np.uint64), n_rows
+    shape = (n_rows, air_columns(air))
+    if out is None:
+        out = np.zeros(shape, dtype=np.uint64)
+    elif out.shape != shape or out.dtype != np.uint64 or not out.flags.c_contiguous:
+        raise ValueError(f"trace buffer must be C-contiguous uint64 {shape}, got {out.dtype} {out.shape}")
+    return out, np.zeros(air_public_inputs(air), dtype=np.uint64), n_rows
 
 
-def trace_fibonacci(x0, x1, n_rows=None):
-    t, pis, n = _trace_alloc(AIR_TEST_FIBONACCI, n_rows)
+def trace_fibonacci(x0, x1, n_rows=None, out=None):
+    t, pis, n = _trace_alloc(AIR_TEST_FIBONACCI, n_rows, out)
     _chk(lib.starkhip_trace_fibonacci(x0, x1, _p64(t), n, _p64(pis)))
     return t, pis
 
 
-def trace_fp12_mul(x, y, n_rows=None):
+def trace_fp12_mul(x, y, n_rows=None, out=None):
     """FP12MulStark::generate_trace + the public inputs of fp12_mul_main (src/aggregate_proof.rs:117-148)."""
-    t, pis, n = _trace_alloc(AIR_FP12_MUL, n_rows)
+    t, pis, n = _trace_alloc(AIR_FP12_MUL, n_rows, out)
     _chk(lib.starkhip_trace_fp12_mul(_p32(_limbs(x, 144)), _p32(_limbs(y, 144)), _p64(t), n, _p64(pis)))
     return t, pis
 
 
-def trace_final_exp(x, n_rows=None):
-    t, pis, n = _trace_alloc(AIR_FINAL_EXP, n_rows)
+def trace_final_exp(x, n_rows=None, out=None):
+    t, pis, n = _trace_alloc(AIR_FINAL_EXP, n_rows, out)
     _chk(lib.starkhip_trace_final_exp(_p32(_limbs(x, 144)), _p64(t), n, _p64(pis)))
     return t, pis
 
@@ -192,10 +203,10 @@ def _ecc_inputs(points, bits):
     return pts, b
 
 
-def trace_ecc_aggregate(points, bits, n_rows=None):
+def trace_ecc_aggregate(points, bits, n_rows=None, out=None):
     """ECCAggStark::generate_trace + ec_aggregate_main's public inputs (src/ecc_aggregate.rs:39-84, src/aggregate_proof.rs:191-209).
     points: [512][24] u32 limbs (x then y); bits: 512 booleans.  The aggregate lands in the last 24 public inputs."""
-    t, pis, n = _trace_alloc(AIR_ECC_AGGREGATE, n_rows)
+    t, pis, n = _trace_alloc(AIR_ECC_AGGREGATE, n_rows, out)
     pts, b = _ecc_inputs(points, bits)
     _chk(lib.starkhip_trace_ecc_aggregate(_p32(pts), b.ctypes.data_as(_u8p), _p64(t), n, _p64(pis)))
     return t, pis
@@ -209,15 +220,15 @@ def native_g1_aggregate(points, bits):
     return out
 
 
-def trace_miller_loop(px, py, qx, qy, qz, n_rows=None):
-    t, pis, n = _trace_alloc(AIR_MILLER_LOOP, n_rows)
+def trace_miller_loop(px, py, qx, qy, qz, n_rows=None, out=None):
+    t, pis, n = _trace_alloc(AIR_MILLER_LOOP, n_rows, out)
     _chk(lib.starkhip_trace_miller_loop(_p32(_limbs(px, 12)), _p32(_limbs(py, 12)), _p32(_limbs(qx, 24)), _p32(_limbs(qy, 24)),
                                         _p32(_limbs(qz, 24)), _p64(t), n, _p64(pis)))
     return t, pis
 
 
-def trace_pairing_precomp(qx, qy, qz, n_rows=None):
-    t, pis, n = _trace_alloc(AIR_PAIRING_PRECOMP, n_rows)
+def trace_pairing_precomp(qx, qy, qz, n_rows=None, out=None):
+    t, pis, n = _trace_alloc(AIR_PAIRING_PRECOMP, n_rows, out)
     _chk(lib.starkhip_trace_pairing_precomp(_p32(_limbs(qx, 24)), _p32(_limbs(qy, 24)), _p32(_limbs(qz, 24)), _p64(t), n, _p64(pis)))
     return t, pis
 
@@ -296,6 +307,17 @@ class Prover:
         proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy() if keep else None
         lib.starkhip_free(out)
         return proof
+
+    def host_array(self, shape, dtype=np.uint64):
+        """Page-locked host array (starkhip_host_alloc) to generate traces into, again and again (`trace_*(…, out=buf)`):
+        no 4.8 GB of first-touch page faults per FinalExp trace.  Freed when the array (and every view of it) is gone."""
+        shape = tuple(int(s) for s in np.atleast_1d(shape))
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        _chk(lib.starkhip_host_alloc(self._ctx, nbytes, C.byref(p)))
+        raw = (C.c_ubyte * nbytes).from_address(p.value)
+        weakref.finalize(raw, lib.starkhip_host_free, p.value)
+        return np.frombuffer(raw, dtype=dtype).reshape(shape)
 
     def last_timings(self):
         ms = (C.c_float * N_PHASES)()

@@ -82,6 +82,14 @@ int starkhip_last_kernel_timings(void* ctx, float ms[3]) {
     return STARKHIP_OK;
 }
 
+int starkhip_host_alloc(void* ctx, size_t bytes, void** out) {
+    if (!out) return STARKHIP_ERR_BAD_SHAPE;
+    *out = nullptr;
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    return host_alloc((Ctx*)ctx, bytes, out);
+}
+void starkhip_host_free(void* p) { host_free(p); }
+
 int starkhip_lde_batch(void* ctx, const uint64_t* values, size_t n_cols, unsigned log_n, unsigned rate_bits, uint64_t* coeffs_out,
                        uint64_t* lde_out) {
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;

@@ -19,6 +19,8 @@ int lde_batch(Ctx* c, const uint64_t* values, size_t n_cols, unsigned log_n, uns
 int merkle_cap(Ctx* c, const uint64_t* lde_natural, size_t n_cols, unsigned log_N, unsigned cap_h, uint64_t* cap_out);
 int permute_batch(Ctx* c, uint64_t* states, size_t n);
 int field_ops(Ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int host_alloc(Ctx* c, size_t bytes, void** out);
+void host_free(void* p);
 
 int verify_proof(const AirInfo& air, const starkhip_config_t& cfg, const uint64_t* proof, size_t words);
 

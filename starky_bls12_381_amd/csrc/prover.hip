@@ -595,4 +595,22 @@ int field_ops(Ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* ou
     return STARKHIP_OK;
 }
 
+int host_alloc(Ctx* c, size_t bytes, void** out) {
+    if (bytes == 0) return STARKHIP_ERR_BAD_SHAPE;
+    HIPCHK(hipSetDevice(c->device));
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        return STARKHIP_ERR_OOM;
+    }
+    HIPCHK(e);
+    *out = p;
+    return STARKHIP_OK;
+}
+
+void host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 }  // namespace starkhip

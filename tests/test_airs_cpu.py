@@ -67,6 +67,24 @@ def test_fp12_mul_edge_operands():
 S_BLS_P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
 
 
+def test_trace_into_a_caller_buffer_ignores_what_was_in_it():
+    """The page-locked hand-over (Prover.host_array) reuses one buffer for many traces: stale contents must not leak."""
+    import ctypes as C
+    x, y = random_fp12(0x5EED0301), random_fp12(0x5EED0302)
+    want, want_pis = S.trace_fp12_mul(x, y)
+    buf = np.full(want.shape, 0xDEADBEEFDEADBEEF, dtype=np.uint64)
+    got, got_pis = S.trace_fp12_mul(x, y, out=buf)
+    assert got is buf and np.array_equal(got, want) and np.array_equal(got_pis, want_pis)
+    with pytest.raises(ValueError):
+        S.trace_fp12_mul(x, y, out=np.zeros((want.shape[0], want.shape[1] + 1), dtype=np.uint64))
+    with pytest.raises(ValueError):
+        S.trace_fp12_mul(x, y, out=np.zeros(want.shape, dtype=np.int64))
+    # no context, no page-locked memory (and no crash)
+    p = C.c_void_p(1)
+    assert S.lib.starkhip_host_alloc(None, 4096, C.byref(p)) == S.ERR_NO_DEVICE and not p.value
+    S.lib.starkhip_host_free(None)
+
+
 def test_fp12_mul_oracle_proof_verifies():
     air = S.AIR_FP12_MUL
     x, y = random_fp12(0x5EED2002), random_fp12(0x5EED2003)

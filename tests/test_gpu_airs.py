@@ -29,6 +29,27 @@ def test_fp12_mul_proof_is_bit_identical_to_oracle(prover, seed):
     assert proof.size == ref.size and np.array_equal(proof, ref)
 
 
+def test_page_locked_trace_buffer_is_reused_across_proofs(prover):
+    """starkhip_host_alloc hand-over: two different traces generated into the same page-locked buffer, each proof
+    bit-identical to the oracle's; the buffer outlives views of it and is released afterwards."""
+    air = S.AIR_FP12_MUL
+    cfg = S.StarkConfig.for_air(air)
+    buf = prover.host_array((S.air_default_rows(air), S.air_columns(air)))
+    assert buf.flags.c_contiguous and buf.dtype == np.uint64
+    for seed in (0x5EED2100, 0x5EED2110):
+        t, pis = S.trace_fp12_mul(random_fp12(seed), random_fp12(seed + 1), out=buf)
+        assert t is buf
+        proof = prover.prove(air, cfg, t, pis)
+        ref = O.prove(S.air_program(air), cfg, S.trace_rows_to_poly_values(t.copy()), pis)
+        assert np.array_equal(proof, ref)
+    row = buf[3]
+    del buf, t
+    assert int(row[0]) == int(row[0])  # a view keeps the allocation alive
+    with pytest.raises(S.StarkhipError) as e:
+        prover.host_array((0,))
+    assert e.value.code == S.ERR_BAD_SHAPE
+
+
 def test_final_exp_proof_verifies_and_matches_golden_digest(prover):
     """Full-size FinalExponentiateStark (73527 x 8192): the product verifier accepts the GPU proof; the proof bytes
     hash to the digest of the CPU oracle's proof for the same input when that fixture exists

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """FinalExp proofs/s when the trace is handed over as a HOST buffer (the reference's boundary: generate_trace returns rows
-in host memory): pageable row-major rows -> H2D -> transpose on the device -> prove.  Never the bench's `value`."""
+in host memory): host rows -> H2D -> transpose on the device -> prove.  Three hand-over forms: pageable row-major rows
+(what a plain caller has), pageable column-major columns, and rows generated straight into a page-locked buffer from
+starkhip_host_alloc (same upload rate - the link is the limit either way - but a reused buffer halves host trace
+generation, which otherwise page-faults 4.8 GB of fresh memory per trace).  Never the bench's `value`."""
 import os
 import sys
 import time
@@ -8,22 +11,35 @@ import time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
 import starky_bls12_381_amd as S  # noqa: E402
 from bls_util import random_fp12  # noqa: E402
 
 air = S.AIR_FINAL_EXP
 cfg = S.StarkConfig.for_air(air)
+x = random_fp12(0x5EED0001)
 t0 = time.perf_counter()
-trace, pis = S.trace_final_exp(random_fp12(0x5EED0001))
+trace, pis = S.trace_final_exp(x)
 t_gen = time.perf_counter() - t0
 pv = S.Prover(0)
-pv.prove(air, cfg, trace, pis)  # warm-up: tables, program, buffers
-for layout, data, name in ((0, trace, "row-major host rows"), (1, S.trace_rows_to_poly_values(trace), "column-major host columns")):
+ref = pv.prove(air, cfg, trace, pis)  # warm-up: tables, program, buffers
+t0 = time.perf_counter()
+pinned = pv.host_array(trace.shape)
+t_pin = time.perf_counter() - t0
+t0 = time.perf_counter()
+S.trace_final_exp(x, out=pinned)
+t_gen_pinned = time.perf_counter() - t0
+assert np.array_equal(pinned, trace)
+cases = ((0, trace, "pageable row-major rows"), (1, S.trace_rows_to_poly_values(trace), "pageable column-major columns"),
+         (0, pinned, "page-locked row-major rows"))
+for layout, data, name in cases:
     ts = []
     for _ in range(3):
         t0 = time.perf_counter()
-        pv.prove(air, cfg, data, pis, layout=layout)
+        proof = pv.prove(air, cfg, data, pis, layout=layout)
         ts.append(time.perf_counter() - t0)
+    assert np.array_equal(proof, ref)
     dev = pv.last_timings()
     print(f"{name}: {min(ts) * 1e3:.0f} ms per proof end to end ({1 / min(ts):.2f} proofs/s); device phases total {dev['total']:.0f} ms, upload {dev['upload']:.0f} ms")
-print(f"host trace generation: {t_gen * 1e3:.0f} ms (one core)")
+print(f"host trace generation: {t_gen * 1e3:.0f} ms into pageable memory, {t_gen_pinned * 1e3:.0f} ms into the page-locked buffer (one core); "
+      f"allocating the {trace.nbytes / 1e6:.0f} MB page-locked buffer: {t_pin * 1e3:.0f} ms (once)")
