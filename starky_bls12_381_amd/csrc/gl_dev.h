@@ -3,8 +3,9 @@
 // A value is any 64-bit representative of its class mod p = 2^64 - 2^32 + 1 (so p..2^64-1 are allowed
 // aliases of 0..2^32-2).  Each routine states which operands may be arbitrary and which must be canonical;
 // every step is exact mod p, so a kernel canonicalises once (gl_canon) where results leave it.
-// The 64 x 64 multiply is written as exactly four v_mad_u64_u32 (quarter-rate on CDNA4, the dominant cost)
-// and the reduction uses 2^64 = 2^32 - 1 and 2^96 = -1 (mod p) with two conditional corrections.
+// Every integer VALU instruction issues at the same quarter rate on CDNA4, so the routines below are written for
+// instruction COUNT: a 64 x 64 multiply-reduce is 13 VALU instructions (four v_mad_u64_u32 + two moves for the product,
+// seven for the reduction with 2^64 = 2^32 - 1 and 2^96 = -1 mod p), with carries kept in scalar flag registers.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -14,42 +15,79 @@ namespace starkhip {
 
 __device__ __forceinline__ gl_t gl_canon(gl_t x) { return x >= GL_P ? x - GL_P : x; }
 
+// ---- reduction of a 128-bit value given as words: (h1 : h0 : l1 : l0) + cin * 2^96, any representative out.
+// cin_mask is a per-lane flag in a scalar register pair (the carry-out of a v_mad_u64_u32), or absent (HAS_CIN = false).
+//
+//   x = (l1:l0) - h1 - cin + h0 * eps          (2^64 = eps = 2^32 - 1, 2^96 = -1 mod p)
+//
+// The subtract's borrow and the multiply-add's carry are taken from the instructions' own scalar flag outputs (the
+// compiler would spend a 64-bit compare on each) and settled with ONE correction:
+//   D = (l1:l0) - h1 - cin mod 2^64, borrow b: true value D - b * 2^64 = D - b * eps
+//   r = D + h0 * eps mod 2^64, carry c:        true value r + c * 2^64 = r + c * eps
+//   b == c: r;  c only: r + eps (r < h0 * eps <= 2^64 - 2^33 + 1: no wrap);  b only: r - eps (r >= D >= 2^64 - 2^32: no wrap)
+// 7 VALU instructions.  A VALU write of a scalar register needs two wait states before a VALU reads it: the s_nop's.
+template <bool HAS_CIN>
+__device__ __forceinline__ gl_t gl_reduce_words(uint32_t l0, uint32_t l1, uint32_t h0, uint32_t h1, uint64_t cin_mask) {
+    uint32_t d0, d1;
+    uint64_t borrow_mask, carry_mask, r;
+    if (HAS_CIN)
+        asm("v_subb_co_u32_e64 %0, %2, %3, %4, %6\n\ts_nop 1\n\tv_subb_co_u32_e64 %1, %2, %5, 0, %2"
+            : "=&v"(d0), "=&v"(d1), "=&s"(borrow_mask)
+            : "v"(l0), "v"(h1), "v"(l1), "s"(cin_mask));
+    else
+        asm("v_sub_co_u32_e64 %0, %2, %3, %4\n\ts_nop 1\n\tv_subb_co_u32_e64 %1, %2, %5, 0, %2"
+            : "=&v"(d0), "=&v"(d1), "=&s"(borrow_mask)
+            : "v"(l0), "v"(h1), "v"(l1));
+    const uint64_t D = ((uint64_t)d1 << 32) | d0;
+    // borrow_mask is listed as in/out only so that none of its readers can be scheduled before this block: after it the
+    // borrow flag is one instruction + two wait states old, the carry flag two wait states
+    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\ts_nop 1"
+        : "=&v"(r), "=&s"(carry_mask), "+s"(borrow_mask)
+        : "v"(h0), "v"(D));  // h0 * eps < p
+    const bool b = __builtin_amdgcn_inverse_ballot_w64(borrow_mask), c = __builtin_amdgcn_inverse_ballot_w64(carry_mask);
+    const uint32_t k_lo = (c != b) ? (b ? 1u : 0xFFFFFFFFu) : 0u;  // +eps = (0, 0xFFFFFFFF); -eps = (0xFFFFFFFF, 1) mod 2^64
+    const uint32_t k_hi = (b && !c) ? 0xFFFFFFFFu : 0u;
+    uint64_t k = ((uint64_t)k_hi << 32) | k_lo;
+    asm("" : "+v"(k));  // one 64-bit add, not one per word
+    return r + k;
+}
+
 // (hi * 2^64 + lo) mod p, any representative; hi, lo arbitrary
 __device__ __forceinline__ gl_t gl_reduce128_nc(uint64_t hi, uint64_t lo) {
-    const uint32_t hi_lo = (uint32_t)hi, hi_hi = (uint32_t)(hi >> 32);
-    // carries are taken from the add / subtract themselves (__builtin_*_overflow), which costs fewer instructions than
-    // comparing afterwards; the corrections are adds of a selected constant, not selects between two 64-bit candidates
-    uint64_t t0, r;
-    const bool borrow = __builtin_sub_overflow(lo, (uint64_t)hi_hi, &t0);
-    t0 -= borrow ? GL_EPS : 0;
-    const bool carry = __builtin_add_overflow(t0, (uint64_t)hi_lo * 0xFFFFFFFFu, &r);  // hi_lo * eps < p
-    r += carry ? GL_EPS : 0;
-    return r;
+    return gl_reduce_words<false>((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0);
 }
 
-// a * b mod p, any representative in [0, 2^64); a, b arbitrary 64-bit
+// a * b mod p, any representative in [0, 2^64); a, b arbitrary 64-bit.
+// 64 x 64 -> 128 as four v_mad_u64_u32 (32 x 32 + 64) and two moves:
+//   p0 = a0 b0;  m1 = a0 b1 + p0_hi  (fits);  m2 + cm 2^64 = a1 b0 + m1  (the carry-out cm stays in a scalar register
+//   pair and enters the reduction as -cm, since 2^96 = -1);  p3 = a1 b1 + m2_hi  (fits)
+//   a b = p3 2^64 + cm 2^96 + (m2_lo : p0_lo)
+// cm is read by the reduction's first subtract, after the move and the multiply-add that form p3: two wait states.
 __device__ __forceinline__ gl_t gl_mul_nc(gl_t a, gl_t b) {
-    // 64 x 64 -> 128 as exactly four v_mad_u64_u32 (32 x 32 + 64): each partial sum below fits 64 bits
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
-    const uint64_t p00 = (uint64_t)a0 * b0;
-    const uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
-    const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
-    const uint64_t hi = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);
-    const uint64_t lo = (p10 << 32) | (uint32_t)p00;
-    return gl_reduce128_nc(hi, lo);
+    const uint64_t p0 = (uint64_t)a0 * b0;
+    const uint64_t m1 = (uint64_t)a0 * b1 + (p0 >> 32);
+    uint64_t m2, cm;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m2), "=s"(cm) : "v"(a1), "v"(b0), "v"(m1));
+    const uint64_t p3 = (uint64_t)a1 * b1 + (m2 >> 32);
+    return gl_reduce_words<true>((uint32_t)p0, (uint32_t)m2, (uint32_t)p3, (uint32_t)(p3 >> 32), cm);
 }
 
-// a * b + c mod p, any representative; a, b, c arbitrary 64-bit (a*b + c < 2^128)
+// a * b + c mod p, any representative; a, b, c arbitrary 64-bit.  As gl_mul_nc with c as the addend of the first
+// multiply-add; its carry-out c0 (weight 2^64) joins m2_hi in the addend of the last one (m2_hi + c0 <= 2^32, and
+// a1 b1 + 2^32 still fits 64 bits).
 __device__ __forceinline__ gl_t gl_mad_nc(gl_t a, gl_t b, gl_t c) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
-    const uint64_t p00 = (uint64_t)a0 * b0;
-    const uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
-    const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
-    uint64_t hi = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);  // <= 2^64 - 2
-    const uint64_t lo0 = (p10 << 32) | (uint32_t)p00;
-    uint64_t lo;
-    hi += __builtin_add_overflow(lo0, c, &lo) ? 1 : 0;
-    return gl_reduce128_nc(hi, lo);
+    uint64_t p0, c0, m2, cm, scratch_mask;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(p0), "=s"(c0) : "v"(a0), "v"(b0), "v"(c));
+    const uint64_t m1 = (uint64_t)a0 * b1 + (p0 >> 32);
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m2), "=s"(cm) : "v"(a1), "v"(b0), "v"(m1));
+    uint32_t t0, t1;  // (t1 : t0) = m2_hi + c0; c0 is three VALU instructions old here
+    asm("v_addc_co_u32_e64 %0, %2, %3, 0, %4\n\ts_nop 1\n\tv_addc_co_u32_e64 %1, %2, 0, 0, %2"
+        : "=&v"(t0), "=&v"(t1), "=&s"(scratch_mask)
+        : "v"((uint32_t)(m2 >> 32)), "s"(c0));
+    const uint64_t p3 = (uint64_t)a1 * b1 + (((uint64_t)t1 << 32) | t0);
+    return gl_reduce_words<true>((uint32_t)p0, (uint32_t)m2, (uint32_t)p3, (uint32_t)(p3 >> 32), cm);
 }
 
 // a arbitrary, b canonical (< p)

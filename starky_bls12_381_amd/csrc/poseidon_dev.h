@@ -29,14 +29,14 @@ __device__ __forceinline__ gl_t sbox_nc(gl_t x) {
 
 // A + B * 2^32 mod p for A, B < 2^44, any representative
 __device__ __forceinline__ gl_t combine_lohi_nc(uint64_t A, uint64_t B) {
-    const uint32_t a0 = (uint32_t)A, a1 = (uint32_t)(A >> 32), b0 = (uint32_t)B, b1 = (uint32_t)(B >> 32);
-    uint32_t t;
-    const bool c = __builtin_add_overflow(a1, b0, &t);    // a1 + b0 < 2^33
-    const uint64_t X = ((uint64_t)t << 32) | a0;          // words (a0, t)
-    const uint32_t k = b1 + (c ? 1u : 0u);                // weight-2^64 part, < 2^13
-    uint64_t r;
-    const bool c2 = __builtin_add_overflow(X, (uint64_t)k * 0xFFFFFFFFu, &r);  // 2^64 = eps (mod p)
-    return r + (c2 ? GL_EPS : 0);                         // after a wrap r < 2^45: cannot wrap again
+    // B * 2^32 = b1 * 2^64 + b0 * 2^32 = b1 * eps + b0 * 2^32 (mod p): one multiply-add, then only the high words add
+    const uint32_t b0 = (uint32_t)B, b1 = (uint32_t)(B >> 32);
+    const uint64_t T = mad32(b1, 0xFFFFFFFFu, A);         // A + b1 * eps < 2^45
+    uint32_t hi;
+    const bool c = __builtin_add_overflow((uint32_t)(T >> 32), b0, &hi);
+    uint64_t r = ((uint64_t)hi << 32) | (uint32_t)T;
+    asm("" : "+v"(r));  // keep (T_lo, hi) one register pair: otherwise the two adds are re-associated through three extra moves
+    return r + (c ? GL_EPS : 0);                          // after a wrap hi < 2^13, r < 2^45: cannot wrap again
 }
 
 // ---------------------------------------------------------------- one permutation per lane
@@ -174,6 +174,9 @@ struct RcPair {
 __device__ __forceinline__ void poseidon_mds_quad(gl_t& s0, gl_t& s1, gl_t& s2, uint32_t diag0, const RcPair& c0, const RcPair& c1,
                                                   const RcPair& c2) {
     constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    uint32_t k16 = 16, k2 = 2;
+    asm("" : "+s"(k16));
+    asm("" : "+s"(k2));
     uint32_t lo[4][3], hi[4][3];  // [r][m]: halves of element 3((l + r) & 3) + m
     lo[0][0] = (uint32_t)s0; hi[0][0] = (uint32_t)(s0 >> 32);
     lo[0][1] = (uint32_t)s1; hi[0][1] = (uint32_t)(s1 >> 32);
@@ -194,9 +197,16 @@ __device__ __forceinline__ void poseidon_mds_quad(gl_t& s0, gl_t& s1, gl_t& s2, 
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int m = 0; m < 3; m++) {
-                const uint32_t k = CIRC[(3 * r + m - mo + 12) % 12];
+                // 16 and 2 from a scalar register: as literals the compiler turns these products into 64-bit shifts,
+                // which need a (value, 0) register pair, i.e. one extra move per rotated operand
+                const uint32_t kc = CIRC[(3 * r + m - mo + 12) % 12];
+                const uint32_t k = kc == 16 ? k16 : kc == 2 ? k2 : kc;
                 A = mad32(lo[r][m], k, A);
                 B = mad32(hi[r][m], k, B);
+                // keep the chain a chain: without these (empty) barriers the sum is re-associated so that the round
+                // constant is added by an instruction of its own instead of being the addend of the first multiply-add
+                asm("" : "+v"(A));
+                asm("" : "+v"(B));
             }
         if (mo == 0) {
             A = mad32(lo[0][0], diag0, A);
