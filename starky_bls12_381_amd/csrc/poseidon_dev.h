@@ -143,6 +143,23 @@ __device__ __forceinline__ uint32_t quad_rot(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, sel, 0xF, 0xF, true);
 }
 
+// The same rotation on the LDS pipe (ds_swizzle_b32 touches no LDS memory): it takes no VALU issue slot, and the MDS layer
+// is VALU-bound.  Its latency is that of an LDS access, so it is used where other work is at hand (the MDS layer starts
+// with the lane's own elements) and not inside the S-box chain.
+template <int ROT>
+__device__ __forceinline__ uint32_t quad_rot_lds(uint32_t v) {
+    constexpr int sel = ((0 + ROT) & 3) | (((1 + ROT) & 3) << 2) | (((2 + ROT) & 3) << 4) | (((3 + ROT) & 3) << 6);
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x8000 | sel);
+}
+
+#ifndef STARKHIP_MDS_SWIZZLE_MASK
+#define STARKHIP_MDS_SWIZZLE_MASK 0
+#endif
+template <int ROT>
+__device__ __forceinline__ uint32_t mds_rot(uint32_t v) {
+    return ((STARKHIP_MDS_SWIZZLE_MASK >> ROT) & 1) ? quad_rot_lds<ROT>(v) : quad_rot<ROT>(v);
+}
+
 template <int ROT>
 __device__ __forceinline__ gl_t quad_rot64(gl_t v) {
     return (gl_t)quad_rot<ROT>((uint32_t)v) | ((gl_t)quad_rot<ROT>((uint32_t)(v >> 32)) << 32);
@@ -183,9 +200,9 @@ __device__ __forceinline__ void poseidon_mds_quad(gl_t& s0, gl_t& s1, gl_t& s2, 
     lo[0][2] = (uint32_t)s2; hi[0][2] = (uint32_t)(s2 >> 32);
 #pragma unroll
     for (int m = 0; m < 3; m++) {
-        lo[1][m] = quad_rot<1>(lo[0][m]); hi[1][m] = quad_rot<1>(hi[0][m]);
-        lo[2][m] = quad_rot<2>(lo[0][m]); hi[2][m] = quad_rot<2>(hi[0][m]);
-        lo[3][m] = quad_rot<3>(lo[0][m]); hi[3][m] = quad_rot<3>(hi[0][m]);
+        lo[1][m] = mds_rot<1>(lo[0][m]); hi[1][m] = mds_rot<1>(hi[0][m]);
+        lo[2][m] = mds_rot<2>(lo[0][m]); hi[2][m] = mds_rot<2>(hi[0][m]);
+        lo[3][m] = mds_rot<3>(lo[0][m]); hi[3][m] = mds_rot<3>(hi[0][m]);
     }
     gl_t out[3];
 #pragma unroll
