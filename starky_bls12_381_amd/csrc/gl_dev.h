@@ -25,7 +25,8 @@ __device__ __forceinline__ gl_t gl_canon(gl_t x) { return x >= GL_P ? x - GL_P :
 //   D = (l1:l0) - h1 - cin mod 2^64, borrow b: true value D - b * 2^64 = D - b * eps
 //   r = D + h0 * eps mod 2^64, carry c:        true value r + c * 2^64 = r + c * eps
 //   b == c: r;  c only: r + eps (r < h0 * eps <= 2^64 - 2^33 + 1: no wrap);  b only: r - eps (r >= D >= 2^64 - 2^32: no wrap)
-// 7 VALU instructions.  A VALU write of a scalar register needs two wait states before a VALU reads it: the s_nop's.
+// 7 VALU instructions, none on the scalar ALU.  A VALU write of a scalar register needs two wait states before a VALU
+// reads it: the s_nop's.
 template <bool HAS_CIN>
 __device__ __forceinline__ gl_t gl_reduce_words(uint32_t l0, uint32_t l1, uint32_t h0, uint32_t h1, uint64_t cin_mask) {
     uint32_t d0, d1;
@@ -39,17 +40,19 @@ __device__ __forceinline__ gl_t gl_reduce_words(uint32_t l0, uint32_t l1, uint32
             : "=&v"(d0), "=&v"(d1), "=&s"(borrow_mask)
             : "v"(l0), "v"(h1), "v"(l1));
     const uint64_t D = ((uint64_t)d1 << 32) | d0;
-    // borrow_mask is listed as in/out only so that none of its readers can be scheduled before this block: after it the
-    // borrow flag is one instruction + two wait states old, the carry flag two wait states
-    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\ts_nop 1"
-        : "=&v"(r), "=&s"(carry_mask), "+s"(borrow_mask)
-        : "v"(h0), "v"(D));  // h0 * eps < p
-    const bool b = __builtin_amdgcn_inverse_ballot_w64(borrow_mask), c = __builtin_amdgcn_inverse_ballot_w64(carry_mask);
-    const uint32_t k_lo = (c != b) ? (b ? 1u : 0xFFFFFFFFu) : 0u;  // +eps = (0, 0xFFFFFFFF); -eps = (0xFFFFFFFF, 1) mod 2^64
-    const uint32_t k_hi = (b && !c) ? 0xFFFFFFFFu : 0u;
-    uint64_t k = ((uint64_t)k_hi << 32) | k_lo;
-    asm("" : "+v"(k));  // one 64-bit add, not one per word
-    return r + k;
+    // r + (c - b) * eps without touching the scalar ALU (a scalar XOR/AND of the two flags and selects on the result
+    // would put a VALU -> SALU -> VALU round trip into every multiply):  t = c - b in {-1, 0, 1} from the flags as
+    // carry/borrow inputs, then r - t (signed multiply-add by -1) and t added to the high word (+ t * 2^32).
+    uint32_t t;
+    uint64_t scratch_mask;
+    asm("v_mad_u64_u32 %0, %2, %4, -1, %5\n\t"
+        "v_subb_co_u32_e64 %1, %3, 0, 0, %6\n\t"  // t = -b; with the s_nop the two wait states between the carry flag's write and read
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %1, %3, %1, 0, %2\n\t"  // t = c - b
+        "v_mad_i64_i32 %0, %3, %1, -1, %0"
+        : "=&v"(r), "=&v"(t), "=&s"(carry_mask), "=&s"(scratch_mask)
+        : "v"(h0), "v"(D), "s"(borrow_mask));  // h0 * eps < p
+    return r + ((uint64_t)t << 32);
 }
 
 // (hi * 2^64 + lo) mod p, any representative; hi, lo arbitrary
