@@ -103,6 +103,61 @@ def test_quotient_cell_cache_does_not_change_the_proof(slots, monkeypatch):
         pv.close()
 
 
+def _multiply_reduce_paths(a, b, c=0):
+    """Word-level model of gl_mul_nc / gl_mad_nc (csrc/gl_dev.h): which internal flags an operand pair raises.
+    (c0: carry of a0*b0 + c, cm: carry of the middle multiply-add, t_ov: m2_hi + c0 reaches 2^32, borrow and carry of the
+    reduction, h0 == 0).  Also checks the header's claim that the single correction never wraps."""
+    M32, M64 = (1 << 32) - 1, (1 << 64) - 1
+    a0, a1, b0, b1 = a & M32, a >> 32, b & M32, b >> 32
+    p0 = a0 * b0 + c
+    c0, p0 = p0 >> 64, p0 & M64
+    m2 = a1 * b0 + a0 * b1 + (p0 >> 32)
+    cm, m2 = m2 >> 64, m2 & M64
+    t = (m2 >> 32) + c0
+    p3 = a1 * b1 + t
+    assert p3 < 1 << 64
+    l, h0, h1 = ((m2 & M32) << 32) | (p0 & M32), p3 & M32, p3 >> 32
+    d = l - h1 - cm
+    borrow, d = int(d < 0), d & M64
+    r = d + h0 * M32
+    carry, r = r >> 64, r & M64
+    x = r + (carry - borrow) * M32
+    assert 0 <= x < 1 << 64 and x % P == (a * b + c) % P
+    return c0, cm, t >> 32, borrow, carry, int(h0 == 0)
+
+
+def test_multiply_reduce_flag_paths(prover):
+    """The 13-instruction multiply keeps its carries in scalar flag registers and settles borrow and carry with one
+    correction; each combination of those flags that operands can produce is driven here (found by search with the
+    model above), for a*b, a*b + (a xor b) and the plain 128-bit reduction."""
+    pairs = [
+        (0x80000000, 0x6ec9d28663ca828d), (0x2, 0x4ba927c3ecf45ccb), (0x8a05a6c4647159, 0xb8b6d8fe442e3d43),
+        (0x8000000000000000, 0x8000000000000000), (0xfffffffe00000001, 0x7fffffff00000000), (0xa6cecc1b78e51061, 0xfffffffffffffffe),
+        (0xfffffffeffffffff, 0x8000000080000001), (0xd66b829e6a8ac4ba, 0xa46d6753ec148cb4), (0xfffffffefffffffe, 0xffffffff00000003),
+        (0xfffffffe, 0x7ffffffffffffffe), (0xfffffffeffffffff, 0xffff0000ffff), (0x1ffffffff, 0xffff0000fffffffd),
+        (0x8000000080000000, 0x7fffffff00000001), (0x7fffffff80000001, 0xffffffffffffffff), (0x7fffffffffffffff, 0x80000001ffffffff),
+        (0xfffffffd80000001, 0x74b31bfbf8449560), (0xfffffffdffffffff, 0xfffffffeffffffff), (0xffffffff7fffffff, 0x4a2f20aaf3c64af7),
+        (0x7fffffffffffffff, 0xffffffffffffffff), (0x2, 0xffffffff00000000), (0x0, 0x0), (0x2, 0xffffffffffffffff),
+        (0x200000000, 0x8000000000000000), (0x180000000, 0xfffffffe00000000), (0x3ffffffff, 0xffffffff80000000),
+        (0xfffffffeffffffff, 0xfffffffdffffffff), (0x2ffffffff, 0xffffffffffffffff), (0xffffffff00000002, 0xffffffffffffffff),
+        (0x300000000, 0xaaaaaaab00000000),
+    ]
+    pairs += [(y, x) for x, y in pairs]
+    mul_paths = {_multiply_reduce_paths(x, y) for x, y in pairs}
+    mad_paths = {_multiply_reduce_paths(x, y, x ^ y) for x, y in pairs}
+    # every flag is seen both ways, and the interesting combinations are present
+    for paths, flags in ((mul_paths, (1, 3, 4, 5)), (mad_paths, (0, 1, 2, 3, 4, 5))):
+        for f in flags:
+            assert {p[f] for p in paths} == {0, 1}, (f, sorted(paths))
+    assert any(p[3] and p[4] for p in mul_paths) and any(p[3] and not p[4] for p in mul_paths) and any(p[4] and not p[3] for p in mul_paths)
+    assert any(p[0] and p[2] for p in mad_paths)  # the carry of a0*b0 + c ripples past m2's high word
+    a = np.array([x for x, _ in pairs], dtype=np.uint64)
+    b = np.array([y for _, y in pairs], dtype=np.uint64)
+    assert [int(g) for g in prover.field_ops(0, a, b)] == [x * y % P for x, y in pairs]
+    assert [int(g) for g in prover.field_ops(1, a, b)] == [(x * y + (x ^ y)) % P for x, y in pairs]
+    assert [int(g) for g in prover.field_ops(7, a, b)] == [((x << 64) + y) % P for x, y in pairs]
+
+
 def test_lazy_reduction_arithmetic_on_boundary_operands(prover):
     """The kernels keep field values as arbitrary 64-bit representatives and correct wraps lazily; the wrap paths fire with
     probability ~2^-32 per operation on proof data, so they are driven here with boundary operands, all pairs."""
