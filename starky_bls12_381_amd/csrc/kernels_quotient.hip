@@ -111,9 +111,28 @@ __device__ __forceinline__ void quotient_eval_batch(const QBatch& cur, const gl_
             x = (ref & QREF_FROM_LDS) ? xl[i] : xg[i];
             if (ref & QREF_STORE) cache_lane[(ref & QREF_SLOT_MASK) << 6] = x;
         }
-        // A sequence of independent `if`s, each updating its own part of the state in place, rather than one switch: the
-        // merge points then carry no register-to-register copies of the rest of the state.
+        // The kernel is bound by SCALAR instruction issue (decode, compare, branch: one per SIMD every four cycles, the
+        // same rate as the vector ALU), so 92 % of the ops -- a term that is +-1 or a constant times one cell -- take a short
+        // path of two or three tests; everything else goes through a sequence of independent `if`s, each updating its own
+        // part of the state in place (a switch there costs register-to-register copies of the state at the merge points).
         const uint32_t op = hdr & 7u;
+        if (hdr & QOP_SIMPLE) {
+            if (((hdr >> QOP_CK_SHIFT) & 7u) == CK_CONST) {
+                S.body = gl_mad_nc(x, cur.op[i].k, S.body);
+            } else {
+                // +x and -x on one path: (x ^ m) + c with wave-uniform (m, c) = (0, 0) or (~0, p + 1), i.e. x or p - x
+                // (x is canonical; p - 0 = p is a harmless alias of 0 for the single-correction add)
+                const bool minus = ((hdr >> QOP_CK_SHIFT) & 7u) == CK_MINUS;
+                const uint64_t m = minus ? ~0ull : 0ull, c = minus ? GL_P + 1 : 0ull;
+                S.body = gl_add_nc(S.body, (x ^ m) + c);
+            }
+            if (hdr & QOP_FOLD) {
+                S.t0 = gl_mad_nc(S.t0, L.a0, S.body);
+                S.t1 = gl_mad_nc(S.t1, L.a1, S.body);
+                S.body = 0;
+            }
+            continue;
+        }
         if (op == QOP_TERM) {
             gl_t u = x;  // the common case (92 % of the terms): one cell, no earlier factor
             if (hdr & (QOP_NOCELL | QOP_PREV)) u = (hdr & QOP_NOCELL) ? (gl_t)1 : gl_canon(gl_mul_nc(S.v, x));

@@ -28,6 +28,7 @@ enum : uint32_t {
     QOP_NOCELL = 1u << 5,  // TERM: no cell factor (the term is a constant)
     QOP_CK_SHIFT = 6,      // TERM: [8:6] = CK_*
     QOP_KIND_SHIFT = 9,    // GROUP: [10:9] = KIND_*
+    QOP_SIMPLE = 1u << 11, // TERM: coefficient (+1, -1 or a constant) times ONE cell: the evaluator's short path
     QOP_IDX_SHIFT = 16     // ENDGROUP: m; TERM with CK_PI / CK_NEG_PI: public input index
 };
 static const unsigned QOP_BATCH = 4;          // ops per scalar fetch
@@ -69,6 +70,7 @@ inline QProgram compile_quotient_ops(const AirProgram& P, unsigned want) {
                 for (uint32_t f = 0; f + 1 < nf; f++) g.push_back({QOP_FACTOR | (f ? QOP_PREV : 0u), code[i++], 0});
                 QOp t;
                 t.hdr = QOP_TERM | (ck << QOP_CK_SHIFT) | ((tw & 32u) ? QOP_FOLD : 0u) | (nf >= 2 ? QOP_PREV : 0u) | (nf == 0 ? QOP_NOCELL : 0u);
+                if (nf == 1 && (ck == CK_PLUS || ck == CK_MINUS || ck == CK_CONST)) t.hdr |= QOP_SIMPLE;
                 t.ref = nf ? code[i++] : 0;
                 t.k = 0;
                 if (ck == CK_CONST) t.k = P.consts[idx];
