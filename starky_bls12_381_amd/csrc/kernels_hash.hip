@@ -49,13 +49,30 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__
     gl_t s0 = 0, s1 = 0, s2 = 0;
     size_t off = 0;
     // full 8-element blocks (overwrite mode): lanes 0, 1 absorb three columns, lane 2 two, lane 3 holds capacity only
+    // The next block's cells are requested before the current permutation (about 10 us of arithmetic) so that their
+    // latency -- column stride N * 8 bytes, a new page per load -- is never waited for with only two waves per SIMD.
     const gl_t* mine = col + (size_t)(3 * l) * N;
+    gl_t n0 = 0, n1 = 0, n2 = 0;
+    if (8 <= n_cols) {
+        if (l <= 2) {
+            n0 = mine[0];
+            n1 = mine[N];
+        }
+        if (l <= 1) n2 = mine[2 * N];
+    }
     for (; off + 8 <= n_cols; off += 8) {
         if (l <= 2) {
-            s0 = mine[off * N];
-            s1 = mine[(off + 1) * N];
+            s0 = n0;
+            s1 = n1;
         }
-        if (l <= 1) s2 = mine[(off + 2) * N];
+        if (l <= 1) s2 = n2;
+        if (off + 16 <= n_cols) {
+            if (l <= 2) {
+                n0 = mine[(off + 8) * N];
+                n1 = mine[(off + 9) * N];
+            }
+            if (l <= 1) n2 = mine[(off + 10) * N];
+        }
         poseidon_permute_quad(s0, s1, s2, diag0, rc, l == 0);
     }
     if (off < n_cols) {

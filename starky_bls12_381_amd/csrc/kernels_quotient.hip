@@ -19,6 +19,7 @@
 // boundaries so that (points / 64) x n_chunks waves fill the chip; a chunk's partial fold is scaled by
 // alpha^(constraints after the chunk) in the combine kernel, which is exact in the field.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "air_ir.h"
 #include "gl_dev.h"
@@ -271,7 +272,10 @@ hipError_t launch_quotient_eval(const QOp* ops, const uint32_t* loads, unsigned 
     if (n_slots)
         hipLaunchKernelGGL(quotient_eval_kernel<true>, dim3((unsigned)((size + 63) / 64), n_chunks), dim3(64), lds_bytes, st, P);
     else
-        hipLaunchKernelGGL(quotient_eval_kernel<false>, dim3((unsigned)((size + 63) / 64), n_chunks), dim3(64), 0, st, P);
+    {
+        static const size_t pad = [] { const char* e = getenv("STARKHIP_QUOTIENT_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+        hipLaunchKernelGGL(quotient_eval_kernel<false>, dim3((unsigned)((size + 63) / 64), n_chunks), dim3(64), pad, st, P);
+    }
     return hipGetLastError();
 }
 
