@@ -23,7 +23,8 @@ def main():
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
         if mode == "stats":
-            w.writerow(["kernel", "calls", "total_ns", "average_ns", "percent"])
+            # rocprofv3's top_kernels view reports microseconds (6 leaf-hash launches: 3 x ~180 ms + 3 small trees)
+            w.writerow(["kernel", "calls", "total_us", "average_us", "percent"])
             for name, calls, total, avg, pct in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
                 w.writerow([short(name), calls, f"{total:.0f}", f"{avg:.0f}", f"{pct:.3f}"])
         else:
