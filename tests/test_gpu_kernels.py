@@ -82,6 +82,29 @@ def test_bad_shapes_are_refused(prover):
     assert e.value.code == S.ERR_BAD_SHAPE
     with pytest.raises(S.StarkhipError):
         prover.prove(S.AIR_TEST_FIBONACCI, cfg, t, pis[:2])
+    # one row, more rows than the reference's largest trace, a public input that is not a canonical field element,
+    # and a blow-up too small for the constraint degree of a real AIR: all refused before any GPU work
+    for rows in (1, 16384):
+        tt, pp = S.trace_fibonacci(3, 5, 64)
+        big = np.zeros((rows, tt.shape[1]), dtype=np.uint64)
+        with pytest.raises(S.StarkhipError) as e:
+            prover.prove(S.AIR_TEST_FIBONACCI, cfg, big, pp)
+        assert e.value.code == S.ERR_BAD_SHAPE
+    bad_pis = pis.copy()
+    bad_pis[0] = np.uint64(P)
+    with pytest.raises(S.StarkhipError) as e:
+        prover.prove(S.AIR_TEST_FIBONACCI, cfg, t, bad_pis)
+    assert e.value.code == S.ERR_BAD_SHAPE
+    from bls_util import random_fp12
+    t12, pis12 = S.trace_fp12_mul(random_fp12(0x5EED3100), random_fp12(0x5EED3101))
+    low = S.StarkConfig.for_air(S.AIR_FP12_MUL)
+    low.rate_bits = 0
+    with pytest.raises(S.StarkhipError) as e:
+        prover.prove(S.AIR_FP12_MUL, low, t12, pis12)
+    assert e.value.code == S.ERR_BAD_SHAPE
+    with pytest.raises(S.StarkhipError) as e:
+        prover.prove(99, cfg, t, pis)
+    assert e.value.code == S.ERR_BAD_AIR
 
 
 @pytest.mark.parametrize("slots", [0, 7, 24])
