@@ -43,3 +43,31 @@ for layout, data, name in cases:
     print(f"{name}: {min(ts) * 1e3:.0f} ms per proof end to end ({1 / min(ts):.2f} proofs/s); device phases total {dev['total']:.0f} ms, upload {dev['upload']:.0f} ms")
 print(f"host trace generation: {t_gen * 1e3:.0f} ms into pageable memory, {t_gen_pinned * 1e3:.0f} ms into the page-locked buffer (one core); "
       f"allocating the {trace.nbytes / 1e6:.0f} MB page-locked buffer: {t_pin * 1e3:.0f} ms (once)")
+
+# two proofs in flight from host rows (two contexts, two host threads), as bench.py does with resident traces:
+# one proof's upload and transpose overlap the other's kernels
+import threading  # noqa: E402
+
+pv2 = S.Prover(0)
+pv2.prove(air, cfg, pinned, pis)  # warm-up of the second context
+steps, todo, lock = 6, [], threading.Lock()
+
+
+def worker(p):
+    while True:
+        with lock:
+            if not todo:
+                return
+            todo.pop()
+        p.prove(air, cfg, pinned, pis)
+
+
+todo.extend(range(steps))
+t0 = time.perf_counter()
+th = [threading.Thread(target=worker, args=(p,)) for p in (pv, pv2)]
+for x in th:
+    x.start()
+for x in th:
+    x.join()
+el = (time.perf_counter() - t0) / steps
+print(f"two proofs in flight from page-locked host rows: {el * 1e3:.0f} ms per proof ({1 / el:.2f} proofs/s), upload included")
