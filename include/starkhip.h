@@ -120,6 +120,22 @@ int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, 
                    int trace_layout, int trace_on_device, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness,
                    uint64_t** proof, size_t* proof_words);
 
+/* --- compact traces: on-device trace expansion -----------------------------------------------
+ * Between starkhip_trace_log_begin and _end the calling thread's ONE starkhip_trace_* call records its writes as runs
+ * (a limb vector + the rows it repeats on) instead of filling n_rows x C cells; its `trace` argument is ignored and may
+ * be NULL, public inputs are produced as usual.  FinalExp: ~150 MB of records instead of 4.8 GB of rows.
+ * starkhip_prove_compact uploads the records and expands them on the device straight into the column-major matrix;
+ * the proof is bit-identical to the one from the dense trace.  A log is immutable after _end and may be proven any
+ * number of times, from any thread; release it with starkhip_trace_log_free. */
+int starkhip_trace_log_begin(void** log);
+int starkhip_trace_log_end(void* log);
+void starkhip_trace_log_free(void* log);
+int starkhip_trace_log_info(const void* log, size_t* n_rows, size_t* n_cols, size_t* n_records, size_t* n_words);
+/* CPU replay into a row-major matrix (tests): *conflicts = cells that two records wrote with different values (must be 0) */
+int starkhip_trace_log_expand_host(const void* log, uint64_t* trace_rowmajor, size_t* conflicts);
+int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const void* log, const uint64_t* public_inputs,
+                           size_t n_pis, uint64_t pow_witness, uint64_t** proof, size_t* proof_words);
+
 /* per-phase device timings of the last prove on this ctx, milliseconds (HIP events):
  * [0] upload/transpose [1] ifft+lde [2] trace leaf hash + merkle [3] quotient [4] quotient commit
  * [5] openings [6] fri combine [7] fri commit [8] pow [9] queries [10] total */

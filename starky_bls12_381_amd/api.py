@@ -90,6 +90,14 @@ lib.starkhip_verify.argtypes = [C.c_int, C.POINTER(StarkConfig), _u64p, C.c_size
 lib.starkhip_free.argtypes = [C.c_void_p]
 lib.starkhip_free.restype = None
 lib.starkhip_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+lib.starkhip_trace_log_begin.argtypes = [C.POINTER(C.c_void_p)]
+lib.starkhip_trace_log_end.argtypes = [C.c_void_p]
+lib.starkhip_trace_log_free.argtypes = [C.c_void_p]
+lib.starkhip_trace_log_free.restype = None
+lib.starkhip_trace_log_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_size_t)] * 4
+lib.starkhip_trace_log_expand_host.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
+lib.starkhip_prove_compact.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint64,
+                                       C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t)]
 lib.starkhip_host_free.argtypes = [C.c_void_p]
 lib.starkhip_host_free.restype = None
 lib.starkhip_trace_fibonacci.argtypes = [C.c_uint64, C.c_uint64, _u64p, C.c_size_t, _u64p]
@@ -165,6 +173,58 @@ def air_program(air):
 
 
 # ----------------------------------------------------------------------------- traces (generate_trace)
+class CompactTrace:
+    """A trace recorded as runs (starkhip_trace_log_*): the generator's limb vectors with the rows they
+    repeat on, expanded on the device by `Prover.prove`.  `shape` is the shape of the dense trace it stands for."""
+
+    def __init__(self, handle):
+        self._h = handle
+        v = [C.c_size_t() for _ in range(4)]
+        _chk(lib.starkhip_trace_log_info(handle, *[C.byref(x) for x in v]))
+        self.shape = (v[0].value, v[1].value)
+        self.n_records, self.nbytes = v[2].value, 4 * (v[3].value + v[2].value)
+        self._fin = weakref.finalize(self, lib.starkhip_trace_log_free, handle)
+
+    def expand(self):
+        """(dense row-major trace, number of cells two records disagree on) -- CPU replay, for tests."""
+        out = np.empty(self.shape, dtype=np.uint64)
+        bad = C.c_size_t()
+        _chk(lib.starkhip_trace_log_expand_host(self._h, _p64(out), C.byref(bad)))
+        return out, bad.value
+
+
+class _Recording:
+    """with _Recording() as r: <one starkhip_trace_* call with a null trace>;  r.trace is the CompactTrace."""
+
+    def __enter__(self):
+        self._h = C.c_void_p()
+        _chk(lib.starkhip_trace_log_begin(C.byref(self._h)))
+        self.trace = None
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = lib.starkhip_trace_log_end(self._h)
+        if et is None and rc == 0:
+            self.trace = CompactTrace(self._h)
+        else:
+            lib.starkhip_trace_log_free(self._h)
+            if et is None:
+                raise StarkhipError(rc)
+        return False
+
+
+def _generate(air, n_rows, out, compact, call):
+    """Run one generator: into a dense array (returned, or `out`), or recorded (compact=True)."""
+    if compact:
+        pis = np.zeros(air_public_inputs(air), dtype=np.uint64)
+        with _Recording() as r:
+            _chk(call(C.cast(None, _u64p), n_rows or air_default_rows(air), _p64(pis)))
+        return r.trace, pis
+    t, pis, n = _trace_alloc(air, n_rows, out)
+    _chk(call(_p64(t), n, _p64(pis)))
+    return t, pis
+
+
 def _trace_alloc(air, n_rows, out=None):
     """`out`: optional C-contiguous uint64 [n_rows][columns] array to generate into (e.g. Prover.host_array); the
     generators clear it themselves."""
@@ -183,17 +243,16 @@ def trace_fibonacci(x0, x1, n_rows=None, out=None):
     return t, pis
 
 
-def trace_fp12_mul(x, y, n_rows=None, out=None):
-    """FP12MulStark::generate_trace + the public inputs of fp12_mul_main (src/aggregate_proof.rs:117-148)."""
-    t, pis, n = _trace_alloc(AIR_FP12_MUL, n_rows, out)
-    _chk(lib.starkhip_trace_fp12_mul(_p32(_limbs(x, 144)), _p32(_limbs(y, 144)), _p64(t), n, _p64(pis)))
-    return t, pis
+def trace_fp12_mul(x, y, n_rows=None, out=None, compact=False):
+    """FP12MulStark::generate_trace + the public inputs of fp12_mul_main (src/aggregate_proof.rs:117-148).
+    compact=True (every generator below): a CompactTrace instead of the dense rows."""
+    xs, ys = _limbs(x, 144), _limbs(y, 144)
+    return _generate(AIR_FP12_MUL, n_rows, out, compact, lambda t, n, p: lib.starkhip_trace_fp12_mul(_p32(xs), _p32(ys), t, n, p))
 
 
-def trace_final_exp(x, n_rows=None, out=None):
-    t, pis, n = _trace_alloc(AIR_FINAL_EXP, n_rows, out)
-    _chk(lib.starkhip_trace_final_exp(_p32(_limbs(x, 144)), _p64(t), n, _p64(pis)))
-    return t, pis
+def trace_final_exp(x, n_rows=None, out=None, compact=False):
+    xs = _limbs(x, 144)
+    return _generate(AIR_FINAL_EXP, n_rows, out, compact, lambda t, n, p: lib.starkhip_trace_final_exp(_p32(xs), t, n, p))
 
 
 def _ecc_inputs(points, bits):
@@ -203,13 +262,12 @@ def _ecc_inputs(points, bits):
     return pts, b
 
 
-def trace_ecc_aggregate(points, bits, n_rows=None, out=None):
+def trace_ecc_aggregate(points, bits, n_rows=None, out=None, compact=False):
     """ECCAggStark::generate_trace + ec_aggregate_main's public inputs (src/ecc_aggregate.rs:39-84, src/aggregate_proof.rs:191-209).
     points: [512][24] u32 limbs (x then y); bits: 512 booleans.  The aggregate lands in the last 24 public inputs."""
-    t, pis, n = _trace_alloc(AIR_ECC_AGGREGATE, n_rows, out)
     pts, b = _ecc_inputs(points, bits)
-    _chk(lib.starkhip_trace_ecc_aggregate(_p32(pts), b.ctypes.data_as(_u8p), _p64(t), n, _p64(pis)))
-    return t, pis
+    return _generate(AIR_ECC_AGGREGATE, n_rows, out, compact,
+                     lambda t, n, p: lib.starkhip_trace_ecc_aggregate(_p32(pts), b.ctypes.data_as(_u8p), t, n, p))
 
 
 def native_g1_aggregate(points, bits):
@@ -220,17 +278,14 @@ def native_g1_aggregate(points, bits):
     return out
 
 
-def trace_miller_loop(px, py, qx, qy, qz, n_rows=None, out=None):
-    t, pis, n = _trace_alloc(AIR_MILLER_LOOP, n_rows, out)
-    _chk(lib.starkhip_trace_miller_loop(_p32(_limbs(px, 12)), _p32(_limbs(py, 12)), _p32(_limbs(qx, 24)), _p32(_limbs(qy, 24)),
-                                        _p32(_limbs(qz, 24)), _p64(t), n, _p64(pis)))
-    return t, pis
+def trace_miller_loop(px, py, qx, qy, qz, n_rows=None, out=None, compact=False):
+    a = [_limbs(px, 12), _limbs(py, 12), _limbs(qx, 24), _limbs(qy, 24), _limbs(qz, 24)]
+    return _generate(AIR_MILLER_LOOP, n_rows, out, compact, lambda t, n, p: lib.starkhip_trace_miller_loop(*[_p32(v) for v in a], t, n, p))
 
 
-def trace_pairing_precomp(qx, qy, qz, n_rows=None, out=None):
-    t, pis, n = _trace_alloc(AIR_PAIRING_PRECOMP, n_rows, out)
-    _chk(lib.starkhip_trace_pairing_precomp(_p32(_limbs(qx, 24)), _p32(_limbs(qy, 24)), _p32(_limbs(qz, 24)), _p64(t), n, _p64(pis)))
-    return t, pis
+def trace_pairing_precomp(qx, qy, qz, n_rows=None, out=None, compact=False):
+    a = [_limbs(qx, 24), _limbs(qy, 24), _limbs(qz, 24)]
+    return _generate(AIR_PAIRING_PRECOMP, n_rows, out, compact, lambda t, n, p: lib.starkhip_trace_pairing_precomp(*[_p32(v) for v in a], t, n, p))
 
 
 def native_fp12_mul(x, y):
@@ -285,7 +340,15 @@ class Prover:
             pass
 
     def prove(self, air, config, trace, public_inputs, pow_witness=POW_SEARCH, layout=0):
-        """trace: numpy uint64, row-major [n][C] (layout 0) or column-major [C][n] (layout 1)."""
+        """trace: numpy uint64, row-major [n][C] (layout 0) or column-major [C][n] (layout 1), or a CompactTrace."""
+        if isinstance(trace, CompactTrace):
+            pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+            out = _u64p()
+            words = C.c_size_t()
+            _chk(lib.starkhip_prove_compact(self._ctx, air, C.byref(config), trace._h, _p64(pis), pis.size, pow_witness, C.byref(out), C.byref(words)))
+            proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy()
+            lib.starkhip_free(out)
+            return proof
         trace = np.ascontiguousarray(trace, dtype=np.uint64)
         n_rows = trace.shape[0] if layout == 0 else trace.shape[1]
         pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)

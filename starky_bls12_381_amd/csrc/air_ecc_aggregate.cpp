@@ -356,8 +356,7 @@ extern "C" int starkhip_trace_ecc_aggregate(const uint32_t* points, const uint8_
     try {
         std::vector<std::array<Fp, 2>> pts;
         load_points(points, pts);
-        memset(trace, 0, n_rows * COLUMNS * sizeof(uint64_t));
-        Trace t{trace, n_rows, COLUMNS};
+        Trace t = open_trace(trace, n_rows, COLUMNS);
         for (size_t i = 0; i < n_rows; i++) t.at(i, ROW_NUM + i % 12) = 1;
         size_t row = 0;
         for (size_t i = 0; i < NUM_POINTS; i++) {

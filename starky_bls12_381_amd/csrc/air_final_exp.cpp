@@ -180,8 +180,7 @@ extern "C" int starkhip_trace_final_exp(const uint32_t x[144], uint64_t* trace, 
     if (n_rows != N_ROWS) return STARKHIP_ERR_BAD_SHAPE;  // the layout holds exactly 8192 row-selector columns
     try {
         const Fp12 X = Fp12::from_limbs(x);
-        memset(trace, 0, n_rows * COLUMNS * sizeof(uint64_t));
-        Trace t{trace, n_rows, COLUMNS};
+        Trace t = open_trace(trace, n_rows, COLUMNS);
         for (size_t row = 0; row < n_rows; row++) {
             t.at(row, FINAL_EXP_ROW_SELECTORS + row) = 1;
             t.put(row, FINAL_EXP_INPUT_OFFSET, X);

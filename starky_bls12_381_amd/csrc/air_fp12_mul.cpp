@@ -36,8 +36,7 @@ extern "C" int starkhip_trace_fp12_mul(const uint32_t x[144], const uint32_t y[1
     if (n_rows < 12 || (n_rows & (n_rows - 1))) return STARKHIP_ERR_BAD_SHAPE;
     try {
         bls::Fp12 X = bls::Fp12::from_limbs(x), Y = bls::Fp12::from_limbs(y);
-        memset(trace, 0, n_rows * lay_fp12mul::COLUMNS * sizeof(uint64_t));
-        Trace t{trace, n_rows, lay_fp12mul::COLUMNS};
+        Trace t = open_trace(trace, n_rows, lay_fp12mul::COLUMNS);
         fill_trace_fp12_multiplication(t, X, Y, 0, 11, 0);
         bls::Fp12 Z = X * Y;
         uint32_t z[144];

@@ -120,8 +120,7 @@ extern "C" int starkhip_trace_miller_loop(const uint32_t px[12], const uint32_t 
         const bls::Fp2 QX = fp2_of(qx), QY = fp2_of(qy), QZ = fp2_of(qz);
         std::vector<bls::EllCoeff> ell = bls::calc_pairing_precomp(QX, QY, QZ);
         Fp12 native_res = bls::miller_loop(x, y, QX, QY, QZ);
-        memset(trace, 0, n_rows * M::COLUMNS * sizeof(uint64_t));
-        Trace t{trace, n_rows, M::COLUMNS};
+        Trace t = open_trace(trace, n_rows, M::COLUMNS);
         for (size_t row = 0; row < n_rows; row++) {
             t.put(row, M::PX_OFFSET, x.l);
             t.put(row, M::PY_OFFSET, y.l);

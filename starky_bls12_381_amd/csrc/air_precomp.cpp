@@ -242,8 +242,7 @@ extern "C" int starkhip_trace_pairing_precomp(const uint32_t qx_[24], const uint
     if (n_rows < 16 || (n_rows & (n_rows - 1))) return STARKHIP_ERR_BAD_SHAPE;
     try {
         const Fp2 x = fp2_of(qx_), y = fp2_of(qy_), z = fp2_of(qz_);
-        memset(trace, 0, n_rows * PC::COLUMNS * sizeof(uint64_t));
-        Trace t{trace, n_rows, PC::COLUMNS};
+        Trace t = open_trace(trace, n_rows, PC::COLUMNS);
         const Fp2 z_inv = z.invert();
         // the three global multiplications span ALL rows as one "12-row" gadget call (App. B.4 item 13)
         generate_trace_fp2_mul(t, z, z_inv, 0, n_rows - 1, PC::Z_MULT_Z_INV_OFFSET);

@@ -2,11 +2,21 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
+
 #include "airs.h"
+#include "trace_log.h"
 #include "poseidon.h"
 #include "prover.h"
 
 using namespace starkhip;
+
+namespace starkhip {
+TraceLog*& armed_trace_log() {
+    static thread_local TraceLog* armed = nullptr;
+    return armed;
+}
+}  // namespace starkhip
 
 extern "C" {
 
@@ -67,7 +77,68 @@ int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, 
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;
     const AirInfo* a = air_get(air);
     if (!a) return STARKHIP_ERR_BAD_AIR;
+    if (trace_layout != 0 && trace_layout != 1) return STARKHIP_ERR_BAD_SHAPE;
     return prove((Ctx*)ctx, *a, *cfg, trace, n_rows, trace_layout, trace_on_device, public_inputs, n_pis, pow_witness, proof, proof_words);
+}
+
+// ---- compact traces (trace_log.h)
+int starkhip_trace_log_begin(void** log) {
+    if (!log) return STARKHIP_ERR_BAD_SHAPE;
+    *log = nullptr;
+    if (armed_trace_log()) return STARKHIP_ERR_BAD_SHAPE;  // already recording on this thread
+    TraceLog* l = new (std::nothrow) TraceLog();
+    if (!l) return STARKHIP_ERR_OOM;
+    armed_trace_log() = l;
+    *log = l;
+    return STARKHIP_OK;
+}
+int starkhip_trace_log_end(void* log) {
+    if (!log || armed_trace_log() != (TraceLog*)log) return STARKHIP_ERR_BAD_SHAPE;
+    armed_trace_log() = nullptr;
+    TraceLog* l = (TraceLog*)log;
+    l->open.clear();
+    l->open.shrink_to_fit();
+    return l->rows ? STARKHIP_OK : STARKHIP_ERR_BAD_SHAPE;  // no generator ran in between
+}
+void starkhip_trace_log_free(void* log) {
+    if (log && armed_trace_log() == (TraceLog*)log) armed_trace_log() = nullptr;
+    delete (TraceLog*)log;
+}
+int starkhip_trace_log_info(const void* log, size_t* n_rows, size_t* n_cols, size_t* n_records, size_t* n_words) {
+    if (!log) return STARKHIP_ERR_BAD_SHAPE;
+    const TraceLog* l = (const TraceLog*)log;
+    if (n_rows) *n_rows = l->rows;
+    if (n_cols) *n_cols = l->cols;
+    if (n_records) *n_records = l->offsets.size();
+    if (n_words) *n_words = l->words.size();
+    return STARKHIP_OK;
+}
+int starkhip_trace_log_expand_host(const void* log, uint64_t* trace_rowmajor, size_t* conflicts) {
+    if (!log || !trace_rowmajor) return STARKHIP_ERR_BAD_SHAPE;
+    const TraceLog* l = (const TraceLog*)log;
+    memset(trace_rowmajor, 0, l->rows * l->cols * sizeof(uint64_t));
+    size_t bad = 0;
+    for (uint32_t off : l->offsets) {
+        const uint32_t* r = &l->words[off];
+        for (uint32_t k = 0; k < r[2]; k++)
+            for (uint32_t i = 0; i < r[3]; i++) {
+                uint64_t& cell = trace_rowmajor[(size_t)(r[1] + k) * l->cols + r[0] + i];
+                if (cell && cell != r[4 + i]) bad++;  // two records disagree: parallel expansion would be order dependent
+                cell = r[4 + i];
+            }
+    }
+    for (size_t i = 0; i + 1 < l->late_zeros.size(); i += 2) trace_rowmajor[(size_t)l->late_zeros[i + 1] * l->cols + l->late_zeros[i]] = 0;
+    if (conflicts) *conflicts = bad;
+    return STARKHIP_OK;
+}
+int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const void* log, const uint64_t* public_inputs,
+                           size_t n_pis, uint64_t pow_witness, uint64_t** proof, size_t* proof_words) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    const AirInfo* a = air_get(air);
+    if (!a) return STARKHIP_ERR_BAD_AIR;
+    const TraceLog* l = (const TraceLog*)log;
+    if (!l || armed_trace_log() == l || l->cols != a->cols || !l->rows) return STARKHIP_ERR_BAD_SHAPE;
+    return prove((Ctx*)ctx, *a, *cfg, (const uint64_t*)l, l->rows, /*layout: compact log*/ 2, 0, public_inputs, n_pis, pow_witness, proof, proof_words);
 }
 
 int starkhip_last_timings(void* ctx, float ms[STARKHIP_N_PHASES]) {

@@ -9,6 +9,7 @@
 #include "air_ir.h"
 #include "air_layout.h"
 #include "native.h"
+#include "trace_log.h"
 
 namespace starkhip {
 
@@ -19,12 +20,27 @@ using bls::Fp6;
 using bls::L12;
 using bls::L24;
 
-// Row-major trace view [rows][cols] of canonical Goldilocks cells.
+// Trace sink of the fillers: either a row-major matrix [rows][cols] of canonical Goldilocks cells (d != nullptr), or a
+// recorder of the same writes as runs (trace_log.h; log != nullptr) that the device expands.
 struct Trace {
     uint64_t* d;
     size_t rows, cols;
-    uint64_t& at(size_t row, size_t col) { return d[row * cols + col]; }
+    TraceLog* log;
+    Trace(uint64_t* dense, size_t r, size_t c, TraceLog* l = nullptr) : d(dense), rows(r), cols(c), log(l) {}
+    struct Cell {  // `t.at(row, col) = v`
+        Trace& t;
+        size_t row, col;
+        void operator=(uint64_t v) {
+            if (t.log) t.log->set(row, col, v);
+            else t.d[row * t.cols + col] = v;
+        }
+    };
+    Cell at(size_t row, size_t col) { return Cell{*this, row, col}; }
     void put(size_t row, size_t col, const uint32_t* v, size_t n) {
+        if (log) {
+            log->put(row, col, v, n);
+            return;
+        }
         uint64_t* p = d + row * cols + col;
         for (size_t i = 0; i < n; i++) p[i] = v[i];
     }
@@ -34,6 +50,20 @@ struct Trace {
     void put(size_t row, size_t col, const Fp6& v) { for (int i = 0; i < 6; i++) put(row, col + 12 * i, v.c[i].l); }
     void put(size_t row, size_t col, const Fp12& v) { for (int i = 0; i < 12; i++) put(row, col + 12 * i, v.c[i].l); }
 };
+
+// What a generator calls first: a zeroed dense matrix over the caller's buffer, or -- when the calling thread is armed by
+// starkhip_trace_log_begin -- a recorder (the buffer argument is then ignored and may be null).
+TraceLog*& armed_trace_log();  // thread-local, capi.cpp
+inline Trace open_trace(uint64_t* dense, size_t rows, size_t cols) {
+    if (TraceLog* log = armed_trace_log()) {
+        if (!log->offsets.empty() || log->rows) throw std::runtime_error("trace_log: one generator call per log");
+        log->reset(rows, cols);
+        return Trace(nullptr, rows, cols, log);
+    }
+    if (!dense) throw std::runtime_error("trace: null buffer");
+    memset(dense, 0, rows * cols * sizeof(uint64_t));
+    return Trace(dense, rows, cols);
+}
 
 // Constraint sink: thin sugar over AirBuilder for the "gate * (a - b)" families that make up most constraints.
 struct CS {

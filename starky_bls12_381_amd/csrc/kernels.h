@@ -15,6 +15,9 @@ namespace starkhip {
 hipError_t launch_fill_powers(gl_t* out, gl_t base, gl_t mult, size_t count, hipStream_t st);  // out[i] = base * mult^i
 hipError_t launch_fill_coset_scale(gl_t* out, unsigned log_n, unsigned rate_bits, hipStream_t st);
 hipError_t launch_transpose(const gl_t* in, gl_t* out, size_t rows, size_t cols, hipStream_t st);
+// compact trace log (trace_log.h) -> column-major values[col][row]; `values` must be zeroed
+hipError_t launch_expand_trace(const uint32_t* words, const uint32_t* offsets, size_t n_records, gl_t* values, size_t n_rows, hipStream_t st);
+hipError_t launch_zero_cells(const uint32_t* col_row, size_t n_cells, gl_t* values, size_t n_rows, hipStream_t st);
 // from_coeffs == 0: `values` holds evaluations on the subgroup (PolynomialBatch::from_values);
 // from_coeffs != 0: `values` already holds coefficients (PolynomialBatch::from_coeffs), coeffs_out unused.
 // 2^1 .. 2^7 rows (radix-2 in LDS, kernels_ntt.hip)

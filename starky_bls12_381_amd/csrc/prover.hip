@@ -12,6 +12,7 @@
 
 #include "airs.h"
 #include "kernels.h"
+#include "trace_log.h"
 #include "poseidon.h"
 #include "proof.h"
 #include "quotient_ops.h"
@@ -256,7 +257,27 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
 
     // ---- phase 0: trace into column-major device memory (trace_rows_to_poly_values)
     const gl_t* d_values;
-    if (on_device && layout == 1) {
+    if (layout == 2) {  // compact trace: upload the generator's write log and expand it here
+        const TraceLog* log = (const TraceLog*)trace;
+        const size_t nw = log->words.size(), nr = log->offsets.size(), nz = log->late_zeros.size();
+        if (log->rows != n || log->cols != C) return STARKHIP_ERR_BAD_SHAPE;
+        HIPCHK(c->values.ensure(C * n * 8));
+        HIPCHK(c->staging.ensure((nw + nr + nz + 2) * 4));
+        uint32_t* d_words = c->staging.as<uint32_t>();
+        uint32_t* d_offsets = d_words + nw;
+        uint32_t* d_zeros = d_offsets + nr;
+        HIPCHK(hipMemsetAsync(c->values.p, 0, C * n * 8, st));
+        if (nr) {
+            HIPCHK(hipMemcpyAsync(d_words, log->words.data(), nw * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_offsets, log->offsets.data(), nr * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(launch_expand_trace(d_words, d_offsets, nr, c->values.as<gl_t>(), n, st));
+        }
+        if (nz) {
+            HIPCHK(hipMemcpyAsync(d_zeros, log->late_zeros.data(), nz * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(launch_zero_cells(d_zeros, nz / 2, c->values.as<gl_t>(), n, st));
+        }
+        d_values = c->values.as<gl_t>();
+    } else if (on_device && layout == 1) {
         d_values = trace;
     } else if (on_device) {
         HIPCHK(c->values.ensure(C * n * 8));

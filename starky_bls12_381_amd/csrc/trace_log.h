@@ -1,0 +1,83 @@
+// Compact trace: instead of filling n_rows x C cells on the host and moving them over PCIe
+// (FinalExp: 4.8 GB), the trace generators can RECORD their writes.  The gadget fillers write limb vectors
+// (`put(row, col, limbs)`), and most of those are the same vector on consecutive rows -- a 12-row gadget block repeats
+// its inputs on every row, FinalExp repeats every intermediate Fp12 on all 8192 rows: 95 % of the cells equal the cell
+// above.  A record is one limb vector and the run of rows it occupies:
+//     words: col, first_row, n_rows_in_run, n, v[0..n)          (uint32; every cell of these AIRs is a u32 limb or bit)
+// A put that repeats the previous row's vector at the same column extends that record instead of adding one.  Zeros at
+// either end of a vector are dropped (the expanded matrix starts zeroed); no generator writes a cell twice with
+// different non-zero values, and the one place a cell is set and then cleared is handled in set()
+// (tests/test_trace_log_cpu.py replays every AIR's log and checks all of this against the dense trace).
+// The device expands the records straight into the column-major matrix the prover wants (kernels_trace.hip).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <stdexcept>
+#include <vector>
+
+namespace starkhip {
+
+struct TraceLog {
+    size_t rows, cols;
+    std::vector<uint32_t> words;    // the records, back to back
+    std::vector<uint32_t> offsets;  // start of each record in `words`
+    std::vector<uint32_t> open;     // per column: offset + 1 of the latest record that starts there (0 = none)
+    std::vector<uint32_t> late_zeros;  // (col, row) pairs zeroed after everything else (see set())
+
+    TraceLog() : rows(0), cols(0) {}
+    void reset(size_t r, size_t c) {
+        rows = r;
+        cols = c;
+        words.clear();
+        offsets.clear();
+        late_zeros.clear();
+        open.assign(c, 0);
+    }
+
+    void put(size_t row, size_t col, const uint32_t* v, size_t n) {
+        while (n && v[n - 1] == 0) n--;
+        while (n && v[0] == 0) { v++; col++; n--; }
+        if (!n) return;
+        if (row >= rows || col + n > cols) throw std::runtime_error("trace_log: write outside the trace");
+        const uint32_t o = open[col];
+        if (o) {
+            uint32_t* r = &words[o - 1];
+            if (r[3] == n && r[1] + r[2] == row && memcmp(r + 4, v, n * sizeof(uint32_t)) == 0) {
+                r[2]++;
+                return;
+            }
+        }
+        if (words.size() + 4 + n > 0xFFFFFFF0u) throw std::runtime_error("trace_log: log too large");
+        offsets.push_back((uint32_t)words.size());
+        open[col] = (uint32_t)words.size() + 1;
+        words.push_back((uint32_t)col);
+        words.push_back((uint32_t)row);
+        words.push_back(1);
+        words.push_back((uint32_t)n);
+        words.insert(words.end(), v, v + n);
+    }
+    void set(size_t row, size_t col, uint64_t v) {
+        if (v >> 32) throw std::runtime_error("trace_log: cell value does not fit 32 bits");
+        if (row >= rows || col >= cols) throw std::runtime_error("trace_log: write outside the trace");
+        if (v == 0) {
+            // the one overwriting idiom of the fillers: "selector = 1 on rows a..b", then "selector(b) = 0".  Take the
+            // row back from the run that just wrote it; anything else is kept as a late zero, applied after expansion.
+            const uint32_t o = open[col];
+            if (o) {
+                uint32_t* r = &words[o - 1];
+                if (r[3] == 1 && r[2] > 0 && r[1] + r[2] - 1 == row) {
+                    r[2]--;
+                    return;
+                }
+            }
+            late_zeros.push_back((uint32_t)col);
+            late_zeros.push_back((uint32_t)row);
+            return;
+        }
+        const uint32_t w = (uint32_t)v;
+        put(row, col, &w, 1);
+    }
+};
+
+}  // namespace starkhip

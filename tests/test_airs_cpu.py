@@ -110,6 +110,11 @@ def test_final_exp_trace_satisfies_all_constraints_on_the_reference_vector():
     assert np.array_equal(pis[144:], fp_arr(1, *([0] * 11)))
     blob = S.air_program(S.AIR_FINAL_EXP)
     assert O.check_trace(blob, t, pis)[0] == 0
+    # the same generator recording its writes as runs stands for exactly this matrix, at 1/30 of the bytes
+    c, cpis = S.trace_final_exp(aa, compact=True)
+    assert c.shape == t.shape and np.array_equal(cpis, pis) and c.nbytes * 20 < t.nbytes
+    e, conflicts = c.expand()
+    assert conflicts == 0 and np.array_equal(e, t)
     # 4441 rows carry operations (TOTAL_ROW), the rest of the op window is zero
     assert not t[4441:, 12949:].any()
     t[100, 20000] = (int(t[100, 20000]) + 1) % S.P

@@ -77,11 +77,40 @@ def test_final_exp_proof_verifies_and_matches_golden_digest(prover):
     bad[-1] = (int(bad[-1]) + 1) % S.P
     with pytest.raises(S.StarkhipError):
         S.verify_stark_proof(air, cfg, bad)
+    # the same trace recorded as runs and expanded on the device: the same proof, bit for bit
+    c, cpis = S.trace_final_exp(aa, compact=True)
+    assert c.nbytes < 300e6 and np.array_equal(cpis, pis)
+    assert np.array_equal(prover.prove(air, cfg, c, cpis), proof)
 
 
 def _bls():
     from bls_util import native_vectors
     return {k: int(s) for k, s in native_vectors()["bls_signature"].items()}
+
+
+def test_compact_traces_prove_to_the_same_bytes_as_dense_ones(prover):
+    """On-device trace expansion for the small AIRs: FP12Mul (16 rows), PairingPrecomp and MillerLoop (1024 rows) and the toy
+    shapes of ECCAgg are proven from the recorded runs and from the dense rows; the proofs must be identical."""
+    from bls_util import fp_arr
+    b = _bls()
+    hm = (fp_arr(b["hm_x1"], b["hm_x2"]), fp_arr(b["hm_y1"], b["hm_y2"]), fp_arr(b["hm_z1"], b["hm_z2"]))
+    cases = [
+        (S.AIR_FP12_MUL, S.trace_fp12_mul, (random_fp12(0x5EED2200), random_fp12(0x5EED2201))),
+        (S.AIR_PAIRING_PRECOMP, S.trace_pairing_precomp, hm),
+        (S.AIR_MILLER_LOOP, S.trace_miller_loop, (fp_arr(b["gx"]), fp_arr(b["gy"])) + hm),
+    ]
+    for air, fn, args in cases:
+        cfg = S.StarkConfig.for_air(air)
+        dense, pis = fn(*args)
+        compact, cpis = fn(*args, compact=True)
+        want = prover.prove(air, cfg, dense, pis)
+        got = prover.prove(air, cfg, compact, cpis)
+        assert np.array_equal(got, want), S.AIR_NAMES[air]
+        assert np.array_equal(prover.prove(air, cfg, compact, cpis), want)  # a log can be proven again
+    # a log recorded for one AIR is refused for another
+    with pytest.raises(S.StarkhipError) as e:
+        prover.prove(S.AIR_MILLER_LOOP, S.StarkConfig.for_air(S.AIR_MILLER_LOOP), S.trace_fp12_mul(*cases[0][2], compact=True)[0], pis)
+    assert e.value.code == S.ERR_BAD_SHAPE
 
 
 def test_pairing_precomp_proof_is_bit_identical_to_oracle(prover):

@@ -1,0 +1,69 @@
+"""Compact traces: a generator that records its writes as runs must stand for exactly the dense matrix
+it would have filled, with no cell that two records disagree on (the device expands records in parallel).
+FinalExp (4.8 GB dense) is covered in test_airs_cpu.py next to the dense trace it already builds."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import starky_bls12_381_amd as S
+from starky_bls12_381_amd import aggregate as A
+from bls_util import random_fp12
+from test_aggregate_cpu import _bls_points
+
+
+def _cases():
+    _, pk, hm, sig = _bls_points()
+    jobs, _ = A.signature_jobs(pk, hm, sig)
+    yield "fp12_mul", S.trace_fp12_mul, (random_fp12(0x5EED4000), random_fp12(0x5EED4001))
+    yield "pairing_precomp", S.trace_pairing_precomp, jobs["pp2"][1]
+    yield "miller_loop", S.trace_miller_loop, jobs["ml2"][1]
+
+
+@pytest.mark.parametrize("name,fn,args", list(_cases()), ids=lambda v: v if isinstance(v, str) else "")
+def test_recorded_trace_expands_to_the_dense_one(name, fn, args):
+    dense, pis = fn(*args)
+    compact, cpis = fn(*args, compact=True)
+    assert compact.shape == dense.shape and np.array_equal(cpis, pis)
+    expanded, conflicts = compact.expand()
+    assert conflicts == 0
+    assert np.array_equal(expanded, dense)
+    assert compact.nbytes * 5 < dense.nbytes  # FP12Mul (16 rows) has the least repetition: 10x; the 1024-row AIRs 7-10x
+
+
+def test_ecc_aggregate_recorded_trace():
+    from test_ecc_aggregate_cpu import pack, reference_vector
+    pts, bits, _ = reference_vector()
+    arr, b = pack(pts, bits)
+    dense, pis = S.trace_ecc_aggregate(arr, b)
+    compact, cpis = S.trace_ecc_aggregate(arr, b, compact=True)
+    expanded, conflicts = compact.expand()
+    assert conflicts == 0 and np.array_equal(expanded, dense) and np.array_equal(cpis, pis)
+
+
+def test_recording_is_one_generator_call_per_log_and_per_thread():
+    x, y = random_fp12(0x5EED4002), random_fp12(0x5EED4003)
+    h, h2 = C.c_void_p(), C.c_void_p()
+    assert S.lib.starkhip_trace_log_begin(C.byref(h)) == 0
+    try:
+        assert S.lib.starkhip_trace_log_begin(C.byref(h2)) == S.ERR_BAD_SHAPE  # this thread is already recording
+        assert S.lib.starkhip_trace_log_end(C.c_void_p(1)) == S.ERR_BAD_SHAPE   # not the armed log
+        pis = np.zeros(S.air_public_inputs(S.AIR_FP12_MUL), dtype=np.uint64)
+        xs, ys = np.ascontiguousarray(x, dtype=np.uint32), np.ascontiguousarray(y, dtype=np.uint32)
+        call = lambda: S.lib.starkhip_trace_fp12_mul(S.api._p32(xs), S.api._p32(ys), None, 16, S.api._p64(pis))  # noqa: E731
+        assert call() == 0
+        assert call() == S.ERR_BAD_SHAPE  # a second generator call would mix two traces in one log
+        assert S.lib.starkhip_trace_log_end(h) == 0
+    finally:
+        S.lib.starkhip_trace_log_free(h)
+    # not recording any more: a null dense buffer is refused, not written through
+    assert S.lib.starkhip_trace_fp12_mul(S.api._p32(xs), S.api._p32(ys), None, 16, S.api._p64(pis)) == S.ERR_BAD_SHAPE
+    # an empty recording is an error, and the prover entry refuses a log without a context and the raw layout code
+    assert S.lib.starkhip_trace_log_begin(C.byref(h)) == 0
+    assert S.lib.starkhip_trace_log_end(h) == S.ERR_BAD_SHAPE
+    S.lib.starkhip_trace_log_free(h)
+    c, cpis = S.trace_fp12_mul(x, y, compact=True)
+    cfg = S.StarkConfig.for_air(S.AIR_FP12_MUL)
+    out, words = C.POINTER(C.c_uint64)(), C.c_size_t()
+    assert S.lib.starkhip_prove_compact(None, S.AIR_FP12_MUL, C.byref(cfg), c._h, S.api._p64(cpis), cpis.size, S.POW_SEARCH, C.byref(out),
+                                        C.byref(words)) == S.ERR_NO_DEVICE
