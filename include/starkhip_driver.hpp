@@ -46,15 +46,16 @@ class Prover {
     Prover(const Prover&) = delete;
     Prover& operator=(const Prover&) = delete;
 
-    // prove + verify_stark_proof (src/aggregate_proof.rs:59-67); `trace` row-major [n_rows][columns]
-    Proof prove(starkhip_air_t air, const std::vector<uint64_t>& trace, size_t n_rows, const std::vector<uint64_t>& pis) {
+    // prove + verify_stark_proof (src/aggregate_proof.rs:59-67) from a recorded (compact) trace: the generator's runs are
+    // expanded on the device, so the 4.8 GB of FinalExp rows never exist on the host
+    Proof prove(starkhip_air_t air, const void* trace_log, const std::vector<uint64_t>& pis) {
         Proof p;
         p.air = air;
         check("starkhip_config_for_air", starkhip_config_for_air(air, &p.config));
         uint64_t* blob = nullptr;
         size_t words = 0;
-        check("starkhip_prove", starkhip_prove(ctx_, air, &p.config, trace.data(), n_rows, /*row-major*/ 0, /*host*/ 0, pis.data(), pis.size(),
-                                                 STARKHIP_POW_SEARCH, &blob, &words));
+        check("starkhip_prove_compact",
+              starkhip_prove_compact(ctx_, air, &p.config, trace_log, pis.data(), pis.size(), STARKHIP_POW_SEARCH, &blob, &words));
         p.words.assign(blob, blob + words);
         starkhip_free(blob);
         p.n_public_inputs = pis.size();
@@ -67,42 +68,53 @@ class Prover {
 };
 
 namespace detail {
+// generate_trace + public inputs of one AIR, recorded: `gen(trace, n_rows, pis)` is the one starkhip_trace_* call
 struct Witness {
-    std::vector<uint64_t> trace, pis;
-    size_t n_rows;
-    explicit Witness(starkhip_air_t air)
-        : trace((size_t)starkhip_air_default_rows(air) * starkhip_air_columns(air)),
-          pis(starkhip_air_public_inputs(air)),
-          n_rows(starkhip_air_default_rows(air)) {}
+    void* log = nullptr;
+    std::vector<uint64_t> pis;
+    template <class Gen>
+    Witness(starkhip_air_t air, const char* what, Gen gen) : pis(starkhip_air_public_inputs(air)) {
+        check("starkhip_trace_log_begin", starkhip_trace_log_begin(&log));
+        const int rc = gen((uint64_t*)nullptr, (size_t)starkhip_air_default_rows(air), pis.data());
+        const int rc_end = starkhip_trace_log_end(log);
+        if (rc != STARKHIP_OK || rc_end != STARKHIP_OK) {
+            starkhip_trace_log_free(log);
+            log = nullptr;
+            throw Error(what, rc != STARKHIP_OK ? rc : rc_end);
+        }
+    }
+    ~Witness() { starkhip_trace_log_free(log); }
+    Witness(const Witness&) = delete;
+    Witness& operator=(const Witness&) = delete;
 };
 }  // namespace detail
 
 inline Proof calc_pairing_precomp(Prover& pv, const uint32_t x[24], const uint32_t y[24], const uint32_t z[24]) {
-    detail::Witness w(STARKHIP_AIR_PAIRING_PRECOMP);
-    check("starkhip_trace_pairing_precomp", starkhip_trace_pairing_precomp(x, y, z, w.trace.data(), w.n_rows, w.pis.data()));
-    return pv.prove(STARKHIP_AIR_PAIRING_PRECOMP, w.trace, w.n_rows, w.pis);
+    detail::Witness w(STARKHIP_AIR_PAIRING_PRECOMP, "starkhip_trace_pairing_precomp",
+                      [&](uint64_t* t, size_t n, uint64_t* pis) { return starkhip_trace_pairing_precomp(x, y, z, t, n, pis); });
+    return pv.prove(STARKHIP_AIR_PAIRING_PRECOMP, w.log, w.pis);
 }
 inline Proof miller_loop_main(Prover& pv, const uint32_t x[12], const uint32_t y[12], const uint32_t q_x[24], const uint32_t q_y[24],
                               const uint32_t q_z[24]) {
-    detail::Witness w(STARKHIP_AIR_MILLER_LOOP);
-    check("starkhip_trace_miller_loop", starkhip_trace_miller_loop(x, y, q_x, q_y, q_z, w.trace.data(), w.n_rows, w.pis.data()));
-    return pv.prove(STARKHIP_AIR_MILLER_LOOP, w.trace, w.n_rows, w.pis);
+    detail::Witness w(STARKHIP_AIR_MILLER_LOOP, "starkhip_trace_miller_loop",
+                      [&](uint64_t* t, size_t n, uint64_t* pis) { return starkhip_trace_miller_loop(x, y, q_x, q_y, q_z, t, n, pis); });
+    return pv.prove(STARKHIP_AIR_MILLER_LOOP, w.log, w.pis);
 }
 inline Proof fp12_mul_main(Prover& pv, const uint32_t x[144], const uint32_t y[144]) {
-    detail::Witness w(STARKHIP_AIR_FP12_MUL);
-    check("starkhip_trace_fp12_mul", starkhip_trace_fp12_mul(x, y, w.trace.data(), w.n_rows, w.pis.data()));
-    return pv.prove(STARKHIP_AIR_FP12_MUL, w.trace, w.n_rows, w.pis);
+    detail::Witness w(STARKHIP_AIR_FP12_MUL, "starkhip_trace_fp12_mul",
+                      [&](uint64_t* t, size_t n, uint64_t* pis) { return starkhip_trace_fp12_mul(x, y, t, n, pis); });
+    return pv.prove(STARKHIP_AIR_FP12_MUL, w.log, w.pis);
 }
 inline Proof final_exponentiate_main(Prover& pv, const uint32_t x[144]) {
-    detail::Witness w(STARKHIP_AIR_FINAL_EXP);
-    check("starkhip_trace_final_exp", starkhip_trace_final_exp(x, w.trace.data(), w.n_rows, w.pis.data()));
-    return pv.prove(STARKHIP_AIR_FINAL_EXP, w.trace, w.n_rows, w.pis);
+    detail::Witness w(STARKHIP_AIR_FINAL_EXP, "starkhip_trace_final_exp",
+                      [&](uint64_t* t, size_t n, uint64_t* pis) { return starkhip_trace_final_exp(x, t, n, pis); });
+    return pv.prove(STARKHIP_AIR_FINAL_EXP, w.log, w.pis);
 }
 // points: 512 x [x(12), y(12)]; bits: 512 bytes.  The aggregate is the last 24 public inputs of the proof.
 inline Proof ec_aggregate_main(Prover& pv, const uint32_t* points, const uint8_t* bits) {
-    detail::Witness w(STARKHIP_AIR_ECC_AGGREGATE);
-    check("starkhip_trace_ecc_aggregate", starkhip_trace_ecc_aggregate(points, bits, w.trace.data(), w.n_rows, w.pis.data()));
-    return pv.prove(STARKHIP_AIR_ECC_AGGREGATE, w.trace, w.n_rows, w.pis);
+    detail::Witness w(STARKHIP_AIR_ECC_AGGREGATE, "starkhip_trace_ecc_aggregate",
+                      [&](uint64_t* t, size_t n, uint64_t* pis) { return starkhip_trace_ecc_aggregate(points, bits, t, n, pis); });
+    return pv.prove(STARKHIP_AIR_ECC_AGGREGATE, w.log, w.pis);
 }
 
 struct SignatureProofs {

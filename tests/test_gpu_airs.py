@@ -89,8 +89,8 @@ def _bls():
 
 
 def test_compact_traces_prove_to_the_same_bytes_as_dense_ones(prover):
-    """On-device trace expansion for the small AIRs: FP12Mul (16 rows), PairingPrecomp and MillerLoop (1024 rows) and the toy
-    shapes of ECCAgg are proven from the recorded runs and from the dense rows; the proofs must be identical."""
+    """On-device trace expansion: FP12Mul (16 rows), PairingPrecomp and MillerLoop (1024 rows) and ECCAgg (8192 rows) are
+    proven from the recorded runs and from the dense rows; the proofs must be identical (FinalExp: in its own test above)."""
     from bls_util import fp_arr
     b = _bls()
     hm = (fp_arr(b["hm_x1"], b["hm_x2"]), fp_arr(b["hm_y1"], b["hm_y2"]), fp_arr(b["hm_z1"], b["hm_z2"]))
@@ -99,6 +99,9 @@ def test_compact_traces_prove_to_the_same_bytes_as_dense_ones(prover):
         (S.AIR_PAIRING_PRECOMP, S.trace_pairing_precomp, hm),
         (S.AIR_MILLER_LOOP, S.trace_miller_loop, (fp_arr(b["gx"]), fp_arr(b["gy"])) + hm),
     ]
+    from test_ecc_aggregate_cpu import pack, reference_vector
+    pts, bits, _ = reference_vector()
+    cases.append((S.AIR_ECC_AGGREGATE, S.trace_ecc_aggregate, pack(pts, bits)))
     for air, fn, args in cases:
         cfg = S.StarkConfig.for_air(air)
         dense, pis = fn(*args)
