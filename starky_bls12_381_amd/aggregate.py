@@ -5,7 +5,8 @@ Mirrors /root/reference/src/aggregate_proof.rs:
   miller_loop_main        :74-118   MillerLoopStark(1024)
   fp12_mul_main           :120-151  FP12MulStark(16)
   final_exponentiate_main :153-179  FinalExponentiateStark(8192), rate_bits 2
-each = build config, generate trace + public inputs, prove, verify_stark_proof, return (air, proof, config);
+each = build config, generate trace + public inputs (recorded as runs and expanded on the device, SURVEY §8f-2: the
+4.8 GB of FinalExp rows never exist on the host), prove, verify_stark_proof, return (air, proof, config);
 and the six-proof plan of one BLS signature check (:304-370): pp1, ml1 on (aggregate pk, H(m)), pp2, ml2 on
 (-G1 generator, signature), fp12_mul on the two Miller-loop values, final_exponentiate on their product.
   ec_aggregate_main       :181-221  ECCAggStark(8192), rate_bits 2 (the aggregate public key the pairing proofs take as pk)
@@ -47,32 +48,32 @@ def _prove_and_verify(prover, air, trace, pis):
 
 def calc_pairing_precomp(prover, x, y, z):
     """src/aggregate_proof.rs:23-72.  x, y, z: Fp2 limb arrays of the G2 point."""
-    trace, pis = S.trace_pairing_precomp(x, y, z)
+    trace, pis = S.trace_pairing_precomp(x, y, z, compact=True)
     return _prove_and_verify(prover, S.AIR_PAIRING_PRECOMP, trace, pis)
 
 
 def miller_loop_main(prover, x, y, q_x, q_y, q_z):
     """src/aggregate_proof.rs:74-118.  (x, y): G1 point (Fp limbs); (q_x, q_y, q_z): G2 point (Fp2 limbs)."""
-    trace, pis = S.trace_miller_loop(x, y, q_x, q_y, q_z)
+    trace, pis = S.trace_miller_loop(x, y, q_x, q_y, q_z, compact=True)
     return _prove_and_verify(prover, S.AIR_MILLER_LOOP, trace, pis)
 
 
 def fp12_mul_main(prover, x, y):
     """src/aggregate_proof.rs:120-151."""
-    trace, pis = S.trace_fp12_mul(x, y)
+    trace, pis = S.trace_fp12_mul(x, y, compact=True)
     return _prove_and_verify(prover, S.AIR_FP12_MUL, trace, pis)
 
 
 def final_exponentiate_main(prover, x):
     """src/aggregate_proof.rs:153-179."""
-    trace, pis = S.trace_final_exp(x)
+    trace, pis = S.trace_final_exp(x, compact=True)
     return _prove_and_verify(prover, S.AIR_FINAL_EXP, trace, pis)
 
 
 def ec_aggregate_main(prover, points, bits):
     """src/aggregate_proof.rs:181-221: ECCAggStark over the 512 sync-committee keys and their participation bits.
     points: [512][24] u32 limbs (x, y); the aggregate (the `pk` of the pairing proofs) is the last 24 public inputs."""
-    trace, pis = S.trace_ecc_aggregate(points, bits)
+    trace, pis = S.trace_ecc_aggregate(points, bits, compact=True)
     return _prove_and_verify(prover, S.AIR_ECC_AGGREGATE, trace, pis)
 
 
