@@ -119,10 +119,10 @@ static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
     if (c->prog_air == air.id && c->prog_chunks == want) return 0;
     QProgram Q = compile_quotient_ops(air.prog, want);
     want = (unsigned)Q.chunk_k_after.size();
-    // per-wave LDS cell cache, OFF by default: measured on FinalExp (MI355X) 0 slots 64 ms, 16: 72, 24: 88, 32: 106, 40: 115 ms.
-    // The kernel is VALU-issue bound (PMC: 3.1e10 VALU wave-instructions per launch = 50 ms at the 4-cycle issue rate); the
-    // column re-reads it saves are served by MALL/L2 behind the arithmetic, while the LDS footprint costs occupancy.
-    // STARKHIP_QUOTIENT_SLOTS (0..64) keeps the path testable.
+    // per-wave LDS cell cache, OFF by default: measured on FinalExp (MI355X) 0 slots 40 ms, 16: 44, 32: 67, 48: 94 ms.
+    // The kernel is bound by memory (253 GB fetched per launch, 6.1 TB/s) and its throughput is proportional to the waves
+    // in flight; Belady replacement would hit 38 / 56 / 64 % with 16 / 32 / 64 slots, but the LDS those slots take costs more
+    // occupancy than the hits return.  STARKHIP_QUOTIENT_SLOTS (0..64) keeps the path testable.
     c->prog_slots = 0;
     if (const char* e = getenv("STARKHIP_QUOTIENT_SLOTS")) c->prog_slots = (unsigned)std::min(64, std::max(0, atoi(e)));
     attach_cell_cache(Q, c->prog_slots);
