@@ -93,6 +93,23 @@ __device__ __forceinline__ gl_t gl_mad_nc(gl_t a, gl_t b, gl_t c) {
     return gl_reduce_words<true>((uint32_t)p0, (uint32_t)m2, (uint32_t)p3, (uint32_t)(p3 >> 32), cm);
 }
 
+// gl_mad_nc with a WAVE-UNIFORM b (a kernel argument, an op-stream constant): its halves are scalar-register operands of
+// the two hand-written multiply-adds instead of being copied to vector registers first (two moves less).  b must be
+// uniform across the wave -- a divergent b would silently be read from the first lane.
+__device__ __forceinline__ gl_t gl_mad_nc_ub(gl_t a, gl_t b, gl_t c) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    uint64_t p0, c0, m2, cm, scratch_mask;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(p0), "=s"(c0) : "v"(a0), "s"(b0), "v"(c));
+    const uint64_t m1 = (uint64_t)a0 * b1 + (p0 >> 32);
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m2), "=s"(cm) : "v"(a1), "s"(b0), "v"(m1));
+    uint32_t t0, t1;
+    asm("v_addc_co_u32_e64 %0, %2, %3, 0, %4\n\ts_nop 1\n\tv_addc_co_u32_e64 %1, %2, 0, 0, %2"
+        : "=&v"(t0), "=&v"(t1), "=&s"(scratch_mask)
+        : "v"((uint32_t)(m2 >> 32)), "s"(c0));
+    const uint64_t p3 = (uint64_t)a1 * b1 + (((uint64_t)t1 << 32) | t0);
+    return gl_reduce_words<true>((uint32_t)p0, (uint32_t)m2, (uint32_t)p3, (uint32_t)(p3 >> 32), cm);
+}
+
 // a arbitrary, b canonical (< p)
 __device__ __forceinline__ gl_t gl_add_nc(gl_t a, gl_t b) {
     uint64_t s;

@@ -119,7 +119,7 @@ __device__ __forceinline__ void quotient_eval_batch(const QBatch& cur, const gl_
         const uint32_t op = hdr & 7u;
         if (hdr & QOP_SIMPLE) {
             if (((hdr >> QOP_CK_SHIFT) & 7u) == CK_CONST) {
-                S.body = gl_mad_nc(x, cur.op[i].k, S.body);
+                S.body = gl_mad_nc_ub(x, cur.op[i].k, S.body);
             } else {
                 // +x and -x on one path: (x ^ m) + c with wave-uniform (m, c) = (0, 0) or (~0, p + 1), i.e. x or p - x
                 // (x is canonical; p - 0 = p is a harmless alias of 0 for the single-correction add)
@@ -128,8 +128,8 @@ __device__ __forceinline__ void quotient_eval_batch(const QBatch& cur, const gl_
                 S.body = gl_add_nc(S.body, (x ^ m) + c);
             }
             if (hdr & QOP_FOLD) {
-                S.t0 = gl_mad_nc(S.t0, L.a0, S.body);
-                S.t1 = gl_mad_nc(S.t1, L.a1, S.body);
+                S.t0 = gl_mad_nc_ub(S.t0, L.a0, S.body);
+                S.t1 = gl_mad_nc_ub(S.t1, L.a1, S.body);
                 S.body = 0;
             }
             continue;
@@ -146,12 +146,12 @@ __device__ __forceinline__ void quotient_eval_batch(const QBatch& cur, const gl_
                     kk = L.pis[hdr >> QOP_IDX_SHIFT];
                     if (ck == CK_NEG_PI) kk = kk ? GL_P - kk : 0;
                 }
-                S.body = gl_mad_nc(u, kk, S.body);
+                S.body = gl_mad_nc_ub(u, kk, S.body);
             }
         }
         if (hdr & QOP_FOLD) {  // only ever set on a TERM: the constraint is complete
-            S.t0 = gl_mad_nc(S.t0, L.a0, S.body);
-            S.t1 = gl_mad_nc(S.t1, L.a1, S.body);
+            S.t0 = gl_mad_nc_ub(S.t0, L.a0, S.body);
+            S.t1 = gl_mad_nc_ub(S.t1, L.a1, S.body);
             S.body = 0;
         }
         if (op == QOP_FACTOR) S.v = (hdr & QOP_PREV) ? gl_mul_nc(S.v, x) : x;
