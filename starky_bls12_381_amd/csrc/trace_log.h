@@ -62,7 +62,8 @@ struct TraceLog {
         if (row >= rows || col >= cols) throw std::runtime_error("trace_log: write outside the trace");
         if (v == 0) {
             // the one overwriting idiom of the fillers: "selector = 1 on rows a..b", then "selector(b) = 0".  Take the
-            // row back from the run that just wrote it; anything else is kept as a late zero, applied after expansion.
+            // row back from the run that just wrote it; a clear inside the latest run is kept as a late zero, applied
+            // after the expansion.
             const uint32_t o = open[col];
             if (o) {
                 uint32_t* r = &words[o - 1];
@@ -70,10 +71,12 @@ struct TraceLog {
                     r[2]--;
                     return;
                 }
+                if (row >= r[1] && row < r[1] + r[2]) {  // clears a cell inside the latest run at this column
+                    late_zeros.push_back((uint32_t)col);
+                    late_zeros.push_back((uint32_t)row);
+                }
             }
-            late_zeros.push_back((uint32_t)col);
-            late_zeros.push_back((uint32_t)row);
-            return;
+            return;  // otherwise a first write of zero (a clear bit of a decomposition): the matrix starts zeroed
         }
         const uint32_t w = (uint32_t)v;
         put(row, col, &w, 1);
