@@ -83,9 +83,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # STARKHIP_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend -- a rehearsal of the N > 1 control flow on a
+    # one-GPU box (the numbers it prints are not a measurement; RCCL refuses two ranks on one device)
+    rehearse = os.environ.get("STARKHIP_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     from starky_bls12_381_amd import parallel
-    dist = parallel.init_distributed("nccl") if world > 1 else None
+    dist = parallel.init_distributed("gloo" if rehearse else "nccl") if world > 1 else None
+    reduce_device = "cpu" if rehearse else f"cuda:{local_rank}"
 
     air = S.AIR_FINAL_EXP
     cfg = S.StarkConfig.for_air(air)
@@ -152,7 +158,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = parallel.max_over_ranks(dist, elapsed, device=f"cuda:{local_rank}")
+    elapsed = parallel.max_over_ranks(dist, elapsed, device=reduce_device)
 
     # untimed: the same kernels with the GPU to themselves (one proof in flight), for the uncontended roofline numbers
     solo_ms = {"lde_columns": 0.0, "leaf_hash": 0.0, "quotient_eval": 0.0}
@@ -190,7 +196,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 (Goldilocks field)", "data": "synthetic",
+            "dtype": "u64 (Goldilocks field)",
+            "data": "synthetic" + (" -- REHEARSAL: all ranks on one GPU over gloo, not a measurement" if rehearse else ""),
             "config": {"workload": "FinalExponentiateStark 73527 cols x 8192 rows, rate_bits 2, 360800 constraints, "
                                    "standard_fast_config (84 queries, 16 pow bits); one independent proof per GPU",
                        "parallelism": f"proof-parallel x{world}", "proofs_in_flight_per_gpu": inflight},
