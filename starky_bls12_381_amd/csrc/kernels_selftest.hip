@@ -34,13 +34,14 @@ __global__ void field_ops_kernel(int op, const gl_t* __restrict__ a, const gl_t*
         case 6: r = combine_lohi_nc(x & 0xFFFFFFFFFFFull, y & 0xFFFFFFFFFFFull); break;
         case 7: r = gl_reduce128_nc(x, y); break;
         case 8: r = x; break;
+        case 9: r = gl_mad_nc_ub(x, b[0], y); break;  // wave-uniform multiplicand: a * b[0] + b[i]
         default: r = pow2_case<0>(x, op - 100); break;
     }
     out[i] = gl_canon(r);
 }
 
 hipError_t launch_field_ops(int op, const gl_t* a, const gl_t* b, gl_t* out, size_t n, hipStream_t st) {
-    if (!((op >= 0 && op <= 8) || (op >= 100 && op < 196))) return hipErrorInvalidValue;
+    if (!((op >= 0 && op <= 9) || (op >= 100 && op < 196))) return hipErrorInvalidValue;
     hipLaunchKernelGGL(field_ops_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op, a, b, out, n);
     return hipGetLastError();
 }

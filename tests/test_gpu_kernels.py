@@ -179,6 +179,11 @@ def test_multiply_reduce_flag_paths(prover):
     assert [int(g) for g in prover.field_ops(0, a, b)] == [x * y % P for x, y in pairs]
     assert [int(g) for g in prover.field_ops(1, a, b)] == [(x * y + (x ^ y)) % P for x, y in pairs]
     assert [int(g) for g in prover.field_ops(7, a, b)] == [((x << 64) + y) % P for x, y in pairs]
+    # the variant with a wave-uniform multiplicand in scalar registers (op 9: a[i] * b[0] + b[i]), every b as b[0] in turn
+    for k in range(len(pairs)):
+        bk = np.roll(b, -k)
+        k0 = int(bk[0])
+        assert [int(g) for g in prover.field_ops(9, a, bk)] == [(x * k0 + int(y)) % P for (x, _), y in zip(pairs, bk)], k
 
 
 def test_lazy_reduction_arithmetic_on_boundary_operands(prover):
