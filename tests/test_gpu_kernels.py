@@ -186,6 +186,27 @@ def test_multiply_reduce_flag_paths(prover):
         assert [int(g) for g in prover.field_ops(9, a, bk)] == [(x * k0 + int(y)) % P for (x, _), y in zip(pairs, bk)], k
 
 
+def test_multiply_reduce_on_a_million_structured_operands(prover):
+    """Operands whose 32-bit words are drawn from {0, 1, 2, 2^31, 2^32 - 2, 2^32 - 1, random}: every word pattern that can
+    raise or suppress a carry in the product or the reduction, 2^20 pairs, against Python integers."""
+    rng = np.random.default_rng(11)
+    special = np.array([0, 1, 2, 1 << 31, (1 << 32) - 2, (1 << 32) - 1], dtype=np.uint64)
+
+    def words(n):
+        w = rng.integers(0, 1 << 32, size=n, dtype=np.uint64)
+        pick = rng.integers(0, 12, size=n)
+        return np.where(pick < 6, special[np.minimum(pick, 5)], w)
+    n = 1 << 20
+    a = (words(n) << np.uint64(32)) | words(n)
+    b = (words(n) << np.uint64(32)) | words(n)
+    ai, bi = [int(v) for v in a], [int(v) for v in b]
+    assert [int(g) for g in prover.field_ops(0, a, b)] == [x * y % P for x, y in zip(ai, bi)]
+    assert [int(g) for g in prover.field_ops(1, a, b)] == [(x * y + (x ^ y)) % P for x, y in zip(ai, bi)]
+    assert [int(g) for g in prover.field_ops(7, a, b)] == [((x << 64) + y) % P for x, y in zip(ai, bi)]
+    k0 = bi[0]
+    assert [int(g) for g in prover.field_ops(9, a, b)] == [(x * k0 + y) % P for x, y in zip(ai, bi)]
+
+
 def test_lazy_reduction_arithmetic_on_boundary_operands(prover):
     """The kernels keep field values as arbitrary 64-bit representatives and correct wraps lazily; the wrap paths fire with
     probability ~2^-32 per operation on proof data, so they are driven here with boundary operands, all pairs."""
