@@ -5,6 +5,9 @@
 // evaluation of the AIR, and runs the FRI query checks.
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "air_eval.h"
@@ -133,16 +136,18 @@ int verify_proof(const AirInfo& air, const starkhip_config_t& cfg, const uint64_
     for (size_t c = C; c-- > 0;) red1 = gl2_add(gl2_mul(red1, fri_alpha), op_next[c]);
     gl2_t alpha_pow_C = gl2_pow(fri_alpha, C);
 
+    // The 84 query rounds are independent and dominated by re-hashing a trace leaf each (FinalExp: 9191 permutations per
+    // leaf, 0.8 M in all -- about a second on one core), so they are checked by a few host threads.
     const size_t d0 = pl.log_N - pl.cap_h;
-    for (size_t qi = 0; qi < pl.n_queries; qi++) {
+    auto check_query = [&](size_t qi) -> bool {
         const uint64_t* qp = proof + pl.off_queries + qi * pl.query_words;
         size_t x_index = indices[qi];
         const gl_t* tleaf = qp; qp += C;
         const gl_t* tsib = qp; qp += 4 * d0;
         const gl_t* qleaf = qp; qp += Q;
         const gl_t* qsib = qp; qp += 4 * d0;
-        if (!merkle_verify_to_cap(tleaf, C, x_index, proof + pl.off_trace_cap, tsib, d0)) return STARKHIP_ERR_VERIFY;
-        if (!merkle_verify_to_cap(qleaf, Q, x_index, proof + pl.off_quot_cap, qsib, d0)) return STARKHIP_ERR_VERIFY;
+        if (!merkle_verify_to_cap(tleaf, C, x_index, proof + pl.off_trace_cap, tsib, d0)) return false;
+        if (!merkle_verify_to_cap(qleaf, Q, x_index, proof + pl.off_quot_cap, qsib, d0)) return false;
         gl_t subgroup_x = gl_mul(GL_GENERATOR, gl_pow(gl_root_of_unity((unsigned)pl.log_N), gl_bitrev((uint32_t)x_index, (unsigned)pl.log_N)));
         // fri_combine_initial
         gl2_t e0 = gl2_zero(), e1 = gl2_zero();
@@ -159,15 +164,28 @@ int verify_proof(const AirInfo& air, const starkhip_config_t& cfg, const uint64_
             const gl2_t* evals = (const gl2_t*)qp; qp += 2 * arity;
             const gl_t* sib = qp; qp += 4 * pl.layer_depth[l];
             size_t coset_index = x_index >> ab, within = x_index & (arity - 1);
-            if (!gl2_eq(evals[within], old_eval)) return STARKHIP_ERR_VERIFY;
+            if (!gl2_eq(evals[within], old_eval)) return false;
             old_eval = fri_fold_eval(subgroup_x, within, ab, evals, betas[l]);
             if (!merkle_verify_to_cap((const gl_t*)evals, 2 * arity, coset_index, proof + pl.off_fri_caps + l * 4 * ncap, sib, pl.layer_depth[l]))
-                return STARKHIP_ERR_VERIFY;
+                return false;
             for (unsigned b = 0; b < ab; b++) subgroup_x = gl_sqr(subgroup_x);
             x_index = coset_index;
         }
-        if (!gl2_eq(eval_poly_ext(final_poly, pl.final_len, gl2_from_base(subgroup_x)), old_eval)) return STARKHIP_ERR_VERIFY;
-    }
+        if (!gl2_eq(eval_poly_ext(final_poly, pl.final_len, gl2_from_base(subgroup_x)), old_eval)) return false;
+        return true;
+    };
+    const size_t n_threads = std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), pl.n_queries);
+    std::atomic<bool> ok(true);
+    std::atomic<size_t> next(0);
+    auto worker = [&]() {
+        for (size_t qi; ok.load(std::memory_order_relaxed) && (qi = next.fetch_add(1)) < pl.n_queries;)
+            if (!check_query(qi)) ok.store(false);
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n_threads; t++) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    if (!ok.load()) return STARKHIP_ERR_VERIFY;
     return STARKHIP_OK;
 }
 
