@@ -21,7 +21,7 @@ python3 tools/rocprof_export.py pmc $(db prof_fetch) $OUT/pmc_fetch_size.csv
 python3 tools/rocprof_export.py pmc $(db prof_write) $OUT/pmc_write_size.csv
 python3 tools/rocprof_export.py pmc $(db prof_sq) $OUT/pmc_sq_counters.csv
 python3 tools/pmc_traffic.py $(db prof_fetch) $(db prof_write) $OUT/pmc_traffic.json
-python3 tools/kernel_overlap.py $(db prof_ov) 0.47 0.85 > $OUT/kernel_overlap.txt
+python3 tools/kernel_overlap.py $(db prof_ov) > $OUT/kernel_overlap.txt
 tail -1 $OUT/prof_kt.log > $OUT/bench_under_rocprof.json
 rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq $OUT/prof_ov
 head -6 $OUT/kernel_stats.csv; cat $OUT/kernel_overlap.txt
