@@ -4,10 +4,106 @@
 // reference reaches through prove() at /root/reference/src/aggregate_proof.rs:59.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "kernels.h"
 #include "poseidon_dev.h"
 
 namespace starkhip {
+
+// ---- tables of the merged partial rounds (poseidon_dev.h), built on the host once per device
+#ifndef STARKHIP_MERGED_PARTIAL
+#define STARKHIP_MERGED_PARTIAL 1
+#endif
+struct QuadMergedTables {
+    uint32_t coef[4][66];  // per lane: n3[3][12], n1[12], n2[12], b2[3], b3[3]
+    uint32_t m00, pad;
+    RcPair tk[2 * QUAD_MERGED_TRIPLES];       // k1, k2 per triple
+    RcPair tk3[4][3 * QUAD_MERGED_TRIPLES];   // per lane: k3[mo] per triple
+};
+__constant__ QuadMergedTables QUAD_MERGED;
+
+// N1 = M, N2 = M Mz, N3 = M Mz Mz (Mz = M with row 0 zeroed; exact integers, < 2^21) and, per triple of partial rounds
+// starting at round r with following constants c1, c2, c3 (c?z = the vector with element 0 zeroed):
+//   k1 = c1[0];   k2 = (M c1z)[0] + c2[0];   k3 = N2 c1z + M c2z + c3   (mod p)
+static void build_quad_merged_tables(QuadMergedTables& T) {
+    static const uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    uint64_t M[12][12], Mz[12][12], N2[12][12], N3[12][12];
+    for (int i = 0; i < 12; i++)
+        for (int j = 0; j < 12; j++) {
+            M[i][j] = CIRC[(j - i + 12) % 12] + ((i == 0 && j == 0) ? 8 : 0);
+            Mz[i][j] = i == 0 ? 0 : M[i][j];
+        }
+    auto mul = [](const uint64_t (&a)[12][12], const uint64_t (&b)[12][12], uint64_t (&o)[12][12]) {
+        for (int i = 0; i < 12; i++)
+            for (int j = 0; j < 12; j++) {
+                uint64_t acc = 0;
+                for (int k = 0; k < 12; k++) acc += a[i][k] * b[k][j];
+                o[i][j] = acc;
+            }
+    };
+    mul(M, Mz, N2);
+    mul(N2, Mz, N3);
+    auto matvec_mod = [](const uint64_t (&a)[12][12], const gl_t* v, gl_t* o) {
+        for (int i = 0; i < 12; i++) {
+            unsigned __int128 acc = 0;
+            for (int j = 0; j < 12; j++) acc += (unsigned __int128)a[i][j] * v[j];
+            o[i] = (gl_t)(acc % GL_P);
+        }
+    };
+    auto split = [](gl_t v) { return RcPair{v & 0xFFFFFFFFull, v >> 32}; };
+    for (int l = 0; l < 4; l++) {
+        uint32_t* c = T.coef[l];
+        for (int r = 0; r < 4; r++)
+            for (int m = 0; m < 3; m++) {
+                const int col = 3 * ((l + r) & 3) + m;
+                for (int mo = 0; mo < 3; mo++) c[12 * mo + 3 * r + m] = (uint32_t)N3[3 * l + mo][col];
+                c[36 + 3 * r + m] = (uint32_t)M[0][col];
+                c[48 + 3 * r + m] = (uint32_t)N2[0][col];
+            }
+        for (int mo = 0; mo < 3; mo++) {
+            c[60 + mo] = (uint32_t)N2[3 * l + mo][0];
+            c[63 + mo] = (uint32_t)M[3 * l + mo][0];
+        }
+    }
+    T.m00 = (uint32_t)M[0][0];
+    T.pad = 0;
+    const uint64_t* RC = POSEIDON_RC_HOST;
+    for (int t = 0; t < QUAD_MERGED_TRIPLES; t++) {
+        const int r = 4 + 3 * t;
+        gl_t c1z[12], c2z[12], a[12], b[12];
+        for (int i = 0; i < 12; i++) {
+            c1z[i] = i ? RC[12 * (r + 1) + i] : 0;
+            c2z[i] = i ? RC[12 * (r + 2) + i] : 0;
+        }
+        matvec_mod(M, c1z, a);
+        T.tk[2 * t] = split(RC[12 * (r + 1)]);
+        T.tk[2 * t + 1] = split(gl_add(a[0], RC[12 * (r + 2)]));
+        matvec_mod(N2, c1z, a);
+        matvec_mod(M, c2z, b);
+        for (int i = 0; i < 12; i++) T.tk3[i / 3][3 * t + i % 3] = split(gl_add(gl_add(a[i], b[i]), RC[12 * (r + 3) + i]));
+    }
+}
+
+static hipError_t ensure_quad_merged_tables() {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu);
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (done[dev]) return hipSuccess;
+    static QuadMergedTables T;  // zero-initialised; filled once
+    static bool built = false;
+    if (!built) {
+        build_quad_merged_tables(T);
+        built = true;
+    }
+    e = hipMemcpyToSymbol(HIP_SYMBOL(QUAD_MERGED), &T, sizeof T);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}
 
 // Leaf digests of a column-major matrix laid out coset-major (see kernels_ntt.hip):
 //   element (column c, physical point q) at mat[c * N + q], q = s * n + k  <->  natural index i = k * R + s.
@@ -24,6 +120,13 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__
         rcs[ll][w].lo = c & 0xFFFFFFFFull;
         rcs[ll][w].hi = c >> 32;
     }
+#if STARKHIP_MERGED_PARTIAL
+    __shared__ RcPair tks[2 * QUAD_MERGED_TRIPLES];
+    __shared__ RcPair tk3s[4][3 * QUAD_MERGED_TRIPLES];
+    for (unsigned idx = threadIdx.x; idx < 2 * QUAD_MERGED_TRIPLES; idx += blockDim.x) tks[idx] = QUAD_MERGED.tk[idx];
+    for (unsigned idx = threadIdx.x; idx < 4 * 3 * QUAD_MERGED_TRIPLES; idx += blockDim.x)
+        tk3s[idx / (3 * QUAD_MERGED_TRIPLES)][idx % (3 * QUAD_MERGED_TRIPLES)] = QUAD_MERGED.tk3[idx / (3 * QUAD_MERGED_TRIPLES)][idx % (3 * QUAD_MERGED_TRIPLES)];
+#endif
     __syncthreads();
     const unsigned log_N = log_n + rate_bits;
     const size_t N = (size_t)1 << log_N;
@@ -46,6 +149,30 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__
     }
     const uint32_t diag0 = l == 0 ? 8u : 0u;
     const RcPair* rc = rcs[l];
+#if STARKHIP_MERGED_PARTIAL
+    QuadMergedCoef mc;
+    {
+        const uint32_t* c = QUAD_MERGED.coef[l];
+#pragma unroll
+        for (int i = 0; i < 36; i++) mc.n3[i / 12][i % 12] = c[i];
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            mc.n1[i] = c[36 + i];
+            mc.n2[i] = c[48 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            mc.b2[i] = c[60 + i];
+            mc.b3[i] = c[63 + i];
+        }
+    }
+    const uint32_t m00 = QUAD_MERGED.m00;
+    const RcPair* tk3 = tk3s[l];
+    const bool even_lane = (l & 1u) == 0;
+#define PERMUTE_QUAD() poseidon_permute_quad_merged(s0, s1, s2, diag0, rc, mc, m00, tks, tk3, l == 0, even_lane)
+#else
+#define PERMUTE_QUAD() poseidon_permute_quad(s0, s1, s2, diag0, rc, l == 0)
+#endif
     gl_t s0 = 0, s1 = 0, s2 = 0;
     size_t off = 0;
     // full 8-element blocks (overwrite mode): lanes 0, 1 absorb three columns, lane 2 two, lane 3 holds capacity only
@@ -73,14 +200,14 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__
             }
             if (l <= 1) n2 = mine[(off + 10) * N];
         }
-        poseidon_permute_quad(s0, s1, s2, diag0, rc, l == 0);
+        PERMUTE_QUAD();
     }
     if (off < n_cols) {
         const size_t rem = n_cols - off;
         if (3 * l + 0 < rem) s0 = mine[off * N];
         if (3 * l + 1 < rem) s1 = mine[(off + 1) * N];
         if (3 * l + 2 < rem) s2 = mine[(off + 2) * N];
-        poseidon_permute_quad(s0, s1, s2, diag0, rc, l == 0);
+        PERMUTE_QUAD();
     }
     // digest = state elements 0..3: lane 0's three and lane 1's first
     if (l == 0) {
@@ -91,6 +218,7 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__
         digests[4 * j + 3] = gl_canon(s0);
     }
 }
+#undef PERMUTE_QUAD
 
 // Leaves stored row-major and already in tree order: leaf j = rows[j][0..width)
 __global__ __launch_bounds__(64) void leaf_hash_rows_kernel(const gl_t* __restrict__ rows, size_t width, size_t n_leaves,
@@ -143,6 +271,9 @@ static inline unsigned nblocks(size_t n, unsigned bs) { return (unsigned)((n + b
 
 hipError_t launch_leaf_hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st) {
     size_t N = (size_t)1 << (log_n + rate_bits);
+#if STARKHIP_MERGED_PARTIAL
+    if (hipError_t e = ensure_quad_merged_tables(); e != hipSuccess) return e;
+#endif
     hipLaunchKernelGGL(leaf_hash_kernel, dim3(nblocks(4 * N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
     return hipGetLastError();
 }

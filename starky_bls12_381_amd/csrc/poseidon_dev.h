@@ -264,4 +264,116 @@ __device__ __forceinline__ void poseidon_permute_quad(gl_t& s0, gl_t& s1, gl_t& 
     }
 }
 
+// ---------------------------------------------------------------- merged partial rounds
+// Only element 0 passes the S-box in a partial round, so three consecutive partial rounds are linear in the eleven other
+// elements.  With M the MDS matrix, Mz = M with row 0 zeroed, and x_k the k-th S-box output:
+//     y1 = (M u')[0] + c1[0]                              u' = (x_1, u_1, .., u_11),  x_1 = u_0^7
+//     y2 = (M Mz u')[0] + M00 x_2 + (M c1z)[0] + c2[0]     x_2 = y1^7
+//     out = M Mz Mz u' + (M Mz e0) x_3' ...               (see build_quad_merged_tables for every term)
+// i.e. ONE dense 12 x 12 layer (72 multiply-adds per lane, entries of M Mz Mz < 2^21: still 32-bit multiplicands with
+// 64-bit accumulators), two 12-term dot products for the intermediate element 0, and the three S-boxes -- instead of
+// three dense layers.  The matrices are not circulant (the diagonal term and the zeroed rows break that), so each lane
+// holds its coefficients in registers: n3[mo][3r+m] = (M Mz Mz)[3l+mo][col], n1[3r+m] = M[0][col], n2[3r+m] = (M Mz)[0][col]
+// with col = 3((l + r) & 3) + m, and the columns that multiply x_2 and x_3.
+struct QuadMergedCoef {
+    uint32_t n3[3][12];
+    uint32_t n1[12], n2[12];
+    uint32_t b2[3], b3[3];  // (M Mz)[3l+mo][0], M[3l+mo][0]
+};
+static const int QUAD_MERGED_TRIPLES = 7;  // partial rounds 0..20; the 22nd stays a plain round
+
+// y is the same value in the four lanes of a quad; returns y^7 in all of them.  Even lanes form x^3, odd lanes x^4 in one
+// multiply, and every lane finds the other factor in its right-hand neighbour.
+__device__ __forceinline__ gl_t sbox_quad_uniform(gl_t y, bool even_lane) {
+    const gl_t x2 = gl_mul_nc(y, y);
+    const gl_t v = gl_mul_nc(x2, even_lane ? y : x2);
+    return gl_mul_nc(v, quad_rot64<1>(v));
+}
+
+__device__ __forceinline__ void quad_dot12(const uint32_t (&lo)[4][3], const uint32_t (&hi)[4][3], const uint32_t* coef, uint64_t& A,
+                                           uint64_t& B) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            A = mad32(lo[r][m], coef[3 * r + m], A);
+            B = mad32(hi[r][m], coef[3 * r + m], B);
+            asm("" : "+v"(A));  // keep the chain a chain (see poseidon_mds_quad)
+            asm("" : "+v"(B));
+        }
+}
+
+// Three partial rounds.  In: (s0, s1, s2) with this round's constants already added (as poseidon_mds_quad leaves them);
+// out: the state three rounds later with the following round's constants added.  k1, k2: the constants of the two
+// intermediate element-0 values; k3: this lane's three output constants.
+__device__ __forceinline__ void poseidon_partial3_quad(gl_t& s0, gl_t& s1, gl_t& s2, const QuadMergedCoef& c, uint32_t m00, const RcPair& k1,
+                                                       const RcPair& k2, const RcPair* k3, bool lane0, bool even_lane) {
+    s0 = sbox_lane0_nc(s0, lane0);  // lane 0: x_1; the other lanes keep their element
+    uint32_t lo[4][3], hi[4][3];
+    lo[0][0] = (uint32_t)s0; hi[0][0] = (uint32_t)(s0 >> 32);
+    lo[0][1] = (uint32_t)s1; hi[0][1] = (uint32_t)(s1 >> 32);
+    lo[0][2] = (uint32_t)s2; hi[0][2] = (uint32_t)(s2 >> 32);
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        lo[1][m] = quad_rot<1>(lo[0][m]); hi[1][m] = quad_rot<1>(hi[0][m]);
+        lo[2][m] = quad_rot<2>(lo[0][m]); hi[2][m] = quad_rot<2>(hi[0][m]);
+        lo[3][m] = quad_rot<3>(lo[0][m]); hi[3][m] = quad_rot<3>(hi[0][m]);
+    }
+    uint64_t A = k1.lo, B = k1.hi;
+    quad_dot12(lo, hi, c.n1, A, B);
+    const gl_t x2 = sbox_quad_uniform(combine_lohi_nc(A, B), even_lane);
+    const uint32_t x2l = (uint32_t)x2, x2h = (uint32_t)(x2 >> 32);
+    A = k2.lo; B = k2.hi;
+    quad_dot12(lo, hi, c.n2, A, B);
+    A = mad32(x2l, m00, A);
+    B = mad32(x2h, m00, B);
+    const gl_t x3 = sbox_quad_uniform(combine_lohi_nc(A, B), even_lane);
+    const uint32_t x3l = (uint32_t)x3, x3h = (uint32_t)(x3 >> 32);
+    gl_t out[3];
+#pragma unroll
+    for (int mo = 0; mo < 3; mo++) {
+        A = k3[mo].lo; B = k3[mo].hi;
+        quad_dot12(lo, hi, c.n3[mo], A, B);
+        A = mad32(x2l, c.b2[mo], A);
+        B = mad32(x2h, c.b2[mo], B);
+        A = mad32(x3l, c.b3[mo], A);
+        B = mad32(x3h, c.b3[mo], B);
+        out[mo] = combine_lohi_nc(A, B);  // A, B < 2^57: 12 terms of (< 2^21) x (< 2^32) and the two single terms
+    }
+    s0 = out[0];
+    s1 = out[1];
+    s2 = out[2];
+}
+
+// poseidon_permute_quad with the partial rounds taken three at a time.  rc as there; tk[t] = {k1, k2} of triple t,
+// tk3 = this lane's k3 constants, three per triple.
+__device__ __forceinline__ void poseidon_permute_quad_merged(gl_t& s0, gl_t& s1, gl_t& s2, uint32_t diag0, const RcPair* __restrict__ rc,
+                                                             const QuadMergedCoef& c, uint32_t m00, const RcPair* __restrict__ tk,
+                                                             const RcPair* __restrict__ tk3, bool lane0, bool even_lane) {
+    s0 = gl_add_nc(s0, rc[0].lo | (rc[0].hi << 32));
+    s1 = gl_add_nc(s1, rc[1].lo | (rc[1].hi << 32));
+    s2 = gl_add_nc(s2, rc[2].lo | (rc[2].hi << 32));
+    int r = 0;
+#pragma unroll 1
+    for (; r < 4; r++) {
+        s0 = sbox_nc(s0);
+        s1 = sbox_nc(s1);
+        s2 = sbox_nc(s2);
+        poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
+    }
+#pragma unroll 1
+    for (int t = 0; t < QUAD_MERGED_TRIPLES; t++) poseidon_partial3_quad(s0, s1, s2, c, m00, tk[2 * t], tk[2 * t + 1], tk3 + 3 * t, lane0, even_lane);
+    r = 4 + 3 * QUAD_MERGED_TRIPLES;  // 25: the last partial round
+    s0 = sbox_lane0_nc(s0, lane0);
+    poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
+    r++;
+#pragma unroll 1
+    for (; r < 30; r++) {
+        s0 = sbox_nc(s0);
+        s1 = sbox_nc(s1);
+        s2 = sbox_nc(s2);
+        poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
+    }
+}
+
 }  // namespace starkhip
