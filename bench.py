@@ -65,13 +65,13 @@ def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=1024, bud
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="proofs in flight per GPU (independent contexts on separate host threads and HIP streams); "
-                         "1 = one proof at a time (latency), 2 (default) hides the host-side Fiat-Shamir hashing and the launch gaps of one "
-                         "proof behind the kernels of another")
+                         "1 = one proof at a time (latency); the default hides the host-side Fiat-Shamir hashing and the launch gaps of "
+                         "each proof behind the kernels of the others (measured: 1: 3.7, 2: 4.5, 3: 5.0, 4: 5.1 proofs/s)")
     args = ap.parse_args()
 
     import numpy as np
