@@ -7,6 +7,8 @@
 //    commitment has only N = 32768 leaves of 9191 sequential permutations each, far too few lanes for 256 CUs
 //    with one lane per leaf.  The other lanes' words arrive through v_mov_b32 quad_perm rotations;
 //  * values inside a permutation are lazily reduced 64-bit representatives (gl_dev.h).
+//  * the 22 partial rounds of the quad form are taken three at a time (only element 0 is non-linear in them): one dense
+//    12 x 12 layer with per-lane integer coefficients, two dot products and three S-boxes per triple (bottom of this file).
 // Semantics are exactly those of poseidon.h (same permutation); tests compare both against the CPU oracle.
 #pragma once
 #include <hip/hip_runtime.h>
