@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4  # wave-instructions/ns: one 4-cycle integer VALU instruction per SIMD (measured, tools/valu_rate_bench.hip)
-POSEIDON_QUAD_INSTRS = 8 * 261 + 7 * 316 + 152  # VALU instructions of one permutation in the 4-lane form (ISA of poseidon_dev.h: 8 full rounds, 7 merged triples of partial rounds, 1 single partial round)
+POSEIDON_QUAD_INSTRS = 8 * 261 + 7 * 309 + 152  # VALU instructions of one permutation in the 4-lane form (ISA of poseidon_dev.h: 8 full rounds, 7 merged triples of partial rounds, 1 single partial round)
 
 
 def synthetic_final_exp_input(seed):
@@ -221,7 +221,7 @@ def main():
         if lh_ms > 0:
             out["leaf_hash_valu"] = {"wave_instructions": wave_instr, "achieved_Ginstr_per_s": wave_instr / (lh_ms * 1e-3) / 1e9,
                                      "peak_Ginstr_per_s": VALU_PEAK_GINSTR, "frac": wave_instr / (lh_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR,
-                                     "basis": "8 full rounds x 261 + 7 merged triples of partial rounds x 316 + 1 partial round x 152 VALU instructions per 4-lane permutation (ISA count); "
+                                     "basis": "8 full rounds x 261 + 7 merged triples of partial rounds x 309 + 1 partial round x 152 VALU instructions per 4-lane permutation (ISA count); "
                                               "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per integer VALU instruction (tools/valu_rate_bench.hip)"}
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: other ranks would sit in the teardown barrier meanwhile
             try:

@@ -16,8 +16,7 @@ namespace starkhip {
 #define STARKHIP_MERGED_PARTIAL 1
 #endif
 struct QuadMergedTables {
-    uint32_t coef[4][66];  // per lane: n3[3][12], n1[12], n2[12], b2[3], b3[3]
-    uint32_t m00, pad;
+    uint32_t coef[4][50];  // per lane: n3[3][12], n1[3], n2[3], m00 (lane 0 only), b2[3], b3[3], pad
     RcPair tk[2 * QUAD_MERGED_TRIPLES];       // k1, k2 per triple
     RcPair tk3[4][3 * QUAD_MERGED_TRIPLES];   // per lane: k3[mo] per triple
 };
@@ -58,16 +57,18 @@ static void build_quad_merged_tables(QuadMergedTables& T) {
             for (int m = 0; m < 3; m++) {
                 const int col = 3 * ((l + r) & 3) + m;
                 for (int mo = 0; mo < 3; mo++) c[12 * mo + 3 * r + m] = (uint32_t)N3[3 * l + mo][col];
-                c[36 + 3 * r + m] = (uint32_t)M[0][col];
-                c[48 + 3 * r + m] = (uint32_t)N2[0][col];
             }
-        for (int mo = 0; mo < 3; mo++) {
-            c[60 + mo] = (uint32_t)N2[3 * l + mo][0];
-            c[63 + mo] = (uint32_t)M[3 * l + mo][0];
+        for (int m = 0; m < 3; m++) {
+            c[36 + m] = (uint32_t)M[0][3 * l + m];   // the lane's own columns of row 0
+            c[39 + m] = (uint32_t)N2[0][3 * l + m];
         }
+        c[42] = l == 0 ? (uint32_t)M[0][0] : 0;
+        for (int mo = 0; mo < 3; mo++) {
+            c[43 + mo] = (uint32_t)N2[3 * l + mo][0];
+            c[46 + mo] = (uint32_t)M[3 * l + mo][0];
+        }
+        c[49] = 0;
     }
-    T.m00 = (uint32_t)M[0][0];
-    T.pad = 0;
     const uint64_t* RC = POSEIDON_RC_HOST;
     for (int t = 0; t < QUAD_MERGED_TRIPLES; t++) {
         const int r = 4 + 3 * t;
@@ -77,8 +78,10 @@ static void build_quad_merged_tables(QuadMergedTables& T) {
             c2z[i] = i ? RC[12 * (r + 2) + i] : 0;
         }
         matvec_mod(M, c1z, a);
-        T.tk[2 * t] = split(RC[12 * (r + 1)]);
-        T.tk[2 * t + 1] = split(gl_add(a[0], RC[12 * (r + 2)]));
+        // every lane seeds its partial sum with a quarter of the constant (4^-1 = (3p + 1) / 4 mod p)
+        const gl_t quarter = (gl_t)((((unsigned __int128)3 * GL_P) + 1) / 4);
+        T.tk[2 * t] = split(gl_mul(RC[12 * (r + 1)], quarter));
+        T.tk[2 * t + 1] = split(gl_mul(gl_add(a[0], RC[12 * (r + 2)]), quarter));
         matvec_mod(N2, c1z, a);
         matvec_mod(M, c2z, b);
         for (int i = 0; i < 12; i++) T.tk3[i / 3][3 * t + i % 3] = split(gl_add(gl_add(a[i], b[i]), RC[12 * (r + 3) + i]));
@@ -156,20 +159,17 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__
 #pragma unroll
         for (int i = 0; i < 36; i++) mc.n3[i / 12][i % 12] = c[i];
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            mc.n1[i] = c[36 + i];
-            mc.n2[i] = c[48 + i];
-        }
-#pragma unroll
         for (int i = 0; i < 3; i++) {
-            mc.b2[i] = c[60 + i];
-            mc.b3[i] = c[63 + i];
+            mc.n1[i] = c[36 + i];
+            mc.n2[i] = c[39 + i];
+            mc.b2[i] = c[43 + i];
+            mc.b3[i] = c[46 + i];
         }
+        mc.m00 = c[42];
     }
-    const uint32_t m00 = QUAD_MERGED.m00;
     const RcPair* tk3 = tk3s[l];
     const bool even_lane = (l & 1u) == 0;
-#define PERMUTE_QUAD() poseidon_permute_quad_merged(s0, s1, s2, diag0, rc, mc, m00, tks, tk3, l == 0, even_lane)
+#define PERMUTE_QUAD() poseidon_permute_quad_merged(s0, s1, s2, diag0, rc, mc, tks, tk3, l == 0, even_lane)
 #else
 #define PERMUTE_QUAD() poseidon_permute_quad(s0, s1, s2, diag0, rc, l == 0)
 #endif

@@ -279,7 +279,9 @@ __device__ __forceinline__ void poseidon_permute_quad(gl_t& s0, gl_t& s1, gl_t& 
 // with col = 3((l + r) & 3) + m, and the columns that multiply x_2 and x_3.
 struct QuadMergedCoef {
     uint32_t n3[3][12];
-    uint32_t n1[12], n2[12];
+    uint32_t n1[3], n2[3];  // row 0 of M and of M Mz at this lane's OWN three columns: the two intermediate dot products
+                            // are per-lane partial sums added up across the quad (6 multiply-adds + a butterfly, not 24)
+    uint32_t m00;           // M[0][0] on lane 0, 0 elsewhere (the x_2 term of y2 is added once)
     uint32_t b2[3], b3[3];  // (M Mz)[3l+mo][0], M[3l+mo][0]
 };
 static const int QUAD_MERGED_TRIPLES = 7;  // partial rounds 0..20; the 22nd stays a plain round
@@ -305,10 +307,25 @@ __device__ __forceinline__ void quad_dot12(const uint32_t (&lo)[4][3], const uin
         }
 }
 
+// a += the same accumulator of the lane's neighbour at distance 1, then at distance 2: the quad's total in all four lanes
+__device__ __forceinline__ uint64_t quad_sum64(uint64_t a) {
+    const uint32_t l1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)a, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
+    const uint32_t h1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(a >> 32), 0xB1, 0xF, 0xF, true);
+    uint64_t n1 = (uint64_t)l1 | ((uint64_t)h1 << 32);
+    asm("" : "+v"(n1));  // one 64-bit add of a register pair (else: one add per word, each with a zeroed partner register)
+    a += n1;
+    const uint32_t l2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)a, 0x4E, 0xF, 0xF, true);          // quad_perm [2,3,0,1]
+    const uint32_t h2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(a >> 32), 0x4E, 0xF, 0xF, true);
+    uint64_t n2 = (uint64_t)l2 | ((uint64_t)h2 << 32);
+    asm("" : "+v"(n2));
+    return a + n2;
+}
+
 // Three partial rounds.  In: (s0, s1, s2) with this round's constants already added (as poseidon_mds_quad leaves them);
 // out: the state three rounds later with the following round's constants added.  k1, k2: the constants of the two
-// intermediate element-0 values; k3: this lane's three output constants.
-__device__ __forceinline__ void poseidon_partial3_quad(gl_t& s0, gl_t& s1, gl_t& s2, const QuadMergedCoef& c, uint32_t m00, const RcPair& k1,
+// intermediate element-0 values, each divided by four (every lane seeds its partial sum with it); k3: this lane's three
+// output constants.
+__device__ __forceinline__ void poseidon_partial3_quad(gl_t& s0, gl_t& s1, gl_t& s2, const QuadMergedCoef& c, const RcPair& k1,
                                                        const RcPair& k2, const RcPair* k3, bool lane0, bool even_lane) {
     s0 = sbox_lane0_nc(s0, lane0);  // lane 0: x_1; the other lanes keep their element
     uint32_t lo[4][3], hi[4][3];
@@ -322,14 +339,22 @@ __device__ __forceinline__ void poseidon_partial3_quad(gl_t& s0, gl_t& s1, gl_t&
         lo[3][m] = quad_rot<3>(lo[0][m]); hi[3][m] = quad_rot<3>(hi[0][m]);
     }
     uint64_t A = k1.lo, B = k1.hi;
-    quad_dot12(lo, hi, c.n1, A, B);
-    const gl_t x2 = sbox_quad_uniform(combine_lohi_nc(A, B), even_lane);
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        A = mad32(lo[0][m], c.n1[m], A);
+        B = mad32(hi[0][m], c.n1[m], B);
+    }
+    const gl_t x2 = sbox_quad_uniform(combine_lohi_nc(quad_sum64(A), quad_sum64(B)), even_lane);  // sums < 2^40
     const uint32_t x2l = (uint32_t)x2, x2h = (uint32_t)(x2 >> 32);
     A = k2.lo; B = k2.hi;
-    quad_dot12(lo, hi, c.n2, A, B);
-    A = mad32(x2l, m00, A);
-    B = mad32(x2h, m00, B);
-    const gl_t x3 = sbox_quad_uniform(combine_lohi_nc(A, B), even_lane);
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        A = mad32(lo[0][m], c.n2[m], A);
+        B = mad32(hi[0][m], c.n2[m], B);
+    }
+    A = mad32(x2l, c.m00, A);
+    B = mad32(x2h, c.m00, B);
+    const gl_t x3 = sbox_quad_uniform(combine_lohi_nc(quad_sum64(A), quad_sum64(B)), even_lane);  // sums < 2^48
     const uint32_t x3l = (uint32_t)x3, x3h = (uint32_t)(x3 >> 32);
     gl_t out[3];
 #pragma unroll
@@ -350,7 +375,7 @@ __device__ __forceinline__ void poseidon_partial3_quad(gl_t& s0, gl_t& s1, gl_t&
 // poseidon_permute_quad with the partial rounds taken three at a time.  rc as there; tk[t] = {k1, k2} of triple t,
 // tk3 = this lane's k3 constants, three per triple.
 __device__ __forceinline__ void poseidon_permute_quad_merged(gl_t& s0, gl_t& s1, gl_t& s2, uint32_t diag0, const RcPair* __restrict__ rc,
-                                                             const QuadMergedCoef& c, uint32_t m00, const RcPair* __restrict__ tk,
+                                                             const QuadMergedCoef& c, const RcPair* __restrict__ tk,
                                                              const RcPair* __restrict__ tk3, bool lane0, bool even_lane) {
     s0 = gl_add_nc(s0, rc[0].lo | (rc[0].hi << 32));
     s1 = gl_add_nc(s1, rc[1].lo | (rc[1].hi << 32));
@@ -364,7 +389,7 @@ __device__ __forceinline__ void poseidon_permute_quad_merged(gl_t& s0, gl_t& s1,
         poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
     }
 #pragma unroll 1
-    for (int t = 0; t < QUAD_MERGED_TRIPLES; t++) poseidon_partial3_quad(s0, s1, s2, c, m00, tk[2 * t], tk[2 * t + 1], tk3 + 3 * t, lane0, even_lane);
+    for (int t = 0; t < QUAD_MERGED_TRIPLES; t++) poseidon_partial3_quad(s0, s1, s2, c, tk[2 * t], tk[2 * t + 1], tk3 + 3 * t, lane0, even_lane);
     r = 4 + 3 * QUAD_MERGED_TRIPLES;  // 25: the last partial round
     s0 = sbox_lane0_nc(s0, lane0);
     poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
