@@ -7,8 +7,8 @@ HBM (column-major) before the timed region, like bench.py.
 --batch B: B signatures scheduled by proof TYPE.  The small AIRs are latency chains (MillerLoop: 2048 leaves of 12 167
   sequential permutations = 128 waves for ~0.2 s), so a single one leaves 7/8 of the SIMDs idle while sixteen of them
   side by side fill the chip; FinalExp's leaf hash is a one-shot grid of exactly two waves per SIMD that any foreign
-  wave stretches.  Hence two phases: all small proofs with --small-inflight contexts, then the B FinalExp proofs two at
-  a time.  The same (synthetic) signature is used B times, so the traces are resident once.
+  wave stretches.  Hence two phases: all small proofs with --small-inflight contexts, then the B FinalExp proofs
+  --big-inflight at a time.  The same (synthetic) signature is used B times, so the traces are resident once.
 Prints one JSON line."""
 import argparse
 import json
@@ -53,8 +53,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--inflight", type=int, default=6)
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--small-inflight", type=int, default=16)
-    ap.add_argument("--big-inflight", type=int, default=2)
+    ap.add_argument("--small-inflight", type=int, default=24)
+    ap.add_argument("--big-inflight", type=int, default=4)
     args = ap.parse_args()
     import numpy as np
     import torch
