@@ -162,6 +162,9 @@ int starkhip_poseidon_permute_batch(void* ctx, uint64_t* states, size_t n_states
 /* device field arithmetic under test: out[i] = canonical(op(a[i], b[i])) with the lazy-reduction helpers the kernels use
  * (op codes: starky_bls12_381_amd/csrc/kernels_selftest.hip); lets the tests feed boundary operands */
 int starkhip_field_ops_batch(void* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* CPU check (no GPU needed) of the constant tables the leaf-hash kernel uses for its merged partial rounds: replays the
+ * merged formulation on n_states inputs against the plain permutation; returns the number of mismatches (0 = good) */
+int starkhip_selfcheck_hash_tables(unsigned n_states);
 /* host-side permutation (the one the Fiat-Shamir challenger uses) */
 void starkhip_poseidon_permute_host(uint64_t state[12]);
 /* n chained host permutations; which = 0: the challenger's tuned permutation, 1: the portable loop */

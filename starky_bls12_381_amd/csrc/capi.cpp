@@ -5,6 +5,7 @@
 #include <new>
 
 #include "airs.h"
+#include "kernels.h"
 #include "trace_log.h"
 #include "poseidon.h"
 #include "prover.h"
@@ -178,6 +179,7 @@ int starkhip_field_ops_batch(void* ctx, int op, const uint64_t* a, const uint64_
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;
     return field_ops((Ctx*)ctx, op, a, b, out, n);
 }
+int starkhip_selfcheck_hash_tables(unsigned n_states) { return quad_merged_tables_selfcheck(n_states); }
 void starkhip_poseidon_permute_host(uint64_t state[12]) { poseidon_permute_host(state); }
 /* n chained permutations with the challenger's host permutation (which = 0) or the portable reference loop (which = 1);
  * lets the tests compare the two and the benchmark report the host hashing rate */

@@ -88,6 +88,78 @@ static void build_quad_merged_tables(QuadMergedTables& T) {
     }
 }
 
+// Host replay of the merged formulation with exactly the tables the kernel gets (per-lane coefficient views included), against
+// the plain host permutation: a CPU-side check of build_quad_merged_tables (tests/test_field_hash_cpu.py).  Returns the
+// number of mismatching states out of `n`.
+int quad_merged_tables_selfcheck(unsigned n) {
+    static QuadMergedTables T;
+    build_quad_merged_tables(T);
+    auto join = [](const RcPair& c) { return (gl_t)(c.lo | (c.hi << 32)); };
+    int bad = 0;
+    uint64_t seed = 0x9E3779B97F4A7C15ull;
+    for (unsigned it = 0; it < n; it++) {
+        gl_t s[12], want[12];
+        for (int i = 0; i < 12; i++) {
+            seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17;
+            s[i] = it == 0 ? 0 : it == 1 ? GL_P - 1 : seed % GL_P;
+            want[i] = s[i];
+        }
+        poseidon_permute(want);
+        const uint64_t* RC = POSEIDON_RC_HOST;
+        int r = 0;
+        for (; r < 4; r++) {
+            for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(gl_add(s[i], RC[12 * r + i]));
+            poseidon_mds(s);
+        }
+        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], RC[12 * r + i]);
+        for (int t = 0; t < QUAD_MERGED_TRIPLES; t++, r += 3) {
+            gl_t u[12];
+            for (int i = 0; i < 12; i++) u[i] = s[i];
+            u[0] = poseidon_sbox(u[0]);
+            // y1, y2: per-lane partial sums with the quartered constants, exactly as the kernel adds them up
+            gl_t y1 = 0, y2p = 0;
+            for (int l = 0; l < 4; l++) {
+                const uint32_t* c = T.coef[l];
+                gl_t a = join(T.tk[2 * t]), b = join(T.tk[2 * t + 1]);
+                for (int m = 0; m < 3; m++) {
+                    a = gl_add(a, gl_mul(u[3 * l + m], c[36 + m]));
+                    b = gl_add(b, gl_mul(u[3 * l + m], c[39 + m]));
+                }
+                y1 = gl_add(y1, a);
+                y2p = gl_add(y2p, b);
+            }
+            const gl_t x2 = poseidon_sbox(y1);
+            gl_t y2 = y2p;
+            for (int l = 0; l < 4; l++) y2 = gl_add(y2, gl_mul(x2, T.coef[l][42]));
+            const gl_t x3 = poseidon_sbox(y2);
+            for (int l = 0; l < 4; l++) {
+                const uint32_t* c = T.coef[l];
+                for (int mo = 0; mo < 3; mo++) {
+                    gl_t acc = join(T.tk3[l][3 * t + mo]);
+                    for (int rr = 0; rr < 4; rr++)
+                        for (int m = 0; m < 3; m++) acc = gl_add(acc, gl_mul(u[3 * ((l + rr) & 3) + m], c[12 * mo + 3 * rr + m]));
+                    acc = gl_add(acc, gl_mul(x2, c[43 + mo]));
+                    acc = gl_add(acc, gl_mul(x3, c[46 + mo]));
+                    s[3 * l + mo] = acc;
+                }
+            }
+        }
+        s[0] = poseidon_sbox(s[0]);  // round 25, plain
+        poseidon_mds(s);
+        r++;
+        for (; r < 30; r++) {
+            for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(gl_add(s[i], RC[12 * r + i]));
+            poseidon_mds(s);
+        }
+        for (int i = 0; i < 12; i++)
+            if (s[i] != want[i]) {
+                bad++;
+                break;
+            }
+    }
+    return bad;
+}
+
 static hipError_t ensure_quad_merged_tables() {
     static std::mutex mu;
     static bool done[64] = {false};

@@ -84,3 +84,12 @@ def test_config_mirrors_standard_fast_config():
     assert S.StarkConfig.for_air(S.AIR_PAIRING_PRECOMP).rate_bits == 2
     assert S.StarkConfig.for_air(S.AIR_MILLER_LOOP).rate_bits == 1
     assert S.StarkConfig.for_air(S.AIR_FP12_MUL).rate_bits == 1
+
+
+def test_merged_partial_round_tables_reproduce_the_permutation():
+    """The leaf-hash kernel takes the 22 partial rounds three at a time from host-built tables (integer matrices M Mz Mz,
+    per-lane coefficient views, folded constants).  The library replays that formulation on the CPU, with exactly those
+    tables, against the plain permutation."""
+    import starky_bls12_381_amd as S
+    assert S.lib.starkhip_selfcheck_hash_tables(200) == 0
+
