@@ -94,7 +94,10 @@ AVX512_TARGET inline __m256i sbox_4(__m256i x) {
 }
 
 // MDS layer: out[r] = sum_i CIRC[i] * s[(i + r) % 12] + (r == 0) * 8 * s[0]
-AVX512_TARGET inline void mds(V12& s) {
+// With `partial` the vector's element 0 is zero and x0 is the value it stands for: its column of the matrix is added at
+// the end, so the scalar S-box that produces x0 runs beside the vector part instead of in front of it.
+template <bool partial>
+AVX512_TARGET inline void mds_t(V12& s, gl_t x0) {
     static const uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     alignas(64) uint64_t lo[24], hi[24];
     const __m512i m32 = _mm512_set1_epi64((long long)EPS);
@@ -119,9 +122,22 @@ AVX512_TARGET inline void mds(V12& s) {
         Lb = _mm256_add_epi64(Lb, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(lo + 8 + i)), ch));  // r = 8..11
         Hb = _mm256_add_epi64(Hb, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(hi + 8 + i)), ch));
     }
-    // + 8 * s[0] on output 0 only
-    La = _mm512_mask_add_epi64(La, 1, La, _mm512_slli_epi64(alo, 3));
-    Ha = _mm512_mask_add_epi64(Ha, 1, Ha, _mm512_slli_epi64(ahi, 3));
+    if (partial) {
+        // column 0: CIRC[(12 - r) % 12] for output r, + 8 on output 0
+        static const long long C0A[8] = {17 + 8, 20, 34, 18, 39, 13, 13, 28};
+        static const long long C0B[4] = {2, 16, 41, 15};
+        const __m512i ca = _mm512_loadu_si512((const void*)C0A);
+        const __m256i cb = _mm256_loadu_si256((const __m256i*)C0B);
+        const long long xl = (long long)(x0 & EPS), xh = (long long)(x0 >> 32);
+        La = _mm512_add_epi64(La, _mm512_mul_epu32(_mm512_set1_epi64(xl), ca));
+        Ha = _mm512_add_epi64(Ha, _mm512_mul_epu32(_mm512_set1_epi64(xh), ca));
+        Lb = _mm256_add_epi64(Lb, _mm256_mul_epu32(_mm256_set1_epi64x(xl), cb));
+        Hb = _mm256_add_epi64(Hb, _mm256_mul_epu32(_mm256_set1_epi64x(xh), cb));
+    } else {
+        // + 8 * s[0] on output 0 only
+        La = _mm512_mask_add_epi64(La, 1, La, _mm512_slli_epi64(alo, 3));
+        Ha = _mm512_mask_add_epi64(Ha, 1, Ha, _mm512_slli_epi64(ahi, 3));
+    }
     // value = L + H * 2^32 with L, H < 2^42
     {
         const __m512i l = _mm512_add_epi64(La, _mm512_slli_epi64(Ha, 32));
@@ -136,6 +152,8 @@ AVX512_TARGET inline void mds(V12& s) {
         s.b = reduce128_4(h, l);
     }
 }
+
+AVX512_TARGET inline void mds(V12& s) { mds_t<false>(s, 0); }
 
 AVX512_TARGET void permute_avx512(gl_t* st) {
     const uint64_t* RC = POSEIDON_RC_HOST;
@@ -152,8 +170,8 @@ AVX512_TARGET void permute_avx512(gl_t* st) {
         s.a = add_8(s.a, _mm512_loadu_si512((const void*)(RC + rc)));
         s.b = add_4(s.b, _mm256_loadu_si256((const __m256i*)(RC + rc + 8)));
         const gl_t x0 = poseidon_sbox((gl_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(s.a)));  // element 0, scalar
-        s.a = _mm512_mask_set1_epi64(s.a, 1, (long long)x0);
-        mds(s);
+        s.a = _mm512_maskz_mov_epi64(0xFE, s.a);  // the vector part does not wait for x0
+        mds_t<true>(s, x0);
     }
     for (int r = 0; r < 4; r++, rc += 12) {
         s.a = sbox_8(add_8(s.a, _mm512_loadu_si512((const void*)(RC + rc))));
