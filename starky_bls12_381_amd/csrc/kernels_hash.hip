@@ -185,11 +185,7 @@ static hipError_t ensure_quad_merged_tables() {
 // Leaf position j in the tree holds natural row bitrev_logN(j) (plonky2 reverse_index_bits_in_place),
 // so the thread that owns physical point q writes digest slot j = bitrev(i).
 // Four lanes (one DPP quad) walk one row; adjacent quads read adjacent k => each load touches whole 128-byte runs.
-// 128 registers per lane (amdgpu_waves_per_eu): a trace commitment fields exactly two waves per SIMD, so two such launches
-// -- two proofs in flight -- can share the SIMDs only if each wave takes a quarter of the register file.  The per-lane
-// coefficient tables of the merged rounds therefore live in LDS (measured with four proofs in flight: 190 against 193 ms per
-// proof; one proof alone 145 against 143 ms).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void leaf_hash_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
+__global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
                                                          gl_t* __restrict__ digests) {
     // lane l of the quad owns sponge state elements 3l, 3l+1, 3l+2 (poseidon_dev.h)
     __shared__ RcPair rcs[4][96];  // per-lane view of the round constants, split in halves, + 3 zeros ("next round" of the last round)
@@ -202,8 +198,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #if STARKHIP_MERGED_PARTIAL
     __shared__ RcPair tks[2 * QUAD_MERGED_TRIPLES];
     __shared__ RcPair tk3s[4][3 * QUAD_MERGED_TRIPLES];
-    __shared__ uint32_t coefs[4][52];
-    for (unsigned idx = threadIdx.x; idx < 4 * 50; idx += blockDim.x) coefs[idx / 50][idx % 50] = QUAD_MERGED.coef[idx / 50][idx % 50];
     for (unsigned idx = threadIdx.x; idx < 2 * QUAD_MERGED_TRIPLES; idx += blockDim.x) tks[idx] = QUAD_MERGED.tk[idx];
     for (unsigned idx = threadIdx.x; idx < 4 * 3 * QUAD_MERGED_TRIPLES; idx += blockDim.x)
         tk3s[idx / (3 * QUAD_MERGED_TRIPLES)][idx % (3 * QUAD_MERGED_TRIPLES)] = QUAD_MERGED.tk3[idx / (3 * QUAD_MERGED_TRIPLES)][idx % (3 * QUAD_MERGED_TRIPLES)];
@@ -231,7 +225,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t diag0 = l == 0 ? 8u : 0u;
     const RcPair* rc = rcs[l];
 #if STARKHIP_MERGED_PARTIAL
-    QuadMergedCoef mc{coefs[l]};
+    QuadMergedCoef mc;
+    {
+        const uint32_t* c = QUAD_MERGED.coef[l];
+#pragma unroll
+        for (int i = 0; i < 36; i++) mc.n3[i / 12][i % 12] = c[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            mc.n1[i] = c[36 + i];
+            mc.n2[i] = c[39 + i];
+            mc.b2[i] = c[43 + i];
+            mc.b3[i] = c[46 + i];
+        }
+        mc.m00 = c[42];
+    }
     const RcPair* tk3 = tk3s[l];
     const bool even_lane = (l & 1u) == 0;
 #define PERMUTE_QUAD() poseidon_permute_quad_merged(s0, s1, s2, diag0, rc, mc, tks, tk3, l == 0, even_lane)

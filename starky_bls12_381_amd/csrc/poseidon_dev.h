@@ -277,14 +277,12 @@ __device__ __forceinline__ void poseidon_permute_quad(gl_t& s0, gl_t& s1, gl_t& 
 // three dense layers.  The matrices are not circulant (the diagonal term and the zeroed rows break that), so each lane
 // holds its coefficients in registers: n3[mo][3r+m] = (M Mz Mz)[3l+mo][col], n1[3r+m] = M[0][col], n2[3r+m] = (M Mz)[0][col]
 // with col = 3((l + r) & 3) + m, and the columns that multiply x_2 and x_3.
-struct QuadMergedCoef {   // view of one lane's 50-word coefficient table (in LDS: registers are what limits co-residency)
-    const uint32_t* t;
-    __device__ __forceinline__ const uint32_t* n3(int mo) const { return t + 12 * mo; }
-    __device__ __forceinline__ uint32_t n1(int m) const { return t[36 + m]; }
-    __device__ __forceinline__ uint32_t n2(int m) const { return t[39 + m]; }
-    __device__ __forceinline__ uint32_t m00() const { return t[42]; }
-    __device__ __forceinline__ uint32_t b2(int mo) const { return t[43 + mo]; }
-    __device__ __forceinline__ uint32_t b3(int mo) const { return t[46 + mo]; }
+struct QuadMergedCoef {
+    uint32_t n3[3][12];
+    uint32_t n1[3], n2[3];  // row 0 of M and of M Mz at this lane's OWN three columns: the two intermediate dot products
+                            // are per-lane partial sums added up across the quad (6 multiply-adds + a butterfly, not 24)
+    uint32_t m00;           // M[0][0] on lane 0, 0 elsewhere (the x_2 term of y2 is added once)
+    uint32_t b2[3], b3[3];  // (M Mz)[3l+mo][0], M[3l+mo][0]
 };
 static const int QUAD_MERGED_TRIPLES = 7;  // partial rounds 0..20; the 22nd stays a plain round
 
@@ -343,30 +341,30 @@ __device__ __forceinline__ void poseidon_partial3_quad(gl_t& s0, gl_t& s1, gl_t&
     uint64_t A = k1.lo, B = k1.hi;
 #pragma unroll
     for (int m = 0; m < 3; m++) {
-        A = mad32(lo[0][m], c.n1(m), A);
-        B = mad32(hi[0][m], c.n1(m), B);
+        A = mad32(lo[0][m], c.n1[m], A);
+        B = mad32(hi[0][m], c.n1[m], B);
     }
     const gl_t x2 = sbox_quad_uniform(combine_lohi_nc(quad_sum64(A), quad_sum64(B)), even_lane);  // sums < 2^40
     const uint32_t x2l = (uint32_t)x2, x2h = (uint32_t)(x2 >> 32);
     A = k2.lo; B = k2.hi;
 #pragma unroll
     for (int m = 0; m < 3; m++) {
-        A = mad32(lo[0][m], c.n2(m), A);
-        B = mad32(hi[0][m], c.n2(m), B);
+        A = mad32(lo[0][m], c.n2[m], A);
+        B = mad32(hi[0][m], c.n2[m], B);
     }
-    A = mad32(x2l, c.m00(), A);
-    B = mad32(x2h, c.m00(), B);
+    A = mad32(x2l, c.m00, A);
+    B = mad32(x2h, c.m00, B);
     const gl_t x3 = sbox_quad_uniform(combine_lohi_nc(quad_sum64(A), quad_sum64(B)), even_lane);  // sums < 2^48
     const uint32_t x3l = (uint32_t)x3, x3h = (uint32_t)(x3 >> 32);
     gl_t out[3];
 #pragma unroll
     for (int mo = 0; mo < 3; mo++) {
         A = k3[mo].lo; B = k3[mo].hi;
-        quad_dot12(lo, hi, c.n3(mo), A, B);
-        A = mad32(x2l, c.b2(mo), A);
-        B = mad32(x2h, c.b2(mo), B);
-        A = mad32(x3l, c.b3(mo), A);
-        B = mad32(x3h, c.b3(mo), B);
+        quad_dot12(lo, hi, c.n3[mo], A, B);
+        A = mad32(x2l, c.b2[mo], A);
+        B = mad32(x2h, c.b2[mo], B);
+        A = mad32(x3l, c.b3[mo], A);
+        B = mad32(x3h, c.b3[mo], B);
         out[mo] = combine_lohi_nc(A, B);  // A, B < 2^57: 12 terms of (< 2^21) x (< 2^32) and the two single terms
     }
     s0 = out[0];
