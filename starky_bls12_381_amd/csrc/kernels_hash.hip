@@ -7,6 +7,7 @@
 #include <mutex>
 
 #include "kernels.h"
+#include "poseidon_merged.h"
 #include "poseidon_dev.h"
 
 namespace starkhip {
@@ -22,69 +23,35 @@ struct QuadMergedTables {
 };
 __constant__ QuadMergedTables QUAD_MERGED;
 
-// N1 = M, N2 = M Mz, N3 = M Mz Mz (Mz = M with row 0 zeroed; exact integers, < 2^21) and, per triple of partial rounds
-// starting at round r with following constants c1, c2, c3 (c?z = the vector with element 0 zeroed):
-//   k1 = c1[0];   k2 = (M c1z)[0] + c2[0];   k3 = N2 c1z + M c2z + c3   (mod p)
+// The per-lane views of poseidon_merged.h's tables: lane l's rotated operand (r, m) is state element 3((l + r) & 3) + m.
 static void build_quad_merged_tables(QuadMergedTables& T) {
-    static const uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    uint64_t M[12][12], Mz[12][12], N2[12][12], N3[12][12];
-    for (int i = 0; i < 12; i++)
-        for (int j = 0; j < 12; j++) {
-            M[i][j] = CIRC[(j - i + 12) % 12] + ((i == 0 && j == 0) ? 8 : 0);
-            Mz[i][j] = i == 0 ? 0 : M[i][j];
-        }
-    auto mul = [](const uint64_t (&a)[12][12], const uint64_t (&b)[12][12], uint64_t (&o)[12][12]) {
-        for (int i = 0; i < 12; i++)
-            for (int j = 0; j < 12; j++) {
-                uint64_t acc = 0;
-                for (int k = 0; k < 12; k++) acc += a[i][k] * b[k][j];
-                o[i][j] = acc;
-            }
-    };
-    mul(M, Mz, N2);
-    mul(N2, Mz, N3);
-    auto matvec_mod = [](const uint64_t (&a)[12][12], const gl_t* v, gl_t* o) {
-        for (int i = 0; i < 12; i++) {
-            unsigned __int128 acc = 0;
-            for (int j = 0; j < 12; j++) acc += (unsigned __int128)a[i][j] * v[j];
-            o[i] = (gl_t)(acc % GL_P);
-        }
-    };
+    static PoseidonMergedTables P;
+    build_poseidon_merged_tables(P);
     auto split = [](gl_t v) { return RcPair{v & 0xFFFFFFFFull, v >> 32}; };
     for (int l = 0; l < 4; l++) {
         uint32_t* c = T.coef[l];
         for (int r = 0; r < 4; r++)
             for (int m = 0; m < 3; m++) {
                 const int col = 3 * ((l + r) & 3) + m;
-                for (int mo = 0; mo < 3; mo++) c[12 * mo + 3 * r + m] = (uint32_t)N3[3 * l + mo][col];
+                for (int mo = 0; mo < 3; mo++) c[12 * mo + 3 * r + m] = (uint32_t)P.N3[3 * l + mo][col];
             }
         for (int m = 0; m < 3; m++) {
-            c[36 + m] = (uint32_t)M[0][3 * l + m];   // the lane's own columns of row 0
-            c[39 + m] = (uint32_t)N2[0][3 * l + m];
+            c[36 + m] = (uint32_t)P.M[0][3 * l + m];   // the lane's own columns of row 0
+            c[39 + m] = (uint32_t)P.N2[0][3 * l + m];
         }
-        c[42] = l == 0 ? (uint32_t)M[0][0] : 0;
+        c[42] = l == 0 ? (uint32_t)P.M[0][0] : 0;
         for (int mo = 0; mo < 3; mo++) {
-            c[43 + mo] = (uint32_t)N2[3 * l + mo][0];
-            c[46 + mo] = (uint32_t)M[3 * l + mo][0];
+            c[43 + mo] = (uint32_t)P.N2[3 * l + mo][0];
+            c[46 + mo] = (uint32_t)P.M[3 * l + mo][0];
         }
         c[49] = 0;
     }
-    const uint64_t* RC = POSEIDON_RC_HOST;
+    // every lane seeds its partial sum of y1 / y2 with a quarter of the constant (4^-1 = (3p + 1) / 4 mod p)
+    const gl_t quarter = (gl_t)((((unsigned __int128)3 * GL_P) + 1) / 4);
     for (int t = 0; t < QUAD_MERGED_TRIPLES; t++) {
-        const int r = 4 + 3 * t;
-        gl_t c1z[12], c2z[12], a[12], b[12];
-        for (int i = 0; i < 12; i++) {
-            c1z[i] = i ? RC[12 * (r + 1) + i] : 0;
-            c2z[i] = i ? RC[12 * (r + 2) + i] : 0;
-        }
-        matvec_mod(M, c1z, a);
-        // every lane seeds its partial sum with a quarter of the constant (4^-1 = (3p + 1) / 4 mod p)
-        const gl_t quarter = (gl_t)((((unsigned __int128)3 * GL_P) + 1) / 4);
-        T.tk[2 * t] = split(gl_mul(RC[12 * (r + 1)], quarter));
-        T.tk[2 * t + 1] = split(gl_mul(gl_add(a[0], RC[12 * (r + 2)]), quarter));
-        matvec_mod(N2, c1z, a);
-        matvec_mod(M, c2z, b);
-        for (int i = 0; i < 12; i++) T.tk3[i / 3][3 * t + i % 3] = split(gl_add(gl_add(a[i], b[i]), RC[12 * (r + 3) + i]));
+        T.tk[2 * t] = split(gl_mul(P.k1[t], quarter));
+        T.tk[2 * t + 1] = split(gl_mul(P.k2[t], quarter));
+        for (int i = 0; i < 12; i++) T.tk3[i / 3][3 * t + i % 3] = split(P.k3[t][i]);
     }
 }
 

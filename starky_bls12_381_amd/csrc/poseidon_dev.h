@@ -284,7 +284,7 @@ struct QuadMergedCoef {
     uint32_t m00;           // M[0][0] on lane 0, 0 elsewhere (the x_2 term of y2 is added once)
     uint32_t b2[3], b3[3];  // (M Mz)[3l+mo][0], M[3l+mo][0]
 };
-static const int QUAD_MERGED_TRIPLES = 7;  // partial rounds 0..20; the 22nd stays a plain round
+static const int QUAD_MERGED_TRIPLES = 7;  // = POSEIDON_MERGED_TRIPLES (poseidon_merged.h): partial rounds 0..20; the 22nd stays a plain round
 
 // y is the same value in the four lanes of a quad; returns y^7 in all of them.  Even lanes form x^3, odd lanes x^4 in one
 // multiply, and every lane finds the other factor in its right-hand neighbour.
