@@ -205,3 +205,43 @@ def test_two_contexts_prove_concurrently_and_agree_with_sequential(prover):
         pv.close()
     for i in range(2):
         assert np.array_equal(got[i], want[i])
+
+
+def test_one_compact_trace_is_proven_by_several_contexts_at_once_and_recorded_on_threads(prover):
+    """A finished trace log is immutable: four contexts on four host threads prove the same one concurrently (the bench's
+    shape), and four threads record different traces at the same time (recording is armed per thread)."""
+    import threading
+    air = S.AIR_FP12_MUL
+    cfg = S.StarkConfig.for_air(air)
+    inputs = [(random_fp12(0x5EED2300 + 2 * i), random_fp12(0x5EED2301 + 2 * i)) for i in range(4)]
+    want = []
+    for x, y in inputs:
+        t, pis = S.trace_fp12_mul(x, y)
+        want.append(prover.prove(air, cfg, t, pis))
+    # record on four threads at once
+    logs = [None] * 4
+
+    def record(i):
+        logs[i] = S.trace_fp12_mul(*inputs[i], compact=True)
+    th = [threading.Thread(target=record, args=(i,)) for i in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    provers = [S.Prover(0) for _ in range(4)]
+    got = [[None] * 4 for _ in range(4)]
+
+    def prove_all(k):  # context k proves every log, starting at a different one
+        for j in range(4):
+            i = (k + j) % 4
+            got[k][i] = provers[k].prove(air, cfg, logs[i][0], logs[i][1])
+    th = [threading.Thread(target=prove_all, args=(k,)) for k in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for pv in provers:
+        pv.close()
+    for k in range(4):
+        for i in range(4):
+            assert np.array_equal(got[k][i], want[i]), (k, i)
