@@ -84,6 +84,14 @@ int starkhip_air_num_constraints(starkhip_air_t air);
 int starkhip_air_default_rows(starkhip_air_t air);
 /* serialised constraint program (format: starky_bls12_381_amd/csrc/air_ir.h); library-owned */
 int starkhip_air_program(starkhip_air_t air, const uint64_t** blob, size_t* words);
+/* What one call of S::eval_packed_generic leaves in the ConstraintConsumer (the reference folds
+ * acc_j = acc_j * alpha_j + mask(kind) * c_k constraint by constraint; e.g. src/final_exponentiate.rs:907-1136) on ONE
+ * frame over the quadratic extension — the host evaluator the verifier uses.  All field arguments are (a0, a1) pairs:
+ * local / next hold starkhip_air_columns() pairs, masks = {1, z_last, L_first, L_last} as the consumer applies them to
+ * constraint / constraint_transition / constraint_first_row / constraint_last_row, acc_out n_alpha pairs.  public_inputs
+ * are base-field.  Host only. */
+int starkhip_air_eval_frame(starkhip_air_t air, const uint64_t* local, const uint64_t* next, const uint64_t* public_inputs,
+                            const uint64_t masks[8], const uint64_t* alphas, int n_alpha, uint64_t* acc_out);
 
 /* --- natives + trace generation (host) ----------------------------------------------- */
 /* inputs are u32 limb arrays: Fp = 12, Fp2 = 24, Fp12 = 144 limbs.

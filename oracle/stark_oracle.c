@@ -333,6 +333,20 @@ static void air_eval(const air_prog* p, const fe* local, const fe* next, const f
     }
 }
 
+/* Every constraint's value mask(kind)*c_k on ONE arbitrary frame (local, next, public inputs need not come from a trace).
+ * tests/test_constraint_schedule_cpu.py compares these with the polynomials extracted from the reference's Rust source,
+ * evaluated in Python on the same random frame: that pins this evaluator's reading of the program to the reference. */
+EXPORT int oracle_eval_frame(const uint64_t* air_blob, size_t air_words, const fe* local, const fe* next, const fe* pis,
+                             const fe masks[4], fe* each_out) {
+    air_prog p;
+    if (air_parse(air_blob, air_words, &p)) return -1;
+    fe acc;
+    fe alpha = 1;
+    air_eval(&p, local, next, pis, masks, &alpha, 1, &acc, each_out);
+    free(p.code);
+    return 0;
+}
+
 /* Check that every constraint vanishes on every row of a trace:
  * plain on all rows (next row wraps), transition on rows 0..n-2, first on row 0, last on row n-1.
  * trace row-major [n][C].  Returns number of violations; first violation reported in out3 =

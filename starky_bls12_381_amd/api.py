@@ -172,6 +172,23 @@ def air_program(air):
     return np.ctypeslib.as_array(blob, shape=(words.value,)).copy()
 
 
+lib.starkhip_air_eval_frame.argtypes = [C.c_int, _u64p, _u64p, _u64p, _u64p, _u64p, C.c_int, _u64p]
+
+
+def air_eval_frame(air, local, nxt, pis, masks, alphas):
+    """The ConstraintConsumer accumulators after one `eval_packed_generic` on an arbitrary frame over the quadratic
+    extension (host evaluator of the verifier).  local / nxt: [columns, 2], masks: [4, 2], alphas: [k, 2] -> [k, 2]."""
+    local, nxt, masks, alphas = (np.ascontiguousarray(x, dtype=np.uint64) for x in (local, nxt, masks, alphas))
+    pis = np.ascontiguousarray(pis, dtype=np.uint64)
+    cols = air_columns(air)
+    if local.shape != (cols, 2) or nxt.shape != (cols, 2) or masks.shape != (4, 2) or alphas.ndim != 2 or alphas.shape[1] != 2 \
+            or pis.size != air_public_inputs(air):
+        raise StarkhipError(ERR_BAD_SHAPE)
+    out = np.zeros_like(alphas)
+    _chk(lib.starkhip_air_eval_frame(air, _p64(local), _p64(nxt), _p64(pis), _p64(masks), _p64(alphas), alphas.shape[0], _p64(out)))
+    return out
+
+
 # ----------------------------------------------------------------------------- traces (generate_trace)
 class CompactTrace:
     """A trace recorded as runs (starkhip_trace_log_*): the generator's limb vectors with the rows they

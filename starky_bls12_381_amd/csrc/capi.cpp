@@ -4,6 +4,7 @@
 
 #include <new>
 
+#include "air_eval.h"
 #include "airs.h"
 #include "kernels.h"
 #include "trace_log.h"
@@ -61,6 +62,31 @@ int starkhip_air_program(starkhip_air_t air, const uint64_t** blob, size_t* word
     if (!a) return STARKHIP_ERR_BAD_AIR;
     *blob = a->blob.data();
     *words = a->blob.size();
+    return STARKHIP_OK;
+}
+
+int starkhip_air_eval_frame(starkhip_air_t air, const uint64_t* local, const uint64_t* next, const uint64_t* public_inputs,
+                            const uint64_t masks[8], const uint64_t* alphas, int n_alpha, uint64_t* acc_out) {
+    const AirInfo* a = air_get(air);
+    if (!a) return STARKHIP_ERR_BAD_AIR;
+    if (!local || !next || !masks || !alphas || !acc_out || n_alpha < 1 || (a->pis && !public_inputs)) return STARKHIP_ERR_BAD_SHAPE;
+    try {
+        std::vector<gl2_t> l(a->cols), n(a->cols), al(n_alpha), acc(n_alpha);
+        for (size_t i = 0; i < a->cols; i++) {
+            l[i] = gl2_make(local[2 * i], local[2 * i + 1]);
+            n[i] = gl2_make(next[2 * i], next[2 * i + 1]);
+        }
+        gl2_t mk[4];
+        for (int i = 0; i < 4; i++) mk[i] = gl2_make(masks[2 * i], masks[2 * i + 1]);
+        for (int j = 0; j < n_alpha; j++) al[j] = gl2_make(alphas[2 * j], alphas[2 * j + 1]);
+        air_eval_folded<ExtOps>(a->prog, l.data(), n.data(), public_inputs, mk, al.data(), n_alpha, acc.data());
+        for (int j = 0; j < n_alpha; j++) {
+            acc_out[2 * j] = acc[j].a0;
+            acc_out[2 * j + 1] = acc[j].a1;
+        }
+    } catch (const std::bad_alloc&) {
+        return STARKHIP_ERR_OOM;
+    }
     return STARKHIP_OK;
 }
 

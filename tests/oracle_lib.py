@@ -96,6 +96,18 @@ def check_trace(air_blob, trace_rows, pis):
     return bad, tuple(int(x) for x in out3)
 
 
+lib.oracle_eval_frame.argtypes = [_u64p, C.c_size_t, _u64p, _u64p, _u64p, _u64p, _u64p]
+
+
+def eval_frame(air_blob, local, nxt, pis, masks):
+    """mask(kind) * c_k of every constraint on one arbitrary frame."""
+    blob = np.ascontiguousarray(air_blob, dtype=np.uint64)
+    a = [np.ascontiguousarray(x, dtype=np.uint64) for x in (local, nxt, pis, masks)]
+    out = np.zeros(int(blob[4]), dtype=np.uint64)
+    assert lib.oracle_eval_frame(_p(blob), blob.size, *[_p(x) for x in a], _p(out)) == 0
+    return out
+
+
 def prove(air_blob, config, trace_cols, pis, pow_witness=0xFFFFFFFFFFFFFFFF):
     """trace_cols column-major [C][n].  `config` any object with the StarkConfig field names."""
     blob = np.ascontiguousarray(air_blob, dtype=np.uint64)

@@ -1,0 +1,1378 @@
+"""A small interpreter for the subset of Rust the reference's packed constraint functions are written in.
+
+Purpose: pin the AIR restatement independently of the product.  The reference's
+`eval_packed_generic` bodies and the `add_*_constraints` gadget functions they call
+(/root/reference/src/{fp,fp2,fp6,fp12,g1,fp12_mul,miller_loop,calc_pairing_precomp,final_exponentiate,ecc_aggregate}.rs)
+are plain control flow (`for` over constant ranges, `if` on constants, calls) around
+`yield_constr.constraint*(<polynomial in local_values / next_values / public_inputs>)`.  This module parses
+that source *as text* (study of the reference, no Rust toolchain needed) and runs it with symbolic field
+elements, so every constraint comes out as (kind, polynomial) in the reference's own order.
+
+It runs in the build container only (it reads /root/reference); what it produces are data fixtures
+(tools/extract_constraint_schedule.py -> tests/golden/constraint_schedule.json).  Nothing in the product
+imports it.
+"""
+import re
+
+P_GL = 0xFFFFFFFF00000001
+
+
+# ----------------------------------------------------------------------------------------------- lexer
+TOKEN_RE = re.compile(r"""
+    (?P<ws>\s+|//[^\n]*|/\*.*?\*/)
+  | (?P<str>b?"(?:\\.|[^"\\])*")
+  | (?P<life>'[A-Za-z_]\w*(?!'))
+  | (?P<chr>'(?:\\.|[^'\\])')
+  | (?P<num>0x[0-9a-fA-F_]+(?:[iu](?:8|16|32|64|128|size))?|[0-9][0-9_]*(?:[iu](?:8|16|32|64|128|size))?)
+  | (?P<id>[A-Za-z_]\w*)
+  | (?P<op>::|->|=>|\.\.=|\.\.|==|!=|<=|>=|&&|\|\||<<=|>>=|<<|>>|\+=|-=|\*=|/=|%=|\^=|&=|\|=|[-+*/%^!&|=<>@.,;:#$?~\[\](){}])
+""", re.X | re.S)
+
+
+class Tok:
+    __slots__ = ("k", "v", "line")
+
+    def __init__(self, k, v, line):
+        self.k, self.v, self.line = k, v, line
+
+    def __repr__(self):
+        return f"{self.k}:{self.v}@{self.line}"
+
+
+def lex(text):
+    toks, pos, line = [], 0, 1
+    n = len(text)
+    while pos < n:
+        m = TOKEN_RE.match(text, pos)
+        if not m:
+            raise SyntaxError(f"lex error at line {line}: {text[pos:pos+30]!r}")
+        k = m.lastgroup
+        v = m.group(k)
+        if k not in ("ws", "life"):
+            toks.append(Tok(k, v, line))
+        line += v.count("\n")
+        pos = m.end()
+    toks.append(Tok("eof", "", line))
+    return toks
+
+
+# ----------------------------------------------------------------------------------------------- values
+class Sym:
+    """Polynomial over Goldilocks in the frame variables.  monomial = sorted tuple of variable codes:
+    local column c -> c, next-row column c -> c | 1<<30, public input i -> i | 1<<31."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+    @staticmethod
+    def const(c):
+        c %= P_GL
+        return Sym({(): c} if c else {})
+
+    @staticmethod
+    def var(code):
+        return Sym({(code,): 1})
+
+    def __add__(self, o):
+        o = as_sym(o)
+        r = dict(self.t)
+        for m, c in o.t.items():
+            v = (r.get(m, 0) + c) % P_GL
+            if v:
+                r[m] = v
+            else:
+                r.pop(m, None)
+        return Sym(r)
+
+    def __sub__(self, o):
+        o = as_sym(o)
+        r = dict(self.t)
+        for m, c in o.t.items():
+            v = (r.get(m, 0) - c) % P_GL
+            if v:
+                r[m] = v
+            else:
+                r.pop(m, None)
+        return Sym(r)
+
+    def __neg__(self):
+        return Sym({m: (P_GL - c) % P_GL for m, c in self.t.items()})
+
+    def __mul__(self, o):
+        o = as_sym(o)
+        r = {}
+        for m1, c1 in self.t.items():
+            for m2, c2 in o.t.items():
+                if m1 and m2:
+                    m = tuple(sorted(m1 + m2))
+                else:
+                    m = m1 or m2
+                v = (r.get(m, 0) + c1 * c2) % P_GL
+                if v:
+                    r[m] = v
+                else:
+                    r.pop(m, None)
+        return Sym(r)
+
+    __radd__ = __add__
+    __rmul__ = __mul__
+
+    def canonical(self):
+        """Deterministic byte string of the polynomial (sorted monomials; u32 degree, u32 vars, u64 coefficient)."""
+        out = bytearray()
+        for m in sorted(self.t):
+            out += len(m).to_bytes(4, "little")
+            for v in m:
+                out += v.to_bytes(4, "little")
+            out += self.t[m].to_bytes(8, "little")
+        return bytes(out)
+
+
+def as_sym(x):
+    if isinstance(x, Sym):
+        return x
+    if isinstance(x, FieldConst):
+        return Sym.const(x.v)
+    raise TypeError(f"not a field value: {x!r}")
+
+
+class FieldConst:
+    """FE::from_canonical_*(..) — a scalar of the extension; only ever multiplied into / added to packed values."""
+    __slots__ = ("v",)
+
+    def __init__(self, v):
+        self.v = v % P_GL
+
+    def __mul__(self, o):
+        if isinstance(o, FieldConst):
+            return FieldConst(self.v * o.v)
+        return as_sym(self) * o
+
+    __rmul__ = __mul__
+
+    def __add__(self, o):
+        if isinstance(o, FieldConst):
+            return FieldConst(self.v + o.v)
+        return as_sym(self) + o
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        if isinstance(o, FieldConst):
+            return FieldConst(self.v - o.v)
+        return as_sym(self) - o
+
+    def __rsub__(self, o):
+        return as_sym(o) - as_sym(self)
+
+    def __neg__(self):
+        return FieldConst(-self.v)
+
+
+class Row:
+    def __init__(self, flag, n):
+        self.flag, self.n = flag, n
+
+    def __getitem__(self, i):
+        if not isinstance(i, int) or i < 0 or (self.n is not None and i >= self.n):
+            raise IndexError(f"frame index {i} out of range {self.n}")
+        return Sym.var(i | self.flag)
+
+
+class TupleStruct:
+    def __init__(self, name, fields):
+        self.name, self.fields = name, fields
+
+    def __repr__(self):
+        return f"{self.name}{self.fields!r}"
+
+
+class SomeV:
+    def __init__(self, v):
+        self.v = v
+
+
+class Closure:
+    def __init__(self, interp, params, body, env, mod):
+        self.interp, self.params, self.body, self.env, self.mod = interp, params, body, env, mod
+
+    def __call__(self, *args):
+        env = Env(self.env)
+        for p, a in zip(self.params, args):
+            bind_pattern(env, p, a)
+        return self.interp.ev(self.body, env, self.mod)
+
+
+class Env:
+    def __init__(self, parent=None):
+        self.v, self.parent = {}, parent
+
+    def get(self, k):
+        e = self
+        while e is not None:
+            if k in e.v:
+                return e.v[k]
+            e = e.parent
+        raise KeyError(k)
+
+    def has(self, k):
+        e = self
+        while e is not None:
+            if k in e.v:
+                return True
+            e = e.parent
+        return False
+
+    def set_existing(self, k, val):
+        e = self
+        while e is not None:
+            if k in e.v:
+                e.v[k] = val
+                return
+            e = e.parent
+        raise KeyError(k)
+
+
+def bind_pattern(env, pat, val):
+    if pat[0] == "id":
+        if pat[1] != "_":
+            env.v[pat[1]] = val
+    elif pat[0] == "tuple":
+        vals = list(val)
+        for p, v in zip(pat[1], vals):
+            bind_pattern(env, p, v)
+    else:
+        raise NotImplementedError(pat)
+
+
+class ReturnEx(Exception):
+    def __init__(self, v):
+        self.v = v
+
+
+class BreakEx(Exception):
+    pass
+
+
+class ContinueEx(Exception):
+    pass
+
+
+# ----------------------------------------------------------------------------------------------- parser
+BINOP_PREC = {
+    "||": 1, "&&": 2,
+    "==": 3, "!=": 3, "<": 3, ">": 3, "<=": 3, ">=": 3,
+    "|": 4, "^": 5, "&": 6, "<<": 7, ">>": 7, "+": 8, "-": 8, "*": 9, "/": 9, "%": 9,
+}
+ASSIGN_OPS = {"=", "+=", "-=", "*=", "/=", "%=", "<<=", ">>=", "|=", "&=", "^="}
+
+
+class Parser:
+    def __init__(self, toks, i=0, fname=""):
+        self.t, self.i, self.fname = toks, i, fname
+
+    # -- token helpers
+    def peek(self, o=0):
+        return self.t[self.i + o]
+
+    def at(self, v, o=0):
+        tk = self.t[self.i + o]
+        return tk.v == v and tk.k in ("op", "id")
+
+    def eat(self, v):
+        tk = self.t[self.i]
+        if tk.v != v:
+            raise SyntaxError(f"{self.fname}:{tk.line}: expected {v!r}, got {tk.v!r}")
+        self.i += 1
+        return tk
+
+    def accept(self, v):
+        if self.at(v):
+            self.i += 1
+            return True
+        return False
+
+    def ident(self):
+        tk = self.t[self.i]
+        if tk.k != "id":
+            raise SyntaxError(f"{self.fname}:{tk.line}: expected identifier, got {tk.v!r}")
+        self.i += 1
+        return tk.v
+
+    # -- types are skipped, never interpreted
+    def skip_generics(self):
+        """at '<': skip the balanced angle-bracket list."""
+        depth = 0
+        while True:
+            v = self.peek().v
+            if self.peek().k == "eof":
+                raise SyntaxError("eof in generics")
+            if v == "<":
+                depth += 1
+            elif v == ">":
+                depth -= 1
+            elif v == ">>":
+                depth -= 2
+            elif v == "<<":
+                depth += 2
+            elif v == "->":
+                pass
+            self.i += 1
+            if depth <= 0:
+                return
+
+    def skip_type(self):
+        while self.at("&") or self.at("&&") or self.at("mut") or self.at("dyn") or self.at("impl") or self.at("*") or self.at("const"):
+            self.i += 1
+        if self.at("["):
+            self.skip_balanced("[", "]")
+            return
+        if self.at("("):
+            self.skip_balanced("(", ")")
+            if self.accept("->"):
+                self.skip_type()
+            return
+        if self.at("<"):
+            self.skip_generics()
+            while self.accept("::"):
+                self.ident()
+            return
+        self.ident()
+        while True:
+            if self.at("::"):
+                self.i += 1
+                if self.at("<"):
+                    self.skip_generics()
+                else:
+                    self.ident()
+            elif self.at("<"):
+                self.skip_generics()
+            else:
+                break
+        if self.at("("):  # Fn(A) -> B
+            self.skip_balanced("(", ")")
+            if self.accept("->"):
+                self.skip_type()
+
+    def skip_balanced(self, o, c):
+        depth = 0
+        while True:
+            v = self.peek().v
+            if self.peek().k == "eof":
+                raise SyntaxError("eof in balanced skip")
+            if self.peek().k == "op":
+                if v == o:
+                    depth += 1
+                elif v == c:
+                    depth -= 1
+            self.i += 1
+            if depth == 0:
+                return
+
+    # -- patterns
+    def pattern(self):
+        while self.at("&") or self.at("mut") or self.at("ref"):
+            self.i += 1
+        if self.at("("):
+            self.eat("(")
+            ps = []
+            while not self.at(")"):
+                ps.append(self.pattern())
+                if not self.accept(","):
+                    break
+            self.eat(")")
+            return ("tuple", ps)
+        return ("id", self.ident())
+
+    # -- blocks / statements
+    def block(self):
+        self.eat("{")
+        stmts = []
+        tail = None
+        while not self.at("}"):
+            if self.accept(";"):
+                continue
+            line = self.peek().line
+            if self.at("let"):
+                self.eat("let")
+                pat = self.pattern()
+                if self.accept(":"):
+                    self.skip_type()
+                init = None
+                if self.accept("="):
+                    init = self.expr()
+                self.eat(";")
+                stmts.append(("let", pat, init, line))
+                continue
+            if self.at("for"):
+                self.eat("for")
+                pat = self.pattern()
+                self.eat("in")
+                it = self.expr(no_struct=True)
+                body = self.block()
+                stmts.append(("for", pat, it, body, line))
+                continue
+            if self.at("while"):
+                self.eat("while")
+                cond = self.expr(no_struct=True)
+                body = self.block()
+                stmts.append(("while", cond, body, line))
+                continue
+            if self.at("return"):
+                self.eat("return")
+                e = None if self.at(";") else self.expr()
+                self.accept(";")
+                stmts.append(("return", e, line))
+                continue
+            if self.at("break"):
+                self.eat("break")
+                self.accept(";")
+                stmts.append(("break", line))
+                continue
+            if self.at("continue"):
+                self.eat("continue")
+                self.accept(";")
+                stmts.append(("continue", line))
+                continue
+            e = self.expr()
+            if self.peek().k == "op" and self.peek().v in ASSIGN_OPS:
+                op = self.peek().v
+                self.i += 1
+                rhs = self.expr()
+                self.accept(";")
+                stmts.append(("assign", op, e, rhs, line))
+                continue
+            if self.accept(";"):
+                stmts.append(("expr", e, line))
+            elif self.at("}"):
+                tail = e
+            elif e[0] in ("if", "block", "match"):
+                stmts.append(("expr", e, line))
+            else:
+                tk = self.peek()
+                raise SyntaxError(f"{self.fname}:{tk.line}: unexpected {tk.v!r} after expression")
+        self.eat("}")
+        return ("block", stmts, tail)
+
+    # -- expressions
+    def expr(self, no_struct=False):
+        return self.range_expr(no_struct)
+
+    def range_expr(self, ns):
+        if self.at("..") or self.at("..="):
+            raise NotImplementedError("prefix range")
+        lhs = self.binary(0, ns)
+        if self.at("..") or self.at("..="):
+            incl = self.peek().v == "..="
+            self.i += 1
+            if self.at("{") or self.at(")") or self.at("]") or self.at(";") or self.at(","):
+                raise NotImplementedError("open range")
+            rhs = self.binary(0, ns)
+            return ("range", lhs, rhs, incl)
+        return lhs
+
+    def binary(self, minp, ns):
+        lhs = self.unary(ns)
+        while True:
+            tk = self.peek()
+            if tk.k != "op" or tk.v not in BINOP_PREC:
+                break
+            p = BINOP_PREC[tk.v]
+            if p < minp + 1 and not (p >= minp + 1):
+                break
+            if p <= minp:
+                break
+            self.i += 1
+            rhs = self.binary(p, ns)
+            lhs = ("bin", tk.v, lhs, rhs, tk.line)
+        return lhs
+
+    def unary(self, ns):
+        tk = self.peek()
+        if tk.k == "op" and tk.v in ("-", "!"):
+            self.i += 1
+            return ("un", tk.v, self.unary(ns))
+        if tk.k == "op" and tk.v in ("&", "&&", "*"):
+            self.i += 1
+            self.accept("mut")
+            return self.unary(ns)  # references and derefs are transparent here
+        e = self.postfix(ns)
+        while self.at("as"):
+            self.eat("as")
+            ty = self.peek().v
+            self.skip_type()
+            e = ("as", e, ty)
+        return e
+
+    def args(self):
+        self.eat("(")
+        a = []
+        while not self.at(")"):
+            a.append(self.expr())
+            if not self.accept(","):
+                break
+        self.eat(")")
+        return a
+
+    def postfix(self, ns):
+        e = self.primary(ns)
+        while True:
+            tk = self.peek()
+            if tk.k != "op":
+                break
+            if tk.v == "(":
+                e = ("call", e, self.args(), tk.line)
+            elif tk.v == "[":
+                self.i += 1
+                idx = self.expr()
+                self.eat("]")
+                e = ("index", e, idx, tk.line)
+            elif tk.v == ".":
+                self.i += 1
+                nt = self.peek()
+                if nt.k == "num":
+                    self.i += 1
+                    e = ("field", e, int(nt.v))
+                else:
+                    name = self.ident()
+                    if self.at("::"):
+                        self.i += 1
+                        self.skip_generics()
+                    if self.at("("):
+                        e = ("method", e, name, self.args(), nt.line)
+                    else:
+                        e = ("field", e, name)
+            elif tk.v == "?":
+                self.i += 1
+            else:
+                break
+        return e
+
+    def primary(self, ns):
+        tk = self.peek()
+        if tk.k == "num":
+            self.i += 1
+            m = re.match(r"(0x[0-9a-fA-F_]+|[0-9][0-9_]*)(.*)", tk.v)
+            return ("int", int(m.group(1).replace("_", ""), 0), m.group(2))
+        if tk.k == "str":
+            self.i += 1
+            return ("str", tk.v[tk.v.index('"') + 1:-1])
+        if tk.k == "op":
+            if tk.v == "(":
+                self.i += 1
+                if self.accept(")"):
+                    return ("tuple", [])
+                first = self.expr()
+                if self.at(","):
+                    items = [first]
+                    while self.accept(","):
+                        if self.at(")"):
+                            break
+                        items.append(self.expr())
+                    self.eat(")")
+                    return ("tuple", items)
+                self.eat(")")
+                return first
+            if tk.v == "[":
+                self.i += 1
+                if self.accept("]"):
+                    return ("array", [])
+                first = self.expr()
+                if self.accept(";"):
+                    cnt = self.expr()
+                    self.eat("]")
+                    return ("repeat", first, cnt)
+                items = [first]
+                while self.accept(","):
+                    if self.at("]"):
+                        break
+                    items.append(self.expr())
+                self.eat("]")
+                return ("array", items)
+            if tk.v == "{":
+                return self.block()
+            if tk.v in ("|", "||"):
+                params = []
+                if tk.v == "||":
+                    self.i += 1
+                else:
+                    self.i += 1
+                    while not self.at("|"):
+                        params.append(self.pattern())
+                        if self.accept(":"):
+                            self.skip_type()
+                        if not self.accept(","):
+                            break
+                    self.eat("|")
+                body = self.expr()
+                return ("closure", params, body)
+            if tk.v == "<":  # <T>::NAME
+                self.skip_generics()
+                path = ["<T>"]
+                while self.accept("::"):
+                    path.append(self.ident())
+                return ("path", path, tk.line)
+        if tk.k == "id":
+            if tk.v == "if":
+                return self.if_expr()
+            if tk.v == "move":
+                self.i += 1
+                return self.primary(ns)
+            if tk.v == "match":
+                raise NotImplementedError(f"{self.fname}:{tk.line}: match")
+            if tk.v == "unsafe":
+                self.i += 1
+                return self.block()
+            path = [self.ident()]
+            while self.at("::"):
+                self.i += 1
+                if self.at("<"):
+                    self.skip_generics()
+                else:
+                    path.append(self.ident())
+            if self.at("!"):
+                # macro invocation
+                if self.peek(1).v in ("(", "[", "{"):
+                    self.i += 1
+                    o = self.peek().v
+                    c = {"(": ")", "[": "]", "{": "}"}[o]
+                    self.i += 1
+                    items, rep = [], None
+                    while not self.at(c):
+                        items.append(self.expr())
+                        if self.accept(";"):
+                            rep = self.expr()
+                            break
+                        if not self.accept(","):
+                            break
+                    self.eat(c)
+                    return ("macro", path[-1], items, rep, tk.line)
+            return ("path", path, tk.line)
+        raise SyntaxError(f"{self.fname}:{tk.line}: unexpected token {tk.v!r}")
+
+    def if_expr(self):
+        line = self.peek().line
+        self.eat("if")
+        cond = self.expr(no_struct=True)
+        then = self.block()
+        els = None
+        if self.accept("else"):
+            if self.at("if"):
+                els = self.if_expr()
+            else:
+                els = self.block()
+        return ("if", cond, then, els, line)
+
+
+# ----------------------------------------------------------------------------------------------- module index
+class FnItem:
+    def __init__(self, mod, name, tok_index, line, owner=None):
+        self.mod, self.name, self.tok_index, self.line, self.owner = mod, name, tok_index, line, owner
+        self.params = None
+        self.body = None
+
+
+class Module:
+    def __init__(self, name, path):
+        self.name, self.path = name, path
+        self.text = open(path).read()
+        self.toks = lex(self.text)
+        self.consts = {}      # name -> (tok index of initialiser)
+        self.const_vals = {}
+        self.fns = {}         # name -> FnItem
+        self.methods = {}     # (Type, name) -> FnItem
+        self.globs = []       # glob-imported module names
+        self.imports = {}     # name -> module name
+        self._index()
+
+    def _index(self):
+        t = self.toks
+        i, depth = 0, 0
+        impl_stack = []  # (depth_at_open, type_name)
+        n = len(t)
+        while i < n:
+            tk = t[i]
+            if tk.k == "op":
+                if tk.v == "{":
+                    depth += 1
+                elif tk.v == "}":
+                    depth -= 1
+                    if impl_stack and impl_stack[-1][0] == depth:
+                        impl_stack.pop()
+                elif tk.v == "#" and t[i + 1].v == "[":
+                    # attribute: skip balanced [...]
+                    j, d = i + 1, 0
+                    while True:
+                        if t[j].v == "[":
+                            d += 1
+                        elif t[j].v == "]":
+                            d -= 1
+                            if d == 0:
+                                break
+                        j += 1
+                    i = j + 1
+                    continue
+                i += 1
+                continue
+            in_item_scope = depth == 0 or (impl_stack and impl_stack[-1][0] == depth - 1)
+            if tk.k == "id" and in_item_scope:
+                if tk.v == "use" and depth == 0:
+                    j = i + 1
+                    while t[j].v != ";":
+                        j += 1
+                    self._use(t[i + 1:j])
+                    i = j + 1
+                    continue
+                if tk.v in ("struct", "enum", "trait", "type", "union"):
+                    # skip the header (generics may contain `const D: usize`) up to the body or the ';'
+                    j, pd = i + 1, 0
+                    while True:
+                        v = t[j].v
+                        if t[j].k == "op":
+                            if v in ("(", "["):
+                                pd += 1
+                            elif v in (")", "]"):
+                                pd -= 1
+                            elif v in ("{", ";") and pd == 0:
+                                break
+                        j += 1
+                    i = j
+                    continue
+                if tk.v == "const" and t[i + 1].k == "id" and t[i + 2].v == ":":
+                    name = t[i + 1].v
+                    j = i + 3
+                    while t[j].v != "=":
+                        j += 1
+                    if depth == 0:
+                        self.consts[name] = j + 1
+                    while t[j].v != ";":
+                        j += 1
+                    i = j + 1
+                    continue
+                if tk.v == "fn" and t[i + 1].k == "id":
+                    name = t[i + 1].v
+                    owner = impl_stack[-1][1] if impl_stack else None
+                    item = FnItem(self, name, i, tk.line, owner)
+                    if owner is None:
+                        self.fns.setdefault(name, item)
+                    else:
+                        self.methods.setdefault((owner, name), item)
+                    # skip the signature up to the body's '{' (or ';' for trait declarations)
+                    j, pd = i + 2, 0
+                    while True:
+                        v = t[j].v
+                        if t[j].k == "op":
+                            if v in ("(", "["):
+                                pd += 1
+                            elif v in (")", "]"):
+                                pd -= 1
+                            elif (v == "{" or v == ";") and pd == 0:
+                                break
+                        j += 1
+                    if t[j].v == "{":
+                        # skip the body
+                        d = 0
+                        while True:
+                            if t[j].k == "op":
+                                if t[j].v == "{":
+                                    d += 1
+                                elif t[j].v == "}":
+                                    d -= 1
+                                    if d == 0:
+                                        break
+                            j += 1
+                    i = j + 1
+                    continue
+                if tk.v == "impl":
+                    # impl<..> [Trait<..> for] Type<..> [where ..] {
+                    j = i + 1
+                    names = []
+                    ad = 0
+                    while not (t[j].v == "{" and ad <= 0):
+                        v = t[j].v
+                        if t[j].k == "op":
+                            if v == "<":
+                                ad += 1
+                            elif v == ">":
+                                ad -= 1
+                            elif v == ">>":
+                                ad -= 2
+                        if t[j].k == "id" and ad == 0:
+                            names.append(v)
+                        j += 1
+                    # type name: identifier after 'for' if present, else first identifier
+                    ty = None
+                    if "for" in names:
+                        ty = names[names.index("for") + 1]
+                    else:
+                        ty = [x for x in names if x not in ("where",)][0]
+                    impl_stack.append((depth, ty))
+                    depth += 1
+                    i = j + 1
+                    continue
+                if tk.v == "macro_rules":
+                    # skip the macro body
+                    j = i
+                    while t[j].v != "{":
+                        j += 1
+                    d = 0
+                    while True:
+                        if t[j].k == "op":
+                            if t[j].v == "{":
+                                d += 1
+                            elif t[j].v == "}":
+                                d -= 1
+                                if d == 0:
+                                    break
+                        j += 1
+                    i = j + 1
+                    continue
+            i += 1
+
+    def _use(self, toks):
+        # flatten `crate::{a::*, b::{c, d}}` into paths
+        def parse(i, prefix):
+            paths = []
+            cur = list(prefix)
+            while i < len(toks):
+                tk = toks[i]
+                if tk.k == "id":
+                    cur.append(tk.v)
+                    i += 1
+                elif tk.v == "::":
+                    i += 1
+                elif tk.v == "*":
+                    cur.append("*")
+                    i += 1
+                elif tk.v == "{":
+                    sub, i = parse(i + 1, cur)
+                    paths += sub
+                    cur = None
+                elif tk.v == ",":
+                    if cur is not None and cur != list(prefix):
+                        paths.append(cur)
+                    cur = list(prefix)
+                    i += 1
+                elif tk.v == "}":
+                    if cur is not None and cur != list(prefix):
+                        paths.append(cur)
+                    return paths, i + 1
+                else:
+                    i += 1
+            if cur is not None and cur != list(prefix):
+                paths.append(cur)
+            return paths, i
+        paths, _ = parse(0, [])
+        for p in paths:
+            if p[0] != "crate" or len(p) < 3:
+                continue
+            if p[-1] == "*":
+                self.globs.append(p[1])
+            else:
+                self.imports[p[-1]] = p[1]
+
+
+# ----------------------------------------------------------------------------------------------- interpreter
+class Interp:
+    def __init__(self, src_dir, modules):
+        self.mods = {m: Module(m, f"{src_dir}/{m}.rs") for m in modules}
+        self.records = []          # (kind, Sym, stack id)
+        self.stack = []            # [(fn name, "file:line" of the call site)]
+        self.stack_ids = {}
+        self.stack_list = []
+        self.fn_counts = {}        # (fn, "file:line") -> {constraints yielded by one invocation incl. nested: invocations}
+
+    # -- name resolution
+    def find_const(self, mod, name):
+        m = self.mods[mod]
+        if name in m.consts:
+            return m
+        if name in m.imports and name in self.mods[m.imports[name]].consts:
+            return self.mods[m.imports[name]]
+        for g in m.globs:
+            if g in self.mods and name in self.mods[g].consts:
+                return self.mods[g]
+        return None
+
+    def const_value(self, m, name):
+        if name not in m.const_vals:
+            p = Parser(m.toks, m.consts[name], m.name + ".rs")
+            e = p.expr()
+            m.const_vals[name] = self.ev(e, Env(), m.name)
+        return m.const_vals[name]
+
+    def find_fn(self, mod, name):
+        m = self.mods[mod]
+        if name in m.fns:
+            return m.fns[name]
+        if name in m.imports and m.imports[name] in self.mods and name in self.mods[m.imports[name]].fns:
+            return self.mods[m.imports[name]].fns[name]
+        for g in m.globs:
+            if g in self.mods and name in self.mods[g].fns:
+                return self.mods[g].fns[name]
+        return None
+
+    def find_method(self, ty, name):
+        for m in self.mods.values():
+            if (ty, name) in m.methods:
+                return m.methods[(ty, name)]
+        return None
+
+    def parse_fn(self, item):
+        if item.body is not None:
+            return
+        m = item.mod
+        p = Parser(m.toks, item.tok_index, m.name + ".rs")
+        p.eat("fn")
+        p.ident()
+        if p.at("<"):
+            p.skip_generics()
+        p.eat("(")
+        params = []
+        while not p.at(")"):
+            while p.at("&") or p.at("mut"):
+                p.i += 1
+            if p.at("self"):
+                p.i += 1
+                params.append(("id", "self"))
+            else:
+                pat = p.pattern()
+                p.eat(":")
+                p.skip_type()
+                params.append(pat)
+            if not p.accept(","):
+                break
+        p.eat(")")
+        if p.accept("->"):
+            p.skip_type()
+        if p.at("where"):
+            while not p.at("{"):
+                p.i += 1
+        item.params = params
+        item.body = p.block()
+
+    def call_fn(self, item, args, call_site):
+        self.parse_fn(item)
+        env = Env()
+        if len(args) != len(item.params):
+            raise TypeError(f"{item.name}: {len(args)} args for {len(item.params)} params")
+        for pat, a in zip(item.params, args):
+            bind_pattern(env, pat, a)
+        self.stack.append((item.name, f"{item.mod.name}.rs:{item.line}", call_site))
+        n0 = len(self.records)
+        try:
+            return self.ev(item.body, env, item.mod.name)
+        except ReturnEx as r:
+            return r.v
+        finally:
+            self.stack.pop()
+            n = len(self.records) - n0
+            if n:
+                c = self.fn_counts.setdefault((item.name, f"{item.mod.name}.rs:{item.line}"), {})
+                c[n] = c.get(n, 0) + 1
+
+    def stack_id(self):
+        key = tuple(self.stack)
+        if key not in self.stack_ids:
+            self.stack_ids[key] = len(self.stack_list)
+            self.stack_list.append(key)
+        return self.stack_ids[key]
+
+    def record(self, kind, val):
+        self.records.append((kind, as_sym(val), self.stack_id()))
+
+    # -- evaluation
+    def ev(self, e, env, mod):
+        k = e[0]
+        if k == "int":
+            return e[1]
+        if k == "path":
+            return self.ev_path(e, env, mod)
+        if k == "bin":
+            op = e[1]
+            if op == "&&":
+                return self.ev(e[2], env, mod) and self.ev(e[3], env, mod)
+            if op == "||":
+                return self.ev(e[2], env, mod) or self.ev(e[3], env, mod)
+            a, b = self.ev(e[2], env, mod), self.ev(e[3], env, mod)
+            return self.binop(op, a, b, mod, e[4])
+        if k == "index":
+            a, i = self.ev(e[1], env, mod), self.ev(e[2], env, mod)
+            if isinstance(i, range):
+                return a[i.start:i.stop]
+            return a[i]
+        if k == "call":
+            return self.ev_call(e, env, mod)
+        if k == "method":
+            return self.ev_method(e, env, mod)
+        if k == "block":
+            return self.ev_block(e, Env(env), mod)
+        if k == "if":
+            c = self.ev(e[1], env, mod)
+            if not isinstance(c, bool):
+                raise TypeError(f"{mod}.rs:{e[4]}: non-boolean if condition")
+            if c:
+                return self.ev_block(e[2], Env(env), mod)
+            if e[3] is not None:
+                return self.ev(e[3], env, mod) if e[3][0] == "if" else self.ev_block(e[3], Env(env), mod)
+            return None
+        if k == "un":
+            v = self.ev(e[2], env, mod)
+            if e[1] == "-":
+                if isinstance(v, TupleStruct):
+                    m = self.find_method(v.name, "neg")
+                    return self.call_fn(m, [v], f"{mod}.rs")
+                return -v
+            return not v
+        if k == "as":
+            v = self.ev(e[1], env, mod)
+            ty = e[2]
+            if ty == "u32":
+                return v & 0xFFFFFFFF
+            if ty in ("u64", "usize"):
+                return v & 0xFFFFFFFFFFFFFFFF
+            if ty in ("u128", "i128", "i64", "i32", "u8", "u16"):
+                return v
+            raise NotImplementedError(f"as {ty}")
+        if k == "field":
+            v = self.ev(e[1], env, mod)
+            if isinstance(v, TupleStruct):
+                return v.fields[e[2]]
+            if isinstance(v, (tuple, list)) and isinstance(e[2], int):
+                return v[e[2]]
+            if isinstance(v, dict):
+                return v[e[2]]
+            raise TypeError(f"field {e[2]} of {v!r}")
+        if k == "tuple":
+            return tuple(self.ev(x, env, mod) for x in e[1])
+        if k == "array":
+            return [self.ev(x, env, mod) for x in e[1]]
+        if k == "repeat":
+            v, n = self.ev(e[1], env, mod), self.ev(e[2], env, mod)
+            return [v for _ in range(n)]
+        if k == "range":
+            a, b = self.ev(e[1], env, mod), self.ev(e[2], env, mod)
+            return range(a, b + 1 if e[3] else b)
+        if k == "closure":
+            return Closure(self, e[1], e[2], env, mod)
+        if k == "str":
+            return e[1]
+        if k == "macro":
+            return self.ev_macro(e, env, mod)
+        raise NotImplementedError(k)
+
+    def ev_block(self, b, env, mod):
+        for s in b[1]:
+            k = s[0]
+            if k == "let":
+                v = self.ev(s[2], env, mod) if s[2] is not None else None
+                bind_pattern(env, s[1], v)
+            elif k == "expr":
+                self.ev(s[1], env, mod)
+            elif k == "for":
+                it = self.ev(s[2], env, mod)
+                for x in it:
+                    inner = Env(env)
+                    bind_pattern(inner, s[1], x)
+                    try:
+                        self.ev_block(s[3], inner, mod)
+                    except BreakEx:
+                        break
+                    except ContinueEx:
+                        continue
+            elif k == "while":
+                while self.ev(s[1], env, mod):
+                    try:
+                        self.ev_block(s[2], Env(env), mod)
+                    except BreakEx:
+                        break
+                    except ContinueEx:
+                        continue
+            elif k == "assign":
+                self.assign(s, env, mod)
+            elif k == "return":
+                raise ReturnEx(self.ev(s[1], env, mod) if s[1] is not None else None)
+            elif k == "break":
+                raise BreakEx()
+            elif k == "continue":
+                raise ContinueEx()
+            else:
+                raise NotImplementedError(k)
+        if b[2] is not None:
+            return self.ev(b[2], env, mod)
+        return None
+
+    def assign(self, s, env, mod):
+        _, op, lhs, rhs, line = s
+        val = self.ev(rhs, env, mod)
+        if op != "=":
+            cur = self.ev(lhs, env, mod)
+            val = self.binop(op[:-1], cur, val, mod, line)
+        if lhs[0] == "path" and len(lhs[1]) == 1:
+            env.set_existing(lhs[1][0], val)
+        elif lhs[0] == "index":
+            self.ev(lhs[1], env, mod)[self.ev(lhs[2], env, mod)] = val
+        else:
+            raise NotImplementedError(f"assignment to {lhs[0]}")
+
+    def binop(self, op, a, b, mod, line):
+        if isinstance(a, (Sym, FieldConst)) or isinstance(b, (Sym, FieldConst)):
+            if op == "+":
+                return a + b
+            if op == "-":
+                return a - b if isinstance(a, (Sym, FieldConst)) else as_sym(a) - b
+            if op == "*":
+                return a * b
+            raise TypeError(f"{mod}.rs:{line}: field op {op}")
+        if isinstance(a, TupleStruct):
+            name = {"+": "add", "-": "sub", "*": "mul", "/": "div"}[op]
+            m = self.find_method(a.name, name)
+            return self.call_fn(m, [a, b], f"{mod}.rs:{line}")
+        if op == "+":
+            return a + b
+        if op == "-":
+            if a - b < 0:
+                raise OverflowError(f"{mod}.rs:{line}: unsigned subtraction underflow {a} - {b}")
+            return a - b
+        if op == "*":
+            return a * b
+        if op == "/":
+            return a // b
+        if op == "%":
+            return a % b
+        if op == "<<":
+            return a << b
+        if op == ">>":
+            return a >> b
+        if op == "&":
+            return a & b
+        if op == "|":
+            return a | b
+        if op == "^":
+            return a ^ b
+        if op == "==":
+            return a == b
+        if op == "!=":
+            return a != b
+        if op == "<":
+            return a < b
+        if op == "<=":
+            return a <= b
+        if op == ">":
+            return a > b
+        if op == ">=":
+            return a >= b
+        raise NotImplementedError(op)
+
+    def ev_path(self, e, env, mod):
+        path = e[1]
+        if len(path) == 1:
+            name = path[0]
+            if env.has(name):
+                return env.get(name)
+            if name == "None":
+                return None
+            if name == "true":
+                return True
+            if name == "false":
+                return False
+            if name == "self":
+                return env.get("self")
+            m = self.find_const(mod, name)
+            if m is not None:
+                return self.const_value(m, name)
+            raise NameError(f"{mod}.rs:{e[2]}: unknown name {name}")
+        head, last = path[-2], path[-1]
+        if head in ("P", "FE", "F", "<T>") and last in ("ONES", "ONE"):
+            return Sym.const(1) if head in ("P", "<T>") else FieldConst(1)
+        if head in ("P", "FE", "F", "<T>") and last in ("ZEROS", "ZERO"):
+            return Sym.const(0) if head in ("P", "<T>") else FieldConst(0)
+        if head in ("FE", "F") and last == "TWO":
+            return FieldConst(2)
+        if path[0] == "crate" and len(path) == 3 and path[1] in self.mods:
+            m = self.mods[path[1]]
+            if last in m.consts:
+                return self.const_value(m, last)
+        if head in ("u32", "u64", "usize") and last == "MAX":
+            return {"u32": 2**32 - 1, "u64": 2**64 - 1, "usize": 2**64 - 1}[head]
+        raise NameError(f"{mod}.rs:{e[2]}: unknown path {'::'.join(path)}")
+
+    def ev_call(self, e, env, mod):
+        f = e[1]
+        line = e[3]
+        if f[0] == "path":
+            path = f[1]
+            name = path[-1]
+            if len(path) == 1:
+                if env.has(name):
+                    return env.get(name)(*[self.ev(a, env, mod) for a in e[2]])
+                if name == "Some":
+                    return SomeV(self.ev(e[2][0], env, mod))
+                if name in ("Ok",):
+                    return self.ev(e[2][0], env, mod)
+                if name == "min":
+                    return min(*[self.ev(a, env, mod) for a in e[2]])
+                if name == "max":
+                    return max(*[self.ev(a, env, mod) for a in e[2]])
+                if name == "mod_inverse":
+                    # native.rs:183-222 computes this with a signed extended Euclid (BigInt); the value is the unique
+                    # inverse in [0, m), taken here from Python's pow
+                    a, m_ = [self.ev(a, env, mod) for a in e[2]]
+                    return pow(a, -1, m_)
+                item = self.find_fn(mod, name)
+                if item is not None:
+                    args = [self.ev(a, env, mod) for a in e[2]]
+                    return self.call_fn(item, args, f"{mod}.rs:{line}")
+                # tuple-struct constructor (Fp, Fp2, ...)
+                if name[0].isupper():
+                    return TupleStruct(name, tuple(self.ev(a, env, mod) for a in e[2]))
+                raise NameError(f"{mod}.rs:{line}: unknown function {name}")
+            head = path[-2]
+            args = [self.ev(a, env, mod) for a in e[2]]
+            if head in ("FE", "F", "Extension") and name in ("from_canonical_u32", "from_canonical_u64", "from_canonical_usize", "from_canonical_u8", "from_canonical_u16"):
+                lim = {"from_canonical_u32": 2**32, "from_canonical_u8": 2**8, "from_canonical_u16": 2**16}.get(name, P_GL)
+                if not (0 <= args[0] < lim):
+                    raise OverflowError(f"{mod}.rs:{line}: {name}({args[0]})")
+                return FieldConst(args[0])
+            if head == "BigUint":
+                if name == "from":
+                    return args[0]
+                if name == "from_str":
+                    return int(args[0])
+                if name == "new":
+                    return sum(int(v) << (32 * i) for i, v in enumerate(args[0]))
+                if name == "from_bytes_le":
+                    return int.from_bytes(bytes(args[0]), "little")
+            if head in ("std", "cmp") and name in ("min", "max"):
+                return (min if name == "min" else max)(*args)
+            if head == "Self":
+                head = self.stack[-1] and self.current_owner()
+            m = self.find_method(head, name)
+            if m is not None:
+                return self.call_fn(m, args, f"{mod}.rs:{line}")
+            if path[0] == "crate" and path[1] in self.mods and name in self.mods[path[1]].fns:
+                return self.call_fn(self.mods[path[1]].fns[name], args, f"{mod}.rs:{line}")
+            raise NameError(f"{mod}.rs:{line}: unknown function {'::'.join(path)}")
+        fn = self.ev(f, env, mod)
+        return fn(*[self.ev(a, env, mod) for a in e[2]])
+
+    def current_owner(self):
+        return None
+
+    def ev_method(self, e, env, mod):
+        _, recv_e, name, arg_es, line = e
+        recv = self.ev(recv_e, env, mod)
+        if isinstance(recv, Consumer):
+            val = self.ev(arg_es[0], env, mod)
+            kind = {"constraint": "plain", "constraint_transition": "transition",
+                    "constraint_first_row": "first", "constraint_last_row": "last"}[name]
+            self.record(kind, val)
+            return None
+        args = [self.ev(a, env, mod) for a in arg_es]
+        if isinstance(recv, Vars):
+            return {"get_local_values": recv.local, "get_next_values": recv.next, "get_public_inputs": recv.pis}[name]
+        if name in ("clone", "to_owned", "iter", "into_iter", "to_vec", "collect", "unwrap", "try_into", "into", "copied", "cloned", "as_slice", "to_biguint", "expect"):
+            if name in ("unwrap", "expect"):
+                if isinstance(recv, SomeV):
+                    return recv.v
+                if recv is None:
+                    raise ValueError(f"{mod}.rs:{line}: unwrap on None")
+                return recv
+            if name == "to_biguint" and isinstance(recv, TupleStruct):
+                return sum(int(v) << (32 * i) for i, v in enumerate(recv.fields[0]))
+            if name in ("collect", "to_vec") and not isinstance(recv, list):
+                return list(recv)
+            if name in ("clone", "to_owned", "to_vec") and isinstance(recv, list):
+                return list(recv)
+            return recv
+        if name == "unwrap_or":
+            if isinstance(recv, SomeV):
+                return recv.v
+            if recv is None:
+                return args[0]
+            raise TypeError("unwrap_or on non-Option")
+        if name == "is_some":
+            return isinstance(recv, SomeV)
+        if name == "is_none":
+            return recv is None
+        if name == "map":
+            if isinstance(recv, SomeV):
+                return SomeV(args[0](recv.v))
+            if recv is None:
+                return None
+            return [args[0](x) for x in recv]
+        if name == "enumerate":
+            return list(enumerate(recv))
+        if name == "zip":
+            return list(zip(recv, args[0]))
+        if name == "rev":
+            return list(reversed(list(recv)))
+        if name == "fold":
+            acc = args[0]
+            for x in recv:
+                acc = args[1](acc, x)
+            return acc
+        if name == "sum":
+            return sum(recv)
+        if name == "len":
+            return len(recv)
+        if name == "push":
+            recv.append(args[0])
+            return None
+        if name == "concat":
+            out = []
+            for x in recv:
+                out.extend(x)
+            return out
+        if name == "to_u32_digits" and isinstance(recv, int):
+            out = []
+            v = recv
+            while v:
+                out.append(v & 0xFFFFFFFF)
+                v >>= 32
+            return out
+        if name == "bits" and isinstance(recv, int):
+            return recv.bit_length()
+        if name == "bit" and isinstance(recv, int):
+            return bool((recv >> args[0]) & 1)
+        if name == "pow" and isinstance(recv, int):
+            return recv ** args[0]
+        if name == "modpow" and isinstance(recv, int):
+            return pow(recv, args[0], args[1])
+        if name in ("wrapping_sub",):
+            return (recv - args[0]) & 0xFFFFFFFFFFFFFFFF
+        if isinstance(recv, TupleStruct):
+            m = self.find_method(recv.name, name)
+            if m is not None:
+                return self.call_fn(m, [recv] + args, f"{mod}.rs:{line}")
+        raise NotImplementedError(f"{mod}.rs:{line}: method {name} on {type(recv).__name__}")
+
+    def ev_macro(self, e, env, mod):
+        _, name, items, rep, line = e
+        if name == "bit_decomp_32":
+            # fp.rs:165-171: (0..32).fold(P::ZEROS, |acc, i| acc + row[col + i] * F::from_canonical_u64(1 << i))
+            row, col = self.ev(items[0], env, mod), self.ev(items[1], env, mod)
+            acc = Sym.const(0)
+            for i in range(32):
+                acc = acc + row[col + i] * FieldConst(1 << i)
+            return acc
+        if name == "vec":
+            if rep is not None:
+                v, n = self.ev(items[0], env, mod), self.ev(rep, env, mod)
+                return [v for _ in range(n)]
+            return [self.ev(x, env, mod) for x in items]
+        if name in ("assert", "assert_eq", "debug_assert", "println", "print", "debug_assert_eq"):
+            return None
+        raise NotImplementedError(f"{mod}.rs:{line}: macro {name}!")
+
+
+class Consumer:
+    pass
+
+
+class Vars:
+    def __init__(self, n_cols, n_pis):
+        self.local = Row(0, n_cols)
+        self.next = Row(1 << 30, n_cols)
+        self.pis = Row(1 << 31, n_pis)
