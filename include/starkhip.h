@@ -122,11 +122,16 @@ void starkhip_shutdown(void* ctx);
  * (already resident in HBM; the benchmark path).  pow_witness: STARKHIP_POW_SEARCH = smallest valid
  * nonce, otherwise use the given one.  *proof is a blob in the layout below.
  * Shapes: n_rows a power of two, 2 <= n_rows <= 8192 (the reference's largest trace; one LDS image per column),
- * n_pis and the column count as the AIR declares, num_challenges = 2, and rate_bits large enough for the AIR's
+ * n_pis and n_cols as the AIR declares (n_cols is checked before the buffer is touched: it is read as n_rows x n_cols words), num_challenges = 2, and rate_bits large enough for the AIR's
  * constraint degree (2^rate_bits >= degree - 1); anything else is STARKHIP_ERR_BAD_SHAPE before any GPU work. */
-int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows,
+int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows, size_t n_cols,
                    int trace_layout, int trace_on_device, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness,
                    uint64_t** proof, size_t* proof_words);
+
+/* Tuning knobs of a context (defaults are the measured best; tests and profiling tools use them to reach the other code
+ * paths): "quotient_impl" 0 = tiled evaluator / 1 = op-stream interpreter, "quotient_chunks" (0 = automatic),
+ * "quotient_waves", "quotient_slots".  Unknown name or value out of range: STARKHIP_ERR_BAD_SHAPE. */
+int starkhip_set_option(void* ctx, const char* name, long value);
 
 /* --- compact traces: on-device trace expansion -----------------------------------------------
  * Between starkhip_trace_log_begin and _end the calling thread's ONE starkhip_trace_* call records its writes as runs
@@ -173,6 +178,12 @@ int starkhip_field_ops_batch(void* ctx, int op, const uint64_t* a, const uint64_
 /* CPU check (no GPU needed) of the constant tables the leaf-hash kernel uses for its merged partial rounds: replays the
  * merged formulation on n_states inputs against the plain permutation; returns the number of mismatches (0 = good) */
 int starkhip_selfcheck_hash_tables(unsigned n_states);
+/* CPU check (no GPU needed) of the tiled constraint plan the quotient kernel executes (csrc/quotient_plan.h): builds the plan
+ * of `air` with `want_chunks` chunks, derives the per-proof weights from random alphas / public inputs and replays the
+ * record streams on one random frame with the kernel's own accumulators; the result must equal the plain fold
+ * acc = acc * alpha + mask * c_k over all constraints.  stats = {chunks, supergroups, pieces, records, LDS cell records,
+ * direct loads, tiles, term contributions}.  0 = equal, STARKHIP_ERR_VERIFY = different, BAD_SHAPE = malformed plan. */
+int starkhip_quotient_plan_check(starkhip_air_t air, unsigned want_chunks, uint64_t seed, uint64_t stats[8]);
 /* host-side permutation (the one the Fiat-Shamir challenger uses) */
 void starkhip_poseidon_permute_host(uint64_t state[12]);
 /* n chained host permutations; which = 0: the challenger's tuned permutation, 1: the portable loop */
@@ -196,6 +207,21 @@ const char* starkhip_error_string(int code);
  *   final_poly[final_poly_len][2]; pow_witness; public_inputs[n_pis]
  */
 #define STARKHIP_PROOF_MAGIC 0x3130304652505353ULL
+
+/* Offsets (in uint64 words) of every field of the blob above, so that a caller fills the fields of
+ * StarkProofWithPublicInputs (src/aggregate_proof.rs:59, consumed at :67 and :435-439) without parsing the layout by hand.
+ * q_* are offsets inside one query round (each round is query_round_words long, round r starts at
+ * off_query_rounds + r * query_round_words); siblings are 4 words each. */
+typedef struct {
+    size_t n_columns, n_quotient_polys, degree_bits, rate_bits, cap_height, n_fri_layers, n_query_rounds, final_poly_len,
+        n_public_inputs, arity_bits;
+    size_t off_trace_cap, off_quotient_cap, off_local_values, off_next_values, off_quotient_openings, off_fri_caps, off_query_rounds,
+        query_round_words, off_final_poly, off_pow_witness, off_public_inputs, total_words;
+    size_t q_trace_leaf, q_trace_siblings, q_quotient_leaf, q_quotient_siblings, initial_sibling_count;
+    size_t q_step_evals[16], q_step_siblings[16], step_sibling_count[16];
+} starkhip_proof_layout_t;
+/* STARKHIP_ERR_BAD_SHAPE when the blob's header is not a proof header or disagrees with proof_words */
+int starkhip_proof_layout(const uint64_t* proof, size_t proof_words, starkhip_proof_layout_t* out);
 
 #ifdef __cplusplus
 }

@@ -76,7 +76,7 @@ lib.starkhip_air_program.argtypes = [C.c_int, C.POINTER(_u64p), C.POINTER(C.c_si
 lib.starkhip_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
 lib.starkhip_shutdown.argtypes = [C.c_void_p]
 lib.starkhip_shutdown.restype = None
-lib.starkhip_prove.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), C.c_void_p, C.c_size_t, C.c_int, C.c_int, _u64p, C.c_size_t,
+lib.starkhip_prove.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _u64p, C.c_size_t,
                                C.c_uint64, C.POINTER(_u64p), C.POINTER(C.c_size_t)]
 lib.starkhip_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
 lib.starkhip_last_kernel_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -170,6 +170,39 @@ def air_program(air):
     words = C.c_size_t()
     _chk(lib.starkhip_air_program(air, C.byref(blob), C.byref(words)))
     return np.ctypeslib.as_array(blob, shape=(words.value,)).copy()
+
+
+lib.starkhip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+lib.starkhip_quotient_plan_check.argtypes = [C.c_int, C.c_uint, C.c_uint64, _u64p]
+
+
+class ProofLayout(C.Structure):
+    """starkhip_proof_layout_t: word offsets of every field of a proof blob."""
+    _fields_ = [(n, C.c_size_t) for n in (
+        "n_columns", "n_quotient_polys", "degree_bits", "rate_bits", "cap_height", "n_fri_layers", "n_query_rounds", "final_poly_len",
+        "n_public_inputs", "arity_bits", "off_trace_cap", "off_quotient_cap", "off_local_values", "off_next_values",
+        "off_quotient_openings", "off_fri_caps", "off_query_rounds", "query_round_words", "off_final_poly", "off_pow_witness",
+        "off_public_inputs", "total_words", "q_trace_leaf", "q_trace_siblings", "q_quotient_leaf", "q_quotient_siblings",
+        "initial_sibling_count")] + [(n, C.c_size_t * 16) for n in ("q_step_evals", "q_step_siblings", "step_sibling_count")]
+
+
+lib.starkhip_proof_layout.argtypes = [_u64p, C.c_size_t, C.POINTER(ProofLayout)]
+
+
+def proof_layout(proof):
+    """Offsets of the fields of a proof blob (starkhip_proof_layout)."""
+    proof = np.ascontiguousarray(proof, dtype=np.uint64)
+    out = ProofLayout()
+    _chk(lib.starkhip_proof_layout(_p64(proof), proof.size, C.byref(out)))
+    return out
+
+
+def quotient_plan_check(air, want_chunks=4, seed=1):
+    """CPU replay of the tiled constraint plan against the plain fold; returns the plan statistics (see starkhip.h)."""
+    stats = np.zeros(8, dtype=np.uint64)
+    _chk(lib.starkhip_quotient_plan_check(air, want_chunks, seed, _p64(stats)))
+    return dict(zip(("chunks", "supergroups", "pieces", "records", "lds_cell_records", "direct_loads", "tiles", "contributions"),
+                    (int(x) for x in stats)))
 
 
 lib.starkhip_air_eval_frame.argtypes = [C.c_int, _u64p, _u64p, _u64p, _u64p, _u64p, C.c_int, _u64p]
@@ -367,22 +400,29 @@ class Prover:
             lib.starkhip_free(out)
             return proof
         trace = np.ascontiguousarray(trace, dtype=np.uint64)
-        n_rows = trace.shape[0] if layout == 0 else trace.shape[1]
+        if trace.ndim != 2 or layout not in (0, 1):
+            raise StarkhipError(ERR_BAD_SHAPE)
+        n_rows, n_cols = trace.shape if layout == 0 else trace.shape[::-1]
         pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         out = _u64p()
         words = C.c_size_t()
-        _chk(lib.starkhip_prove(self._ctx, air, C.byref(config), trace.ctypes.data_as(C.c_void_p), n_rows, layout, 0, _p64(pis), pis.size,
+        _chk(lib.starkhip_prove(self._ctx, air, C.byref(config), trace.ctypes.data_as(C.c_void_p), n_rows, n_cols, layout, 0, _p64(pis), pis.size,
                                 pow_witness, C.byref(out), C.byref(words)))
         proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy()
         lib.starkhip_free(out)
         return proof
 
+    def set_option(self, name, value):
+        """Tuning knob of this context (starkhip_set_option)."""
+        _chk(lib.starkhip_set_option(self._ctx, name.encode(), int(value)))
+
     def prove_device(self, air, config, trace_ptr, n_rows, public_inputs, pow_witness=POW_SEARCH, layout=1, keep=True):
-        """trace_ptr: integer device address of a uint64 trace already resident in HBM (benchmark path)."""
+        """trace_ptr: integer device address of a uint64 trace (n_rows x air_columns(air) words) already resident in HBM
+        (benchmark path)."""
         pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         out = _u64p()
         words = C.c_size_t()
-        _chk(lib.starkhip_prove(self._ctx, air, C.byref(config), C.c_void_p(trace_ptr), n_rows, layout, 1, _p64(pis), pis.size, pow_witness,
+        _chk(lib.starkhip_prove(self._ctx, air, C.byref(config), C.c_void_p(trace_ptr), n_rows, air_columns(air), layout, 1, _p64(pis), pis.size, pow_witness,
                                 C.byref(out), C.byref(words)))
         proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy() if keep else None
         lib.starkhip_free(out)

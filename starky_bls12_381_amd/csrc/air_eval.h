@@ -20,6 +20,18 @@ struct ExtOps {
     static T mul_base(T a, gl_t b) { return gl2_mul_base(a, b); }
 };
 
+// Field policy for gl_t (base field)
+struct BaseOps {
+    typedef gl_t T;
+    static T zero() { return 0; }
+    static T one() { return 1; }
+    static T from_base(gl_t x) { return x; }
+    static T add(T a, T b) { return gl_add(a, b); }
+    static T sub(T a, T b) { return gl_sub(a, b); }
+    static T mul(T a, T b) { return gl_mul(a, b); }
+    static T mul_base(T a, gl_t b) { return gl_mul(a, b); }
+};
+
 // acc[j] = sum_k mask(kind_k) * c_k * alpha_j^(K-1-k)
 template <class O>
 void air_eval_folded(const AirProgram& p, const typename O::T* local, const typename O::T* next, const gl_t* pis,

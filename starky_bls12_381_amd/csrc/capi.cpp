@@ -10,6 +10,8 @@
 #include "trace_log.h"
 #include "poseidon.h"
 #include "prover.h"
+#include "proof.h"
+#include "quotient_plan.h"
 
 using namespace starkhip;
 
@@ -90,6 +92,40 @@ int starkhip_air_eval_frame(starkhip_air_t air, const uint64_t* local, const uin
     return STARKHIP_OK;
 }
 
+int starkhip_quotient_plan_check(starkhip_air_t air, unsigned want_chunks, uint64_t seed, uint64_t stats[8]) {
+    const AirInfo* a = air_get(air);
+    if (!a) return STARKHIP_ERR_BAD_AIR;
+    try {
+        QTPlan Q = build_quotient_plan(a->prog, want_chunks);
+        uint64_t s = seed;
+        auto rnd = [&]() {  // splitmix64, reduced
+            s += 0x9E3779B97F4A7C15ULL;
+            uint64_t z = s;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            return gl_from_u64((z ^ (z >> 31)) % GL_P);
+        };
+        std::vector<gl_t> local(a->cols), next(a->cols), pis(a->pis ? a->pis : 1);
+        for (auto& v : local) v = rnd();
+        for (auto& v : next) v = rnd();
+        for (auto& v : pis) v = rnd();
+        gl_t masks[4] = {1, rnd(), rnd(), rnd()}, alphas[2] = {rnd(), rnd()}, want[2], got[2];
+        air_eval_folded<BaseOps>(a->prog, local.data(), next.data(), pis.data(), masks, alphas, 2, want);
+        quotient_plan_weights_host(a->prog, Q, alphas, pis.data());
+        const bool ok = quotient_plan_eval_host(Q, local.data(), next.data(), masks, got);
+        if (stats) {
+            stats[0] = Q.n_chunks; stats[1] = Q.n_supergroups; stats[2] = Q.n_pieces; stats[3] = Q.recs.size();
+            stats[4] = Q.n_cell_records; stats[5] = Q.n_direct_loads; stats[6] = Q.tile_list.size(); stats[7] = Q.contribs.size();
+        }
+        if (!ok) return STARKHIP_ERR_BAD_SHAPE;
+        return (want[0] == got[0] && want[1] == got[1]) ? STARKHIP_OK : STARKHIP_ERR_VERIFY;
+    } catch (const std::bad_alloc&) {
+        return STARKHIP_ERR_OOM;
+    } catch (const std::exception&) {
+        return STARKHIP_ERR_BAD_SHAPE;
+    }
+}
+
 int starkhip_init(int device_ordinal, void** ctx) {
     Ctx* c = nullptr;
     int rc = ctx_create(device_ordinal, &c);
@@ -98,14 +134,54 @@ int starkhip_init(int device_ordinal, void** ctx) {
 }
 void starkhip_shutdown(void* ctx) { ctx_destroy((Ctx*)ctx); }
 
-int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows, int trace_layout,
-                   int trace_on_device, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness, uint64_t** proof,
+int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows, size_t n_cols,
+                   int trace_layout, int trace_on_device, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness, uint64_t** proof,
                    size_t* proof_words) {
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;
     const AirInfo* a = air_get(air);
     if (!a) return STARKHIP_ERR_BAD_AIR;
+    if (!cfg || !trace || !proof || !proof_words || (n_pis && !public_inputs)) return STARKHIP_ERR_BAD_SHAPE;
     if (trace_layout != 0 && trace_layout != 1) return STARKHIP_ERR_BAD_SHAPE;
-    return prove((Ctx*)ctx, *a, *cfg, trace, n_rows, trace_layout, trace_on_device, public_inputs, n_pis, pow_witness, proof, proof_words);
+    if (n_cols != a->cols) return STARKHIP_ERR_BAD_SHAPE;  // the caller's buffer is read as n_rows x columns words
+    try {
+        return prove((Ctx*)ctx, *a, *cfg, trace, n_rows, trace_layout, trace_on_device, public_inputs, n_pis, pow_witness, proof, proof_words);
+    } catch (const std::bad_alloc&) {
+        return STARKHIP_ERR_OOM;
+    } catch (const std::exception&) {
+        return STARKHIP_ERR_BAD_SHAPE;
+    }
+}
+
+int starkhip_set_option(void* ctx, const char* name, long value) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    return ctx_set_option((Ctx*)ctx, name, value);
+}
+
+int starkhip_proof_layout(const uint64_t* proof, size_t proof_words, starkhip_proof_layout_t* out) {
+    if (!proof || !out) return STARKHIP_ERR_BAD_SHAPE;
+    ProofLayout pl;
+    if (!pl.read_header(proof, proof_words)) return STARKHIP_ERR_BAD_SHAPE;
+    memset(out, 0, sizeof *out);
+    out->n_columns = pl.C; out->n_quotient_polys = pl.Q; out->degree_bits = pl.log_n; out->rate_bits = pl.rate_bits;
+    out->cap_height = pl.cap_h; out->n_fri_layers = pl.L; out->n_query_rounds = pl.n_queries; out->final_poly_len = pl.final_len;
+    out->n_public_inputs = pl.n_pis; out->arity_bits = pl.arity_bits;
+    out->off_trace_cap = pl.off_trace_cap; out->off_quotient_cap = pl.off_quot_cap; out->off_local_values = pl.off_local;
+    out->off_next_values = pl.off_next; out->off_quotient_openings = pl.off_quot_open; out->off_fri_caps = pl.off_fri_caps;
+    out->off_query_rounds = pl.off_queries; out->query_round_words = pl.query_words; out->off_final_poly = pl.off_final;
+    out->off_pow_witness = pl.off_pow; out->off_public_inputs = pl.off_pis; out->total_words = pl.total;
+    const size_t d0 = pl.log_N - pl.cap_h;
+    size_t o = 0;
+    out->q_trace_leaf = o; o += pl.C;
+    out->q_trace_siblings = o; o += 4 * d0;
+    out->q_quotient_leaf = o; o += pl.Q;
+    out->q_quotient_siblings = o; o += 4 * d0;
+    for (size_t l = 0; l < pl.L && l < 16; l++) {
+        out->q_step_evals[l] = o; o += 2 * ((size_t)1 << pl.arity_bits);
+        out->q_step_siblings[l] = o; o += 4 * pl.layer_depth[l];
+        out->step_sibling_count[l] = pl.layer_depth[l];
+    }
+    out->initial_sibling_count = d0;
+    return STARKHIP_OK;
 }
 
 // ---- compact traces (trace_log.h)
@@ -165,7 +241,15 @@ int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_
     if (!a) return STARKHIP_ERR_BAD_AIR;
     const TraceLog* l = (const TraceLog*)log;
     if (!l || armed_trace_log() == l || l->cols != a->cols || !l->rows) return STARKHIP_ERR_BAD_SHAPE;
-    return prove((Ctx*)ctx, *a, *cfg, (const uint64_t*)l, l->rows, /*layout: compact log*/ 2, 0, public_inputs, n_pis, pow_witness, proof, proof_words);
+    if (!cfg || !proof || !proof_words || (n_pis && !public_inputs)) return STARKHIP_ERR_BAD_SHAPE;
+    try {
+        return prove((Ctx*)ctx, *a, *cfg, (const uint64_t*)l, l->rows, /*layout: compact log*/ 2, 0, public_inputs, n_pis, pow_witness, proof,
+                     proof_words);
+    } catch (const std::bad_alloc&) {
+        return STARKHIP_ERR_OOM;
+    } catch (const std::exception&) {
+        return STARKHIP_ERR_BAD_SHAPE;
+    }
 }
 
 int starkhip_last_timings(void* ctx, float ms[STARKHIP_N_PHASES]) {

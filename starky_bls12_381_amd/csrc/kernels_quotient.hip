@@ -25,6 +25,7 @@
 #include "gl_dev.h"
 #include "kernels.h"
 #include "quotient_ops.h"
+#include "quotient_plan.h"
 
 namespace starkhip {
 
@@ -252,6 +253,306 @@ __global__ void quotient_combine_kernel(const gl_t* __restrict__ partial, const 
         for (unsigned p = 0; p < n_chunks; p++) acc = gl_add(acc, gl_mul(partial[((size_t)p * 2 + j) * size + t], chunk_scale[p * 2 + j]));
         out[(size_t)j * size + i] = gl_mul(acc, zhi);
     }
+}
+
+
+// =====================================================================================================================
+// Tiled evaluator (quotient_plan.h): LDS-staged column tiles, one pass over the LDE.
+//
+// A workgroup of QT_WAVES waves owns 64 coset points and one chunk of the plan.  For every tile of the chunk it stages
+// the 64-point slice of QT_TILE_COLS columns (+ the successor row) in LDS -- double buffered: the next tile's cells are
+// requested before the current tile's records are processed and stored afterwards, one barrier per tile -- and each
+// wave runs its own stream of wave-uniform records over the staged cells:
+//     x = cell (LDS), product of cells, or 1;   S_j[i][l] += x_i * w_j,l     (x = x_1 2^32 + x_0, w_j = sum_l w_j,l 2^(22 l))
+// i.e. twelve v_mad_u64_u32 with the weight limb as scalar operand and no carries (each product < 2^54, a piece has at most
+// 96 records); at the end of a piece the six sums of each alpha are folded mod p, multiplied by mask * G and added to acc_j.
+// Gate cells and factors outside the tile are direct loads; a piece's gate cells are requested when the previous piece ends.
+struct QTParams {
+    const QTRec* recs;
+    const QTPiece* pieces;
+    const QTStream* streams;          // [n_chunks][QT_WAVES]
+    const uint32_t* chunk_tile_off;   // [n_chunks + 1]
+    const uint32_t* tile_list;
+    const gl_t* lde;                  // [C][N] coset-major
+    const gl_t* tab;                  // quotient_tables_kernel output
+    gl_t* partial;                    // [n_chunks][2][size]
+    unsigned log_n, rate_bits, qdb, n_cols;
+};
+
+struct alignas(64) QTBatch {
+    QTRec r[2];
+};
+
+// sum_l 2^(22 l) * (S[l] + 2^32 S[3 + l]) mod p, any representative
+__device__ __forceinline__ gl_t qt_fold_sums(const uint64_t (&S)[6]) {
+    gl_t y[3];
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        uint64_t lo;
+        const bool c = __builtin_add_overflow(S[l], S[3 + l] << 32, &lo);
+        const uint64_t hi = (S[3 + l] >> 32) + (c ? 1u : 0u);
+        y[l] = gl_reduce128_nc(hi, lo);
+    }
+    return gl_add_nn(gl_add_nn(y[0], gl_mul_pow2_nn(y[1], QT_LIMB_BITS)), gl_mul_pow2_nn(y[2], 2 * QT_LIMB_BITS));
+}
+
+template <bool SMALL_N>
+__global__ __launch_bounds__(64 * QT_WAVES) void quotient_tiles_kernel(QTParams P) {
+    __shared__ gl_t tile[2][QT_TILE_COLS * QT_TILE_ROWS];
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63u;
+    const size_t n = (size_t)1 << P.log_n, size = n << P.qdb;
+    const unsigned t_raw = blockIdx.x * 64u + lane;
+    const bool live = t_raw < size;  // domains smaller than a wave (FP12Mul: 32 points): idle lanes shadow point 0
+    const unsigned t = live ? t_raw : 0;
+    const unsigned chunk = blockIdx.y;
+    const unsigned sp = t >> P.log_n, k = t & (unsigned)(n - 1);
+    const unsigned s = sp << (P.rate_bits - P.qdb);  // LDE coset of this quotient point
+    const unsigned k_next = (k + 1) & (unsigned)(n - 1);
+    const char* const lde = (const char*)P.lde;
+    const unsigned col_shift = P.log_n + P.rate_bits + 3;
+    const uint32_t boff_local = (s * (unsigned)n + k) * 8u;  // < 2^32: N * 8 <= 2^(13+3+3)
+    const uint32_t boff_next = (s * (unsigned)n + k_next) * 8u;
+    const uint32_t boff_next_last = __builtin_amdgcn_readlane(boff_next, 63);  // successor of the block's last point: row 64
+    const gl_t mask_tr = P.tab[t], mask_first = P.tab[size + t], mask_last = P.tab[2 * size + t];
+    // LDS addressing: a record's offset already holds slot * 520 (+ 8 for the next row); the lane adds its row.  Blocks that
+    // lie inside one coset with n >= 64 have "next row = lane + 1" (row 64 = boff_next_last).  Otherwise (SMALL_N: n < 64, several
+    // cosets or idle lanes in a wave) the next row of a lane is the lane that holds point (sp, k + 1 mod n).
+    const uint32_t lds_local = lane * 8u;
+    uint32_t lds_next = lds_local;
+    if (SMALL_N) {
+        const unsigned t_next = sp * (unsigned)n + k_next;              // quotient-domain index of the successor
+        const unsigned base = blockIdx.x * 64u;
+        const unsigned row = (live && t_next >= base && t_next < base + 64u) ? t_next - base : (live ? 64u : (k_next & 63u));
+        lds_next = row * 8u - 8u;  // the record offset carries + 8
+    }
+
+    const QTStream stream = P.streams[chunk * QT_WAVES + wave];
+    const QTRec* rec = P.recs + stream.rec_off;
+    const QTPiece* pc = P.pieces + stream.piece_off;
+    const uint32_t* tiles = P.tile_list + P.chunk_tile_off[chunk];
+    const unsigned n_tiles = P.chunk_tile_off[chunk + 1] - P.chunk_tile_off[chunk];
+
+    auto direct = [&](uint32_t col, bool next) -> gl_t {
+        const char* base = lde + ((uint64_t)col << col_shift);
+        return *(const gl_t*)(base + (next ? boff_next : boff_local));
+    };
+    // this wave's share of a tile: columns c0 + 8 wave + i, and (lanes 0..7) their row 64
+    gl_t pre[QT_TILE_COLS / QT_WAVES], pre_ext = 0;
+    auto tile_request = [&](uint32_t tile_idx) {
+        const uint32_t c0 = tile_idx * QT_TILE_COLS + wave * (QT_TILE_COLS / QT_WAVES);
+#pragma unroll
+        for (unsigned i = 0; i < QT_TILE_COLS / QT_WAVES; i++) {
+            const uint32_t col = c0 + i;
+            pre[i] = 0;
+            if (col < P.n_cols) pre[i] = *(const gl_t*)(lde + ((uint64_t)col << col_shift) + boff_local);
+        }
+        const uint32_t ecol = c0 + lane;
+        pre_ext = 0;
+        if (lane < QT_TILE_COLS / QT_WAVES && ecol < P.n_cols) pre_ext = *(const gl_t*)(lde + ((uint64_t)ecol << col_shift) + boff_next_last);
+    };
+    auto tile_store = [&](unsigned buf) {
+        gl_t* dst = tile[buf] + wave * (QT_TILE_COLS / QT_WAVES) * QT_TILE_ROWS;
+#pragma unroll
+        for (unsigned i = 0; i < QT_TILE_COLS / QT_WAVES; i++) dst[i * QT_TILE_ROWS + lane] = pre[i];
+        if (lane < QT_TILE_COLS / QT_WAVES) dst[lane * QT_TILE_ROWS + 64] = pre_ext;
+    };
+
+    gl_t acc0 = 0, acc1 = 0, v = 1;
+    uint64_t S0[6] = {0, 0, 0, 0, 0, 0}, S1[6] = {0, 0, 0, 0, 0, 0};
+    QTPiece piece = *pc;
+    gl_t gate[4] = {0, 0, 0, 0};
+    auto gates_request = [&]() {
+        const uint32_t ng = (piece.ctl >> 2) & 7u;
+#pragma unroll
+        for (unsigned g = 0; g < 4; g++)
+            if (g < ng) gate[g] = direct(piece.gate[g] & REF_COL_MASK, piece.gate[g] & REF_NEXT);
+    };
+    gates_request();
+
+    if (n_tiles) {
+        tile_request(tiles[0]);
+        tile_store(0);
+    }
+    __syncthreads();
+
+    bool stop = false;
+    for (unsigned ti = 0; ti < n_tiles && !stop; ti++) {
+        const bool more = ti + 1 < n_tiles;
+        if (more) tile_request(tiles[ti + 1]);
+        const char* const cur = (const char*)tile[ti & 1u];
+        auto lds_read = [&](uint32_t ctl) -> gl_t {
+            uint32_t a = (ctl & QT_OFF_MASK) + lds_local;
+            if (SMALL_N) a = (ctl & QT_OFF_MASK) + ((ctl & QT_NEXT) ? lds_next : lds_local);
+            return *(const gl_t*)(cur + a);
+        };
+        // three record batches in scalar registers: `A` is being processed, `B` has its cells on the way, `C` is being fetched
+        const QTBatch* bp = (const QTBatch*)rec;
+        QTBatch A = bp[0], B = bp[1], C = bp[2];
+        gl_t xa[2] = {lds_read(A.r[0].ctl), lds_read(A.r[1].ctl)}, xb[2], xc[2];
+        unsigned consumed = 0;  // records of this tile's stream already processed
+        bool tile_done = false;
+#define QT_RECORD(R, X)                                                                                               \
+    if (!tile_done) {                                                                                                 \
+        const uint32_t ctl = (R).ctl;                                                                                 \
+        gl_t x = (X);                                                                                                 \
+        bool accumulate = true;                                                                                       \
+        if (ctl & QT_SPECIAL) {                                                                                       \
+            if (ctl & (QT_TILE | QT_STOP)) {                                                                          \
+                tile_done = true;                                                                                     \
+                stop = (ctl & QT_STOP) != 0;                                                                          \
+                accumulate = false;                                                                                   \
+            } else {                                                                                                  \
+                if (ctl & QT_SRC_ONE) x = 1;                                                                          \
+                if (ctl & QT_SRC_GLOBAL) x = direct((R).aux, ctl & QT_NEXT);                                          \
+                if (ctl & QT_MULV) x = gl_mul_nc(v, x);                                                               \
+                if (ctl & QT_SETV) {                                                                                  \
+                    v = x;                                                                                            \
+                    accumulate = false;                                                                               \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+        if (!tile_done) consumed++;                                                                                   \
+        if (accumulate) {                                                                                             \
+            const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);                                                \
+            _Pragma("unroll") for (int l = 0; l < 3; l++) {                                                           \
+                S0[l] += (uint64_t)x0 * (R).w[l];                                                                     \
+                S0[3 + l] += (uint64_t)x1 * (R).w[l];                                                                 \
+                S1[l] += (uint64_t)x0 * (R).w[3 + l];                                                                 \
+                S1[3 + l] += (uint64_t)x1 * (R).w[3 + l];                                                             \
+            }                                                                                                         \
+            if (ctl & QT_END) {                                                                                       \
+                const uint32_t kind = piece.ctl & 3u, ng = (piece.ctl >> 2) & 7u, cm = piece.ctl >> 5;                \
+                gl_t G = kind == KIND_PLAIN ? (gl_t)1 : kind == KIND_TRANSITION ? mask_tr : kind == KIND_FIRST ? mask_first : mask_last; \
+                _Pragma("unroll") for (unsigned g = 0; g < 4; g++) if (g < ng) {                                      \
+                    gl_t gv = gate[g];                                                                                \
+                    if (cm & (1u << g)) gv = gl_sub_nc(1, gv);                                                        \
+                    G = gl_mul_nc(G, gv);                                                                             \
+                }                                                                                                     \
+                acc0 = gl_add_nn(acc0, gl_mul_nc(G, qt_fold_sums(S0)));                                               \
+                acc1 = gl_add_nn(acc1, gl_mul_nc(G, qt_fold_sums(S1)));                                               \
+                _Pragma("unroll") for (int l = 0; l < 6; l++) S0[l] = S1[l] = 0;                                      \
+                pc++;                                                                                                 \
+                piece = *pc;                                                                                          \
+                gates_request();                                                                                      \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
+#define QT_STEP(CUR, NXT, FAR, XC, XN)                          \
+    {                                                           \
+        XN[0] = lds_read(NXT.r[0].ctl);                         \
+        XN[1] = lds_read(NXT.r[1].ctl);                         \
+        QT_RECORD(CUR.r[0], XC[0])                              \
+        QT_RECORD(CUR.r[1], XC[1])                              \
+        bp++;                                                   \
+        CUR = bp[2]; /* becomes FAR of the next step */         \
+    }
+        while (!tile_done) {
+            QT_STEP(A, B, C, xa, xb)
+            if (tile_done) break;
+            QT_STEP(B, C, A, xb, xc)
+            if (tile_done) break;
+            QT_STEP(C, A, B, xc, xa)
+        }
+#undef QT_STEP
+#undef QT_RECORD
+        rec += consumed + 1;  // behind the TILE marker
+        if (more) tile_store((ti + 1) & 1u);
+        __syncthreads();
+    }
+
+    // acc of the eight waves -> partial[chunk]
+    gl_t* red = tile[0];
+    red[(wave * 2 + 0) * 64 + lane] = gl_canon(acc0);
+    red[(wave * 2 + 1) * 64 + lane] = gl_canon(acc1);
+    __syncthreads();
+    if (wave < 2 && live) {
+        gl_t sum = 0;
+        for (unsigned w = 0; w < QT_WAVES; w++) sum = gl_add(sum, red[(w * 2 + wave) * 64 + lane]);
+        P.partial[((size_t)chunk * 2 + wave) * size + t] = sum;
+    }
+}
+
+// apow[j][e] = alpha_j^e, e < K
+__global__ void quotient_alpha_powers_kernel(gl_t* apow, gl_t alpha0, gl_t alpha1, uint32_t K) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * K) return;
+    const uint32_t j = i >= K, e = j ? i - K : i;
+    apow[i] = gl_pow(j ? alpha1 : alpha0, e);
+}
+
+// per-proof weights of every record: w_j = sum over its terms of coefficient * alpha_j^e, split into three 22-bit limbs
+__global__ void quotient_weights_kernel(QTRec* recs, const uint32_t* contrib_off, const QTContrib* contribs, uint32_t n_recs,
+                                        const gl_t* apow, uint32_t K, const gl_t* consts, const gl_t* pis) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_recs) return;
+    const uint32_t c0 = contrib_off[r], c1 = contrib_off[r + 1];
+    gl_t w[2] = {0, 0};
+    for (uint32_t c = c0; c < c1; c++) {
+        const QTContrib t = contribs[c];
+        const uint32_t ck = t.coef & 7u, idx = t.coef >> 3;
+        for (int j = 0; j < 2; j++) {
+            const gl_t a = apow[(size_t)j * K + t.e];
+            gl_t term;
+            if (ck == CK_PLUS) term = a;
+            else if (ck == CK_MINUS) term = gl_neg(a);
+            else if (ck == CK_CONST) term = gl_mul(a, consts[idx]);
+            else if (ck == CK_PI) term = gl_mul(a, pis[idx]);
+            else term = gl_neg(gl_mul(a, pis[idx]));
+            w[j] = gl_add(w[j], term);
+        }
+    }
+    const uint32_t M = (1u << QT_LIMB_BITS) - 1;
+    for (int j = 0; j < 2; j++) {
+        recs[r].w[3 * j + 0] = (uint32_t)(w[j] & M);
+        recs[r].w[3 * j + 1] = (uint32_t)((w[j] >> QT_LIMB_BITS) & M);
+        recs[r].w[3 * j + 2] = (uint32_t)(w[j] >> (2 * QT_LIMB_BITS));
+    }
+}
+
+// out[j][i] (natural quotient index i) = (sum_c partial[c][j][t]) / Z_H(x_i)
+__global__ void quotient_tiles_combine_kernel(const gl_t* __restrict__ partial, unsigned n_chunks, const gl_t* __restrict__ tab, unsigned log_n,
+                                              unsigned qdb, gl_t* __restrict__ out) {
+    const size_t n = (size_t)1 << log_n, size = n << qdb;
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= size) return;
+    size_t sp = t >> log_n, k = t & (n - 1);
+    size_t i = (k << qdb) + sp;
+    gl_t zhi = tab[3 * size + t];
+    for (int j = 0; j < 2; j++) {
+        gl_t acc = 0;
+        for (unsigned p = 0; p < n_chunks; p++) acc = gl_add(acc, partial[((size_t)p * 2 + j) * size + t]);
+        out[(size_t)j * size + i] = gl_mul(acc, zhi);
+    }
+}
+
+hipError_t launch_quotient_weights(QTRec* recs, const uint32_t* contrib_off, const QTContrib* contribs, uint32_t n_recs, gl_t* apow, uint32_t K,
+                                   const gl_t* consts, const gl_t* pis, gl_t alpha0, gl_t alpha1, hipStream_t st) {
+    if (K) hipLaunchKernelGGL(quotient_alpha_powers_kernel, dim3((2 * K + 255) / 256), dim3(256), 0, st, apow, alpha0, alpha1, K);
+    hipLaunchKernelGGL(quotient_weights_kernel, dim3((n_recs + 255) / 256), dim3(256), 0, st, recs, contrib_off, contribs, n_recs, apow, K, consts, pis);
+    return hipGetLastError();
+}
+
+hipError_t launch_quotient_tiles(const QTRec* recs, const QTPiece* pieces, const QTStream* streams, const uint32_t* chunk_tile_off,
+                                 const uint32_t* tile_list, unsigned n_chunks, const gl_t* lde, const gl_t* tab, gl_t* partial, unsigned log_n,
+                                 unsigned rate_bits, unsigned qdb, unsigned n_cols, hipStream_t st) {
+    QTParams P;
+    P.recs = recs; P.pieces = pieces; P.streams = streams; P.chunk_tile_off = chunk_tile_off; P.tile_list = tile_list;
+    P.lde = lde; P.tab = tab; P.partial = partial; P.log_n = log_n; P.rate_bits = rate_bits; P.qdb = qdb; P.n_cols = n_cols;
+    const size_t size = (size_t)1 << (log_n + qdb);
+    const dim3 grid((unsigned)((size + 63) / 64), n_chunks), block(64 * QT_WAVES);
+    if (log_n < 6 || size < 64)
+        hipLaunchKernelGGL(quotient_tiles_kernel<true>, grid, block, 0, st, P);
+    else
+        hipLaunchKernelGGL(quotient_tiles_kernel<false>, grid, block, 0, st, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_quotient_tiles_combine(const gl_t* partial, unsigned n_chunks, const gl_t* tab, unsigned log_n, unsigned qdb, gl_t* out,
+                                         hipStream_t st) {
+    size_t size = (size_t)1 << (log_n + qdb);
+    hipLaunchKernelGGL(quotient_tiles_combine_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, st, partial, n_chunks, tab, log_n, qdb, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_quotient_tables(gl_t* tab, unsigned log_n, unsigned qdb, hipStream_t st) {

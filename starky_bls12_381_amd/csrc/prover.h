@@ -12,6 +12,7 @@ int ctx_create(int device, Ctx** out);
 void ctx_destroy(Ctx* c);
 const float* ctx_timings(Ctx* c);
 const float* ctx_kernel_timings(Ctx* c);
+int ctx_set_option(Ctx* c, const char* name, long value);
 
 int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64_t* trace, size_t n_rows, int layout, int on_device,
           const uint64_t* pis, size_t n_pis, uint64_t pow_witness, uint64_t** proof_out, size_t* proof_words);

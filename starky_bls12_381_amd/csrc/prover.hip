@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "airs.h"
@@ -16,6 +17,7 @@
 #include "poseidon.h"
 #include "proof.h"
 #include "quotient_ops.h"
+#include "quotient_plan.h"
 #include "prover.h"
 
 namespace starkhip {
@@ -25,6 +27,7 @@ namespace starkhip {
         hipError_t _e = (expr);                                                                            \
         if (_e != hipSuccess) {                                                                            \
             fprintf(stderr, "starkhip: HIP error %s at %s:%d (%s)\n", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+            (void)hipDeviceSynchronize(); /* pending async copies target host buffers that are about to go out of scope */ \
             return _e == hipErrorOutOfMemory ? STARKHIP_ERR_OOM : STARKHIP_ERR_HIP;                        \
         }                                                                                                  \
     } while (0)
@@ -55,8 +58,11 @@ struct Ctx {
     hipStream_t st = nullptr;
     hipEvent_t ev[STARKHIP_N_PHASES + 1];
     float timings[STARKHIP_N_PHASES] = {0};
-    hipEvent_t kev[4];            // leaf-hash and quotient-eval kernels bracketed on their own
+    hipEvent_t kev[6];            // the three heavy kernels bracketed on their own: leaf hash, quotient evaluation, trace LDE
     float ktimings[3] = {0};      // lde_columns, leaf_hash (trace), quotient_eval
+    // tuning (starkhip_set_option; defaults are the measured best)
+    long opt_quotient_impl = 0;   // 0: tiled evaluator (quotient_plan.h), 1: op-stream interpreter (quotient_ops.h)
+    long opt_quotient_waves = 65536, opt_quotient_slots = 0, opt_quotient_chunks = 0;
     // shape-dependent tables
     int tab_log_n = -1, tab_rate = -1, tab_qdb = -1;
     DevBuf tw_fwd, tw_inv, coset_scale, qtab, qshift_inv;
@@ -67,6 +73,11 @@ struct Ctx {
     DevBuf d_ops, d_loads, d_chunk_off;  // compile_quotient_ops() + attach_cell_cache() output for prog_air
     unsigned prog_slots = 0;
     std::vector<uint32_t> chunk_k_after;
+    // tiled plan (quotient_plan.h) for plan_air
+    int plan_air = -1;
+    unsigned plan_chunks = 0, plan_want = 0;
+    uint32_t plan_recs = 0;
+    DevBuf q_recs, q_pieces, q_streams, q_chunk_tile_off, q_tile_list, q_contrib_off, q_contribs, q_consts, q_apow;
     // work buffers
     DevBuf staging, values, coeffs, lde, digests, pis, apow, chunk_scale, partial, qvals, qcoef, qlde, qdigests, zpow, gzpow, open_local,
         open_next, open_q, ext_apow, comb_partial, comb_out, fri_coef, fri_vals, fri_rows[16], fri_digests[16], scale_tab, pow_state,
@@ -112,8 +123,7 @@ static hipError_t run_lde(Ctx* c, const gl_t* values, gl_t* coeffs, gl_t* lde, s
 static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
     // enough (point-block x chunk) waves to fill 256 CUs several times over
     size_t blocks = (quotient_points + 63) / 64;
-    size_t target_waves = 65536;  // measured on FinalExp: 8 K waves 61.3 ms, 16 K 56.4, 32 K 54.3, 64 K 53.5, 128 K 52.9
-    if (const char* e = getenv("STARKHIP_QUOTIENT_WAVES")) target_waves = (size_t)std::max(64, atoi(e));  // tuning knob
+    size_t target_waves = (size_t)std::max(64L, c->opt_quotient_waves);  // measured on FinalExp: 8 K waves 61.3 ms, 16 K 56.4, 32 K 54.3, 64 K 53.5, 128 K 52.9
     unsigned want = (unsigned)std::min<size_t>(256, std::max<size_t>(1, (target_waves + blocks - 1) / blocks));
     want = (unsigned)std::min<size_t>(want, air.prog.group_off.size());
     if (c->prog_air == air.id && c->prog_chunks == want) return 0;
@@ -122,9 +132,8 @@ static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
     // per-wave LDS cell cache, OFF by default: measured on FinalExp (MI355X) 0 slots 40 ms, 16: 44, 32: 67, 48: 94 ms.
     // The kernel is bound by memory (253 GB fetched per launch, 6.1 TB/s) and its throughput is proportional to the waves
     // in flight; Belady replacement would hit 38 / 56 / 64 % with 16 / 32 / 64 slots, but the LDS those slots take costs more
-    // occupancy than the hits return.  STARKHIP_QUOTIENT_SLOTS (0..64) keeps the path testable.
-    c->prog_slots = 0;
-    if (const char* e = getenv("STARKHIP_QUOTIENT_SLOTS")) c->prog_slots = (unsigned)std::min(64, std::max(0, atoi(e)));
+    // occupancy than the hits return.  Option "quotient_slots" (0..64) keeps the path testable.
+    c->prog_slots = (unsigned)std::min(64L, std::max(0L, c->opt_quotient_slots));
     attach_cell_cache(Q, c->prog_slots);
     HIPCHK(c->d_loads.ensure(Q.loads.size() * 4));
     HIPCHK(hipMemcpyAsync(c->d_loads.p, Q.loads.data(), Q.loads.size() * 4, hipMemcpyHostToDevice, c->st));
@@ -136,6 +145,37 @@ static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
     HIPCHK(hipStreamSynchronize(c->st));  // Q goes out of scope
     c->prog_air = air.id;
     c->prog_chunks = want;
+    return 0;
+}
+
+// Tiled plan of `air` on the device.  Chunks: enough (64-point block x chunk) workgroups to fill 256 CUs several times over.
+static int ensure_plan(Ctx* c, const AirInfo& air, size_t quotient_points) {
+    const size_t blocks = (quotient_points + 63) / 64;
+    unsigned want = (unsigned)std::min<size_t>(512, std::max<size_t>(1, (4096 + blocks - 1) / blocks));
+    if (c->opt_quotient_chunks > 0) want = (unsigned)c->opt_quotient_chunks;
+    if (c->plan_air == air.id && c->plan_want == want) return 0;
+    const QTPlan Q = build_quotient_plan(air.prog, want);
+    struct Up { DevBuf* b; const void* src; size_t bytes; };
+    const std::vector<gl_t>& consts = air.prog.consts;
+    const gl_t zero = 0;
+    const Up ups[] = {{&c->q_recs, Q.recs.data(), Q.recs.size() * sizeof(QTRec)},
+                      {&c->q_pieces, Q.pieces.data(), Q.pieces.size() * sizeof(QTPiece)},
+                      {&c->q_streams, Q.streams.data(), Q.streams.size() * sizeof(QTStream)},
+                      {&c->q_chunk_tile_off, Q.chunk_tile_off.data(), Q.chunk_tile_off.size() * 4},
+                      {&c->q_tile_list, Q.tile_list.empty() ? (const void*)&zero : (const void*)Q.tile_list.data(), std::max<size_t>(1, Q.tile_list.size()) * 4},
+                      {&c->q_contrib_off, Q.contrib_off.data(), Q.contrib_off.size() * 4},
+                      {&c->q_contribs, Q.contribs.empty() ? (const void*)&zero : (const void*)Q.contribs.data(), std::max<size_t>(1, Q.contribs.size()) * sizeof(QTContrib)},
+                      {&c->q_consts, consts.empty() ? (const void*)&zero : (const void*)consts.data(), std::max<size_t>(1, consts.size()) * 8}};
+    for (const Up& u : ups) {
+        HIPCHK(u.b->ensure(u.bytes));
+        HIPCHK(hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, c->st));
+    }
+    HIPCHK(c->q_apow.ensure(std::max<size_t>(1, air.prog.n_constraints) * 16));
+    HIPCHK(hipStreamSynchronize(c->st));  // Q goes out of scope
+    c->plan_air = air.id;
+    c->plan_want = want;
+    c->plan_chunks = Q.n_chunks;
+    c->plan_recs = (uint32_t)Q.recs.size();
     return 0;
 }
 
@@ -172,7 +212,8 @@ void ctx_destroy(Ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
-    DevBuf* bufs[] = {&c->tw_fwd, &c->tw_inv, &c->coset_scale, &c->qtab, &c->qshift_inv, &c->lde2_fwd, &c->lde2_inv, &c->lde2_cs, &c->d_ops, &c->d_loads, &c->d_chunk_off, &c->staging,
+    DevBuf* bufs[] = {&c->tw_fwd, &c->tw_inv, &c->coset_scale, &c->qtab, &c->qshift_inv, &c->lde2_fwd, &c->lde2_inv, &c->lde2_cs, &c->d_ops, &c->d_loads, &c->d_chunk_off, &c->q_recs, &c->q_pieces, &c->q_streams, &c->q_chunk_tile_off, &c->q_tile_list,
+                      &c->q_contrib_off, &c->q_contribs, &c->q_consts, &c->q_apow, &c->staging,
                       &c->values, &c->coeffs, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial, &c->qvals, &c->qcoef,
                       &c->qlde, &c->qdigests, &c->zpow, &c->gzpow, &c->open_local, &c->open_next, &c->open_q, &c->ext_apow, &c->comb_partial,
                       &c->comb_out, &c->fri_coef, &c->fri_vals, &c->scale_tab, &c->pow_state, &c->pow_best, &c->qidx, &c->gather_t,
@@ -187,6 +228,16 @@ void ctx_destroy(Ctx* c) {
 }
 
 hipStream_t ctx_stream(Ctx* c) { return c->st; }
+int ctx_set_option(Ctx* c, const char* name, long value) {
+    if (!c || !name) return STARKHIP_ERR_BAD_SHAPE;
+    const std::string k(name);
+    if (k == "quotient_impl" && (value == 0 || value == 1)) c->opt_quotient_impl = value;
+    else if (k == "quotient_waves" && value >= 64) { c->opt_quotient_waves = value; c->prog_air = -1; }
+    else if (k == "quotient_slots" && value >= 0 && value <= 64) { c->opt_quotient_slots = value; c->prog_air = -1; }
+    else if (k == "quotient_chunks" && value >= 0 && value <= 4096) { c->opt_quotient_chunks = value; c->plan_air = -1; }
+    else return STARKHIP_ERR_BAD_SHAPE;
+    return STARKHIP_OK;
+}
 const float* ctx_timings(Ctx* c) { return c->timings; }
 const float* ctx_kernel_timings(Ctx* c) { return c->ktimings; }
 
@@ -221,8 +272,9 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     hipStream_t st = c->st;
     int rc;
     if ((rc = ensure_tables(c, log_n, r, qdb))) return rc;
-    if ((rc = ensure_program(c, air, size))) return rc;
-    const unsigned n_chunks = c->prog_chunks;
+    const bool tiled = c->opt_quotient_impl == 0;
+    if ((rc = tiled ? ensure_plan(c, air, size) : ensure_program(c, air, size))) return rc;
+    const unsigned n_chunks = tiled ? c->plan_chunks : c->prog_chunks;
 
     // ---- buffers
     HIPCHK(c->coeffs.ensure(C * n * 8));
@@ -297,7 +349,9 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(hipEventRecord(c->ev[evi++], st));
 
     // ---- phase 1: IFFT + LDE (PolynomialBatch::from_values, App. A.3)
+    HIPCHK(hipEventRecord(c->kev[4], st));
     HIPCHK(run_lde(c, d_values, c->coeffs.as<gl_t>(), c->lde.as<gl_t>(), C, log_n, r, 0));
+    HIPCHK(hipEventRecord(c->kev[5], st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
 
     // ---- phase 2: Merkle tree over bit-reversed LDE rows
@@ -316,22 +370,35 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
 
     // ---- phase 3: quotient polynomials (App. A.6)
     {
-        std::vector<gl_t> apow(2 * (AIR_MAX_GROUP + 1)), cscale(2 * n_chunks);
-        for (int j = 0; j < 2; j++) {
-            apow[j * (AIR_MAX_GROUP + 1)] = 1;
-            for (unsigned m = 1; m <= AIR_MAX_GROUP; m++) apow[j * (AIR_MAX_GROUP + 1) + m] = gl_mul(apow[j * (AIR_MAX_GROUP + 1) + m - 1], alphas[j]);
-            for (unsigned p = 0; p < n_chunks; p++) cscale[p * 2 + j] = gl_pow(alphas[j], c->chunk_k_after[p]);
-        }
-        HIPCHK(hipMemcpyAsync(c->apow.p, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(c->chunk_scale.p, cscale.data(), cscale.size() * 8, hipMemcpyHostToDevice, st));
         if (n_pis) HIPCHK(hipMemcpyAsync(c->pis.p, pis_host, n_pis * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipEventRecord(c->kev[2], st));
-        HIPCHK(launch_quotient_eval(c->d_ops.as<QOp>(), c->d_loads.as<uint32_t>(), c->prog_slots, c->d_chunk_off.as<uint32_t>(), n_chunks,
-                                    c->pis.as<gl_t>(), c->lde.as<gl_t>(), c->qtab.as<gl_t>(), c->apow.as<gl_t>(), alphas[0], alphas[1],
-                                    c->partial.as<gl_t>(), log_n, r, qdb, st));
-        HIPCHK(hipEventRecord(c->kev[3], st));
-        HIPCHK(launch_quotient_combine(c->partial.as<gl_t>(), c->chunk_scale.as<gl_t>(), n_chunks, c->qtab.as<gl_t>(), log_n, qdb,
-                                       c->qvals.as<gl_t>(), st));
+        if (tiled) {
+            // per-proof weights of the plan's records, then one pass over the LDE in LDS-staged column tiles
+            HIPCHK(launch_quotient_weights(c->q_recs.as<QTRec>(), c->q_contrib_off.as<uint32_t>(), c->q_contribs.as<QTContrib>(), c->plan_recs,
+                                           c->q_apow.as<gl_t>(), P.n_constraints, c->q_consts.as<gl_t>(), c->pis.as<gl_t>(), alphas[0], alphas[1], st));
+            HIPCHK(hipEventRecord(c->kev[2], st));
+            HIPCHK(launch_quotient_tiles(c->q_recs.as<QTRec>(), c->q_pieces.as<QTPiece>(), c->q_streams.as<QTStream>(),
+                                         c->q_chunk_tile_off.as<uint32_t>(), c->q_tile_list.as<uint32_t>(), n_chunks, c->lde.as<gl_t>(),
+                                         c->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, st));
+            HIPCHK(hipEventRecord(c->kev[3], st));
+            HIPCHK(launch_quotient_tiles_combine(c->partial.as<gl_t>(), n_chunks, c->qtab.as<gl_t>(), log_n, qdb, c->qvals.as<gl_t>(), st));
+        } else {
+            std::vector<gl_t> apow(2 * (AIR_MAX_GROUP + 1)), cscale(2 * n_chunks);
+            for (int j = 0; j < 2; j++) {
+                apow[j * (AIR_MAX_GROUP + 1)] = 1;
+                for (unsigned m = 1; m <= AIR_MAX_GROUP; m++) apow[j * (AIR_MAX_GROUP + 1) + m] = gl_mul(apow[j * (AIR_MAX_GROUP + 1) + m - 1], alphas[j]);
+                for (unsigned p = 0; p < n_chunks; p++) cscale[p * 2 + j] = gl_pow(alphas[j], c->chunk_k_after[p]);
+            }
+            HIPCHK(hipMemcpyAsync(c->apow.p, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(c->chunk_scale.p, cscale.data(), cscale.size() * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(hipEventRecord(c->kev[2], st));
+            HIPCHK(launch_quotient_eval(c->d_ops.as<QOp>(), c->d_loads.as<uint32_t>(), c->prog_slots, c->d_chunk_off.as<uint32_t>(), n_chunks,
+                                        c->pis.as<gl_t>(), c->lde.as<gl_t>(), c->qtab.as<gl_t>(), c->apow.as<gl_t>(), alphas[0], alphas[1],
+                                        c->partial.as<gl_t>(), log_n, r, qdb, st));
+            HIPCHK(hipEventRecord(c->kev[3], st));
+            HIPCHK(launch_quotient_combine(c->partial.as<gl_t>(), c->chunk_scale.as<gl_t>(), n_chunks, c->qtab.as<gl_t>(), log_n, qdb,
+                                           c->qvals.as<gl_t>(), st));
+            HIPCHK(hipStreamSynchronize(st));  // apow / cscale go out of scope
+        }
         // coset_ifft(7): inverse transform, scale by size^-1 and by 7^-i
         HIPCHK(launch_ntt_global(c->qvals.as<gl_t>(), 2, size, log_n + qdb, c->tw_inv.as<gl_t>(), log_N, nullptr, c->qshift_inv.as<gl_t>(),
                                  gl_inv((gl_t)size), st));
@@ -541,11 +608,13 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         out[pl.off_pow] = pow_witness;
         if (n_pis) memcpy(out + pl.off_pis, pis_host, n_pis * 8);
     }
-    HIPCHK(hipEventRecord(c->ev[evi++], st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (hipEventRecord(c->ev[evi++], st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        free(out);
+        return STARKHIP_ERR_HIP;
+    }
     for (int i = 0; i < STARKHIP_N_PHASES - 1; i++) (void)hipEventElapsedTime(&c->timings[i], c->ev[i], c->ev[i + 1]);
     (void)hipEventElapsedTime(&c->timings[STARKHIP_N_PHASES - 1], c->ev[0], c->ev[STARKHIP_N_PHASES - 1]);
-    c->ktimings[0] = c->timings[1];
+    (void)hipEventElapsedTime(&c->ktimings[0], c->kev[4], c->kev[5]);
     (void)hipEventElapsedTime(&c->ktimings[1], c->kev[0], c->kev[1]);
     (void)hipEventElapsedTime(&c->ktimings[2], c->kev[2], c->kev[3]);
     *proof_out = out;

@@ -1,0 +1,493 @@
+// Tiled form of an AIR constraint program for the quotient kernel (kernels_quotient.hip).
+//
+// What the reference computes per LDE point is  acc_j = sum_k mask(kind_k) * c_k * alpha_j^(K-1-k)  (the ConstraintConsumer
+// fold of S::eval_packed_generic, e.g. /root/reference/src/final_exponentiate.rs:907-1136).  Field
+// arithmetic is exact, so the sum may be regrouped freely as long as every constraint keeps its own power of alpha:
+//
+//  * constraints with the same (kind, gates) anywhere in the program form a SUPERGROUP with common factor
+//    mask(kind) * G, G = product of the gate cells (or 1 - cell);
+//  * inside a supergroup the bodies collapse to  T_j = sum_m  w_j(m) * m  over the distinct monomials m (one trace cell for
+//    92 % of the terms, a product of two or three cells otherwise, or the constant 1) with per-proof weights
+//        w_j(m) = sum over the terms (k, coefficient) with monomial m of  coefficient * alpha_j^(K-1-k)
+//    (coefficient = +-1, a table constant, or +-public_input) -- computed once per proof on the device;
+//  * the sum over m is cut by COLUMN TILE: a tile is QT_TILE_COLS consecutive trace columns whose 64-point slice a
+//    workgroup stages in LDS once; a PIECE = (supergroup, tile) holds the monomials whose first cell lies in the tile, and
+//    contributes  mask * G * T_j(piece)  to acc_j.  Every LDE cell is thus read from HBM once per point (plus the gate
+//    cells and the few factors that live in another tile, which are loaded directly).
+//
+// FinalExp: 360 800 constraints / 1.10 M terms -> 15 982 supergroups, 0.68 M monomial records, ~30 K pieces, 1 149 tiles.
+//
+// Layout for the kernel: the tiles of the program are cut into `n_chunks` contiguous ranges of about equal cost; a
+// workgroup of QT_WAVES waves handles (64 points) x (one chunk) and walks the chunk's tiles in step (one barrier per tile);
+// inside a tile the pieces are dealt to the waves (largest first), big pieces are split -- the contribution is linear in T.
+// Each wave reads its own stream of 32-byte wave-uniform records and a stream of piece descriptors.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "air_ir.h"
+
+namespace starkhip {
+
+static const unsigned QT_TILE_COLS = 64;    // columns per LDS tile
+static const unsigned QT_TILE_ROWS = 65;    // 64 points + the successor of the last one (next-row reads are "lane + 1")
+static const unsigned QT_WAVES = 8;         // waves per workgroup
+static const unsigned QT_MAX_PIECE = 96;    // records per piece after splitting (accumulators overflow beyond 1024)
+static const unsigned QT_LIMB_BITS = 22;    // weights are split into three limbs of 22 bits
+
+// record control word
+enum : uint32_t {
+    QT_OFF_MASK = 0xFFFFu,     // [15:0] byte offset of the cell inside the LDS tile: slot * QT_TILE_ROWS * 8 (+ 8 for the next row)
+    QT_NEXT = 1u << 16,        // the cell is taken from the next row (already in the offset for the LDS path; SMALL_N kernels and
+                               // direct loads look at the flag)
+    QT_SRC_ONE = 1u << 17,     // x = 1 (constant term)
+    QT_SRC_GLOBAL = 1u << 18,  // x = direct load of column `aux` (a factor outside the tile)
+    QT_SETV = 1u << 19,        // v = x (SETV alone) or v = v * x (SETV | MULV); no accumulation
+    QT_MULV = 1u << 20,        // x = v * x before accumulating
+    QT_END = 1u << 21,         // last record of its piece: acc_j += mask * G * T_j, next piece descriptor
+    QT_TILE = 1u << 22,        // no cell: the wave is done with this tile (barrier, next tile)
+    QT_STOP = 1u << 23,        // end of stream
+    QT_SPECIAL = QT_SRC_ONE | QT_SRC_GLOBAL | QT_SETV | QT_MULV | QT_END | QT_TILE | QT_STOP
+};
+
+struct QTRec {
+    uint32_t ctl;
+    uint32_t aux;   // QT_SRC_GLOBAL: column
+    uint32_t w[6];  // limbs of the weights for alpha_0 then alpha_1 (written per proof by quotient_weights_kernel)
+};
+static_assert(sizeof(QTRec) == 32, "records are fetched as 8 dwords");
+
+// piece descriptor: ctl = kind | n_gates << 2 | complement mask << 5
+struct QTPiece {
+    uint32_t ctl;
+    uint32_t gate[4];  // cellrefs (column | REF_NEXT)
+    uint32_t pad[3];
+};
+static_assert(sizeof(QTPiece) == 32, "piece descriptors are fetched as 8 dwords");
+
+// one term's share of a record's weight: coefficient * alpha^e
+struct QTContrib {
+    uint32_t e;    // exponent K - 1 - k
+    uint32_t coef; // [2:0] CK_*  [31:3] index (constant table / public input)
+};
+
+struct QTStream {
+    uint32_t rec_off, piece_off;
+};
+
+struct QTPlan {
+    uint32_t n_cols = 0, n_constraints = 0, n_chunks = 0;
+    std::vector<QTRec> recs;              // all streams, chunk after chunk, wave after wave
+    std::vector<QTPiece> pieces;
+    std::vector<QTStream> streams;        // [n_chunks][QT_WAVES]
+    std::vector<uint32_t> chunk_tile_off; // [n_chunks + 1] into tile_list
+    std::vector<uint32_t> tile_list;      // tile indices (first column / QT_TILE_COLS) in walking order
+    std::vector<uint32_t> contrib_off;    // [recs.size() + 1]
+    std::vector<QTContrib> contribs;
+    // statistics
+    size_t n_supergroups = 0, n_pieces = 0, n_cell_records = 0, n_direct_loads = 0;
+};
+
+namespace qt_detail {
+
+struct Term {
+    uint32_t sg;
+    uint32_t cells[3];  // sorted; unused = 0xFFFFFFFF
+    uint32_t e, coef;
+};
+
+inline uint32_t tile_of(uint32_t cellref) { return (cellref & REF_COL_MASK) / QT_TILE_COLS; }
+
+}  // namespace qt_detail
+
+// Build the plan.  `want_chunks` >= 1; the result may have fewer (never more than the number of non-empty tiles).
+inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
+    using namespace qt_detail;
+    const uint32_t K = P.n_constraints;
+    const uint32_t NONE = 0xFFFFFFFFu;
+    // ---- pass 1: terms with their supergroup
+    std::unordered_map<std::string, uint32_t> sg_index;
+    std::vector<std::vector<uint32_t>> sg_gates;
+    std::vector<uint32_t> sg_kind;
+    std::vector<Term> terms;
+    terms.reserve(P.code.size() / 2);
+    const std::vector<uint32_t>& code = P.code;
+    size_t i = 0;
+    uint32_t k = 0;
+    while (i < code.size() && code[i] != 0) {
+        const uint32_t gw = code[i++];
+        const uint32_t kind = (gw >> 4) & 3u, ng = (gw >> 8) & 255u, m = gw >> 16;
+        if (ng > 4) throw std::runtime_error("quotient_plan: more than four gates");
+        std::string key((const char*)&kind, 4);
+        key.append((const char*)&code[i], ng * 4);  // gates are stored sorted by the builder
+        uint32_t sg;
+        auto it = sg_index.find(key);
+        if (it == sg_index.end()) {
+            sg = (uint32_t)sg_gates.size();
+            sg_index.emplace(std::move(key), sg);
+            sg_gates.emplace_back(code.begin() + i, code.begin() + i + ng);
+            sg_kind.push_back(kind);
+        } else {
+            sg = it->second;
+        }
+        i += ng;
+        for (uint32_t c = 0; c < m; c++, k++) {
+            uint32_t tw;
+            do {
+                tw = code[i++];
+                const uint32_t nf = tw & 3u, ck = (tw >> 2) & 7u, idx = tw >> 6;
+                Term t;
+                t.sg = sg;
+                t.cells[0] = t.cells[1] = t.cells[2] = NONE;
+                for (uint32_t f = 0; f < nf; f++) t.cells[f] = code[i++] & (REF_COL_MASK | REF_NEXT);
+                std::sort(t.cells, t.cells + nf);
+                t.e = K - 1 - k;
+                t.coef = ck | (idx << 3);
+                if (ck == CK_CONST && P.consts[idx] == 0) continue;  // explicit zero term of an identically-zero constraint
+                terms.push_back(t);
+            } while (!(tw & 32u));
+        }
+    }
+    if (k != K) throw std::runtime_error("quotient_plan: constraint count mismatch");
+
+    // ---- pass 2: merge terms with the same (supergroup, monomial) into records; order by (tile, supergroup, monomial)
+    // the tile of a monomial is the tile of its first cell; constants go with the supergroup's first gate (or tile 0)
+    auto term_tile = [&](const Term& t) -> uint32_t {
+        if (t.cells[0] != NONE) {
+            // prefer the tile that holds most factors
+            uint32_t t0 = tile_of(t.cells[0]);
+            if (t.cells[1] != NONE && t.cells[2] != NONE && tile_of(t.cells[1]) == tile_of(t.cells[2])) return tile_of(t.cells[1]);
+            return t0;
+        }
+        return sg_gates[t.sg].empty() ? 0u : tile_of(sg_gates[t.sg][0]);
+    };
+    std::vector<uint32_t> order(terms.size());
+    std::vector<uint32_t> ttile(terms.size());
+    for (size_t j = 0; j < terms.size(); j++) {
+        order[j] = (uint32_t)j;
+        ttile[j] = term_tile(terms[j]);
+    }
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        const Term &x = terms[a], &y = terms[b];
+        if (ttile[a] != ttile[b]) return ttile[a] < ttile[b];
+        if (x.sg != y.sg) return x.sg < y.sg;
+        for (int f = 0; f < 3; f++)
+            if (x.cells[f] != y.cells[f]) return x.cells[f] < y.cells[f];
+        return x.e > y.e;
+    });
+
+    struct Mono {
+        uint32_t cells[3];
+        uint32_t c_begin, c_end;  // contributions
+    };
+    struct Piece {
+        uint32_t sg, tile;
+        uint32_t m_begin, m_end;  // monomials
+        uint32_t cost;
+    };
+    std::vector<Mono> monos;
+    std::vector<QTContrib> contribs;
+    std::vector<Piece> pieces;
+    contribs.reserve(terms.size());
+    for (size_t j = 0; j < order.size(); j++) {
+        const Term& t = terms[order[j]];
+        const uint32_t tl = ttile[order[j]];
+        const bool same_piece = !pieces.empty() && pieces.back().sg == t.sg && pieces.back().tile == tl;
+        const bool same_mono = same_piece && !monos.empty() && monos.back().cells[0] == t.cells[0] && monos.back().cells[1] == t.cells[1] &&
+                               monos.back().cells[2] == t.cells[2] && pieces.back().m_end == monos.size();
+        if (!same_piece) pieces.push_back({t.sg, tl, (uint32_t)monos.size(), (uint32_t)monos.size(), 0});
+        if (!same_mono) {
+            monos.push_back({{t.cells[0], t.cells[1], t.cells[2]}, (uint32_t)contribs.size(), (uint32_t)contribs.size()});
+            pieces.back().m_end = (uint32_t)monos.size();
+        }
+        contribs.push_back({t.e, t.coef});
+        monos.back().c_end = (uint32_t)contribs.size();
+    }
+    auto mono_records = [&](const Mono& m) -> uint32_t { return m.cells[0] == NONE ? 1u : m.cells[1] == NONE ? 1u : m.cells[2] == NONE ? 2u : 3u; };
+    // split big pieces (the contribution is linear in T, so a piece may be cut anywhere)
+    {
+        std::vector<Piece> cut;
+        cut.reserve(pieces.size() + pieces.size() / 4);
+        for (const Piece& p : pieces) {
+            uint32_t b = p.m_begin, recs = 0, start = p.m_begin;
+            for (; b < p.m_end; b++) {
+                const uint32_t r = mono_records(monos[b]);
+                if (recs + r > QT_MAX_PIECE && recs) {
+                    cut.push_back({p.sg, p.tile, start, b, 0});
+                    start = b;
+                    recs = 0;
+                }
+                recs += r;
+            }
+            cut.push_back({p.sg, p.tile, start, p.m_end, 0});
+        }
+        pieces.swap(cut);
+    }
+    const uint32_t PIECE_COST = 220, REC_COST = 13, TILE_COST = 150;
+    for (Piece& p : pieces) {
+        uint32_t recs = 0;
+        for (uint32_t b = p.m_begin; b < p.m_end; b++) recs += mono_records(monos[b]);
+        p.cost = PIECE_COST + REC_COST * recs;
+    }
+
+    // ---- pass 3: tiles in walking order, cut into chunks of about equal cost
+    std::vector<uint32_t> tile_first_piece;  // index into pieces of each non-empty tile (+ sentinel)
+    std::vector<uint32_t> tiles;
+    std::vector<uint64_t> tile_cost;
+    for (size_t j = 0; j < pieces.size(); j++) {
+        if (j == 0 || pieces[j].tile != pieces[j - 1].tile) {
+            tiles.push_back(pieces[j].tile);
+            tile_first_piece.push_back((uint32_t)j);
+            tile_cost.push_back(TILE_COST * QT_WAVES);
+        }
+        tile_cost.back() += pieces[j].cost;
+    }
+    tile_first_piece.push_back((uint32_t)pieces.size());
+    uint64_t total_cost = 0;
+    for (uint64_t c : tile_cost) total_cost += c;
+
+    QTPlan Q;
+    Q.n_cols = P.n_cols;
+    Q.n_constraints = K;
+    Q.n_supergroups = sg_gates.size();
+    Q.n_pieces = pieces.size();
+    if (tiles.empty()) {  // a program without terms: one empty chunk
+        Q.n_chunks = 1;
+        Q.chunk_tile_off = {0, 0};
+        for (unsigned w = 0; w < QT_WAVES; w++) {
+            Q.streams.push_back({(uint32_t)Q.recs.size(), (uint32_t)Q.pieces.size()});
+            Q.recs.push_back({QT_STOP, 0, {0, 0, 0, 0, 0, 0}});
+            Q.pieces.push_back({0, {0, 0, 0, 0}, {0, 0, 0}});
+        }
+        Q.contrib_off.assign(Q.recs.size() + 1, 0);
+        return Q;
+    }
+    unsigned n_chunks = std::max(1u, std::min<unsigned>(want_chunks, (unsigned)tiles.size()));
+    std::vector<uint32_t> chunk_first_tile;
+    {
+        uint64_t done = 0;
+        size_t t = 0;
+        for (unsigned c = 0; c < n_chunks && t < tiles.size(); c++) {
+            chunk_first_tile.push_back((uint32_t)t);
+            const uint64_t target = total_cost * (c + 1) / n_chunks;
+            do {
+                done += tile_cost[t];
+                t++;
+            } while (t < tiles.size() && (c + 1 == n_chunks || (done < target && tiles.size() - t > n_chunks - 1 - c)));
+        }
+        n_chunks = (unsigned)chunk_first_tile.size();
+        chunk_first_tile.push_back((uint32_t)tiles.size());
+    }
+    Q.n_chunks = n_chunks;
+
+    // ---- pass 4: deal the pieces of each tile to the waves and emit the streams
+    std::vector<std::vector<uint32_t>> contrib_of_rec;  // parallel to Q.recs while building: [begin, end) pairs
+    std::vector<uint32_t> rec_c_begin, rec_c_end;
+    auto push_rec = [&](uint32_t ctl, uint32_t aux, uint32_t cb, uint32_t ce) {
+        Q.recs.push_back({ctl, aux, {0, 0, 0, 0, 0, 0}});
+        rec_c_begin.push_back(cb);
+        rec_c_end.push_back(ce);
+    };
+    // streams are built wave by wave, so first decide the assignment for every tile of the chunk
+    for (unsigned c = 0; c < n_chunks; c++) {
+        const uint32_t t_lo = chunk_first_tile[c], t_hi = chunk_first_tile[c + 1];
+        Q.chunk_tile_off.push_back((uint32_t)Q.tile_list.size());
+        for (uint32_t t = t_lo; t < t_hi; t++) Q.tile_list.push_back(tiles[t]);
+        // assignment[tile - t_lo][wave] = piece indices
+        std::vector<std::vector<std::vector<uint32_t>>> assign(t_hi - t_lo, std::vector<std::vector<uint32_t>>(QT_WAVES));
+        for (uint32_t t = t_lo; t < t_hi; t++) {
+            std::vector<uint32_t> ps;
+            for (uint32_t p = tile_first_piece[t]; p < tile_first_piece[t + 1]; p++) ps.push_back(p);
+            std::stable_sort(ps.begin(), ps.end(), [&](uint32_t a, uint32_t b) { return pieces[a].cost > pieces[b].cost; });
+            uint64_t load[QT_WAVES] = {0};
+            for (uint32_t p : ps) {
+                unsigned best = 0;
+                for (unsigned w = 1; w < QT_WAVES; w++)
+                    if (load[w] < load[best]) best = w;
+                load[best] += pieces[p].cost;
+                assign[t - t_lo][best].push_back(p);
+            }
+        }
+        for (unsigned w = 0; w < QT_WAVES; w++) {
+            Q.streams.push_back({(uint32_t)Q.recs.size(), (uint32_t)Q.pieces.size()});
+            for (uint32_t t = t_lo; t < t_hi; t++) {
+                const uint32_t tile = tiles[t];
+                for (uint32_t p : assign[t - t_lo][w]) {
+                    const Piece& pc = pieces[p];
+                    const std::vector<uint32_t>& gates = sg_gates[pc.sg];
+                    QTPiece d = {0, {0, 0, 0, 0}, {0, 0, 0}};
+                    uint32_t compl_mask = 0;
+                    for (size_t g = 0; g < gates.size(); g++) {
+                        d.gate[g] = gates[g] & (REF_COL_MASK | REF_NEXT);
+                        if (gates[g] & REF_COMPL) compl_mask |= 1u << g;
+                    }
+                    d.ctl = sg_kind[pc.sg] | ((uint32_t)gates.size() << 2) | (compl_mask << 5);
+                    Q.pieces.push_back(d);
+                    Q.n_direct_loads += gates.size();
+                    for (uint32_t b = pc.m_begin; b < pc.m_end; b++) {
+                        const Mono& mo = monos[b];
+                        const bool last = b + 1 == pc.m_end;
+                        if (mo.cells[0] == NONE) {
+                            push_rec(QT_SRC_ONE | (last ? QT_END : 0u), 0, mo.c_begin, mo.c_end);
+                            continue;
+                        }
+                        // factors inside the tile first (LDS), direct loads after; the last factor carries the weights
+                        uint32_t f[3], nf = 0;
+                        for (int q = 0; q < 3; q++)
+                            if (mo.cells[q] != NONE && tile_of(mo.cells[q]) == tile) f[nf++] = mo.cells[q];
+                        for (int q = 0; q < 3; q++)
+                            if (mo.cells[q] != NONE && tile_of(mo.cells[q]) != tile) f[nf++] = mo.cells[q];
+                        for (uint32_t q = 0; q < nf; q++) {
+                            const uint32_t cell = f[q];
+                            uint32_t ctl = 0, aux = 0;
+                            if (tile_of(cell) == tile) {
+                                const uint32_t slot = (cell & REF_COL_MASK) - tile * QT_TILE_COLS;
+                                ctl = slot * QT_TILE_ROWS * 8 + ((cell & REF_NEXT) ? 8u : 0u);
+                                if (cell & REF_NEXT) ctl |= QT_NEXT;
+                                aux = slot;
+                                Q.n_cell_records++;
+                            } else {
+                                ctl = QT_SRC_GLOBAL | ((cell & REF_NEXT) ? QT_NEXT : 0u);
+                                aux = cell & REF_COL_MASK;
+                                Q.n_direct_loads++;
+                            }
+                            const bool final_factor = q + 1 == nf;
+                            if (nf > 1) {
+                                if (q == 0) ctl |= QT_SETV;
+                                else if (!final_factor) ctl |= QT_SETV | QT_MULV;
+                                else ctl |= QT_MULV;
+                            }
+                            if (final_factor && last) ctl |= QT_END;
+                            push_rec(ctl, aux, final_factor ? mo.c_begin : 0, final_factor ? mo.c_end : 0);
+                        }
+                    }
+                }
+                push_rec(QT_TILE, 0, 0, 0);
+            }
+            push_rec(QT_STOP, 0, 0, 0);
+            // the kernel fetches a few records / one descriptor beyond the end of a stream
+            for (int z = 0; z < 4; z++) push_rec(QT_STOP, 0, 0, 0);
+            Q.pieces.push_back({0, {0, 0, 0, 0}, {0, 0, 0}});
+        }
+    }
+    Q.chunk_tile_off.push_back((uint32_t)Q.tile_list.size());
+    // contributions in record order (CSR)
+    Q.contrib_off.resize(Q.recs.size() + 1);
+    Q.contribs.reserve(contribs.size());
+    for (size_t r = 0; r < Q.recs.size(); r++) {
+        Q.contrib_off[r] = (uint32_t)Q.contribs.size();
+        Q.contribs.insert(Q.contribs.end(), contribs.begin() + rec_c_begin[r], contribs.begin() + rec_c_end[r]);
+    }
+    Q.contrib_off[Q.recs.size()] = (uint32_t)Q.contribs.size();
+    return Q;
+}
+
+// ---- host replay (tests): exactly what the kernel does for ONE point, with the accumulators the kernel uses
+// local / next: the frame; masks = {1, z_last, L_first, L_last}.  weights are derived here from alphas and public inputs.
+inline void quotient_plan_weights_host(const AirProgram& P, QTPlan& Q, const gl_t alphas[2], const gl_t* pis) {
+    std::vector<gl_t> apow[2];
+    for (int j = 0; j < 2; j++) {
+        apow[j].resize(std::max<uint32_t>(1, P.n_constraints));
+        apow[j][0] = 1;
+        for (uint32_t e = 1; e < P.n_constraints; e++) apow[j][e] = gl_mul(apow[j][e - 1], alphas[j]);
+    }
+    for (size_t r = 0; r < Q.recs.size(); r++) {
+        for (int j = 0; j < 2; j++) {
+            gl_t w = 0;
+            for (uint32_t c = Q.contrib_off[r]; c < Q.contrib_off[r + 1]; c++) {
+                const uint32_t ck = Q.contribs[c].coef & 7u, idx = Q.contribs[c].coef >> 3;
+                gl_t coef = ck == CK_PLUS ? 1 : ck == CK_MINUS ? GL_P - 1 : ck == CK_CONST ? P.consts[idx] : ck == CK_PI ? pis[idx] : gl_neg(pis[idx]);
+                w = gl_add(w, gl_mul(coef, apow[j][Q.contribs[c].e]));
+            }
+            const uint32_t M = (1u << QT_LIMB_BITS) - 1;
+            Q.recs[r].w[3 * j + 0] = (uint32_t)(w & M);
+            Q.recs[r].w[3 * j + 1] = (uint32_t)((w >> QT_LIMB_BITS) & M);
+            Q.recs[r].w[3 * j + 2] = (uint32_t)(w >> (2 * QT_LIMB_BITS));
+        }
+    }
+}
+
+// value of the six partial sums S[i][l] (x limb i in {lo, hi}, weight limb l) as a field element
+inline gl_t qt_fold_sums_host(const uint64_t S[6]) {
+    gl_t r = 0;
+    for (int i = 0; i < 2; i++)
+        for (int l = 0; l < 3; l++) {
+            gl_t v = gl_from_u64(S[3 * i + l]);
+            v = gl_mul(v, gl_pow(2, 32 * i + QT_LIMB_BITS * l));
+            r = gl_add(r, v);
+        }
+    return r;
+}
+
+inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl_t* next, const gl_t masks[4], gl_t acc[2]) {
+    acc[0] = acc[1] = 0;
+    for (unsigned c = 0; c < Q.n_chunks; c++)
+        for (unsigned w = 0; w < QT_WAVES; w++) {
+            const QTStream& st = Q.streams[c * QT_WAVES + w];
+            const QTRec* rec = &Q.recs[st.rec_off];
+            const QTPiece* pc = &Q.pieces[st.piece_off];
+            uint32_t ti = Q.chunk_tile_off[c];
+            uint64_t S[2][6] = {{0}};
+            unsigned n_in_piece = 0;
+            gl_t v = 1;
+            for (;; rec++) {
+                const uint32_t ctl = rec->ctl;
+                if (ctl & QT_STOP) break;
+                if (ctl & QT_TILE) {
+                    if (n_in_piece) return false;  // a piece must not straddle tiles
+                    ti++;
+                    continue;
+                }
+                if (ti >= Q.chunk_tile_off[c + 1]) return false;
+                const uint32_t tile = Q.tile_list[ti];
+                gl_t x;
+                if (ctl & QT_SRC_ONE) x = 1;
+                else if (ctl & QT_SRC_GLOBAL) x = ((ctl & QT_NEXT) ? next : local)[rec->aux];
+                else {
+                    const uint32_t off = ctl & QT_OFF_MASK, slot = off / (QT_TILE_ROWS * 8), row = (off % (QT_TILE_ROWS * 8)) / 8;
+                    if (row > 1 || slot >= QT_TILE_COLS || (row == 1) != !!(ctl & QT_NEXT)) return false;
+                    const uint32_t col = tile * QT_TILE_COLS + slot;
+                    if (col >= Q.n_cols) return false;
+                    x = (row ? next : local)[col];
+                }
+                if (ctl & QT_MULV) x = gl_mul(v, x);
+                if (ctl & QT_SETV) {
+                    v = x;
+                    if (ctl & QT_END) return false;
+                    continue;
+                }
+                const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
+                for (int j = 0; j < 2; j++)
+                    for (int l = 0; l < 3; l++) {
+                        if (rec->w[3 * j + l] >> QT_LIMB_BITS) return false;
+                        S[j][l] += (uint64_t)x0 * rec->w[3 * j + l];
+                        S[j][3 + l] += (uint64_t)x1 * rec->w[3 * j + l];
+                    }
+                if (++n_in_piece > 1024) return false;  // 2^54 * 2^10: the 64-bit sums would wrap
+                if (ctl & QT_END) {
+                    const uint32_t kind = pc->ctl & 3u, ng = (pc->ctl >> 2) & 7u, cm = pc->ctl >> 5;
+                    gl_t G = masks[kind];
+                    for (uint32_t g = 0; g < ng; g++) {
+                        gl_t gv = ((pc->gate[g] & REF_NEXT) ? next : local)[pc->gate[g] & REF_COL_MASK];
+                        if (cm & (1u << g)) gv = gl_sub(1, gv);
+                        G = gl_mul(G, gv);
+                    }
+                    for (int j = 0; j < 2; j++) {
+                        acc[j] = gl_add(acc[j], gl_mul(G, qt_fold_sums_host(S[j])));
+                        for (int l = 0; l < 6; l++) S[j][l] = 0;
+                    }
+                    n_in_piece = 0;
+                    pc++;
+                }
+            }
+            if (n_in_piece) return false;
+        }
+    return true;
+}
+
+}  // namespace starkhip
