@@ -277,29 +277,63 @@ struct QTParams {
     const gl_t* tab;                  // quotient_tables_kernel output
     gl_t* partial;                    // [n_chunks][2][size]
     unsigned log_n, rate_bits, qdb, n_cols;
+    unsigned dbg;  // profiling only: 1 = the producer loads nothing, 2 = the evaluators skip the arithmetic (results are garbage)
 };
 
-struct alignas(64) QTBatch {
-    QTRec r[2];
-};
+// (hi:lo) += (xh:xl) as one carry chain (the sums involved stay far below 2^128)
+__device__ __forceinline__ void qt_add128(uint64_t& lo, uint64_t& hi, uint64_t xl, uint64_t xh) {
+    uint32_t l0 = (uint32_t)lo, l1 = (uint32_t)(lo >> 32), h0 = (uint32_t)hi, h1 = (uint32_t)(hi >> 32);
+    asm("v_add_co_u32_e32 %0, vcc, %4, %0\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %5, %1, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %6, %2, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %7, %3, vcc"
+        : "+v"(l0), "+v"(l1), "+v"(h0), "+v"(h1)
+        : "v"((uint32_t)xl), "v"((uint32_t)(xl >> 32)), "v"((uint32_t)xh), "v"((uint32_t)(xh >> 32))
+        : "vcc");
+    lo = ((uint64_t)l1 << 32) | l0;
+    hi = ((uint64_t)h1 << 32) | h0;
+}
 
-// sum_l 2^(22 l) * (S[l] + 2^32 S[3 + l]) mod p, any representative
+// sum_l 2^(22 l) * (S[l] + 2^32 S[3 + l]) mod p, any representative.  Every S < 2^61 (at most QT_MAX_PIECE products < 2^54).
+//   U = S0 + S1 2^22 + S2 2^44,  V = S3 + S4 2^22 + S5 2^44  (both < 2^106),  total = U + V 2^32 = sum_k t_k 2^(32 k), k < 5
+//   total mod p = (t1:t0) - (t4:t3) + t2 eps          (2^64 = eps, 2^96 = -1, 2^128 = -2^32)
+// with the borrow / carry settled as in gl_reduce_words (the subtrahend is < 2^42, so the same bounds hold).
 __device__ __forceinline__ gl_t qt_fold_sums(const uint64_t (&S)[6]) {
-    gl_t y[3];
-#pragma unroll
-    for (int l = 0; l < 3; l++) {
-        uint64_t lo;
-        const bool c = __builtin_add_overflow(S[l], S[3 + l] << 32, &lo);
-        const uint64_t hi = (S[3 + l] >> 32) + (c ? 1u : 0u);
-        y[l] = gl_reduce128_nc(hi, lo);
-    }
-    return gl_add_nn(gl_add_nn(y[0], gl_mul_pow2_nn(y[1], QT_LIMB_BITS)), gl_mul_pow2_nn(y[2], 2 * QT_LIMB_BITS));
+    uint64_t ul = S[0], uh = 0, vl = S[3], vh = 0;
+    qt_add128(ul, uh, S[1] << QT_LIMB_BITS, S[1] >> (64 - QT_LIMB_BITS));
+    qt_add128(ul, uh, S[2] << (2 * QT_LIMB_BITS), S[2] >> (64 - 2 * QT_LIMB_BITS));
+    qt_add128(vl, vh, S[4] << QT_LIMB_BITS, S[4] >> (64 - QT_LIMB_BITS));
+    qt_add128(vl, vh, S[5] << (2 * QT_LIMB_BITS), S[5] >> (64 - 2 * QT_LIMB_BITS));
+    uint32_t t0 = (uint32_t)ul, t1 = (uint32_t)(ul >> 32), t2 = (uint32_t)uh, t3 = (uint32_t)(uh >> 32), t4 = (uint32_t)(vh >> 32);
+    asm("v_add_co_u32_e32 %0, vcc, %4, %0\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %5, %1, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %6, %2, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc"
+        : "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4)
+        : "v"((uint32_t)vl), "v"((uint32_t)(vl >> 32)), "v"((uint32_t)vh)
+        : "vcc");
+    // D = (t1:t0) - (t4:t3), borrow b;  r = D + t2 * eps, carry c;  result r + (c - b) * eps
+    uint32_t d0, d1, t;
+    uint64_t borrow_mask, carry_mask, scratch_mask, r;
+    asm("v_sub_co_u32_e64 %0, %2, %3, %4\n\ts_nop 1\n\tv_subb_co_u32_e64 %1, %2, %5, %6, %2"
+        : "=&v"(d0), "=&v"(d1), "=&s"(borrow_mask)
+        : "v"(t0), "v"(t3), "v"(t1), "v"(t4));
+    const uint64_t D = ((uint64_t)d1 << 32) | d0;
+    asm("v_mad_u64_u32 %0, %2, %4, -1, %5\n\t"
+        "v_subb_co_u32_e64 %1, %3, 0, 0, %6\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %1, %3, %1, 0, %2\n\t"
+        "v_mad_i64_i32 %0, %3, %1, -1, %0"
+        : "=&v"(r), "=&v"(t), "=&s"(carry_mask), "=&s"(scratch_mask)
+        : "v"(t2), "v"(D), "s"(borrow_mask));
+    return r + ((uint64_t)t << 32);
 }
 
 template <bool SMALL_N>
-__global__ __launch_bounds__(64 * QT_WAVES) void quotient_tiles_kernel(QTParams P) {
+__global__ __launch_bounds__(64 * (QT_WAVES + 1)) void quotient_tiles_kernel(QTParams P) {
     __shared__ gl_t tile[2][QT_TILE_COLS * QT_TILE_ROWS];
-    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ uint32_t rec_ring[QT_WAVES][1][64][4];  // per evaluating wave: two blocks of 16 records (32 x 16 bytes each)
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 .. QT_WAVES - 1 evaluate, QT_WAVES stages the tiles
     const unsigned lane = threadIdx.x & 63u;
     const size_t n = (size_t)1 << P.log_n, size = n << P.qdb;
     const unsigned t_raw = blockIdx.x * 64u + lane;
@@ -313,98 +347,162 @@ __global__ __launch_bounds__(64 * QT_WAVES) void quotient_tiles_kernel(QTParams 
     const unsigned col_shift = P.log_n + P.rate_bits + 3;
     const uint32_t boff_local = (s * (unsigned)n + k) * 8u;  // < 2^32: N * 8 <= 2^(13+3+3)
     const uint32_t boff_next = (s * (unsigned)n + k_next) * 8u;
-    const uint32_t boff_next_last = __builtin_amdgcn_readlane(boff_next, 63);  // successor of the block's last point: row 64
+    const uint32_t* tiles = P.tile_list + P.chunk_tile_off[chunk];
+    const unsigned n_tiles = P.chunk_tile_off[chunk + 1] - P.chunk_tile_off[chunk];
+
+    if (wave == QT_WAVES) {
+        // ---- producer: tile ti + 1 goes from HBM straight into the other LDS buffer (global_load_lds_dwordx4: no vector
+        // registers, all 64 column loads of a tile in flight at once) while the eight evaluating waves work on tile ti.  Its
+        // loads are the only ones it waits for, and nobody else waits for them: the evaluators meet it at the barrier.
+        const uint32_t boff_next_last = __builtin_amdgcn_readlane(boff_next, 63);  // successor of the block's last point: row 64
+        const uint32_t boff_block = __builtin_amdgcn_readfirstlane(boff_local);    // !SMALL_N: the 64 points are 512 contiguous bytes
+        for (unsigned ti = 0; ti <= n_tiles; ti++) {
+            if (ti < n_tiles && P.dbg != 1) {
+                const uint32_t c0 = tiles[ti] * QT_TILE_COLS;
+                gl_t* dst = tile[ti & 1u];
+                const uint32_t ecol = c0 + lane;  // row 64: one lane per column
+                gl_t ext = 0;
+                if (ecol < P.n_cols) ext = *(const gl_t*)(lde + ((uint64_t)ecol << col_shift) + boff_next_last);
+                if (SMALL_N) {
+#pragma unroll 1
+                    for (unsigned b = 0; b < QT_TILE_COLS; b += 16) {
+                        gl_t v[16];
+#pragma unroll
+                        for (unsigned i = 0; i < 16; i++) {
+                            const uint32_t col = c0 + b + i;
+                            v[i] = 0;
+                            if (col < P.n_cols) v[i] = *(const gl_t*)(lde + ((uint64_t)col << col_shift) + boff_local);
+                        }
+#pragma unroll
+                        for (unsigned i = 0; i < 16; i++) dst[(b + i) * QT_TILE_ROWS + lane] = v[i];
+                    }
+                } else if (lane < 32) {  // 32 lanes x 16 bytes = the 64 rows of one column per instruction
+                    const unsigned ncol = min((unsigned)QT_TILE_COLS, P.n_cols - c0);
+                    const char* src = lde + ((uint64_t)c0 << col_shift) + boff_block + lane * 16u;
+#pragma unroll 4
+                    for (unsigned col = 0; col < ncol; col++) {
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)(dst + col * QT_TILE_ROWS), 16, 0, 0);
+                        src += (size_t)1 << col_shift;
+                    }
+                }
+                dst[lane * QT_TILE_ROWS + 64] = ext;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");  // the evaluators' reduction barrier
+        return;
+    }
+
     const gl_t mask_tr = P.tab[t], mask_first = P.tab[size + t], mask_last = P.tab[2 * size + t];
     // LDS addressing: a record's offset already holds slot * 520 (+ 8 for the next row); the lane adds its row.  Blocks that
-    // lie inside one coset with n >= 64 have "next row = lane + 1" (row 64 = boff_next_last).  Otherwise (SMALL_N: n < 64, several
-    // cosets or idle lanes in a wave) the next row of a lane is the lane that holds point (sp, k + 1 mod n).
+    // lie inside one coset with n >= 64 have "next row = lane + 1" (row 64 = successor of the last point).  Otherwise (SMALL_N:
+    // n < 64, several cosets or idle lanes in a wave) the next row of a lane is the lane that holds point (sp, k + 1 mod n).
     const uint32_t lds_local = lane * 8u;
     uint32_t lds_next = lds_local;
     if (SMALL_N) {
-        const unsigned t_next = sp * (unsigned)n + k_next;              // quotient-domain index of the successor
+        const unsigned t_next = sp * (unsigned)n + k_next;  // quotient-domain index of the successor
         const unsigned base = blockIdx.x * 64u;
         const unsigned row = (live && t_next >= base && t_next < base + 64u) ? t_next - base : (live ? 64u : (k_next & 63u));
         lds_next = row * 8u - 8u;  // the record offset carries + 8
     }
 
+    // The record stream is wave-uniform.  Scalar loads would share the LGKM counter with the LDS reads (and return out of
+    // order, so that every wait for a staged cell also waits for the record fetch issued just before it: 1 300 cycles per
+    // record, measured); per-lane vector loads of the same address hold 8 registers per record in flight for an L2 latency.
+    // So every wave streams its records through a private 1 KB ring in LDS, filled 512 bytes (16 records) at a time by a
+    // direct-to-LDS load issued 16 .. 32 records ahead of use, and reads a record with two broadcast ds_read_b128.
     const QTStream stream = P.streams[chunk * QT_WAVES + wave];
-    const QTRec* rec = P.recs + stream.rec_off;
-    const QTPiece* pc = P.pieces + stream.piece_off;
-    const uint32_t* tiles = P.tile_list + P.chunk_tile_off[chunk];
-    const unsigned n_tiles = P.chunk_tile_off[chunk + 1] - P.chunk_tile_off[chunk];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4* GlobalQuad;  // global address space: plain global_load, not flat
+    u32x4* const ring = (u32x4*)&rec_ring[wave][0][0][0];
+    const char* const rec_base = (const char*)(P.recs + stream.rec_off);
+    auto ring_fill = [&](unsigned block) {  // records 16 block .. 16 block + 15 -> ring slot (block & 1)
+        if (lane < 32)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec_base + (size_t)block * 512u + lane * 16u),
+                                             (__attribute__((address_space(3))) void*)(ring + (block & 1u) * 32u), 16, 0, 0);
+    };
+    struct Rec {
+        u32x4 a, b;  // {ctl, aux, w0[0], w0[1]}, {w0[2], w1[0], w1[1], w1[2]}
+    };
+    auto ring_read = [&](unsigned g, Rec& r) {
+        const u32x4* q = ring + (g & 31u) * 2u;
+        r.a = q[0];
+        r.b = q[1];
+    };
+    uint64_t pc_addr = (uint64_t)(P.pieces + stream.piece_off);
+    asm volatile("" : "+v"(pc_addr));  // formally divergent: the descriptor is fetched with a vector load (VM counter)
 
     auto direct = [&](uint32_t col, bool next) -> gl_t {
         const char* base = lde + ((uint64_t)col << col_shift);
         return *(const gl_t*)(base + (next ? boff_next : boff_local));
     };
-    // this wave's share of a tile: columns c0 + 8 wave + i, and (lanes 0..7) their row 64
-    gl_t pre[QT_TILE_COLS / QT_WAVES], pre_ext = 0;
-    auto tile_request = [&](uint32_t tile_idx) {
-        const uint32_t c0 = tile_idx * QT_TILE_COLS + wave * (QT_TILE_COLS / QT_WAVES);
-#pragma unroll
-        for (unsigned i = 0; i < QT_TILE_COLS / QT_WAVES; i++) {
-            const uint32_t col = c0 + i;
-            pre[i] = 0;
-            if (col < P.n_cols) pre[i] = *(const gl_t*)(lde + ((uint64_t)col << col_shift) + boff_local);
-        }
-        const uint32_t ecol = c0 + lane;
-        pre_ext = 0;
-        if (lane < QT_TILE_COLS / QT_WAVES && ecol < P.n_cols) pre_ext = *(const gl_t*)(lde + ((uint64_t)ecol << col_shift) + boff_next_last);
-    };
-    auto tile_store = [&](unsigned buf) {
-        gl_t* dst = tile[buf] + wave * (QT_TILE_COLS / QT_WAVES) * QT_TILE_ROWS;
-#pragma unroll
-        for (unsigned i = 0; i < QT_TILE_COLS / QT_WAVES; i++) dst[i * QT_TILE_ROWS + lane] = pre[i];
-        if (lane < QT_TILE_COLS / QT_WAVES) dst[lane * QT_TILE_ROWS + 64] = pre_ext;
-    };
 
     gl_t acc0 = 0, acc1 = 0, v = 1;
     uint64_t S0[6] = {0, 0, 0, 0, 0, 0}, S1[6] = {0, 0, 0, 0, 0, 0};
-    QTPiece piece = *pc;
+    uint32_t piece_ctl = 0;
     gl_t gate[4] = {0, 0, 0, 0};
-    auto gates_request = [&]() {
-        const uint32_t ng = (piece.ctl >> 2) & 7u;
+    auto gates_request = [&]() {  // descriptor of the piece that starts now + its gate cells (used when the piece ends)
+        const u32x4 d0 = ((GlobalQuad)pc_addr)[0];
+        const uint32_t d4 = ((const __attribute__((address_space(1))) uint32_t*)pc_addr)[4];
+        const uint32_t dgate[4] = {d0.y, d0.z, d0.w, d4};
+        piece_ctl = __builtin_amdgcn_readfirstlane(d0.x);
+        const uint32_t ng = (piece_ctl >> 2) & 7u;
 #pragma unroll
         for (unsigned g = 0; g < 4; g++)
-            if (g < ng) gate[g] = direct(piece.gate[g] & REF_COL_MASK, piece.gate[g] & REF_NEXT);
+            if (g < ng) {
+                const uint32_t ref = __builtin_amdgcn_readfirstlane(dgate[g]);
+                gate[g] = direct(ref & REF_COL_MASK, ref & REF_NEXT);
+            }
     };
+    ring_fill(0);
+    ring_fill(1);
     gates_request();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // record pipeline: R[(g + 2) & 3] is read from the ring while the cell of record g + 1 is on its way and record g is evaluated
+    Rec R0, R1, R2, R3;
+    ring_read(0, R0);
+    ring_read(1, R1);
+    unsigned g = 0;  // index of the record being evaluated
+    uint32_t ctl_cur = __builtin_amdgcn_readfirstlane(R0.a.x);
+    asm volatile("s_barrier" ::: "memory");  // tile 0 is staged
 
-    if (n_tiles) {
-        tile_request(tiles[0]);
-        tile_store(0);
-    }
-    __syncthreads();
-
-    bool stop = false;
-    for (unsigned ti = 0; ti < n_tiles && !stop; ti++) {
-        const bool more = ti + 1 < n_tiles;
-        if (more) tile_request(tiles[ti + 1]);
-        const char* const cur = (const char*)tile[ti & 1u];
-        auto lds_read = [&](uint32_t ctl) -> gl_t {
-            uint32_t a = (ctl & QT_OFF_MASK) + lds_local;
-            if (SMALL_N) a = (ctl & QT_OFF_MASK) + ((ctl & QT_NEXT) ? lds_next : lds_local);
-            return *(const gl_t*)(cur + a);
-        };
-        // three record batches in scalar registers: `A` is being processed, `B` has its cells on the way, `C` is being fetched
-        const QTBatch* bp = (const QTBatch*)rec;
-        QTBatch A = bp[0], B = bp[1], C = bp[2];
-        gl_t xa[2] = {lds_read(A.r[0].ctl), lds_read(A.r[1].ctl)}, xb[2], xc[2];
-        unsigned consumed = 0;  // records of this tile's stream already processed
-        bool tile_done = false;
-#define QT_RECORD(R, X)                                                                                               \
-    if (!tile_done) {                                                                                                 \
-        const uint32_t ctl = (R).ctl;                                                                                 \
-        gl_t x = (X);                                                                                                 \
+    const char* cur = (const char*)tile[0];
+    auto lds_read = [&](uint32_t ctl) -> gl_t {
+        uint32_t a = (ctl & QT_OFF_MASK) + lds_local;
+        if (SMALL_N) a = (ctl & QT_OFF_MASK) + ((ctl & QT_NEXT) ? lds_next : lds_local);
+        return *(const gl_t*)(cur + a);
+    };
+    gl_t xa = lds_read(ctl_cur), xb = 0;
+    unsigned ti = 0;
+    bool stop = n_tiles == 0;
+    // one step: fetch record g + 2, request the cell of record g + 1, evaluate record g
+#define QT_STEP(CUR, NXT, FAR, XC, XN)                                                                                \
+    if (!stop) {                                                                                                      \
+        if (((g + 2u) & 15u) == 0) { /* the read-ahead enters a new block: it has landed; refill the slot left behind. */ \
+            /* lgkmcnt(0): the reads of that slot's last records have RETURNED -- a ds_read still queued behind other */ \
+            /* waves' LDS traffic would otherwise see the refill (which can land within ~100 cycles from L1)        */ \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
+            ring_fill(((g + 2u) >> 4) + 1u);                                                                          \
+        }                                                                                                             \
+        ring_read(g + 2u, FAR);                                                                                       \
+        const uint32_t ctl = ctl_cur;                                                                                 \
+        ctl_cur = __builtin_amdgcn_readfirstlane(NXT.a.x);                                                            \
+        XN = lds_read(ctl_cur);                                                                                       \
+        gl_t x = XC;                                                                                                  \
         bool accumulate = true;                                                                                       \
         if (ctl & QT_SPECIAL) {                                                                                       \
             if (ctl & (QT_TILE | QT_STOP)) {                                                                          \
-                tile_done = true;                                                                                     \
-                stop = (ctl & QT_STOP) != 0;                                                                          \
                 accumulate = false;                                                                                   \
+                /* every LDS read of this tile has returned; the gate loads of the next piece stay in flight */       \
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \
+                ti++;                                                                                                 \
+                stop = (ctl & QT_STOP) != 0 || ti >= n_tiles;                                                         \
+                cur = (const char*)tile[ti & 1u];                                                                     \
+                XN = lds_read(ctl_cur); /* the cell of the next record lives in the new tile */                       \
             } else {                                                                                                  \
                 if (ctl & QT_SRC_ONE) x = 1;                                                                          \
-                if (ctl & QT_SRC_GLOBAL) x = direct((R).aux, ctl & QT_NEXT);                                          \
+                if (ctl & QT_SRC_GLOBAL) x = direct(__builtin_amdgcn_readfirstlane(CUR.a.y), ctl & QT_NEXT);          \
                 if (ctl & QT_MULV) x = gl_mul_nc(v, x);                                                               \
                 if (ctl & QT_SETV) {                                                                                  \
                     v = x;                                                                                            \
@@ -412,60 +510,47 @@ __global__ __launch_bounds__(64 * QT_WAVES) void quotient_tiles_kernel(QTParams 
                 }                                                                                                     \
             }                                                                                                         \
         }                                                                                                             \
-        if (!tile_done) consumed++;                                                                                   \
-        if (accumulate) {                                                                                             \
+        if (accumulate && P.dbg != 2) {                                                                               \
             const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);                                                \
+            const uint32_t w0[3] = {CUR.a.z, CUR.a.w, CUR.b.x}, w1[3] = {CUR.b.y, CUR.b.z, CUR.b.w};                  \
             _Pragma("unroll") for (int l = 0; l < 3; l++) {                                                           \
-                S0[l] += (uint64_t)x0 * (R).w[l];                                                                     \
-                S0[3 + l] += (uint64_t)x1 * (R).w[l];                                                                 \
-                S1[l] += (uint64_t)x0 * (R).w[3 + l];                                                                 \
-                S1[3 + l] += (uint64_t)x1 * (R).w[3 + l];                                                             \
+                S0[l] += (uint64_t)x0 * w0[l];                                                                        \
+                S0[3 + l] += (uint64_t)x1 * w0[l];                                                                    \
+                S1[l] += (uint64_t)x0 * w1[l];                                                                        \
+                S1[3 + l] += (uint64_t)x1 * w1[l];                                                                    \
             }                                                                                                         \
             if (ctl & QT_END) {                                                                                       \
-                const uint32_t kind = piece.ctl & 3u, ng = (piece.ctl >> 2) & 7u, cm = piece.ctl >> 5;                \
+                const uint32_t kind = piece_ctl & 3u, ng = (piece_ctl >> 2) & 7u, cm = piece_ctl >> 5;                \
                 gl_t G = kind == KIND_PLAIN ? (gl_t)1 : kind == KIND_TRANSITION ? mask_tr : kind == KIND_FIRST ? mask_first : mask_last; \
-                _Pragma("unroll") for (unsigned g = 0; g < 4; g++) if (g < ng) {                                      \
-                    gl_t gv = gate[g];                                                                                \
-                    if (cm & (1u << g)) gv = gl_sub_nc(1, gv);                                                        \
-                    G = gl_mul_nc(G, gv);                                                                             \
+                _Pragma("unroll") for (unsigned q = 0; q < 4; q++) if (q < ng) {                                      \
+                    gl_t gv = gate[q];                                                                                \
+                    if (cm & (1u << q)) gv = gl_sub_nc(1, gv);                                                        \
+                    G = (q == 0 && kind == KIND_PLAIN) ? gv : gl_mul_nc(G, gv);                                       \
                 }                                                                                                     \
-                acc0 = gl_add_nn(acc0, gl_mul_nc(G, qt_fold_sums(S0)));                                               \
-                acc1 = gl_add_nn(acc1, gl_mul_nc(G, qt_fold_sums(S1)));                                               \
+                acc0 = gl_mad_nc(G, qt_fold_sums(S0), acc0);                                                          \
+                acc1 = gl_mad_nc(G, qt_fold_sums(S1), acc1);                                                          \
                 _Pragma("unroll") for (int l = 0; l < 6; l++) S0[l] = S1[l] = 0;                                      \
-                pc++;                                                                                                 \
-                piece = *pc;                                                                                          \
+                pc_addr += sizeof(QTPiece);                                                                           \
                 gates_request();                                                                                      \
             }                                                                                                         \
         }                                                                                                             \
+        g++;                                                                                                          \
     }
-#define QT_STEP(CUR, NXT, FAR, XC, XN)                          \
-    {                                                           \
-        XN[0] = lds_read(NXT.r[0].ctl);                         \
-        XN[1] = lds_read(NXT.r[1].ctl);                         \
-        QT_RECORD(CUR.r[0], XC[0])                              \
-        QT_RECORD(CUR.r[1], XC[1])                              \
-        bp++;                                                   \
-        CUR = bp[2]; /* becomes FAR of the next step */         \
+    while (!stop) {
+        QT_STEP(R0, R1, R2, xa, xb)
+        QT_STEP(R1, R2, R3, xb, xa)
+        QT_STEP(R2, R3, R0, xa, xb)
+        QT_STEP(R3, R0, R1, xb, xa)
     }
-        while (!tile_done) {
-            QT_STEP(A, B, C, xa, xb)
-            if (tile_done) break;
-            QT_STEP(B, C, A, xb, xc)
-            if (tile_done) break;
-            QT_STEP(C, A, B, xc, xa)
-        }
 #undef QT_STEP
-#undef QT_RECORD
-        rec += consumed + 1;  // behind the TILE marker
-        if (more) tile_store((ti + 1) & 1u);
-        __syncthreads();
-    }
+    // waves whose stream ended before the chunk's last tile (never by construction) would desynchronise the barrier count
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
     // acc of the eight waves -> partial[chunk]
     gl_t* red = tile[0];
     red[(wave * 2 + 0) * 64 + lane] = gl_canon(acc0);
     red[(wave * 2 + 1) * 64 + lane] = gl_canon(acc1);
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (wave < 2 && live) {
         gl_t sum = 0;
         for (unsigned w = 0; w < QT_WAVES; w++) sum = gl_add(sum, red[(w * 2 + wave) * 64 + lane]);
@@ -535,12 +620,13 @@ hipError_t launch_quotient_weights(QTRec* recs, const uint32_t* contrib_off, con
 
 hipError_t launch_quotient_tiles(const QTRec* recs, const QTPiece* pieces, const QTStream* streams, const uint32_t* chunk_tile_off,
                                  const uint32_t* tile_list, unsigned n_chunks, const gl_t* lde, const gl_t* tab, gl_t* partial, unsigned log_n,
-                                 unsigned rate_bits, unsigned qdb, unsigned n_cols, hipStream_t st) {
+                                 unsigned rate_bits, unsigned qdb, unsigned n_cols, unsigned dbg, hipStream_t st) {
     QTParams P;
+    P.dbg = dbg;
     P.recs = recs; P.pieces = pieces; P.streams = streams; P.chunk_tile_off = chunk_tile_off; P.tile_list = tile_list;
     P.lde = lde; P.tab = tab; P.partial = partial; P.log_n = log_n; P.rate_bits = rate_bits; P.qdb = qdb; P.n_cols = n_cols;
     const size_t size = (size_t)1 << (log_n + qdb);
-    const dim3 grid((unsigned)((size + 63) / 64), n_chunks), block(64 * QT_WAVES);
+    const dim3 grid((unsigned)((size + 63) / 64), n_chunks), block(64 * (QT_WAVES + 1));
     if (log_n < 6 || size < 64)
         hipLaunchKernelGGL(quotient_tiles_kernel<true>, grid, block, 0, st, P);
     else

@@ -62,7 +62,7 @@ struct Ctx {
     float ktimings[3] = {0};      // lde_columns, leaf_hash (trace), quotient_eval
     // tuning (starkhip_set_option; defaults are the measured best)
     long opt_quotient_impl = 0;   // 0: tiled evaluator (quotient_plan.h), 1: op-stream interpreter (quotient_ops.h)
-    long opt_quotient_waves = 65536, opt_quotient_slots = 0, opt_quotient_chunks = 0;
+    long opt_quotient_waves = 65536, opt_quotient_slots = 0, opt_quotient_chunks = 0, opt_quotient_debug = 0;
     // shape-dependent tables
     int tab_log_n = -1, tab_rate = -1, tab_qdb = -1;
     DevBuf tw_fwd, tw_inv, coset_scale, qtab, qshift_inv;
@@ -234,6 +234,7 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
     if (k == "quotient_impl" && (value == 0 || value == 1)) c->opt_quotient_impl = value;
     else if (k == "quotient_waves" && value >= 64) { c->opt_quotient_waves = value; c->prog_air = -1; }
     else if (k == "quotient_slots" && value >= 0 && value <= 64) { c->opt_quotient_slots = value; c->prog_air = -1; }
+    else if (k == "quotient_debug" && value >= 0 && value <= 3) c->opt_quotient_debug = value;  // profiling: wrong results
     else if (k == "quotient_chunks" && value >= 0 && value <= 4096) { c->opt_quotient_chunks = value; c->plan_air = -1; }
     else return STARKHIP_ERR_BAD_SHAPE;
     return STARKHIP_OK;
@@ -378,7 +379,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             HIPCHK(hipEventRecord(c->kev[2], st));
             HIPCHK(launch_quotient_tiles(c->q_recs.as<QTRec>(), c->q_pieces.as<QTPiece>(), c->q_streams.as<QTStream>(),
                                          c->q_chunk_tile_off.as<uint32_t>(), c->q_tile_list.as<uint32_t>(), n_chunks, c->lde.as<gl_t>(),
-                                         c->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, st));
+                                         c->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, (unsigned)c->opt_quotient_debug, st));
             HIPCHK(hipEventRecord(c->kev[3], st));
             HIPCHK(launch_quotient_tiles_combine(c->partial.as<gl_t>(), n_chunks, c->qtab.as<gl_t>(), log_n, qdb, c->qvals.as<gl_t>(), st));
         } else {
@@ -398,6 +399,32 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             HIPCHK(launch_quotient_combine(c->partial.as<gl_t>(), c->chunk_scale.as<gl_t>(), n_chunks, c->qtab.as<gl_t>(), log_n, qdb,
                                            c->qvals.as<gl_t>(), st));
             HIPCHK(hipStreamSynchronize(st));  // apow / cscale go out of scope
+        }
+        if (c->opt_quotient_debug == 3 && !tiled) {
+            // development aid: the tiled evaluator's values against the interpreter's on this very proof (stderr)
+            int rc2;
+            if ((rc2 = ensure_plan(c, air, size))) return rc2;
+            std::vector<gl_t> ref(2 * size), got(2 * size);
+            HIPCHK(hipMemcpyAsync(ref.data(), c->qvals.p, 2 * size * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(c->partial.ensure((size_t)std::max(n_chunks, c->plan_chunks) * 2 * size * 8));
+            HIPCHK(launch_quotient_weights(c->q_recs.as<QTRec>(), c->q_contrib_off.as<uint32_t>(), c->q_contribs.as<QTContrib>(), c->plan_recs,
+                                           c->q_apow.as<gl_t>(), P.n_constraints, c->q_consts.as<gl_t>(), c->pis.as<gl_t>(), alphas[0], alphas[1], st));
+            HIPCHK(launch_quotient_tiles(c->q_recs.as<QTRec>(), c->q_pieces.as<QTPiece>(), c->q_streams.as<QTStream>(),
+                                         c->q_chunk_tile_off.as<uint32_t>(), c->q_tile_list.as<uint32_t>(), c->plan_chunks, c->lde.as<gl_t>(),
+                                         c->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, 0, st));
+            HIPCHK(launch_quotient_tiles_combine(c->partial.as<gl_t>(), c->plan_chunks, c->qtab.as<gl_t>(), log_n, qdb, c->comb_partial.as<gl_t>(), st));
+            HIPCHK(hipMemcpyAsync(got.data(), c->comb_partial.p, 2 * size * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            size_t bad = 0;
+            size_t last_blk = (size_t)-1;
+            for (size_t i = 0; i < 2 * size; i++)
+                if (ref[i] != got[i]) {
+                    const size_t ii = i % size, k = ii >> qdb, spp = ii & (((size_t)1 << qdb) - 1), tt = spp * n + k, blk = tt / 64;
+                    if (blk != last_blk && bad < 4096) fprintf(stderr, "quotient mismatch alpha %zu point-block %zu (sp %zu, k %zu..)\n", i / size, blk, spp, k & ~(size_t)63);
+                    last_blk = blk;
+                    bad++;
+                }
+            fprintf(stderr, "quotient compare: %zu of %zu values differ\n", bad, 2 * size);
         }
         // coset_ifft(7): inverse transform, scale by size^-1 and by 7^-i
         HIPCHK(launch_ntt_global(c->qvals.as<gl_t>(), 2, size, log_n + qdb, c->tw_inv.as<gl_t>(), log_N, nullptr, c->qshift_inv.as<gl_t>(),

@@ -35,8 +35,9 @@
 namespace starkhip {
 
 static const unsigned QT_TILE_COLS = 64;    // columns per LDS tile
-static const unsigned QT_TILE_ROWS = 65;    // 64 points + the successor of the last one (next-row reads are "lane + 1")
-static const unsigned QT_WAVES = 8;         // waves per workgroup
+static const unsigned QT_TILE_ROWS = 66;    // 64 points + the successor of the last one (next-row reads are "lane + 1") + 8 bytes so
+                                            // that every column starts on a 16-byte boundary (direct-to-LDS loads write 16 bytes per lane)
+static const unsigned QT_WAVES = 7;         // evaluating waves per workgroup (an eighth wave stages the tiles)
 static const unsigned QT_MAX_PIECE = 96;    // records per piece after splitting (accumulators overflow beyond 1024)
 static const unsigned QT_LIMB_BITS = 22;    // weights are split into three limbs of 22 bits
 
@@ -91,6 +92,7 @@ struct QTPlan {
     std::vector<QTContrib> contribs;
     // statistics
     size_t n_supergroups = 0, n_pieces = 0, n_cell_records = 0, n_direct_loads = 0;
+    uint64_t cost_sum_max = 0, cost_sum_mean = 0;  // per tile: the busiest wave's cost / the mean over the waves (model units)
 };
 
 namespace qt_detail {
@@ -312,6 +314,13 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                 load[best] += pieces[p].cost;
                 assign[t - t_lo][best].push_back(p);
             }
+            uint64_t mx = 0, sum = 0;
+            for (unsigned w = 0; w < QT_WAVES; w++) {
+                mx = std::max(mx, load[w]);
+                sum += load[w];
+            }
+            Q.cost_sum_max += mx;
+            Q.cost_sum_mean += sum / QT_WAVES;
         }
         for (unsigned w = 0; w < QT_WAVES; w++) {
             Q.streams.push_back({(uint32_t)Q.recs.size(), (uint32_t)Q.pieces.size()});
@@ -376,6 +385,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         }
     }
     Q.chunk_tile_off.push_back((uint32_t)Q.tile_list.size());
+    for (int z = 0; z < 64; z++) push_rec(QT_STOP, 0, 0, 0);  // the kernel's record ring is filled up to 32 records ahead
     // contributions in record order (CSR)
     Q.contrib_off.resize(Q.recs.size() + 1);
     Q.contribs.reserve(contribs.size());

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--air", default="final_exp", choices=["final_exp", "miller", "precomp", "fp12_mul"])
     ap.add_argument("--chunks", default="0,2,4,8,16")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--debug", type=int, default=0, help="quotient_debug option (1: no tile loads, 2: no arithmetic) -- timing only")
     args = ap.parse_args()
     import torch
     import starky_bls12_381_amd as S
@@ -43,14 +44,18 @@ def main():
         pv.set_option("quotient_impl", impl)
         if impl == 0:
             pv.set_option("quotient_chunks", chunks)
+            pv.set_option("quotient_debug", args.debug)
         ts = []
         for r in range(args.reps):
-            proof = pv.prove_device(air, cfg, d.data_ptr(), n, pis, layout=1, keep=(r == 0))
+            try:
+                proof = pv.prove_device(air, cfg, d.data_ptr(), n, pis, layout=1, keep=(r == 0))
+            except S.StarkhipError:
+                proof = None  # debug modes compute garbage: the quotient is not divisible
             if r == 0:
                 if ref is None:
                     ref = proof
                     S.verify_stark_proof(air, cfg, proof)
-                same = bool(np.array_equal(ref, proof))
+                same = proof is not None and bool(np.array_equal(ref, proof))
             ts.append(pv.last_kernel_timings()["quotient_eval"])
         out[f"impl{impl}_chunks{chunks}"] = {"quotient_ms": [round(t, 2) for t in ts], "identical_to_interpreter": same,
                                              "phase_ms": {k: round(v, 2) for k, v in pv.last_timings().items()}}
