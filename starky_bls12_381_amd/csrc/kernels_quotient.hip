@@ -3,7 +3,19 @@
 // (/root/reference/src/final_exponentiate.rs:907, src/miller_loop.rs:644,
 //  src/calc_pairing_precomp.rs:376, src/fp12_mul.rs:58).
 //
-// The AIR arrives as the op stream of quotient_ops.h (the flat program of air_ir.h in 16-byte ops).
+// Two evaluators live here; both produce exactly the reference's fold  acc_j = sum_k mask_k c_k alpha_j^(K-1-k).
+//
+//  * quotient_tiles_kernel (default): the tiled plan of quotient_plan.h.  Constraints are regrouped by (kind, gates) and by
+//    64-column tile, with per-proof alpha weights; a workgroup stages each tile's 64-point slice in LDS once (a producer wave,
+//    direct-to-LDS loads) and seven waves run wave-uniform record streams over it: every LDE cell is read from HBM once
+//    (FinalExp: 30 GB fetched per launch against 253 GB for the interpreter; 29 ms against 40 ms).  Measured on MI355X:
+//    vector and scalar instructions of a SIMD's waves do NOT overlap for this kind of code -- time = (VALU + SALU + LDS
+//    instructions) x 4 cycles per SIMD -- so the kernel is written for total instruction count: 12 multiply-adds per record,
+//    everything else amortised (details at the kernel).
+//  * quotient_eval_kernel (ctx option "quotient_impl" = 1): the op-stream interpreter of round 1, one global load per op.
+//    Kept as the second implementation the tests cross-check the first against on the GPU.
+//
+// Interpreter: the AIR arrives as the op stream of quotient_ops.h (the flat program of air_ir.h in 16-byte ops).
 // One lane owns one coset point; ops are wave-uniform and are fetched four at a time with one scalar load.
 //
 // Memory: a chunk of the FinalExp program touches each trace column ~15 times, a few hundred ops apart --
@@ -329,10 +341,10 @@ __device__ __forceinline__ gl_t qt_fold_sums(const uint64_t (&S)[6]) {
     return r + ((uint64_t)t << 32);
 }
 
-template <bool SMALL_N>
+template <bool SMALL_N, unsigned DBG>
 __global__ __launch_bounds__(64 * (QT_WAVES + 1)) void quotient_tiles_kernel(QTParams P) {
     __shared__ gl_t tile[2][QT_TILE_COLS * QT_TILE_ROWS];
-    __shared__ uint32_t rec_ring[QT_WAVES][1][64][4];  // per evaluating wave: two blocks of 16 records (32 x 16 bytes each)
+    __shared__ uint32_t rec_ring[QT_WAVES][3][32][4];  // per evaluating wave: three blocks of 16 records (32 x 16 bytes each)
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 .. QT_WAVES - 1 evaluate, QT_WAVES stages the tiles
     const unsigned lane = threadIdx.x & 63u;
     const size_t n = (size_t)1 << P.log_n, size = n << P.qdb;
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1)) void quotient_tiles_kernel(QTP
         const uint32_t boff_next_last = __builtin_amdgcn_readlane(boff_next, 63);  // successor of the block's last point: row 64
         const uint32_t boff_block = __builtin_amdgcn_readfirstlane(boff_local);    // !SMALL_N: the 64 points are 512 contiguous bytes
         for (unsigned ti = 0; ti <= n_tiles; ti++) {
-            if (ti < n_tiles && P.dbg != 1) {
+            if (ti < n_tiles && !(DBG & 1u)) {
                 const uint32_t c0 = tiles[ti] * QT_TILE_COLS;
                 gl_t* dst = tile[ti & 1u];
                 const uint32_t ecol = c0 + lane;  // row 64: one lane per column
@@ -417,19 +429,32 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1)) void quotient_tiles_kernel(QTP
     typedef const __attribute__((address_space(1))) u32x4* GlobalQuad;  // global address space: plain global_load, not flat
     u32x4* const ring = (u32x4*)&rec_ring[wave][0][0][0];
     const char* const rec_base = (const char*)(P.recs + stream.rec_off);
-    auto ring_fill = [&](unsigned block) {  // records 16 block .. 16 block + 15 -> ring slot (block & 1)
-        if (lane < 32)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rec_base + (size_t)block * 512u + lane * 16u),
-                                             (__attribute__((address_space(3))) void*)(ring + (block & 1u) * 32u), 16, 0, 0);
+    // The refill is issued from inline asm: once hipcc sees an LDS-DMA builtin in the loop it waits lgkmcnt(0) / vmcnt(0) at
+    // every LDS read (the DMA may alias any of them), i.e. one full LDS round trip per record.  Its completion is waited for
+    // explicitly (QT_STEP); hipcc's own vmcnt counts only over-wait because of the extra operation (returns are in order).
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;  // LDS byte address of this wave's ring
+    auto ring_fill = [&](unsigned block, unsigned slot) {  // records 16 block .. 16 block + 15 -> ring slot (= block % 3)
+        if (lane < 32) {
+            const char* src = rec_base + (size_t)block * 512u + lane * 16u;
+            const uint32_t dst = ring_lds + slot * 512u;
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src), "s"(dst)
+                         : "memory");
+        }
     };
     struct Rec {
         u32x4 a, b;  // {ctl, aux, w0[0], w0[1]}, {w0[2], w1[0], w1[1], w1[2]}
     };
-    auto ring_read = [&](unsigned g, Rec& r) {
-        const u32x4* q = ring + (g & 31u) * 2u;
+    // a record's ring position: byte offset `base` of its group of four + 32 * (index in the group); groups never straddle
+    // the ring's end (48 records)
+    auto ring_read = [&](uint32_t base, unsigned i, Rec& r) {
+        const u32x4* q = (const u32x4*)((const char*)ring + base) + i * 2u;
         r.a = q[0];
         r.b = q[1];
     };
+    auto ring_read_ctl = [&](uint32_t base, unsigned i) -> uint32_t { return *(const uint32_t*)((const char*)ring + base + i * 32u); };
     uint64_t pc_addr = (uint64_t)(P.pieces + stream.piece_off);
     asm volatile("" : "+v"(pc_addr));  // formally divergent: the descriptor is fetched with a vector load (VM counter)
 
@@ -455,71 +480,94 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1)) void quotient_tiles_kernel(QTP
                 gate[g] = direct(ref & REF_COL_MASK, ref & REF_NEXT);
             }
     };
-    ring_fill(0);
-    ring_fill(1);
+    ring_fill(0, 0);
+    ring_fill(1, 1);
     gates_request();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // record pipeline: R[(g + 2) & 3] is read from the ring while the cell of record g + 1 is on its way and record g is evaluated
-    Rec R0, R1, R2, R3;
-    ring_read(0, R0);
-    ring_read(1, R1);
-    unsigned g = 0;  // index of the record being evaluated
-    uint32_t ctl_cur = __builtin_amdgcn_readfirstlane(R0.a.x);
+    // Record pipeline.  While record g is evaluated (slot U = g % 4 of the unrolled loop):
+    //   the control word of record g + 4 is requested from the ring                        (used two steps later)
+    //   the control word of record g + 2, requested two steps ago, goes to a scalar register; with it the cell of record
+    //   g + 2 and the whole record g + 2 (weights) are requested                           (used two steps later)
+    // so nothing a step needs was requested less than two steps (~100+ instructions) before: no LDS round trip is exposed.
+    Rec W0, W1, W2, W3;            // records g .. g + 2 (weights)
+    uint32_t cv0, cv1, cv2, cv3;   // control words as read from the ring (vector registers), records g + 2 .. g + 4
+    uint32_t sc0, sc1, sc2, sc3;   // control words in scalar registers, records g .. g + 2
+    gl_t x0, x1, x2 = 0, x3 = 0;   // cells of records g .. g + 2
+    unsigned g = 0;                // index of the record being evaluated, a multiple of four at the top of the loop
+    uint32_t b0 = 0, b1 = 128;     // ring offsets of the groups of four that hold records g and g + 4
+    unsigned next_block = 2, next_slot = 2;
+    ring_read(b0, 0, W0);
+    ring_read(b0, 1, W1);
+    cv2 = ring_read_ctl(b0, 2);
+    cv3 = ring_read_ctl(b0, 3);
+    sc0 = __builtin_amdgcn_readfirstlane(W0.a.x);
+    sc1 = __builtin_amdgcn_readfirstlane(W1.a.x);
+    sc2 = sc3 = 0;
+    cv0 = cv1 = 0;
+    W2 = W0;
+    W3 = W0;
     asm volatile("s_barrier" ::: "memory");  // tile 0 is staged
 
-    const char* cur = (const char*)tile[0];
-    auto lds_read = [&](uint32_t ctl) -> gl_t {
-        uint32_t a = (ctl & QT_OFF_MASK) + lds_local;
-        if (SMALL_N) a = (ctl & QT_OFF_MASK) + ((ctl & QT_NEXT) ? lds_next : lds_local);
-        return *(const gl_t*)(cur + a);
+    uint32_t lds_cur = lds_local;  // this lane's row in the tile buffer in use (byte offset from tile[0])
+    // `c` may be the control word as it came from the ring (a vector register): offset = low half, one add
+    auto lds_read = [&](uint32_t c, gl_t& x) {
+        uint32_t a = (c & QT_OFF_MASK) + lds_cur;
+        if (SMALL_N) a = (c & QT_OFF_MASK) + ((c & QT_NEXT) ? lds_cur - lds_local + lds_next : lds_cur);
+        x = *(const gl_t*)((const char*)tile[0] + a);
     };
-    gl_t xa = lds_read(ctl_cur), xb = 0;
+    lds_read(sc0, x0);
+    lds_read(sc1, x1);
     unsigned ti = 0;
-    bool stop = n_tiles == 0;
-    // one step: fetch record g + 2, request the cell of record g + 1, evaluate record g
-#define QT_STEP(CUR, NXT, FAR, XC, XN)                                                                                \
-    if (!stop) {                                                                                                      \
-        if (((g + 2u) & 15u) == 0) { /* the read-ahead enters a new block: it has landed; refill the slot left behind. */ \
-            /* lgkmcnt(0): the reads of that slot's last records have RETURNED -- a ds_read still queued behind other */ \
-            /* waves' LDS traffic would otherwise see the refill (which can land within ~100 cycles from L1)        */ \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
-            ring_fill(((g + 2u) >> 4) + 1u);                                                                          \
+    // U: slot; (CV4, B4, I4): where the control word of record g + 4 goes / comes from; CV2: control word of g + 2 (vector);
+    // (SC, W, X): scalar control word, weights, cell of record g; (SC1, X1): of record g + 1; (SC2, W2, X2, BW2, IW2): of record g + 2
+#define QT_STEP(U, CV4, I4, CV2, SC, W, X, SC1, X1, SC2, WW2, X2, BW2, IW2)                                           \
+    {                                                                                                                 \
+        if ((U) == 0) {                                                                                               \
+            if (__builtin_expect(((g + 4u) & 15u) == 0, 0)) {                                                         \
+                /* the read-ahead enters a new block: it has landed (requested 16 records ago); refill the slot the   */ \
+                /* readers left longest ago.  lgkmcnt(0): every read of that slot has RETURNED -- a ds_read still     */ \
+                /* queued behind other waves' LDS traffic would otherwise see the refill                              */ \
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
+                ring_fill(next_block, next_slot);                                                                     \
+                next_block++;                                                                                         \
+                next_slot = next_slot == 2 ? 0 : next_slot + 1;                                                       \
+            }                                                                                                         \
         }                                                                                                             \
-        ring_read(g + 2u, FAR);                                                                                       \
-        const uint32_t ctl = ctl_cur;                                                                                 \
-        ctl_cur = __builtin_amdgcn_readfirstlane(NXT.a.x);                                                            \
-        XN = lds_read(ctl_cur);                                                                                       \
-        gl_t x = XC;                                                                                                  \
-        bool accumulate = true;                                                                                       \
-        if (ctl & QT_SPECIAL) {                                                                                       \
+        CV4 = ring_read_ctl(b1, I4);                                                                                  \
+        SC2 = __builtin_amdgcn_readfirstlane(CV2);                                                                    \
+        lds_read(CV2, X2);                                                                                            \
+        ring_read(BW2, IW2, WW2);                                                                                     \
+        const uint32_t ctl = SC;                                                                                      \
+        gl_t x = X;                                                                                                   \
+        if (__builtin_expect((ctl & QT_ODD_SOURCE) != 0, 0)) {                                                        \
             if (ctl & (QT_TILE | QT_STOP)) {                                                                          \
-                accumulate = false;                                                                                   \
                 /* every LDS read of this tile has returned; the gate loads of the next piece stay in flight */       \
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \
                 ti++;                                                                                                 \
-                stop = (ctl & QT_STOP) != 0 || ti >= n_tiles;                                                         \
-                cur = (const char*)tile[ti & 1u];                                                                     \
-                XN = lds_read(ctl_cur); /* the cell of the next record lives in the new tile */                       \
-            } else {                                                                                                  \
-                if (ctl & QT_SRC_ONE) x = 1;                                                                          \
-                if (ctl & QT_SRC_GLOBAL) x = direct(__builtin_amdgcn_readfirstlane(CUR.a.y), ctl & QT_NEXT);          \
-                if (ctl & QT_MULV) x = gl_mul_nc(v, x);                                                               \
-                if (ctl & QT_SETV) {                                                                                  \
-                    v = x;                                                                                            \
-                    accumulate = false;                                                                               \
-                }                                                                                                     \
+                if ((ctl & QT_STOP) != 0 || ti >= n_tiles) goto stream_done;                                          \
+                lds_cur = lds_local + (ti & 1u) * (uint32_t)(QT_TILE_COLS * QT_TILE_ROWS * sizeof(gl_t));             \
+                lds_read(SC1, X1); /* the cells of the next two records live in the new tile */                       \
+                lds_read(SC2, X2);                                                                                    \
+                goto next_##U;                                                                                        \
+            }                                                                                                         \
+            if (ctl & QT_SRC_ONE) x = 1;                                                                              \
+            if (ctl & QT_SRC_GLOBAL) x = direct(__builtin_amdgcn_readfirstlane(W.a.y), ctl & QT_NEXT);                \
+            if (ctl & QT_MULV) x = gl_mul_nc(v, x);                                                                   \
+            if (ctl & QT_SETV) {                                                                                      \
+                v = x;                                                                                                \
+                goto next_##U;                                                                                        \
             }                                                                                                         \
         }                                                                                                             \
-        if (accumulate && P.dbg != 2) {                                                                               \
-            const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);                                                \
-            const uint32_t w0[3] = {CUR.a.z, CUR.a.w, CUR.b.x}, w1[3] = {CUR.b.y, CUR.b.z, CUR.b.w};                  \
+        if (!(DBG & 2u)) {                                                                                            \
+            const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);                                                \
+            const uint32_t w0[3] = {W.a.z, W.a.w, W.b.x}, w1[3] = {W.b.y, W.b.z, W.b.w};                              \
             _Pragma("unroll") for (int l = 0; l < 3; l++) {                                                           \
-                S0[l] += (uint64_t)x0 * w0[l];                                                                        \
-                S0[3 + l] += (uint64_t)x1 * w0[l];                                                                    \
-                S1[l] += (uint64_t)x0 * w1[l];                                                                        \
-                S1[3 + l] += (uint64_t)x1 * w1[l];                                                                    \
+                S0[l] += (uint64_t)xl * w0[l];                                                                        \
+                S0[3 + l] += (uint64_t)xh * w0[l];                                                                    \
+                S1[l] += (uint64_t)xl * w1[l];                                                                        \
+                S1[3 + l] += (uint64_t)xh * w1[l];                                                                    \
             }                                                                                                         \
-            if (ctl & QT_END) {                                                                                       \
+            if (__builtin_expect((ctl & QT_END) != 0, 0) && !(DBG & 4u)) {                                            \
                 const uint32_t kind = piece_ctl & 3u, ng = (piece_ctl >> 2) & 7u, cm = piece_ctl >> 5;                \
                 gl_t G = kind == KIND_PLAIN ? (gl_t)1 : kind == KIND_TRANSITION ? mask_tr : kind == KIND_FIRST ? mask_first : mask_last; \
                 _Pragma("unroll") for (unsigned q = 0; q < 4; q++) if (q < ng) {                                      \
@@ -534,14 +582,20 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1)) void quotient_tiles_kernel(QTP
                 gates_request();                                                                                      \
             }                                                                                                         \
         }                                                                                                             \
+    next_##U:                                                                                                         \
         g++;                                                                                                          \
     }
-    while (!stop) {
-        QT_STEP(R0, R1, R2, xa, xb)
-        QT_STEP(R1, R2, R3, xb, xa)
-        QT_STEP(R2, R3, R0, xa, xb)
-        QT_STEP(R3, R0, R1, xb, xa)
-    }
+    if (n_tiles)
+        for (;;) {
+            //       U  CV4  I4 CV2  SC   W   X   SC1  X1  SC2  WW2 X2  BW2 IW2
+            QT_STEP(0, cv0, 0, cv2, sc0, W0, x0, sc1, x1, sc2, W2, x2, b0, 2)
+            QT_STEP(1, cv1, 1, cv3, sc1, W1, x1, sc2, x2, sc3, W3, x3, b0, 3)
+            QT_STEP(2, cv2, 2, cv0, sc2, W2, x2, sc3, x3, sc0, W0, x0, b1, 0)
+            QT_STEP(3, cv3, 3, cv1, sc3, W3, x3, sc0, x0, sc1, W1, x1, b1, 1)
+            b0 = b1;
+            b1 = b1 == 1408 ? 0 : b1 + 128;
+        }
+stream_done:
 #undef QT_STEP
     // waves whose stream ended before the chunk's last tile (never by construction) would desynchronise the barrier count
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -627,10 +681,17 @@ hipError_t launch_quotient_tiles(const QTRec* recs, const QTPiece* pieces, const
     P.lde = lde; P.tab = tab; P.partial = partial; P.log_n = log_n; P.rate_bits = rate_bits; P.qdb = qdb; P.n_cols = n_cols;
     const size_t size = (size_t)1 << (log_n + qdb);
     const dim3 grid((unsigned)((size + 63) / 64), n_chunks), block(64 * (QT_WAVES + 1));
-    if (log_n < 6 || size < 64)
-        hipLaunchKernelGGL(quotient_tiles_kernel<true>, grid, block, 0, st, P);
-    else
-        hipLaunchKernelGGL(quotient_tiles_kernel<false>, grid, block, 0, st, P);
+    const bool small = log_n < 6 || size < 64;
+    switch (dbg) {  // 1..4: profiling variants with parts switched off (1 tile loads, 2 arithmetic, 3 both, 4 piece ends)
+        case 0:
+            if (small) hipLaunchKernelGGL((quotient_tiles_kernel<true, 0>), grid, block, 0, st, P);
+            else hipLaunchKernelGGL((quotient_tiles_kernel<false, 0>), grid, block, 0, st, P);
+            break;
+        case 1: hipLaunchKernelGGL((quotient_tiles_kernel<false, 1>), grid, block, 0, st, P); break;
+        case 2: hipLaunchKernelGGL((quotient_tiles_kernel<false, 2>), grid, block, 0, st, P); break;
+        case 3: hipLaunchKernelGGL((quotient_tiles_kernel<false, 3>), grid, block, 0, st, P); break;
+        default: hipLaunchKernelGGL((quotient_tiles_kernel<false, 4>), grid, block, 0, st, P); break;
+    }
     return hipGetLastError();
 }
 

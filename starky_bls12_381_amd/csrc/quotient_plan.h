@@ -38,7 +38,7 @@ static const unsigned QT_TILE_COLS = 64;    // columns per LDS tile
 static const unsigned QT_TILE_ROWS = 66;    // 64 points + the successor of the last one (next-row reads are "lane + 1") + 8 bytes so
                                             // that every column starts on a 16-byte boundary (direct-to-LDS loads write 16 bytes per lane)
 static const unsigned QT_WAVES = 7;         // evaluating waves per workgroup (an eighth wave stages the tiles)
-static const unsigned QT_MAX_PIECE = 96;    // records per piece after splitting (accumulators overflow beyond 1024)
+static const unsigned QT_MAX_PIECE = 192;   // records per piece after splitting (the 64-bit sums hold 1024 products of 54 bits)
 static const unsigned QT_LIMB_BITS = 22;    // weights are split into three limbs of 22 bits
 
 // record control word
@@ -53,7 +53,8 @@ enum : uint32_t {
     QT_END = 1u << 21,         // last record of its piece: acc_j += mask * G * T_j, next piece descriptor
     QT_TILE = 1u << 22,        // no cell: the wave is done with this tile (barrier, next tile)
     QT_STOP = 1u << 23,        // end of stream
-    QT_SPECIAL = QT_SRC_ONE | QT_SRC_GLOBAL | QT_SETV | QT_MULV | QT_END | QT_TILE | QT_STOP
+    QT_SPECIAL = QT_SRC_ONE | QT_SRC_GLOBAL | QT_SETV | QT_MULV | QT_END | QT_TILE | QT_STOP,
+    QT_ODD_SOURCE = QT_SRC_ONE | QT_SRC_GLOBAL | QT_SETV | QT_MULV | QT_TILE | QT_STOP
 };
 
 struct QTRec {
@@ -92,7 +93,7 @@ struct QTPlan {
     std::vector<QTContrib> contribs;
     // statistics
     size_t n_supergroups = 0, n_pieces = 0, n_cell_records = 0, n_direct_loads = 0;
-    uint64_t cost_sum_max = 0, cost_sum_mean = 0;  // per tile: the busiest wave's cost / the mean over the waves (model units)
+    uint64_t cost_sum_max = 0, cost_sum_mean = 0, rec_sum_max = 0, rec_sum_total = 0, tile_phases = 0;  // per tile: the busiest wave's cost / the mean over the waves (model units)
 };
 
 namespace qt_detail {
@@ -321,6 +322,15 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
             }
             Q.cost_sum_max += mx;
             Q.cost_sum_mean += sum / QT_WAVES;
+            uint64_t rmx = 0;
+            for (unsigned w = 0; w < QT_WAVES; w++) {
+                uint64_t r = 0;
+                for (uint32_t p : assign[t - t_lo][w]) r += (pieces[p].cost - PIECE_COST) / REC_COST;
+                rmx = std::max(rmx, r);
+                Q.rec_sum_total += r;
+            }
+            Q.rec_sum_max += rmx;
+            Q.tile_phases++;
         }
         for (unsigned w = 0; w < QT_WAVES; w++) {
             Q.streams.push_back({(uint32_t)Q.recs.size(), (uint32_t)Q.pieces.size()});

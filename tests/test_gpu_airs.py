@@ -245,3 +245,28 @@ def test_one_compact_trace_is_proven_by_several_contexts_at_once_and_recorded_on
     for k in range(4):
         for i in range(4):
             assert np.array_equal(got[k][i], want[i]), (k, i)
+
+
+def test_both_constraint_evaluators_give_the_same_proof():
+    """The tiled evaluator (default: quotient_plan.h, LDS-staged column tiles) and the op-stream interpreter are two
+    independent device implementations of the same fold; proofs from either must be identical bytes, for a 1024-row AIR
+    with several chunkings and for the small-domain path (FP12Mul: 32 points, less than a wave)."""
+    from bls_util import fp_arr, random_fp12
+    b = _bls()
+    cases = [(S.AIR_PAIRING_PRECOMP, S.trace_pairing_precomp(fp_arr(b["hm_x1"], b["hm_x2"]), fp_arr(b["hm_y1"], b["hm_y2"]),
+                                                              fp_arr(b["hm_z1"], b["hm_z2"]))),
+             (S.AIR_FP12_MUL, S.trace_fp12_mul(random_fp12(7), random_fp12(8)))]
+    pv = S.Prover(0)
+    try:
+        for air, (t, pis) in cases:
+            cfg = S.StarkConfig.for_air(air)
+            pv.set_option("quotient_impl", 1)
+            ref = pv.prove(air, cfg, t, pis)
+            pv.set_option("quotient_impl", 0)
+            for chunks in (0, 1, 5):
+                pv.set_option("quotient_chunks", chunks)
+                assert np.array_equal(pv.prove(air, cfg, t, pis), ref), (S.AIR_NAMES[air], chunks)
+        with pytest.raises(S.StarkhipError):
+            pv.set_option("no_such_option", 1)
+    finally:
+        pv.close()

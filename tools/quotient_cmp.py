@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development aid: prove PairingPrecomp (or --air) with the interpreter and let the prover compare the tiled evaluator's
-values with it point by point (ctx option quotient_debug = 3; mismatches are printed on stderr)."""
+values with it point by point (ctx option quotient_debug = 9; mismatches are printed on stderr)."""
 import os
 import sys
 
@@ -28,5 +28,5 @@ cfg = S.StarkConfig.for_air(air)
 pv = S.Prover(0)
 pv.set_option("quotient_impl", 1)
 pv.set_option("quotient_chunks", chunks)
-pv.set_option("quotient_debug", 3)
+pv.set_option("quotient_debug", 9)
 pv.prove(air, cfg, t, pis)
