@@ -2,16 +2,25 @@
 """Benchmark: starky proofs/s for FinalExponentiateStark (73527 columns x 8192 rows) on N MI355X.
 
 A "step" is one full prove() of one FinalExp trace whose column-major u64[C][n] values are already
-resident in HBM (BASELINE.json configs[2]).  Each rank proves its own independent proof (the six proofs
+resident in HBM (BASELINE.json configs[2]).  Each rank proves its own independent proofs (the six proofs
 of a signature verification shard at proof granularity): weak scaling, no data-path
 collective; torch.distributed is used only for the barrier and the max-over-ranks time.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+Prints ONE JSON line on rank 0.  What is measured where (DESIGN.md §6 has every field):
+
+  value / ms_per_step     the timed region: `--inflight` contexts per GPU, each with its OWN trace resident in HBM
+  roofline, kernels       an untimed pass with ONE proof in flight on rank 0 (uncontended HIP-event durations of the three
+                          heavy kernels, the figures the committed rocprof summaries under profiles/ must agree with);
+                          HBM-side traffic per launch from profiles/pmc_traffic_latest.json
+  value_host_boundary     rank 0, untimed: host rows in page-locked memory -> H2D -> transpose -> proof (the boundary the
+                          reference has), two in flight;  value_compact: the same from recorded (compact) traces
+  cpu_baseline            rank 0 at N = 1: the CPU oracle on a bounded sample of the same workload
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -19,8 +28,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4  # wave-instructions/ns: one 4-cycle integer VALU instruction per SIMD (measured, tools/valu_rate_bench.hip)
-POSEIDON_QUAD_INSTRS = 8 * 261 + 7 * 309 + 152  # VALU instructions of one permutation in the 4-lane form (ISA of poseidon_dev.h: 8 full rounds, 7 merged triples of partial rounds, 1 single partial round)
+# wave-instructions per ns: one integer VALU instruction per SIMD every 4 cycles (measured: tools/valu_rate_bench.hip,
+# profiles/r02_valu_rates.txt); 256 CUs x 4 SIMDs x 2.4 GHz / 4
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
+# VALU instructions of one permutation in the 4-lane form (ISA of poseidon_dev.h: 8 full rounds, 7 merged triples of
+# partial rounds, 1 single partial round)
+POSEIDON_QUAD_INSTRS = 8 * 261 + 7 * 309 + 152
+KERNELS = ("lde_columns", "leaf_hash", "quotient_eval")
+PMC_NAMES = {"lde_columns": ("lde_columns_v2_kernel",), "leaf_hash": ("leaf_hash_kernel",),
+             "quotient_eval": ("quotient_tiles_kernel", "quotient_eval_kernel")}
 
 
 def synthetic_final_exp_input(seed):
@@ -29,7 +45,7 @@ def synthetic_final_exp_input(seed):
     return random_fp12(seed)
 
 
-def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=1024, budget_points=256):
+def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=4096, budget_points=1024):
     """Time the CPU oracle on a bounded slice of the same workload and scale to one whole proof.
 
     LDE + Merkle leaf hashing run on `budget_cols` of the C columns (cost linear in C); the constraint
@@ -47,6 +63,7 @@ def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=1024, bud
     t0 = time.time()
     O.merkle_cap(lde_rows, 4)
     t_hash = time.time() - t0
+    del lde_rows
     rows = rng.integers(0, S.P, size=(budget_points + 1, n_cols), dtype=np.uint64)
     pis = np.zeros(S.air_public_inputs(S.AIR_FINAL_EXP), dtype=np.uint64)
     t0 = time.time()
@@ -54,12 +71,43 @@ def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=1024, bud
     t_q = time.time() - t0
     scale_c = n_cols / budget_cols
     total = t_lde * scale_c + t_hash * scale_c + t_q * (N / budget_points)
+    full = ""
+    try:
+        full = " A whole FinalExp oracle proof was timed once: " + open(os.path.join(ROOT, "profiles", "r01_oracle_full_final_exp.txt")).readline().strip() + "."
+    except OSError:
+        pass
     return {
         "value": 1.0 / total, "unit": "proofs/s", "cores": int(O.lib.oracle_num_threads()), "kind": "port",
-        "sample": (f"CPU oracle (OpenMP C restatement, not the reference's Rust): LDE+leaf-hash on {budget_cols}/{n_cols} columns x {n} rows, "
-                   f"constraint evaluation on {budget_points}/{N} coset points; scaled linearly to one proof "
-                   f"(lde {t_lde * scale_c:.1f}s + hash {t_hash * scale_c:.1f}s + quotient {t_q * N / budget_points:.1f}s); openings/FRI omitted"),
+        "sample": (f"CPU oracle (OpenMP C restatement, not the reference's Rust), {t_lde + t_hash + t_q:.1f} s of work: LDE + leaf hash on "
+                   f"{budget_cols}/{n_cols} columns x {n} rows, constraint evaluation on {budget_points}/{N} coset points; scaled linearly "
+                   f"to one proof (lde {t_lde * scale_c:.1f} s + hash {t_hash * scale_c:.1f} s + quotient {t_q * N / budget_points:.1f} s); "
+                   f"openings / FRI omitted." + full),
     }
+
+
+def run_in_flight(provers, jobs):
+    """Run the callables of `jobs` on the contexts of `provers` (one host thread per context); returns the wall time."""
+    lock = threading.Lock()
+    todo = list(jobs)
+
+    def worker(pv):
+        while True:
+            with lock:
+                if not todo:
+                    return
+                job = todo.pop()
+            job(pv)
+
+    t0 = time.perf_counter()
+    if len(provers) == 1:
+        worker(provers[0])
+    else:
+        threads = [threading.Thread(target=worker, args=(pv,)) for pv in provers]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -68,10 +116,11 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the untimed host-boundary / compact-trace legs")
     ap.add_argument("--inflight", type=int, default=4,
                     help="proofs in flight per GPU (independent contexts on separate host threads and HIP streams); "
                          "1 = one proof at a time (latency); the default hides the host-side Fiat-Shamir hashing and the launch gaps of "
-                         "each proof behind the kernels of the others (measured: 1: 3.7, 2: 4.5, 3: 5.0, 4: 5.1 proofs/s)")
+                         "each proof behind the kernels of the others")
     args = ap.parse_args()
 
     import numpy as np
@@ -99,96 +148,98 @@ def main():
     log_n = n.bit_length() - 1
     N = n << cfg.rate_bits
 
-    # synthetic input, different per rank; trace generated on the host (the reference's generate_trace side),
-    # moved to HBM as column-major u64 (as int64 bit patterns) before the timed region
-    x = synthetic_final_exp_input(0x5EED0000 + 1 + rank)
-    trace, pis = S.trace_final_exp(x)
-    d_rows = torch.from_numpy(trace.view(np.int64)).to(f"cuda:{local_rank}")
-    del trace
-    d_cols = d_rows.t().contiguous()  # trace_rows_to_poly_values
-    del d_rows
-    torch.cuda.synchronize()
-    import threading
+    # synthetic inputs, a different one per rank AND per context; traces generated on the host (the reference's generate_trace
+    # side), moved to HBM as column-major u64 (as int64 bit patterns) before the timed region
     inflight = max(1, args.inflight)
     provers = [S.Prover(local_rank) for _ in range(inflight)]
-    prover = provers[0]
+    work = {}
+    host_rows = provers[0].host_array((n, C))  # page-locked, reused for every generated trace
+    for i, pv in enumerate(provers):
+        x = synthetic_final_exp_input(0x5EED0000 + 1 + rank * inflight + i)
+        _, pis = S.trace_final_exp(x, out=host_rows)
+        d_rows = torch.from_numpy(host_rows.view(np.int64)).to(f"cuda:{local_rank}")
+        work[pv] = (d_rows.t().contiguous(), pis, x)  # trace_rows_to_poly_values
+        del d_rows
+    torch.cuda.synchronize()
 
     def step(pv, keep=False):
+        d_cols, pis, _ = work[pv]
         return pv.prove_device(air, cfg, d_cols.data_ptr(), n, pis, layout=1, keep=keep)
 
-    proof = None
     for w in range(args.warmup):
         for i, pv in enumerate(provers):
             pr = step(pv, keep=(w == 0 and i == 0))
-            proof = pr if pr is not None else proof
-    if proof is not None and rank == 0:
-        S.verify_stark_proof(air, cfg, proof)  # untimed: the product's CPU verifier accepts what we time
+            if pr is not None and rank == 0:
+                S.verify_stark_proof(air, cfg, pr)  # untimed: the product's CPU verifier accepts what we time
     phase_ms = {k: 0.0 for k in S.PHASE_NAMES}
-    kern_ms = {"lde_columns": 0.0, "leaf_hash": 0.0, "quotient_eval": 0.0}
     lock = threading.Lock()
-    todo = list(range(args.steps))
 
-    def worker(pv):
-        while True:
-            with lock:
-                if not todo:
-                    return
-                todo.pop()
-            step(pv)
-            tm, km = pv.last_timings(), pv.last_kernel_timings()
-            with lock:
-                for k, v in tm.items():
-                    phase_ms[k] += v
-                for k, v in km.items():
-                    kern_ms[k] += v
+    def timed_job(pv):
+        step(pv)
+        tm = pv.last_timings()
+        with lock:
+            for k, v in tm.items():
+                phase_ms[k] += v
 
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    if inflight == 1:
-        worker(prover)
-    else:
-        threads = [threading.Thread(target=worker, args=(pv,)) for pv in provers]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+    run_in_flight(provers, [timed_job] * args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = parallel.max_over_ranks(dist, elapsed, device=reduce_device)
 
-    # untimed: the same kernels with the GPU to themselves (one proof in flight), for the uncontended roofline numbers
-    solo_ms = {"lde_columns": 0.0, "leaf_hash": 0.0, "quotient_eval": 0.0}
-    solo_phase = {k: 0.0 for k in S.PHASE_NAMES}
-    n_solo = 2 if (rank == 0 and inflight > 1) else 0
-    for _ in range(n_solo):
-        step(prover)
-        for k, v in prover.last_kernel_timings().items():
-            solo_ms[k] += v / n_solo
-        for k, v in prover.last_timings().items():
-            solo_phase[k] += v / n_solo
-
     if rank == 0:
         steps = max(1, args.steps)
-        phase_ms = {k: v / steps for k, v in phase_ms.items()}
-        kern_ms = {k: v / steps for k, v in kern_ms.items()}
+        # ---- untimed: the same proof with the GPU to itself (one in flight): uncontended kernel and phase durations
+        solo_ms = {k: 0.0 for k in KERNELS}
+        solo_phase = {k: 0.0 for k in S.PHASE_NAMES}
+        n_solo = 3
+        t_solo = time.perf_counter()
+        for _ in range(n_solo):
+            step(provers[0])
+            for k, v in provers[0].last_kernel_timings().items():
+                solo_ms[k] += v / n_solo
+            for k, v in provers[0].last_timings().items():
+                solo_phase[k] += v / n_solo
+        t_solo = (time.perf_counter() - t_solo) / n_solo
         # algorithmic bytes per launch: u64 cells, dense, minimum traffic of the decomposition
         alg = {"lde_columns": 8.0 * C * (n + n + N),  # read values, write coeffs + LDE (IFFT and LDE fused in one kernel)
                "leaf_hash": 8.0 * C * N,              # read the LDE once
                "quotient_eval": 8.0 * C * N}          # read the LDE on the quotient coset once
-        dominant = max(kern_ms, key=kern_ms.get)
         # HBM-side bytes per launch from the committed PMC passes (bench.py cannot collect counters itself)
-        traffic, traffic_src = None, None
+        pmc, pmc_src = {}, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-            key = {"lde_columns": "lde_columns_v2_kernel", "leaf_hash": "leaf_hash_kernel", "quotient_eval": "quotient_eval_kernel"}[dominant]
-            traffic, traffic_src = pmc[key]["traffic_bytes"], pmc["_source"]
+            raw = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+            pmc_src = raw.get("_source")
+            for k, names in PMC_NAMES.items():
+                for nm in names:
+                    if nm in raw:
+                        pmc[k] = raw[nm]["traffic_bytes"]
+                        break
         except Exception:
             pass
-        gbs = {k: alg[k] / (kern_ms[k] * 1e-3) / 1e9 if kern_ms[k] > 0 else 0.0 for k in alg}
+        kernels = {}
+        for k in KERNELS:
+            ms = solo_ms[k]
+            gbs = alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            kernels[k] = {"avg_ms": ms, "algorithmic_bytes": alg[k], "algorithmic_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                          "traffic_bytes": pmc.get(k), "traffic_over_algorithmic": (pmc[k] / alg[k]) if k in pmc else None}
+        dominant = max(KERNELS, key=lambda k: solo_ms[k])
+        # the leaf hash is bound by integer-VALU instruction issue, not by HBM: static instruction count of one quad
+        # permutation x permutations / 16 quads per wave, against one instruction per SIMD per 4 cycles
+        perms = (C + 7) // 8 * N
+        wave_instr = perms * POSEIDON_QUAD_INSTRS / 16.0
+        lh_ms = solo_ms["leaf_hash"]
+        valu = {"kernel": "leaf_hash_kernel", "wave_instructions": wave_instr,
+                "achieved_Ginstr_per_s": wave_instr / (lh_ms * 1e-3) / 1e9 if lh_ms > 0 else 0.0, "peak_Ginstr_per_s": VALU_PEAK_GINSTR,
+                "basis": "8 full rounds x 261 + 7 merged triples of partial rounds x 309 + 1 partial round x 152 VALU instructions per 4-lane "
+                         "permutation (ISA count); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per integer VALU instruction "
+                         "(tools/valu_rate_bench.hip, profiles/r02_valu_rates.txt)"}
+        valu["frac"] = valu["achieved_Ginstr_per_s"] / VALU_PEAK_GINSTR
         out = {
             "metric": "starky proofs/sec (FinalExponentiateStark 73527x8192)",
             "value": world * args.steps / elapsed,
@@ -199,30 +250,41 @@ def main():
             "dtype": "u64 (Goldilocks field)",
             "data": "synthetic" + (" -- REHEARSAL: all ranks on one GPU over gloo, not a measurement" if rehearse else ""),
             "config": {"workload": "FinalExponentiateStark 73527 cols x 8192 rows, rate_bits 2, 360800 constraints, "
-                                   "standard_fast_config (84 queries, 16 pow bits); one independent proof per GPU",
+                                   "standard_fast_config (84 queries, 16 pow bits); independent proofs, a different input per context and rank",
                        "parallelism": f"proof-parallel x{world}", "proofs_in_flight_per_gpu": inflight},
-            "roofline": {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": gbs[dominant], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs[dominant] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": kern_ms[dominant]},
-            "kernels": {k: {"avg_ms": kern_ms[k], "algorithmic_GBps": gbs[k], "hbm_frac": gbs[k] / HBM_PEAK_GBS} for k in alg},
-            "phase_ms": phase_ms,
-            "note": ("kernel and phase times above are HIP-event durations inside the timed region; with more than one proof in flight "
-                     "they include the time a kernel shares the CUs with the other proof's kernels. 'solo' repeats them with one proof in flight."),
+            "roofline": {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": kernels[dominant]["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": kernels[dominant]["hbm_frac"], "traffic": kernels[dominant]["traffic_bytes"],
+                         "traffic_source": pmc_src, "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": solo_ms[dominant],
+                         "durations": "one proof in flight (uncontended), HIP events on the library's stream, mean of 3 launches",
+                         "limiter": "integer VALU issue" if dominant == "leaf_hash" else "see kernels", "valu": valu if dominant == "leaf_hash" else None},
+            "kernels": kernels,
+            "latency_ms_one_in_flight": t_solo * 1e3,
+            "phase_ms_one_in_flight": solo_phase,
+            "phase_ms_timed_region": {k: v / steps for k, v in phase_ms.items()},
+            "note": ("roofline / kernels: durations with ONE proof in flight; phase_ms_timed_region: HIP-event phase durations inside the timed "
+                     "region, which include the time a kernel shares the CUs with the other contexts' kernels"),
             "reference_published": {"value": 1 / 92.0, "unit": "proofs/s", "hardware": "AWS r6a.8xlarge, 32-core EPYC 7R13 (reference README.md:39)"},
         }
-        if n_solo:
-            out["solo"] = {"kernels": {k: {"avg_ms": solo_ms[k], "algorithmic_GBps": alg[k] / (solo_ms[k] * 1e-3) / 1e9,
-                                           "hbm_frac": alg[k] / (solo_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS} for k in alg if solo_ms[k] > 0},
-                           "phase_ms": solo_phase}
-        # the leaf hash is VALU-issue bound, not HBM bound: static instruction count of one quad permutation x permutations / 16 quads per wave
-        perms = (C + 7) // 8 * N
-        wave_instr = perms * POSEIDON_QUAD_INSTRS / 16.0
-        lh_ms = (solo_ms["leaf_hash"] if n_solo else kern_ms["leaf_hash"])
-        if lh_ms > 0:
-            out["leaf_hash_valu"] = {"wave_instructions": wave_instr, "achieved_Ginstr_per_s": wave_instr / (lh_ms * 1e-3) / 1e9,
-                                     "peak_Ginstr_per_s": VALU_PEAK_GINSTR, "frac": wave_instr / (lh_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR,
-                                     "basis": "8 full rounds x 261 + 7 merged triples of partial rounds x 309 + 1 partial round x 152 VALU instructions per 4-lane permutation (ISA count); "
-                                              "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per integer VALU instruction (tools/valu_rate_bench.hip)"}
+        if not args.no_boundary and world == 1:  # per-GPU figures, taken at N = 1 (other ranks would wait in the teardown meanwhile)
+            # ---- untimed: the reference's own boundary (host rows in, proof out) and the compact-trace hand-over, two in flight
+            try:
+                nb = min(2, inflight)
+                x0 = work[provers[0]][2]
+                _, pis0 = S.trace_final_exp(x0, out=host_rows)
+                for pv in provers[:nb]:
+                    pv.prove(air, cfg, host_rows, pis0)  # warm-up: staging buffers
+                reps = 2 * nb + 2
+                t_host = run_in_flight(provers[:nb], [lambda pv: pv.prove(air, cfg, host_rows, pis0)] * reps)
+                compact, cpis = S.trace_final_exp(x0, compact=True)
+                for pv in provers[:nb]:
+                    pv.prove(air, cfg, compact, cpis)
+                t_comp = run_in_flight(provers[:nb], [lambda pv: pv.prove(air, cfg, compact, cpis)] * reps)
+                out["value_host_boundary"] = {"value": reps / t_host, "unit": "proofs/s per GPU", "in_flight": nb,
+                                              "what": "page-locked host rows (4.8 GB) -> H2D -> transpose -> proof -> D2H, end to end"}
+                out["value_compact"] = {"value": reps / t_comp, "unit": "proofs/s per GPU", "in_flight": nb,
+                                        "what": "recorded trace (153 MB of runs) -> upload -> expansion on the device -> proof -> D2H"}
+            except Exception as e:  # never lose the main line to an auxiliary leg
+                out["value_host_boundary"] = {"value": None, "error": str(e)}
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: other ranks would sit in the teardown barrier meanwhile
             try:
                 out["cpu_baseline"] = cpu_baseline_sample(S, S.air_program(air), C, log_n, cfg.rate_bits)

@@ -13,13 +13,17 @@ def main():
     res = {}
     for f, ctr in ((fdb, "FETCH_SIZE"), (wdb, "WRITE_SIZE")):
         cur = sqlite3.connect(f).cursor()
-        for k in ("leaf_hash_kernel", "quotient_eval_kernel", "lde_columns_v2_kernel"):
+        for k in ("leaf_hash_kernel", "quotient_tiles_kernel", "lde_columns_v2_kernel"):
             rows = list(cur.execute("select value, duration from counters_collection where kernel_name like ? and counter_name = ? order by duration desc",
                                     ("%" + k + "%", ctr)))
+            if not rows:
+                continue
             big = [r for r in rows if r[1] > 0.5 * rows[0][1]]
             res.setdefault(k, {})[ctr] = (sum(r[0] for r in big) / len(big), len(big), sum(r[1] for r in big) / len(big) / 1e6)
     out = {}
     for k, v in res.items():
+        if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+            continue
         fetch = v["FETCH_SIZE"][0] * 1024 * 2  # gfx950: 128-byte requests are tallied as 64 bytes
         write = v["WRITE_SIZE"][0] * 1024
         out[k] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "traffic_bytes": fetch + write, "fetch_size_raw_KB": v["FETCH_SIZE"][0],

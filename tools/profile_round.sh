@@ -1,27 +1,32 @@
 #!/bin/bash
-# How the files under profiles/ are produced (run on the GPU box from the repo root; outputs land in gpurun_out/):
+# How the files under profiles/ are produced (run on the GPU box from the repo root; outputs land in gpurun_out/ as
+# <tag>_*; copy the ones to be judged into profiles/):
 #   kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in separate PMC passes (never together with a trace),
-#   the SQ instruction counters, and the kernel-overlap figure of the default two-in-flight run.
+#   the SQ instruction counters, the kernel-overlap figure of the default four-in-flight run, the integer-VALU issue
+#   rates behind the "4 cycles per instruction" peak, and the default bench line.
 # rocprofv3 gets `python3 ...` directly after `--` (no wrapper that would exec after the GPU is initialised).
 set -e
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ONE="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --inflight 1"
-rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -o kt -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > $OUT/prof_kt.log 2>&1
+ONE="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-boundary --inflight 1"
+rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -o kt -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-boundary --inflight 1 > $OUT/prof_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_fetch -o fetch -- $ONE > $OUT/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/prof_write -o write -- $ONE > $OUT/prof_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_BUSY_CYCLES -d $OUT/prof_sq -o sq -- $ONE > $OUT/prof_sq.log 2>&1
-rocprofv3 --kernel-trace -d $OUT/prof_ov -o ov -- python3 $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline > $OUT/prof_ov.log 2>&1
+rocprofv3 --kernel-trace -d $OUT/prof_ov -o ov -- python3 $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-boundary > $OUT/prof_ov.log 2>&1
 cd $R
 db() { find $OUT/$1 -name "*results.db" | head -1; }
-python3 tools/rocprof_export.py stats $(db prof_kt) $OUT/kernel_stats.csv
-python3 tools/rocprof_export.py pmc $(db prof_fetch) $OUT/pmc_fetch_size.csv
-python3 tools/rocprof_export.py pmc $(db prof_write) $OUT/pmc_write_size.csv
-python3 tools/rocprof_export.py pmc $(db prof_sq) $OUT/pmc_sq_counters.csv
-python3 tools/pmc_traffic.py $(db prof_fetch) $(db prof_write) $OUT/pmc_traffic.json
-python3 tools/kernel_overlap.py $(db prof_ov) > $OUT/kernel_overlap.txt
-tail -1 $OUT/prof_kt.log > $OUT/bench_under_rocprof.json
+python3 tools/rocprof_export.py stats $(db prof_kt) $OUT/${TAG}_kernel_stats.csv
+python3 tools/rocprof_export.py pmc $(db prof_fetch) $OUT/${TAG}_pmc_fetch_size.csv
+python3 tools/rocprof_export.py pmc $(db prof_write) $OUT/${TAG}_pmc_write_size.csv
+python3 tools/rocprof_export.py pmc $(db prof_sq) $OUT/${TAG}_pmc_sq_counters.csv
+python3 tools/pmc_traffic.py $(db prof_fetch) $(db prof_write) $OUT/${TAG}_pmc_traffic.json
+python3 tools/kernel_overlap.py $(db prof_ov) > $OUT/${TAG}_kernel_overlap.txt
+tail -1 $OUT/prof_kt.log > $OUT/${TAG}_bench_under_rocprof.json
 rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq $OUT/prof_ov
-head -6 $OUT/kernel_stats.csv; cat $OUT/kernel_overlap.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rate_bench tools/valu_rate_bench.hip && /tmp/valu_rate_bench > $OUT/${TAG}_valu_rates.txt 2>&1 || true
+python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+head -8 $OUT/${TAG}_kernel_stats.csv; cat $OUT/${TAG}_kernel_overlap.txt; cat $OUT/${TAG}_pmc_traffic.json | head -40; tail -c 3000 $OUT/${TAG}_bench.json
