@@ -100,11 +100,47 @@ def signature_jobs(pk, hm, sig):
     return jobs, natives
 
 
-def signature_is_valid(natives):
-    """e(pk, H(m)) * e(-G, sig) == 1  <=>  final_exponentiate(ml1 * ml2) == 1 (src/native.rs:1522-1526)."""
+def signature_is_valid(natives, proofs=None):
+    """e(pk, H(m)) * e(-G, sig) == 1  <=>  final_exponentiate(ml1 * ml2) == 1 (src/native.rs:1522-1526).
+
+    With `proofs` (the six finished proofs) the verdict is read from what was PROVEN -- the output public inputs of the
+    final_exp proof, as the reference's recursion does (src/aggregate_proof.rs:590-598) -- and the host natives must agree
+    with it; without, it is the host natives' value only (a scheduling aid before anything is proven)."""
     one = np.zeros(144, dtype=np.uint32)
     one[0] = 1
-    return bool(np.array_equal(np.asarray(natives["final"], dtype=np.uint32), one))
+    native_ok = bool(np.array_equal(np.asarray(natives["final"], dtype=np.uint32), one))
+    if proofs is None:
+        return native_ok
+    fe = _pis(proofs, "final_exp")
+    if not np.array_equal(fe[144:288], np.asarray(natives["final"], dtype=np.uint64)):
+        raise ValueError("final_exp proof attests to a different value than the host natives computed")
+    return bool(np.array_equal(fe[144:288], one.astype(np.uint64)))
+
+
+def _pis(proofs, name):
+    air, proof, _ = proofs[name]
+    n = S.air_public_inputs(air)
+    return np.asarray(proof[-n:], dtype=np.uint64)
+
+
+def check_statement(proofs, hm, sig):
+    """The CONSTANT bindings the reference's recursive aggregation puts on the public inputs, besides the cross-proof links
+    of `check_links` (src/aggregate_proof.rs:507-520, 552-568, 576-581, 590-598): the first precompute ran on H(m) with
+    Z = (1, 0); the second on the signature point with Z = (1, 0); the second Miller loop's G1 operand is -G; the final
+    exponentiation's output is 1.  hm, sig: (x, y[, z]) Fp2 limb arrays of the points the statement is about.
+    Proofs that verify and link but attest to other points make this False."""
+    one = np.zeros(24, dtype=np.uint64)
+    one[0] = 1
+    pp1, pp2, ml2, fe = _pis(proofs, "pp1"), _pis(proofs, "pp2"), _pis(proofs, "ml2"), _pis(proofs, "final_exp")
+    ok = bool(np.array_equal(pp1[0:24], np.asarray(hm[0], dtype=np.uint64)) and np.array_equal(pp1[24:48], np.asarray(hm[1], dtype=np.uint64)))
+    ok &= bool(np.array_equal(pp1[48:72], one))
+    ok &= bool(np.array_equal(pp2[0:24], np.asarray(sig[0], dtype=np.uint64)) and np.array_equal(pp2[24:48], np.asarray(sig[1], dtype=np.uint64)))
+    ok &= bool(np.array_equal(pp2[48:72], one))
+    ok &= bool(np.array_equal(ml2[0:12], fp_limbs(NEG_G1_X).astype(np.uint64)) and np.array_equal(ml2[12:24], fp_limbs(NEG_G1_Y).astype(np.uint64)))
+    fe_one = np.zeros(144, dtype=np.uint64)
+    fe_one[0] = 1
+    ok &= bool(np.array_equal(fe[144:288], fe_one))
+    return ok
 
 
 def check_links(proofs):
@@ -112,9 +148,7 @@ def check_links(proofs):
     ell_coeffs produced by pp_i are the ones ml_i consumed; ml outputs are the fp12_mul inputs; its output is the
     final_exp input.  `proofs[name]` = (air, proof, cfg); public inputs are the tail of each proof blob."""
     def pis(name):
-        air, proof, _ = proofs[name]
-        n = S.air_public_inputs(air)
-        return np.asarray(proof[-n:], dtype=np.uint64)
+        return _pis(proofs, name)
     ok = True
     for i in ("1", "2"):
         pp, ml = pis("pp" + i), pis("ml" + i)
@@ -150,20 +184,28 @@ def prove_signature(prover, pk, hm, sig, dist=None, names=JOB_ORDER):
     return out, natives
 
 
-def collect_proofs(dist, mine):
+def collect_proofs(dist, mine, device="cpu"):
     """Every rank's share {name: (air, proof, cfg)} merged into one dict on every rank, so that any of them can run
-    `check_links` and hand the six proofs to the recursion stage.  Proof blobs (0.2-0.7 MB each) travel as objects
-    after the timed data path has finished; this is result collection, not a data-path collective."""
+    `check_links` / `check_statement` and hand the six proofs to the recursion stage.  Proofs are tens of MB each (FinalExp
+    52 MB, MillerLoop 68 MB): the ranks first exchange a small table (name, AIR, words) and then every proof travels ONCE as a
+    raw u64 buffer, broadcast by the rank that made it -- never pickled.  This is result collection after the timed data
+    path, not a data-path collective."""
     if dist is None:
         return dict(mine)
-    world = dist.get_world_size()
-    share = [(name, int(air), np.asarray(proof, dtype=np.uint64)) for name, (air, proof, _) in mine.items()]
-    shares = [None] * world
-    dist.all_gather_object(shares, share)
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    table = [(name, int(air), int(np.asarray(proof).size)) for name, (air, proof, _) in sorted(mine.items())]
+    tables = [None] * world
+    dist.all_gather_object(tables, table)  # a few dozen bytes per proof
     merged = {}
-    for part in shares:
-        for name, air, proof in part:
+    for src, part in enumerate(tables):
+        for name, air, words in part:
             if name in merged:
                 raise ValueError(f"proof {name!r} was produced by more than one rank")
-            merged[name] = (air, proof, S.StarkConfig.for_air(air))
+            if src == rank:
+                buf = torch.from_numpy(np.ascontiguousarray(mine[name][1], dtype=np.uint64).view(np.int64).copy()).to(device)
+            else:
+                buf = torch.empty(words, dtype=torch.int64, device=device)
+            dist.broadcast(buf, src=src)
+            merged[name] = (air, buf.cpu().numpy().view(np.uint64), S.StarkConfig.for_air(air))
     return merged

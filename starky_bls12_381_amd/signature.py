@@ -1,0 +1,220 @@
+"""End-to-end driver of BLS signature checks: operands -> traces -> the six STARK proofs per signature, on one or many GPUs.
+
+What the reference does in `generate_aggregate_proof` between the milagro calls and the plonky2 recursion
+(/root/reference/src/aggregate_proof.rs:304-370): for each signature, natively compute the two Miller-loop values, then
+run the six drivers (generate_trace + prove + verify each, :23-179) one after the other on one thread.  Here:
+
+  * a BATCH of signatures becomes 6 x B independent jobs, dealt to the ranks (one process per GPU) longest first
+    (`plan_batch`; FinalExp is ~3/4 of a signature's work, so every GPU gets whole FinalExp proofs first);
+  * rank 0 owns the input and broadcasts the operands -- 168 u32 limbs per signature: pk (x, y), H(m) (x, y), signature
+    (x, y) -- with ONE collective (`broadcast_operands`: RCCL over xGMI on GPUs, gloo in the CPU tests); nothing else
+    crosses ranks on the data path;
+  * on a rank, generator threads record the traces of its jobs as compact runs (starkhip_trace_log_*: recording is
+    per-thread, 0.3 s for FinalExp) while prover contexts consume them, so trace generation is INSIDE the timed region and
+    overlapped with proving (`run_jobs`);
+  * afterwards the proofs can be collected (`aggregate.collect_proofs`), verified and checked against the statement
+    (`aggregate.check_links`, `check_statement`).
+
+`synthetic_signatures` makes B different valid signatures from the reference's vector (src/native.rs:1480-1498): with secret
+scalars s_i, t_i:  H_i = t_i * H(m),  sig_i = s_i * H_i,  pk_i = s_i * G1  =>  e(pk_i, H_i) * e(-G1, sig_i) = 1.
+"""
+import queue
+import threading
+import time
+
+import numpy as np
+
+from . import aggregate as A
+from . import api as S
+from . import parallel
+from .eth_input import P as BLS_P
+from .eth_input import ec2_mul
+
+OPERAND_WORDS = 24 + 48 + 48  # pk (x, y: 12 limbs each), H(m) (x, y: 24 each), signature (x, y: 24 each); z = (1, 0) is implied
+
+
+# ------------------------------------------------------------------------------------------------ inputs
+def _g1_add(p1, p2):
+    if p1 is None:
+        return p2
+    if p2 is None:
+        return p1
+    (x1, y1), (x2, y2) = p1, p2
+    if x1 == x2:
+        if (y1 + y2) % BLS_P == 0:
+            return None
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, BLS_P) % BLS_P
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, BLS_P) % BLS_P
+    x3 = (lam * lam - x1 - x2) % BLS_P
+    return x3, (lam * (x1 - x3) - y1) % BLS_P
+
+
+def _g1_mul(p, k):
+    r = None
+    while k:
+        if k & 1:
+            r = _g1_add(r, p)
+        p = _g1_add(p, p)
+        k >>= 1
+    return r
+
+
+def synthetic_signatures(count, vector, seed=0x51607A7E):
+    """`count` different VALID signatures derived from the reference's test vector `vector` (the dict of decimal strings in
+    tests/golden/native_vectors.json["bls_signature"]: generator gx, gy and the message point hm_*).
+    Returns a list of (pk, hm, sig) limb tuples as `aggregate.signature_jobs` takes them (hm, sig with z = (1, 0))."""
+    b = {k: int(v) for k, v in vector.items()}
+    g1 = (b["gx"], b["gy"])
+    hm0 = ((b["hm_x1"], b["hm_x2"]), (b["hm_y1"], b["hm_y2"]))
+    one = A.fp2_limbs(1, 0)
+    state = seed & 0xFFFFFFFFFFFFFFFF
+
+    def nxt():
+        nonlocal state  # splitmix64
+        state = (state + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return (z ^ (z >> 31)) | 1
+
+    out = []
+    for _ in range(count):
+        s, t = nxt(), nxt()
+        h = ec2_mul(hm0, t)
+        sig = ec2_mul(h, s)
+        pk = _g1_mul(g1, s)
+        out.append(((A.fp_limbs(pk[0]), A.fp_limbs(pk[1])),
+                    (A.fp2_limbs(*h[0]), A.fp2_limbs(*h[1]), one.copy()),
+                    (A.fp2_limbs(*sig[0]), A.fp2_limbs(*sig[1]), one.copy())))
+    return out
+
+
+def pack_operands(signatures):
+    """[(pk, hm, sig)] -> uint64 [B, OPERAND_WORDS] (one u32 limb per word: what travels in the broadcast)."""
+    out = np.zeros((len(signatures), OPERAND_WORDS), dtype=np.uint64)
+    for i, (pk, hm, sig) in enumerate(signatures):
+        out[i] = np.concatenate([pk[0], pk[1], hm[0], hm[1], sig[0], sig[1]]).astype(np.uint64)
+    return out
+
+
+def unpack_operands(words):
+    one = A.fp2_limbs(1, 0)
+    sigs = []
+    for row in np.asarray(words, dtype=np.uint64).reshape(-1, OPERAND_WORDS):
+        r = row.astype(np.uint32)
+        sigs.append(((r[0:12].copy(), r[12:24].copy()), (r[24:48].copy(), r[48:72].copy(), one.copy()), (r[72:96].copy(), r[96:120].copy(), one.copy())))
+    return sigs
+
+
+def broadcast_operands(dist, signatures, batch, device="cpu", src=0):
+    """Rank `src` holds `signatures` (others pass None); every rank returns the same list.  One broadcast of
+    batch x 120 words (the "RCCL broadcast of public inputs over xGMI" of the north star: everything a rank needs to derive
+    the public inputs of its proofs)."""
+    if dist is None:
+        return list(signatures)
+    rank = dist.get_rank()
+    words = pack_operands(signatures) if rank == src else np.zeros((batch, OPERAND_WORDS), dtype=np.uint64)
+    return unpack_operands(parallel.broadcast_u64(dist, words.reshape(-1), src=src, device=device))
+
+
+# ------------------------------------------------------------------------------------------------ plan
+def plan_batch(batch, world):
+    """Per-rank job lists [(signature index, job name)], longest-processing-time-first over the 6 x batch jobs."""
+    jobs = [(i, name) for i in range(batch) for name in A.JOB_ORDER]
+    costs = [parallel.AIR_COST[A.JOB_AIR[name]] for _, name in jobs]
+    return [[jobs[j] for j in idxs] for idxs in parallel.assign_jobs(costs, world)]
+
+
+GENERATORS = {"pp1": S.trace_pairing_precomp, "pp2": S.trace_pairing_precomp, "ml1": S.trace_miller_loop, "ml2": S.trace_miller_loop,
+              "fp12_mul": S.trace_fp12_mul, "final_exp": S.trace_final_exp}
+
+
+def job_arguments(signatures, my_jobs):
+    """Arguments of the trace generators for this rank's jobs; the natives (two Miller loops and their product per signature)
+    are computed only for the signatures that need them here (fp12_mul and final_exp jobs), as the reference does at :352-363."""
+    cache = {}
+    out = {}
+    for i, name in my_jobs:
+        if i not in cache:
+            cache[i] = A.signature_jobs(*signatures[i])
+        out[(i, name)] = cache[i][0][name][1]
+    return out, {i: v[1] for i, v in cache.items()}
+
+
+# ------------------------------------------------------------------------------------------------ execution on one rank
+def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, queue_depth=None):
+    """Generate and prove `my_jobs` on this rank: `gen_threads` host threads record compact traces (largest job first) into a
+    bounded queue, one host thread per context of `provers` takes them and proves.  Returns ({(i, name): (air, proof, cfg)},
+    {"generate_s": sum of generator time, "prove_s": sum of prover time, "wall_s": wall time}).
+
+    `prove(prover, air, cfg, trace, pis)` and `generate(name, *args)` are injectable (CPU tests run the control flow without
+    a GPU); defaults: Prover.prove and the compact trace generators."""
+    if prove is None:
+        def prove(pv, air, cfg, trace, pis):
+            return pv.prove(air, cfg, trace, pis)
+    if generate is None:
+        def generate(name, *a):
+            return GENERATORS[name](*a, compact=True)
+    order = sorted(my_jobs, key=lambda j: -parallel.AIR_COST[A.JOB_AIR[j[1]]])
+    todo = list(order)
+    lock = threading.Lock()
+    ready = queue.Queue(maxsize=queue_depth or max(2, 2 * len(provers)))
+    results, errors = {}, []
+    t_gen, t_prove = [0.0], [0.0]
+
+    def generator():
+        while True:
+            with lock:
+                if not todo or errors:
+                    return
+                job = todo.pop(0)
+            try:
+                t0 = time.perf_counter()
+                trace, pis = generate(job[1], *args[job])
+                with lock:
+                    t_gen[0] += time.perf_counter() - t0
+                ready.put((job, trace, pis))
+            except Exception as e:  # noqa: BLE001 -- reported to the caller below
+                with lock:
+                    errors.append(e)
+                return
+
+    def prover_loop(pv):
+        while True:
+            item = ready.get()
+            if item is None:
+                return
+            job, trace, pis = item
+            try:
+                air = A.JOB_AIR[job[1]]
+                cfg = S.StarkConfig.for_air(air)
+                t0 = time.perf_counter()
+                proof = prove(pv, air, cfg, trace, pis)
+                with lock:
+                    t_prove[0] += time.perf_counter() - t0
+                    results[job] = (air, proof, cfg)
+            except Exception as e:  # noqa: BLE001
+                with lock:
+                    errors.append(e)
+
+    t0 = time.perf_counter()
+    gens = [threading.Thread(target=generator) for _ in range(max(1, min(gen_threads, len(order) or 1)))]
+    pros = [threading.Thread(target=prover_loop, args=(pv,)) for pv in provers]
+    for t in gens + pros:
+        t.start()
+    for t in gens:
+        t.join()
+    for _ in pros:
+        ready.put(None)
+    for t in pros:
+        t.join()
+    wall = time.perf_counter() - t0
+    if errors:
+        raise errors[0]
+    return results, {"generate_s": t_gen[0], "prove_s": t_prove[0], "wall_s": wall}
+
+
+def signature_proofs(results, index):
+    """The six proofs of signature `index` out of `run_jobs` / collected results, keyed by job name."""
+    return {name: results[(index, name)] for name in A.JOB_ORDER if (index, name) in results}

@@ -130,8 +130,85 @@ def test_collect_rejects_a_proof_produced_twice():
         def get_world_size(self):
             return 2
 
+        def get_rank(self):
+            return 0
+
+        def broadcast(self, buf, src=0):
+            pass
+
         def all_gather_object(self, out, obj):
             out[0] = obj
             out[1] = obj
     with pytest.raises(ValueError):
         A.collect_proofs(TwoRanksBothRanFp12Mul(), {"fp12_mul": (A.JOB_AIR["fp12_mul"], np.zeros(4, dtype=np.uint64), None)})
+
+
+# ---- the end-to-end signature driver (starky_bls12_381_amd/signature.py, tools/bench_signature.py) over gloo ranks
+def _fake_prove(pv, air, cfg, trace, pis):
+    """Stand-in for Prover.prove on a box without a GPU: a blob that ends in the public inputs, as every proof does."""
+    return np.concatenate([np.full(5, 7 + air, dtype=np.uint64), np.asarray(pis, dtype=np.uint64)])
+
+
+def _signature_worker(rank, world, port, batch, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from starky_bls12_381_amd import aggregate as A
+    from starky_bls12_381_amd import parallel as P
+    from starky_bls12_381_amd import signature as G
+    from bls_util import native_vectors
+    dist = P.init_distributed("gloo")
+    # exactly the control flow of tools/bench_signature.py's one_step()
+    signatures = G.synthetic_signatures(batch, native_vectors()["bls_signature"], 0x2000) if rank == 0 else None
+    dist.barrier()
+    sigs = G.broadcast_operands(dist, signatures, batch)
+    plan = G.plan_batch(batch, world)
+    mine = plan[rank]
+    job_args, natives = G.job_arguments(sigs, mine)
+    results, stats = G.run_jobs([object(), object()], mine, job_args, gen_threads=3, prove=_fake_prove)
+    dist.barrier()
+    slowest = P.max_over_ranks(dist, stats["wall_s"])
+    flat = {f"{i}:{name}": v for (i, name), v in results.items()}
+    merged = {(int(k.split(":")[0]), k.split(":")[1]): v for k, v in A.collect_proofs(dist, flat).items()}
+    verdicts = []
+    for i in range(batch):
+        six = G.signature_proofs(merged, i)
+        ok = len(six) == 6 and A.check_links(six) and A.check_statement(six, sigs[i][1], sigs[i][2])
+        if i in natives:
+            ok = ok and A.signature_is_valid(natives[i], six)
+        verdicts.append(bool(ok))
+    digest = int(np.bitwise_xor.reduce(G.pack_operands(sigs).reshape(-1)))
+    q.put((rank, sorted(mine), verdicts, digest, slowest >= stats["wall_s"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_signature_ranks(world, batch):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_signature_worker, args=(r, world, port, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return results
+
+
+def test_signature_driver_on_two_gloo_ranks():
+    res = _run_signature_ranks(2, 1)
+    assert res[0][1] == [(0, "final_exp")]                                    # FinalExp alone on one rank
+    assert sorted(res[0][1] + res[1][1]) == sorted((0, n) for n in ("pp1", "ml1", "pp2", "ml2", "fp12_mul", "final_exp"))
+    assert res[0][3] == res[1][3] != 0                                          # the operand broadcast reached both ranks
+    assert all(r[2] == [True] and r[4] for r in res)                            # links + statement hold on every rank after collection
+
+
+def test_signature_driver_on_six_gloo_ranks_one_proof_per_rank():
+    """BASELINE configs[3]: the six proofs of one signature check, one per rank."""
+    res = _run_signature_ranks(6, 1)
+    assert sorted(len(r[1]) for r in res) == [1] * 6
+    assert len({r[3] for r in res}) == 1
+    assert all(r[2] == [True] for r in res)

@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
-"""Signatures/s on one MI355X: the six STARK proofs of one BLS signature check (2 x PairingPrecomp, 2 x MillerLoop,
-FP12Mul, FinalExp; BASELINE.json configs[3]/[4] in single-GPU form).  Traces are generated on the host and moved to
-HBM (column-major) before the timed region, like bench.py.
+"""Signatures/s END TO END on N MI355X: operands in -> (trace generation + the six STARK proofs per signature) -> proofs out.
 
---batch 1 (default): one signature at a time, its six proofs on --inflight contexts (latency of one check).
---batch B: B signatures scheduled by proof TYPE.  The small AIRs are latency chains (MillerLoop: 2048 leaves of 12 167
-  sequential permutations = 128 waves for ~0.2 s), so a single one leaves 7/8 of the SIMDs idle while sixteen of them
-  side by side fill the chip; FinalExp's leaf hash is a one-shot grid of exactly two waves per SIMD that any foreign
-  wave stretches.  Hence two phases: all small proofs with --small-inflight contexts, then the B FinalExp proofs
-  --big-inflight at a time.  The same (synthetic) signature is used B times, so the traces are resident once.
-Prints one JSON line."""
+BASELINE.json configs[3] (six proofs of one signature sharded over GPUs) and configs[4] (a batch of 8 signatures = 48 proofs):
+
+    python tools/bench_signature.py --batch 8                                   # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        tools/bench_signature.py --gpus N --batch 8                             # one process per GPU, RCCL
+
+Per step: rank 0 owns the B (different, valid, synthetic) signatures and broadcasts their operands with one collective;
+every rank derives the same longest-first plan over the 6 B jobs, computes the natives its jobs need, records the traces of
+its jobs on host threads (compact runs, expanded on the device) and proves them on `--inflight` contexts -- trace generation
+is inside the timed region and overlaps proving.  The timed region is bracketed by barrier + synchronize; the time is the
+max over ranks.  Afterwards (untimed) every proof is verified by the product's CPU verifier and, for the signatures whose six
+proofs are on this rank (always at N = 1; with --collect at N > 1), the links and the statement are checked.
+
+Prints one JSON line on rank 0."""
 import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 # one hardware queue per in-flight proof: with the HIP default of 4, more streams share queues and their kernels serialise
@@ -24,100 +28,105 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run_pool(S, A, provers, jobs, resident, record=None):
-    """jobs: list of names; each free context takes the next one."""
-    todo = list(jobs)
-    lock = threading.Lock()
-
-    def worker(pv):
-        while True:
-            with lock:
-                if not todo:
-                    return
-                name = todo.pop(0)
-            d, n, pis = resident[name]
-            air = A.JOB_AIR[name]
-            t = time.perf_counter()
-            pv.prove_device(air, S.StarkConfig.for_air(air), d.data_ptr(), n, pis, layout=1, keep=False)
-            if record is not None:
-                record.setdefault(name, []).append((time.perf_counter() - t) * 1e3)
-    th = [threading.Thread(target=worker, args=(pv,)) for pv in provers]
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-
-
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1, help="signatures per step (6 proofs each)")
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--inflight", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--small-inflight", type=int, default=24)
-    ap.add_argument("--big-inflight", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--inflight", type=int, default=6, help="prover contexts per GPU")
+    ap.add_argument("--gen-threads", type=int, default=6, help="host threads recording traces per GPU")
+    ap.add_argument("--collect", action="store_true", help="N > 1: gather every proof on every rank afterwards (raw buffers) and check all signatures")
+    ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
-    import numpy as np
+
     import torch
     import starky_bls12_381_amd as S
     from starky_bls12_381_amd import aggregate as A
     from starky_bls12_381_amd import parallel
-    from test_aggregate_cpu import _bls_points
+    from starky_bls12_381_amd import signature as G
+    from bls_util import native_vectors
 
-    _, pk, hm, sig = _bls_points()
-    jobs, natives = A.signature_jobs(pk, hm, sig)
-    gens = {"pp1": S.trace_pairing_precomp, "pp2": S.trace_pairing_precomp, "ml1": S.trace_miller_loop, "ml2": S.trace_miller_loop,
-            "fp12_mul": S.trace_fp12_mul, "final_exp": S.trace_final_exp}
-    resident = {}
-    t0 = time.perf_counter()
-    for name in A.JOB_ORDER:
-        trace, pis = gens[name](*jobs[name][1])
-        d = torch.from_numpy(trace.view(np.int64)).to("cuda:0").t().contiguous()
-        resident[name] = (d, trace.shape[0], pis)
-        del trace
-    torch.cuda.synchronize()
-    t_gen = time.perf_counter() - t0
-    by_cost = sorted(A.JOB_ORDER, key=lambda n: -parallel.AIR_COST[A.JOB_AIR[n]])
-    out = {"metric": "BLS signature checks/s (6 STARK proofs each) on 1 MI355X", "unit": "signatures/s", "batch": args.batch,
-           "host_trace_generation_and_upload_s": t_gen, "signature_valid": A.signature_is_valid(natives),
-           "data": "reference test vector src/native.rs:1480-1498" + (f", used {args.batch} times" if args.batch > 1 else "")}
-    per_proof = {}
-    if args.batch <= 1:
-        provers = [S.Prover(0) for _ in range(max(1, args.inflight))]
-        run_pool(S, A, provers, by_cost, resident)  # warm-up (tables, programs, buffers)
+    rank, local_rank, world = parallel.rank_info()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    rehearse = os.environ.get("STARKHIP_BENCH_REHEARSE") == "1"  # all ranks on cuda:0 over gloo: control-flow rehearsal, not a measurement
+    if rehearse:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)  # the launcher exec'd us before anything touched the GPU
+    dist = parallel.init_distributed("gloo" if rehearse else "nccl") if world > 1 else None
+    dev = "cpu" if rehearse else f"cuda:{local_rank}"
+
+    provers = [S.Prover(local_rank) for _ in range(max(1, args.inflight))]
+    plan = G.plan_batch(args.batch, world)
+    mine = plan[rank]
+    results, stats = {}, {}
+
+    def one_step(seed):
+        signatures = G.synthetic_signatures(args.batch, native_vectors()["bls_signature"], seed) if rank == 0 else None
         torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run_pool(S, A, provers, by_cost, resident, per_proof)
+        sigs = G.broadcast_operands(dist, signatures, args.batch, device=dev)
+        job_args, natives = G.job_arguments(sigs, mine)
+        res, st = G.run_jobs(provers, mine, job_args, gen_threads=args.gen_threads)
         torch.cuda.synchronize()
-        el = (time.perf_counter() - t0) / args.steps
-        out.update({"value": 1.0 / el, "ms_per_signature": el * 1e3, "proofs_in_flight": len(provers)})
-    else:
-        small = [n for n in by_cost if n != "final_exp"] * args.batch
-        small.sort(key=lambda n: -parallel.AIR_COST[A.JOB_AIR[n]])  # all MillerLoop first, then PairingPrecomp, then FP12Mul
-        big = ["final_exp"] * args.batch
-        small_pv = [S.Prover(0) for _ in range(max(1, args.small_inflight))]
-        big_pv = [S.Prover(0) for _ in range(max(1, args.big_inflight))]
-        run_pool(S, A, small_pv, [n for n in by_cost if n != "final_exp"] * len(small_pv), resident)  # warm every context on every small AIR
-        run_pool(S, A, big_pv, ["final_exp"] * len(big_pv), resident)
-        torch.cuda.synchronize()
-        t_small = t_big = 0.0
-        for _ in range(args.steps):
-            t0 = time.perf_counter()
-            run_pool(S, A, small_pv, small, resident, per_proof)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            run_pool(S, A, big_pv, big, resident, per_proof)
-            torch.cuda.synchronize()
-            t_small += t1 - t0
-            t_big += time.perf_counter() - t1
-        el = (t_small + t_big) / args.steps
-        out.update({"value": args.batch / el, "ms_per_signature": el * 1e3 / args.batch, "ms_small_phase": t_small / args.steps * 1e3,
-                    "ms_final_exp_phase": t_big / args.steps * 1e3, "small_in_flight": len(small_pv), "final_exp_in_flight": len(big_pv)})
-        provers = small_pv + big_pv
-    out["per_proof_wall_ms"] = {k: round(sum(v) / len(v), 1) for k, v in per_proof.items()}
-    print(json.dumps(out))
+        if dist is not None:
+            dist.barrier()
+        el = parallel.max_over_ranks(dist, time.perf_counter() - t0, device=dev)
+        return el, res, st, sigs, natives
+
+    for w in range(args.warmup):
+        one_step(0x1000 + w)
+    total = 0.0
+    for k in range(args.steps):
+        el, results, stats, sigs, natives = one_step(0x2000 + k)
+        total += el
+    el = total / max(1, args.steps)
+
+    # ---- untimed: what the reference does right after each prove (verify_stark_proof) and what its recursion enforces
+    verified = 0
+    if not args.no_verify:
+        for (_, name), (air, proof, cfg) in results.items():
+            S.verify_stark_proof(air, cfg, proof)
+            verified += 1
+    merged = results
+    if dist is not None and args.collect:
+        flat = {f"{i}:{name}": v for (i, name), v in results.items()}
+        merged = {(int(k.split(":")[0]), k.split(":")[1]): v for k, v in A.collect_proofs(dist, flat, device=dev).items()}
+    checked = valid = 0
+    for i in range(args.batch):
+        six = G.signature_proofs(merged, i)
+        if len(six) == 6:
+            ok = A.check_links(six) and A.check_statement(six, sigs[i][1], sigs[i][2])
+            if i in natives:
+                ok = ok and A.signature_is_valid(natives[i], six)
+            checked += 1
+            valid += bool(ok)
+    n_verified = int(parallel.sum_over_ranks(dist, verified, device=dev))
+    if rank == 0:
+        per_air = {}
+        for (_, name), (air, proof, _) in results.items():
+            per_air.setdefault(S.AIR_NAMES[air], []).append(int(proof.size) * 8)
+        out = {
+            "metric": "BLS signature checks/s, end to end (operands -> trace generation -> 6 STARK proofs each)",
+            "value": args.batch / el, "unit": "signatures/s", "n_gpus": world, "batch": args.batch, "steps": args.steps,
+            "ms_per_step": el * 1e3, "ms_per_signature": el * 1e3 / args.batch,
+            "proofs_per_step": 6 * args.batch, "contexts_per_gpu": len(provers), "generator_threads_per_gpu": args.gen_threads,
+            "rank0": {"jobs": len(mine), "generate_s_sum": stats.get("generate_s"), "prove_s_sum": stats.get("prove_s"), "wall_s": stats.get("wall_s")},
+            "proofs_verified_after_timing": n_verified, "signatures_checked_on_rank0": checked, "signatures_valid_on_rank0": valid,
+            "proof_bytes_on_rank0": {k: v[0] for k, v in per_air.items()},
+            "data": "synthetic valid signatures derived from the reference vector src/native.rs:1480-1498 (a different set each step)"
+                    + (" -- REHEARSAL over gloo on one GPU, not a measurement" if rehearse else ""),
+            "plan": {str(r): [f"{i}:{n}" for i, n in jobs] for r, jobs in enumerate(plan)} if args.batch <= 2 else f"{6 * args.batch} jobs, longest first over {world} rank(s)",
+        }
+        print(json.dumps(out), flush=True)
     for pv in provers:
         pv.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
