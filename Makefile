@@ -29,7 +29,24 @@ build/signature_demo: tools/signature_demo.cpp include/starkhip_driver.hpp $(OUT
 	@mkdir -p build
 	g++ -O2 -std=c++17 -Iinclude $< -o $@ -Lstarky_bls12_381_amd -lstarkhip -Wl,-rpath,'$$ORIGIN/../starky_bls12_381_amd'
 
+# Sanitizer build of the HOST code (AddressSanitizer + UndefinedBehaviorSanitizer; GPU sanitizers are not available on this
+# pool): csrc/*.cpp + stand-ins for the device entry points -> build/asan/libstarkhip_host_asan.so, and the oracle likewise.
+# `make asan-test` runs the CPU tests that exercise natives, trace generators, AIR builders, verifier and plan builder on it.
+ASAN_FLAGS := -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined -Iinclude -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
+ASAN_SRCS := $(wildcard $(CSRC)/*.cpp) $(CSRC)/host_only_stubs.cc
+asan: build/asan/libstarkhip_host_asan.so build/asan/liboracle_asan.so
+build/asan/libstarkhip_host_asan.so: $(ASAN_SRCS) $(HDRS)
+	@mkdir -p build/asan
+	g++ $(ASAN_FLAGS) -shared -o $@ $(ASAN_SRCS)
+build/asan/liboracle_asan.so: oracle/stark_oracle.c oracle/oracle_field.h
+	@mkdir -p build/asan
+	gcc -O1 -g -fopenmp -fPIC -fvisibility=hidden -std=gnu11 -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o $@ oracle/stark_oracle.c
+asan-test: asan
+	LD_PRELOAD=$$(gcc -print-file-name=libasan.so):$$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \
+	STARKHIP_LIBRARY=$(CURDIR)/build/asan/libstarkhip_host_asan.so STARKHIP_ORACLE_LIBRARY=$(CURDIR)/build/asan/liboracle_asan.so \
+	python -m pytest tests/test_native_cpu.py tests/test_quotient_plan_cpu.py tests/test_toy_air_cpu.py tests/test_trace_log_cpu.py tests/test_ecc_aggregate_cpu.py -x -q -m "not gpu" -p no:cacheprovider
+
 clean:
 	rm -rf build $(OUT)
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean demo
+.PHONY: all oracle clean demo asan asan-test

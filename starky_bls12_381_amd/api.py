@@ -12,7 +12,9 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstarkhip.so")
+# STARKHIP_LIBRARY: another build of the same C ABI (the sanitizer build of the host code, `make asan`); never a CPU fallback --
+# that build answers NO_DEVICE on every device path
+LIB_PATH = os.environ.get("STARKHIP_LIBRARY") or os.path.join(_HERE, "libstarkhip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

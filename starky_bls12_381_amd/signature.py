@@ -143,10 +143,18 @@ def job_arguments(signatures, my_jobs):
 
 
 # ------------------------------------------------------------------------------------------------ execution on one rank
+BIG = ("final_exp",)  # jobs that get their own contexts: the FinalExp leaf hash is a one-shot grid of two waves per SIMD
+
+
 def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, queue_depth=None):
-    """Generate and prove `my_jobs` on this rank: `gen_threads` host threads record compact traces (largest job first) into a
-    bounded queue, one host thread per context of `provers` takes them and proves.  Returns ({(i, name): (air, proof, cfg)},
+    """Generate and prove `my_jobs` on this rank: `gen_threads` host threads record compact traces into bounded queues, one
+    host thread per prover context takes them and proves.  Returns ({(i, name): (air, proof, cfg)},
     {"generate_s": sum of generator time, "prove_s": sum of prover time, "wall_s": wall time}).
+
+    `provers`: a list of contexts (one pool), or {"big": [...], "small": [...]}: FinalExp proofs (4.8 GB traces, 25 GB of
+    buffers each) go to the few `big` contexts, the 1024-row AIRs -- latency chains that only fill the chip side by side --
+    to the many `small` ones; both pools run at once.  Half of the generator threads start on the FinalExp traces (0.3 s
+    each), the other half on the small ones, so neither pool waits for the other's traces.
 
     `prove(prover, air, cfg, trace, pis)` and `generate(name, *args)` are injectable (CPU tests run the control flow without
     a GPU); defaults: Prover.prove and the compact trace generators."""
@@ -156,33 +164,42 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
     if generate is None:
         def generate(name, *a):
             return GENERATORS[name](*a, compact=True)
+    pools = provers if isinstance(provers, dict) else {"big": list(provers), "small": None}
+    shared = pools.get("small") is None  # one pool takes everything
     order = sorted(my_jobs, key=lambda j: -parallel.AIR_COST[A.JOB_AIR[j[1]]])
-    todo = list(order)
+    todo = {"big": [j for j in order if j[1] in BIG], "small": [j for j in order if j[1] not in BIG]}
     lock = threading.Lock()
-    ready = queue.Queue(maxsize=queue_depth or max(2, 2 * len(provers)))
+    n_ctx = {"big": len(pools["big"]), "small": len(pools["big"]) if shared else len(pools["small"])}
+    ready = {k: queue.Queue(maxsize=queue_depth or max(2, 2 * n_ctx[k])) for k in ("big", "small")}
+    if shared:
+        ready["small"] = ready["big"]
     results, errors = {}, []
     t_gen, t_prove = [0.0], [0.0]
 
-    def generator():
+    def generator(first):
+        second = "small" if first == "big" else "big"
         while True:
             with lock:
-                if not todo or errors:
+                if errors:
                     return
-                job = todo.pop(0)
+                kind = first if todo[first] else second
+                if not todo[kind]:
+                    return
+                job = todo[kind].pop(0)
             try:
                 t0 = time.perf_counter()
                 trace, pis = generate(job[1], *args[job])
                 with lock:
                     t_gen[0] += time.perf_counter() - t0
-                ready.put((job, trace, pis))
+                ready[kind].put((job, trace, pis))
             except Exception as e:  # noqa: BLE001 -- reported to the caller below
                 with lock:
                     errors.append(e)
                 return
 
-    def prover_loop(pv):
+    def prover_loop(pv, kind):
         while True:
-            item = ready.get()
+            item = ready[kind].get()
             if item is None:
                 return
             job, trace, pis = item
@@ -199,14 +216,21 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
                     errors.append(e)
 
     t0 = time.perf_counter()
-    gens = [threading.Thread(target=generator) for _ in range(max(1, min(gen_threads, len(order) or 1)))]
-    pros = [threading.Thread(target=prover_loop, args=(pv,)) for pv in provers]
+    n_gen = max(1, min(gen_threads, len(order) or 1))
+    n_big_gen = min(len(todo["big"]), max(1, n_gen // 2)) if todo["big"] else 0
+    gens = [threading.Thread(target=generator, args=("big" if g < n_big_gen else "small",)) for g in range(n_gen)]
+    pros = [threading.Thread(target=prover_loop, args=(pv, "big")) for pv in pools["big"]]
+    if not shared:
+        pros += [threading.Thread(target=prover_loop, args=(pv, "small")) for pv in pools["small"]]
     for t in gens + pros:
         t.start()
     for t in gens:
         t.join()
-    for _ in pros:
-        ready.put(None)
+    for pv in pools["big"]:
+        ready["big"].put(None)
+    if not shared:
+        for pv in pools["small"]:
+            ready["small"].put(None)
     for t in pros:
         t.join()
     wall = time.perf_counter() - t0

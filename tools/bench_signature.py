@@ -34,8 +34,11 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="signatures per step (6 proofs each)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--inflight", type=int, default=6, help="prover contexts per GPU")
-    ap.add_argument("--gen-threads", type=int, default=6, help="host threads recording traces per GPU")
+    ap.add_argument("--inflight", type=int, default=6, help="prover contexts per GPU when --small-inflight is 0 (one pool)")
+    ap.add_argument("--big-inflight", type=int, default=3, help="contexts for FinalExp proofs (two pools)")
+    ap.add_argument("--small-inflight", type=int, default=0, help="contexts for the 1024-row AIRs; 0 = one pool of --inflight contexts; "
+                                                                   "default for --batch > 1: 16")
+    ap.add_argument("--gen-threads", type=int, default=12, help="host threads recording traces per GPU")
     ap.add_argument("--collect", action="store_true", help="N > 1: gather every proof on every rank afterwards (raw buffers) and check all signatures")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -57,7 +60,15 @@ def main():
     dist = parallel.init_distributed("gloo" if rehearse else "nccl") if world > 1 else None
     dev = "cpu" if rehearse else f"cuda:{local_rank}"
 
-    provers = [S.Prover(local_rank) for _ in range(max(1, args.inflight))]
+    if args.small_inflight == 0 and args.batch > 1:
+        args.small_inflight = 16
+    if args.small_inflight > 0:
+        provers = {"big": [S.Prover(local_rank) for _ in range(max(1, args.big_inflight))],
+                   "small": [S.Prover(local_rank) for _ in range(args.small_inflight)]}
+        all_provers = provers["big"] + provers["small"]
+    else:
+        provers = [S.Prover(local_rank) for _ in range(max(1, args.inflight))]
+        all_provers = provers
     plan = G.plan_batch(args.batch, world)
     mine = plan[rank]
     results, stats = {}, {}
@@ -113,7 +124,7 @@ def main():
             "metric": "BLS signature checks/s, end to end (operands -> trace generation -> 6 STARK proofs each)",
             "value": args.batch / el, "unit": "signatures/s", "n_gpus": world, "batch": args.batch, "steps": args.steps,
             "ms_per_step": el * 1e3, "ms_per_signature": el * 1e3 / args.batch,
-            "proofs_per_step": 6 * args.batch, "contexts_per_gpu": len(provers), "generator_threads_per_gpu": args.gen_threads,
+            "proofs_per_step": 6 * args.batch, "contexts_per_gpu": ({k: len(v) for k, v in provers.items()} if isinstance(provers, dict) else len(provers)), "generator_threads_per_gpu": args.gen_threads,
             "rank0": {"jobs": len(mine), "generate_s_sum": stats.get("generate_s"), "prove_s_sum": stats.get("prove_s"), "wall_s": stats.get("wall_s")},
             "proofs_verified_after_timing": n_verified, "signatures_checked_on_rank0": checked, "signatures_valid_on_rank0": valid,
             "proof_bytes_on_rank0": {k: v[0] for k, v in per_air.items()},
@@ -122,7 +133,7 @@ def main():
             "plan": {str(r): [f"{i}:{n}" for i, n in jobs] for r, jobs in enumerate(plan)} if args.batch <= 2 else f"{6 * args.batch} jobs, longest first over {world} rank(s)",
         }
         print(json.dumps(out), flush=True)
-    for pv in provers:
+    for pv in all_provers:
         pv.close()
     if dist is not None:
         dist.barrier()
