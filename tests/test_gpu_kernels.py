@@ -108,13 +108,14 @@ def test_bad_shapes_are_refused(prover):
 
 
 @pytest.mark.parametrize("slots", [0, 7, 24])
-def test_quotient_cell_cache_does_not_change_the_proof(slots, monkeypatch):
-    """The optional per-wave LDS cell cache of the quotient kernel (STARKHIP_QUOTIENT_SLOTS, off by default) is a pure
-    re-scheduling of cell loads: FP12Mul proofs are identical to the oracle's for every slot count."""
+def test_quotient_cell_cache_does_not_change_the_proof(slots):
+    """The optional per-wave LDS cell cache of the op-stream interpreter (options quotient_impl = 1, quotient_slots; off by
+    default) is a pure re-scheduling of cell loads: FP12Mul proofs are identical to the oracle's for every slot count."""
     import oracle_lib as O
     from bls_util import random_fp12
-    monkeypatch.setenv("STARKHIP_QUOTIENT_SLOTS", str(slots))
-    pv = S.Prover(0)  # the slot count is read when a context compiles an AIR's op stream
+    pv = S.Prover(0)
+    pv.set_option("quotient_impl", 1)
+    pv.set_option("quotient_slots", slots)
     try:
         air = S.AIR_FP12_MUL
         t, pis = S.trace_fp12_mul(random_fp12(0x5EED3000), random_fp12(0x5EED3001))
