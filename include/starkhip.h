@@ -141,6 +141,11 @@ int starkhip_set_option(void* ctx, const char* name, long value);
  * the proof is bit-identical to the one from the dense trace.  A log is immutable after _end and may be proven any
  * number of times, from any thread; release it with starkhip_trace_log_free. */
 int starkhip_trace_log_begin(void** log);
+/* Host threads ONE recording generator call may use (process-wide, default 1; returns the previous value).  Only
+ * starkhip_trace_final_exp uses more than one so far: the reference's generate_trace (src/final_exponentiate.rs:240-279) fills
+ * its 32 ops one after the other, but once the 32 native results are known every op's rows are independent.  The recorded
+ * trace -- and the proof -- does not depend on the setting.  A driver that records many traces at once keeps it at 1. */
+int starkhip_trace_set_threads(int n);
 int starkhip_trace_log_end(void* log);
 void starkhip_trace_log_free(void* log);
 int starkhip_trace_log_info(const void* log, size_t* n_rows, size_t* n_cols, size_t* n_records, size_t* n_words);

@@ -94,6 +94,7 @@ lib.starkhip_free.restype = None
 lib.starkhip_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
 lib.starkhip_trace_log_begin.argtypes = [C.POINTER(C.c_void_p)]
 lib.starkhip_trace_log_end.argtypes = [C.c_void_p]
+lib.starkhip_trace_set_threads.argtypes = [C.c_int]
 lib.starkhip_trace_log_free.argtypes = [C.c_void_p]
 lib.starkhip_trace_log_free.restype = None
 lib.starkhip_trace_log_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_size_t)] * 4
@@ -263,6 +264,12 @@ class _Recording:
             if et is None:
                 raise StarkhipError(rc)
         return False
+
+
+def set_trace_threads(n):
+    """Host threads one RECORDING generator call may use (starkhip_trace_set_threads; only trace_final_exp uses more than
+    one).  Returns the previous setting.  The recorded trace does not depend on it."""
+    return int(lib.starkhip_trace_set_threads(int(n)))
 
 
 def _generate(air, n_rows, out, compact, call):

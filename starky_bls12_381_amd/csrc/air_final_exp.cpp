@@ -4,6 +4,8 @@
 // constraint_degree (:1362-1364); public inputs as built by final_exponentiate_main, src/aggregate_proof.rs:158-165.
 #include <stdio.h>
 
+#include <vector>
+
 #include "airs.h"
 #include "gadgets.h"
 #include "wiring.h"
@@ -175,42 +177,70 @@ AirProgram build_air_final_exp() {
 
 using namespace starkhip;
 
-// FinalExponentiateStark::generate_trace (:240-279) + public inputs (src/aggregate_proof.rs:158-165)
+// FinalExponentiateStark::generate_trace (:240-279) + public inputs (src/aggregate_proof.rs:158-165).
+// The 32 results come from the native chain first (12 ms); after that every op's rows depend only on its operands, so the ops
+// -- the five cyclotomic exponentiations, 88 % of the time, cut into step ranges -- are tasks for fill_tasks (trace_tasks.cpp).
+namespace {
+struct FillTask {
+    int op;          // index into OPS, or -1: the columns that span all rows (row selectors, input, the T_j blocks)
+    size_t j0, j1;   // step range of a cyclotomic exponentiation
+};
+
+void fill_task(Trace& t, const FillTask& task, const Fp12& X, const Fp12 (&T)[32], size_t n_rows) {
+    auto val = [&](int s) -> const Fp12& { return s < 0 ? X : T[s]; };
+    if (task.op < 0) {
+        for (size_t row = 0; row < n_rows; row++) {
+            t.at(row, FINAL_EXP_ROW_SELECTORS + row) = 1;
+            t.put(row, FINAL_EXP_INPUT_OFFSET, X);
+        }
+        for (const Op& op : OPS)
+            for (size_t row = 0; row < n_rows; row++) t.put(row, T_OFF[op.out], T[op.out]);
+        return;
+    }
+    const Op& op = OPS[task.op];
+    const size_t r0 = op.row, r1 = op.row + op_rows(op.kind) - 1;
+    const Fp12& a = val(op.a);
+    if (task.j0 == 0)
+        for (size_t row = r0; row <= r1; row++) t.at(row, op_selector(op.kind)) = 1;
+    switch (op.kind) {
+        case OP_FROB: fill_trace_fp12_forbenius_map(t, a, op.pow, r0, r1, OPW); break;
+        case OP_MUL: fill_trace_fp12_multiplication(t, a, val(op.b), r0, r1, OPW); break;
+        case OP_DIV: fill_trace_fp12_multiplication(t, T[op.out], val(op.b), r0, r1, OPW); break;  // res * y == x
+        case OP_CEXP: fill_trace_cyclotomic_exp_steps(t, a, r0, r1, OPW, task.j0, task.j1); break;
+        case OP_CONJ: fill_trace_fp12_conjugate(t, a, r0, OPW); break;
+        case OP_CSQ: fill_trace_cyclotomic_sq(t, a, r0, r1, OPW); break;
+    }
+}
+}  // namespace
+
 extern "C" int starkhip_trace_final_exp(const uint32_t x[144], uint64_t* trace, size_t n_rows, uint64_t* public_inputs) {
     if (n_rows != N_ROWS) return STARKHIP_ERR_BAD_SHAPE;  // the layout holds exactly 8192 row-selector columns
     try {
         const Fp12 X = Fp12::from_limbs(x);
         Trace t = open_trace(trace, n_rows, COLUMNS);
-        for (size_t row = 0; row < n_rows; row++) {
-            t.at(row, FINAL_EXP_ROW_SELECTORS + row) = 1;
-            t.put(row, FINAL_EXP_INPUT_OFFSET, X);
-        }
         Fp12 T[32];
-        auto val = [&](int s) -> const Fp12& { return s < 0 ? X : T[s]; };
-        for (const Op& op : OPS) {
-            const size_t r0 = op.row, r1 = op.row + op_rows(op.kind) - 1;
-            const Fp12& a = val(op.a);
-            Fp12 res;
+        for (const Op& op : OPS) {  // src/native.rs:1311-1345
+            const Fp12& a = op.a < 0 ? X : T[op.a];
+            const Fp12& b = op.b < 0 ? X : T[op.b];
             switch (op.kind) {
-                case OP_FROB: res = a.forbenius_map(op.pow); break;
-                case OP_MUL: res = a * val(op.b); break;
-                case OP_DIV: res = a / val(op.b); break;
-                case OP_CEXP: res = a.cyclotomic_exponent(); break;
-                case OP_CONJ: res = a.conjugate(); break;
-                case OP_CSQ: res = a.cyclotomic_square(); break;
+                case OP_FROB: T[op.out] = a.forbenius_map(op.pow); break;
+                case OP_MUL: T[op.out] = a * b; break;
+                case OP_DIV: T[op.out] = a / b; break;
+                case OP_CEXP: T[op.out] = a.cyclotomic_exponent(); break;
+                case OP_CONJ: T[op.out] = a.conjugate(); break;
+                case OP_CSQ: T[op.out] = a.cyclotomic_square(); break;
             }
-            for (size_t row = r0; row <= r1; row++) t.at(row, op_selector(op.kind)) = 1;
-            for (size_t row = 0; row < n_rows; row++) t.put(row, T_OFF[op.out], res);
-            switch (op.kind) {
-                case OP_FROB: fill_trace_fp12_forbenius_map(t, a, op.pow, r0, r1, OPW); break;
-                case OP_MUL: fill_trace_fp12_multiplication(t, a, val(op.b), r0, r1, OPW); break;
-                case OP_DIV: fill_trace_fp12_multiplication(t, res, val(op.b), r0, r1, OPW); break;  // res * y == x
-                case OP_CEXP: fill_trace_cyclotomic_exp(t, a, r0, r1, OPW); break;
-                case OP_CONJ: fill_trace_fp12_conjugate(t, a, r0, OPW); break;
-                case OP_CSQ: fill_trace_cyclotomic_sq(t, a, r0, r1, OPW); break;
-            }
-            T[op.out] = res;
         }
+        std::vector<FillTask> tasks;
+        const size_t cuts = t.log && trace_threads() > 1 ? 5 : 1;  // parts per cyclotomic exponentiation: 53 tasks of comparable weight
+        tasks.push_back({-1, 0, 70});
+        for (int k = 0; k < 32; k++) {
+            if (OPS[k].kind == OP_CEXP)
+                for (size_t c = 0; c < cuts; c++) tasks.push_back({k, 70 * c / cuts, 70 * (c + 1) / cuts});
+            else
+                tasks.push_back({k, 0, 70});
+        }
+        fill_tasks(t, tasks.size(), [&](Trace& part, size_t k) { fill_task(part, tasks[k], X, T, n_rows); });
         uint32_t out[144];
         T[31].to_limbs(out);
         for (int i = 0; i < 144; i++) {

@@ -118,29 +118,36 @@ void fill_trace_cyclotomic_sq(Trace& t, const Fp12& x, size_t r0, size_t r1, siz
 }
 // fp12.rs:333-374.  70 steps of 12 rows: square every step; when the current bit of |x| is set, the NEXT step
 // multiplies by the input instead (bitone).  Row start_row + 840 carries the result.
-void fill_trace_cyclotomic_exp(Trace& t, const Fp12& x, size_t start_row, size_t end_row, size_t col) {
-    for (size_t row = start_row; row <= end_row; row++) {
-        t.put(row, col + INPUT_OFFSET, x);
-        t.at(row, col + CYCLOTOMIC_EXP_SELECTOR_OFFSET) = 1;
+// Steps j0 .. j1-1 of the 70 twelve-row steps (the whole gadget: 0, 70).  The part with j0 == 0 also writes what spans all
+// 841 rows (input, selector, start row), the part with j1 == 70 the result row; a later part recomputes the running value z
+// natively up to its first step (a few Fp12 operations), so disjoint parts can be filled by different threads.
+void fill_trace_cyclotomic_exp_steps(Trace& t, const Fp12& x, size_t start_row, size_t end_row, size_t col, size_t j0, size_t j1) {
+    if (end_row + 1 - start_row != 70 * 12 + 1) throw std::runtime_error("fill_trace_cyclotomic_exp: needs 841 rows");
+    if (j0 == 0) {
+        for (size_t row = start_row; row <= end_row; row++) {
+            t.put(row, col + INPUT_OFFSET, x);
+            t.at(row, col + CYCLOTOMIC_EXP_SELECTOR_OFFSET) = 1;
+        }
+        t.at(end_row, col + CYCLOTOMIC_EXP_SELECTOR_OFFSET) = 0;
+        t.at(start_row, col + CYCLOTOMIC_EXP_START_ROW) = 1;
     }
-    t.at(end_row, col + CYCLOTOMIC_EXP_SELECTOR_OFFSET) = 0;
-    t.at(start_row, col + CYCLOTOMIC_EXP_START_ROW) = 1;
     Fp12 z = Fp12::one();
     int i = 63;
     bool bitone = false;
-    if (end_row + 1 - start_row != 70 * 12 + 1) throw std::runtime_error("fill_trace_cyclotomic_exp: needs 841 rows");
-    for (size_t j = 0; j < 70; j++) {
+    for (size_t j = 0; j < j1; j++) {
         const size_t s_row = start_row + j * 12, e_row = s_row + 11;
-        for (size_t row = s_row; row <= e_row; row++) {
-            if (bitone) t.at(row, col + BIT1_SELECTOR_OFFSET) = 1;
-            t.put(row, col + Z_OFFSET, z);
+        if (j >= j0) {
+            for (size_t row = s_row; row <= e_row; row++) {
+                if (bitone) t.at(row, col + BIT1_SELECTOR_OFFSET) = 1;
+                t.put(row, col + Z_OFFSET, z);
+            }
+            t.at(s_row, col + FIRST_ROW_SELECTOR_OFFSET) = 1;
         }
-        t.at(s_row, col + FIRST_ROW_SELECTOR_OFFSET) = 1;
         if (bitone) {
-            fill_trace_fp12_multiplication(t, z, x, s_row, e_row, col + Z_MUL_INPUT_OFFSET);
+            if (j >= j0) fill_trace_fp12_multiplication(t, z, x, s_row, e_row, col + Z_MUL_INPUT_OFFSET);
             z = z * x;
         } else {
-            fill_trace_cyclotomic_sq(t, z, s_row, e_row, col + Z_CYCLOTOMIC_SQ_OFFSET);
+            if (j >= j0) fill_trace_cyclotomic_sq(t, z, s_row, e_row, col + Z_CYCLOTOMIC_SQ_OFFSET);
             z = z.cyclotomic_square();
         }
         if (((BLS_X >> i) & 1) && !bitone) {
@@ -150,8 +157,13 @@ void fill_trace_cyclotomic_exp(Trace& t, const Fp12& x, size_t start_row, size_t
             bitone = false;
         }
     }
-    t.at(start_row + 70 * 12, col + RES_ROW_SELECTOR_OFFSET) = 1;
-    t.put(start_row + 70 * 12, col + Z_OFFSET, z);
+    if (j1 == 70) {
+        t.at(start_row + 70 * 12, col + RES_ROW_SELECTOR_OFFSET) = 1;
+        t.put(start_row + 70 * 12, col + Z_OFFSET, z);
+    }
+}
+void fill_trace_cyclotomic_exp(Trace& t, const Fp12& x, size_t start_row, size_t end_row, size_t col) {
+    fill_trace_cyclotomic_exp_steps(t, x, start_row, end_row, col, 0, 70);
 }
 void fill_trace_fp12_forbenius_map(Trace& t, const Fp12& x, size_t pow, size_t r0, size_t r1, size_t col) {  // fp12.rs:377-409
     const size_t div = pow / 12, rem = pow % 12;

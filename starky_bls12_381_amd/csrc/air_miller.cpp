@@ -121,45 +121,71 @@ extern "C" int starkhip_trace_miller_loop(const uint32_t px[12], const uint32_t 
         std::vector<bls::EllCoeff> ell = bls::calc_pairing_precomp(QX, QY, QZ);
         Fp12 native_res = bls::miller_loop(x, y, QX, QY, QZ);
         Trace t = open_trace(trace, n_rows, M::COLUMNS);
-        for (size_t row = 0; row < n_rows; row++) {
-            t.put(row, M::PX_OFFSET, x.l);
-            t.put(row, M::PY_OFFSET, y.l);
-        }
-        Fp12 f12 = Fp12::one();
-        int i = 62;  // bits() - 2
-        bool bitone = false;
+        // The running value f12 at the start of every 12-row block comes from a native pass first (68 sparse products and
+        // squarings); after that a block's rows depend only on (f12, bit state, ell[j]), so ranges of blocks -- and the columns
+        // that span all rows -- are tasks for fill_tasks (trace_tasks.cpp).
+        struct Block {
+            Fp12 f12;
+            int i;
+            bool bitone;
+        };
         const size_t blocks = std::min(n_rows / 12, ell.size());
-        for (size_t j = 0; j < blocks; j++) {
-            const size_t s_row = j * 12, e_row = (j + 1) * 12 - 1;
-            for (size_t row = s_row; row <= e_row; row++) {
-                if (j == 0) t.at(row, M::FIRST_BIT_SELECTOR_OFFSET) = 1;
-                if (i == 0) t.at(row, M::LAST_BIT_SELECTOR_OFFSET) = 1;
-                if (bitone) t.at(row, M::BIT1_SELECTOR_OFFSET) = 1;
-                t.at(row, M::ELL_COEFFS_INDEX_OFFEST + j) = 1;
-                for (size_t k = 0; k < 3; k++) t.put(row, M::ELL_COEFFS_OFFSET + k * 24, ell[j][k]);
-                t.put(row, M::F12_OFFSET, f12);
-            }
-            if (j != 0) t.at(s_row, M::FIRST_ROW_SELECTOR_OFFSET) = 1;
-            const bls::EllCoeff& e = ell[j];
-            fill_trace_fp2_fp_mul(t, e[1], x, s_row, e_row, M::O1_CALC_OFFSET);
-            Fp2 o1 = e[1] * x;
-            fill_trace_fp2_fp_mul(t, e[2], y, s_row, e_row, M::O4_CALC_OFFSET);
-            Fp2 o4 = e[2] * y;
-            fill_trace_multiply_by_014(t, f12, e[0], o1, o4, s_row, e_row, M::F12_MUL_BY_014_OFFSET);
-            f12 = f12.multiply_by_014(e[0], o1, o4);
-            fill_trace_fp12_multiplication(t, f12, f12, s_row, e_row, M::F12_SQ_CALC_OFFSET);
-            Fp12 f12_sq = f12 * f12;
-            if (((bls::BLS_X >> i) & 1) && !bitone) {
-                bitone = true;
-            } else if (j + 1 < ell.size()) {
-                f12 = f12_sq;
-                i -= 1;
-                bitone = false;
+        std::vector<Block> at(blocks);
+        Fp12 f12 = Fp12::one();
+        {
+            int i = 62;  // bits() - 2
+            bool bitone = false;
+            for (size_t j = 0; j < blocks; j++) {
+                at[j] = {f12, i, bitone};
+                const bls::EllCoeff& e = ell[j];
+                f12 = f12.multiply_by_014(e[0], e[1] * x, e[2] * y);
+                if (((bls::BLS_X >> i) & 1) && !bitone) {
+                    bitone = true;
+                } else if (j + 1 < ell.size()) {
+                    f12 = f12 * f12;
+                    i -= 1;
+                    bitone = false;
+                }
             }
         }
         f12 = f12.conjugate();
-        for (size_t row = 0; row < n_rows; row++) t.put(row, M::MILLER_LOOP_RES_OFFSET, f12);
-        for (size_t row = 0; row < n_rows; row++) fill_trace_negate_fp6(t, f12.c6(1), row, M::RES_CONJUGATE_OFFSET);
+        const size_t per_task = t.log && trace_threads() > 1 ? 4 : blocks ? blocks : 1;  // blocks per task
+        const size_t n_block_tasks = (blocks + per_task - 1) / per_task;
+        fill_tasks(t, n_block_tasks + 2, [&](Trace& part, size_t k) {
+            if (k == n_block_tasks) {
+                for (size_t row = 0; row < n_rows; row++) {
+                    part.put(row, M::PX_OFFSET, x.l);
+                    part.put(row, M::PY_OFFSET, y.l);
+                }
+                for (size_t row = 0; row < n_rows; row++) part.put(row, M::MILLER_LOOP_RES_OFFSET, f12);
+                return;
+            }
+            if (k == n_block_tasks + 1) {
+                for (size_t row = 0; row < n_rows; row++) fill_trace_negate_fp6(part, f12.c6(1), row, M::RES_CONJUGATE_OFFSET);
+                return;
+            }
+            for (size_t j = k * per_task; j < std::min(blocks, (k + 1) * per_task); j++) {
+                const size_t s_row = j * 12, e_row = (j + 1) * 12 - 1;
+                const Block& b = at[j];
+                for (size_t row = s_row; row <= e_row; row++) {
+                    if (j == 0) part.at(row, M::FIRST_BIT_SELECTOR_OFFSET) = 1;
+                    if (b.i == 0) part.at(row, M::LAST_BIT_SELECTOR_OFFSET) = 1;
+                    if (b.bitone) part.at(row, M::BIT1_SELECTOR_OFFSET) = 1;
+                    part.at(row, M::ELL_COEFFS_INDEX_OFFEST + j) = 1;
+                    for (size_t c = 0; c < 3; c++) part.put(row, M::ELL_COEFFS_OFFSET + c * 24, ell[j][c]);
+                    part.put(row, M::F12_OFFSET, b.f12);
+                }
+                if (j != 0) part.at(s_row, M::FIRST_ROW_SELECTOR_OFFSET) = 1;
+                const bls::EllCoeff& e = ell[j];
+                fill_trace_fp2_fp_mul(part, e[1], x, s_row, e_row, M::O1_CALC_OFFSET);
+                const Fp2 o1 = e[1] * x;
+                fill_trace_fp2_fp_mul(part, e[2], y, s_row, e_row, M::O4_CALC_OFFSET);
+                const Fp2 o4 = e[2] * y;
+                fill_trace_multiply_by_014(part, b.f12, e[0], o1, o4, s_row, e_row, M::F12_MUL_BY_014_OFFSET);
+                const Fp12 g = b.f12.multiply_by_014(e[0], o1, o4);
+                fill_trace_fp12_multiplication(part, g, g, s_row, e_row, M::F12_SQ_CALC_OFFSET);
+            }
+        });
         // public inputs
         size_t p = 0;
         for (int k = 0; k < 12; k++) public_inputs[p++] = x.l[k];

@@ -8,6 +8,8 @@
 #include "airs.h"
 #include "kernels.h"
 #include "trace_log.h"
+
+#include <atomic>
 #include "poseidon.h"
 #include "prover.h"
 #include "proof.h"
@@ -20,6 +22,8 @@ TraceLog*& armed_trace_log() {
     static thread_local TraceLog* armed = nullptr;
     return armed;
 }
+static std::atomic<int> g_trace_threads(1);
+int trace_threads() { return g_trace_threads.load(); }
 }  // namespace starkhip
 
 extern "C" {
@@ -187,6 +191,11 @@ int starkhip_proof_layout(const uint64_t* proof, size_t proof_words, starkhip_pr
 }
 
 // ---- compact traces (trace_log.h)
+int starkhip_trace_set_threads(int n) {
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return g_trace_threads.exchange(n);
+}
 int starkhip_trace_log_begin(void** log) {
     if (!log) return STARKHIP_ERR_BAD_SHAPE;
     *log = nullptr;
@@ -214,8 +223,8 @@ int starkhip_trace_log_info(const void* log, size_t* n_rows, size_t* n_cols, siz
     const TraceLog* l = (const TraceLog*)log;
     if (n_rows) *n_rows = l->rows;
     if (n_cols) *n_cols = l->cols;
-    if (n_records) *n_records = l->offsets.size();
-    if (n_words) *n_words = l->words.size();
+    if (n_records) *n_records = l->total_records();
+    if (n_words) *n_words = l->total_words();
     return STARKHIP_OK;
 }
 int starkhip_trace_log_expand_host(const void* log, uint64_t* trace_rowmajor, size_t* conflicts) {
@@ -223,16 +232,21 @@ int starkhip_trace_log_expand_host(const void* log, uint64_t* trace_rowmajor, si
     const TraceLog* l = (const TraceLog*)log;
     memset(trace_rowmajor, 0, l->rows * l->cols * sizeof(uint64_t));
     size_t bad = 0;
-    for (uint32_t off : l->offsets) {
-        const uint32_t* r = &l->words[off];
-        for (uint32_t k = 0; k < r[2]; k++)
-            for (uint32_t i = 0; i < r[3]; i++) {
-                uint64_t& cell = trace_rowmajor[(size_t)(r[1] + k) * l->cols + r[0] + i];
-                if (cell && cell != r[4 + i]) bad++;  // two records disagree: parallel expansion would be order dependent
-                cell = r[4 + i];
-            }
-    }
-    for (size_t i = 0; i + 1 < l->late_zeros.size(); i += 2) trace_rowmajor[(size_t)l->late_zeros[i + 1] * l->cols + l->late_zeros[i]] = 0;
+    l->for_each_part([&](const TraceLog& part) {
+        for (uint32_t off : part.offsets) {
+            const uint32_t* r = &part.words[off - part.base];
+            for (uint32_t k = 0; k < r[2]; k++)
+                for (uint32_t i = 0; i < r[3]; i++) {
+                    uint64_t& cell = trace_rowmajor[(size_t)(r[1] + k) * l->cols + r[0] + i];
+                    if (cell && cell != r[4 + i]) bad++;  // two records disagree: parallel expansion would be order dependent
+                    cell = r[4 + i];
+                }
+        }
+    });
+    l->for_each_part([&](const TraceLog& part) {
+        for (size_t i = 0; i + 1 < part.late_zeros.size(); i += 2)
+            trace_rowmajor[(size_t)part.late_zeros[i + 1] * l->cols + part.late_zeros[i]] = 0;
+    });
     if (conflicts) *conflicts = bad;
     return STARKHIP_OK;
 }

@@ -6,6 +6,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <functional>
+
 #include "air_ir.h"
 #include "air_layout.h"
 #include "native.h"
@@ -54,6 +56,7 @@ struct Trace {
 // What a generator calls first: a zeroed dense matrix over the caller's buffer, or -- when the calling thread is armed by
 // starkhip_trace_log_begin -- a recorder (the buffer argument is then ignored and may be null).
 TraceLog*& armed_trace_log();  // thread-local, capi.cpp
+int trace_threads();           // host threads one generator call may use when recording (starkhip_trace_set_threads), capi.cpp
 inline Trace open_trace(uint64_t* dense, size_t rows, size_t cols) {
     if (TraceLog* log = armed_trace_log()) {
         if (!log->offsets.empty() || log->rows) throw std::runtime_error("trace_log: one generator call per log");
@@ -64,6 +67,10 @@ inline Trace open_trace(uint64_t* dense, size_t rows, size_t cols) {
     memset(dense, 0, rows * cols * sizeof(uint64_t));
     return Trace(dense, rows, cols);
 }
+
+// Run fill(trace, k) for k < n_tasks; the tasks must write disjoint cells.  Serially into `t`, or -- when `t` records and
+// trace_threads() > 1 -- on a pool, every task into a log of its own that `t`'s log takes over in task order (trace_tasks.cpp).
+void fill_tasks(Trace& t, size_t n_tasks, const std::function<void(Trace&, size_t)>& fill);
 
 // Constraint sink: thin sugar over AirBuilder for the "gate * (a - b)" families that make up most constraints.
 struct CS {
@@ -182,6 +189,7 @@ void fill_trace_multiply_by_014(Trace& t, const Fp12& x, const Fp2& o0, const Fp
 void fill_trace_fp12_multiplication(Trace& t, const Fp12& x, const Fp12& y, size_t start_row, size_t end_row, size_t col);
 void fill_trace_cyclotomic_sq(Trace& t, const Fp12& x, size_t start_row, size_t end_row, size_t col);
 void fill_trace_cyclotomic_exp(Trace& t, const Fp12& x, size_t start_row, size_t end_row, size_t col);
+void fill_trace_cyclotomic_exp_steps(Trace& t, const Fp12& x, size_t start_row, size_t end_row, size_t col, size_t j0, size_t j1);
 void fill_trace_fp12_forbenius_map(Trace& t, const Fp12& x, size_t pow, size_t start_row, size_t end_row, size_t col);
 void fill_trace_fp12_conjugate(Trace& t, const Fp12& x, size_t row, size_t col);
 

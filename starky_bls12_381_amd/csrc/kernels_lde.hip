@@ -112,7 +112,8 @@ __device__ __forceinline__ void lde_pass(gl_t (&v)[16], gl_t* __restrict__ lds, 
         for (int i = 0; i < 16; i++) v[i] = lds[tpad + i * (T + T / 16)];
         // twiddles w_{NS*R}^{i * (j mod NS)}, j = t + m * T; the inverse transform's last pass also carries n^-1 (row 0).
         // Uniform row base + 32-bit lane offset => scalar-base loads, no per-load address registers.
-        const gl_t* twp = tw + PL::tw_off(P);
+        constexpr int TW_OFF = PL::tw_off(P);  // constexpr variable: otherwise the recursive helper survives as a CALL in the 2^13 kernel
+        const gl_t* twp = tw + TW_OFF;
 #pragma unroll
         for (int m = 0; m < S; m++) {
             const uint32_t jj8 = (uint32_t)((t + m * T) % NS) * 8u;

@@ -312,7 +312,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     const gl_t* d_values;
     if (layout == 2) {  // compact trace: upload the generator's write log and expand it here
         const TraceLog* log = (const TraceLog*)trace;
-        const size_t nw = log->words.size(), nr = log->offsets.size(), nz = log->late_zeros.size();
+        const size_t nw = log->total_words(), nr = log->total_records(), nz = log->total_late_zeros();
         if (log->rows != n || log->cols != C) return STARKHIP_ERR_BAD_SHAPE;
         HIPCHK(c->values.ensure(C * n * 8));
         HIPCHK(c->staging.ensure((nw + nr + nz + 2) * 4));
@@ -320,15 +320,24 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         uint32_t* d_offsets = d_words + nw;
         uint32_t* d_zeros = d_offsets + nr;
         HIPCHK(hipMemsetAsync(c->values.p, 0, C * n * 8, st));
-        if (nr) {
-            HIPCHK(hipMemcpyAsync(d_words, log->words.data(), nw * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_offsets, log->offsets.data(), nr * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(launch_expand_trace(d_words, d_offsets, nr, c->values.as<gl_t>(), n, st));
+        {  // a log recorded by several threads comes in parts (trace_log.h): each part's words land at its base, its offsets
+           // (already shifted by that base) and late zeros back to back
+            size_t at_r = 0, at_z = 0;
+            hipError_t up = hipSuccess;
+            log->for_each_part([&](const TraceLog& part) {
+                if (up != hipSuccess) return;
+                if (!part.words.empty()) up = hipMemcpyAsync(d_words + part.base, part.words.data(), part.words.size() * 4, hipMemcpyHostToDevice, st);
+                if (up == hipSuccess && !part.offsets.empty())
+                    up = hipMemcpyAsync(d_offsets + at_r, part.offsets.data(), part.offsets.size() * 4, hipMemcpyHostToDevice, st);
+                if (up == hipSuccess && !part.late_zeros.empty())
+                    up = hipMemcpyAsync(d_zeros + at_z, part.late_zeros.data(), part.late_zeros.size() * 4, hipMemcpyHostToDevice, st);
+                at_r += part.offsets.size();
+                at_z += part.late_zeros.size();
+            });
+            HIPCHK(up);
         }
-        if (nz) {
-            HIPCHK(hipMemcpyAsync(d_zeros, log->late_zeros.data(), nz * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(launch_zero_cells(d_zeros, nz / 2, c->values.as<gl_t>(), n, st));
-        }
+        if (nr) HIPCHK(launch_expand_trace(d_words, d_offsets, nr, c->values.as<gl_t>(), n, st));
+        if (nz) HIPCHK(launch_zero_cells(d_zeros, nz / 2, c->values.as<gl_t>(), n, st));
         d_values = c->values.as<gl_t>();
     } else if (on_device && layout == 1) {
         d_values = trace;

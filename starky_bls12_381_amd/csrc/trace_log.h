@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <stdexcept>
 #include <vector>
 
@@ -32,6 +33,8 @@ struct TraceLog {
         words.clear();
         offsets.clear();
         late_zeros.clear();
+        parts.clear();
+        base = 0;
         open.assign(c, 0);
     }
 
@@ -56,6 +59,42 @@ struct TraceLog {
         words.push_back(1);
         words.push_back((uint32_t)n);
         words.insert(words.end(), v, v + n);
+    }
+    // Logs of the same trace recorded separately (other threads filling other gadgets), taken over whole: nothing is
+    // copied, a part keeps its own `words` and its `offsets` are shifted by `base`, its position in the concatenation
+    // (this log's own words first, then the parts in order).  Runs are not joined across parts; the expansion does not
+    // depend on the order of records.
+    std::vector<TraceLog> parts;
+    uint32_t base = 0;
+    size_t total_words() const {
+        size_t n = words.size();
+        for (const TraceLog& p : parts) n += p.words.size();
+        return n;
+    }
+    size_t total_records() const {
+        size_t n = offsets.size();
+        for (const TraceLog& p : parts) n += p.offsets.size();
+        return n;
+    }
+    size_t total_late_zeros() const {
+        size_t n = late_zeros.size();
+        for (const TraceLog& p : parts) n += p.late_zeros.size();
+        return n;
+    }
+    template <class F>
+    void for_each_part(F f) const {  // f(const TraceLog&): this log's own records, then every part's
+        f(*this);
+        for (const TraceLog& p : parts) f(p);
+    }
+    void adopt(TraceLog&& part) {
+        if (part.rows != rows || part.cols != cols || !part.parts.empty()) throw std::runtime_error("trace_log: adopt of a different trace");
+        const size_t at = total_words();
+        if (at + part.words.size() > 0xFFFFFFF0u) throw std::runtime_error("trace_log: log too large");
+        part.base = (uint32_t)at;
+        for (uint32_t& o : part.offsets) o += part.base;
+        part.open = std::vector<uint32_t>();
+        parts.push_back(std::move(part));
+        std::fill(open.begin(), open.end(), 0);  // no run of this log may be extended past records that came later
     }
     void set(size_t row, size_t col, uint64_t v) {
         if (v >> 32) throw std::runtime_error("trace_log: cell value does not fit 32 bits");

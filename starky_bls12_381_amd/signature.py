@@ -146,7 +146,7 @@ def job_arguments(signatures, my_jobs):
 BIG = ("final_exp",)  # jobs that get their own contexts: the FinalExp leaf hash is a one-shot grid of two waves per SIMD
 
 
-def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, queue_depth=None):
+def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, queue_depth=None, trace_threads=None):
     """Generate and prove `my_jobs` on this rank: `gen_threads` host threads record compact traces into bounded queues, one
     host thread per prover context takes them and proves.  Returns ({(i, name): (air, proof, cfg)},
     {"generate_s": sum of generator time, "prove_s": sum of prover time, "wall_s": wall time}).
@@ -156,6 +156,10 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
     to the many `small` ones; both pools run at once.  Half of the generator threads start on the FinalExp traces (0.3 s
     each), the other half on the small ones, so neither pool waits for the other's traces.
 
+    `trace_threads`: host threads ONE recording generator call may use (starkhip_trace_set_threads: the FinalExp and
+    MillerLoop generators fill their gadget blocks in parallel once the native chain is known).  Default: with few jobs on
+    this rank (one signature) the generator threads would idle, so 2 x gen_threads / jobs each, at most 8; 1 for a batch.
+
     `prove(prover, air, cfg, trace, pis)` and `generate(name, *args)` are injectable (CPU tests run the control flow without
     a GPU); defaults: Prover.prove and the compact trace generators."""
     if prove is None:
@@ -164,6 +168,9 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
     if generate is None:
         def generate(name, *a):
             return GENERATORS[name](*a, compact=True)
+        if trace_threads is None:
+            trace_threads = max(1, min(8, 2 * gen_threads // max(1, len(my_jobs))))
+        S.set_trace_threads(trace_threads)
     pools = provers if isinstance(provers, dict) else {"big": list(provers), "small": None}
     shared = pools.get("small") is None  # one pool takes everything
     order = sorted(my_jobs, key=lambda j: -parallel.AIR_COST[A.JOB_AIR[j[1]]])

@@ -115,6 +115,21 @@ def test_final_exp_trace_satisfies_all_constraints_on_the_reference_vector():
     assert c.shape == t.shape and np.array_equal(cpis, pis) and c.nbytes * 20 < t.nbytes
     e, conflicts = c.expand()
     assert conflicts == 0 and np.array_equal(e, t)
+    # recorded on several host threads (starkhip_trace_set_threads: the 32 ops become tasks once the native chain is known): the
+    # same matrix, and the same records for any thread count > 1
+    del e
+    counts = []
+    try:
+        for threads in (3, 8):
+            S.set_trace_threads(threads)
+            cp, ppis = S.trace_final_exp(aa, compact=True)
+            e, conflicts = cp.expand()
+            assert conflicts == 0 and np.array_equal(e, t) and np.array_equal(ppis, pis)
+            counts.append((cp.n_records, cp.nbytes))
+            del e
+    finally:
+        assert S.set_trace_threads(1) == 8
+    assert counts[0] == counts[1] and counts[0][0] < c.n_records * 1.02
     # 4441 rows carry operations (TOTAL_ROW), the rest of the op window is zero
     assert not t[4441:, 12949:].any()
     t[100, 20000] = (int(t[100, 20000]) + 1) % S.P

@@ -31,6 +31,27 @@ def test_recorded_trace_expands_to_the_dense_one(name, fn, args):
     assert compact.nbytes * 5 < dense.nbytes  # FP12Mul (16 rows) has the least repetition: 10x; the 1024-row AIRs 7-10x
 
 
+def test_miller_loop_recorded_on_several_threads():
+    """starkhip_trace_set_threads: the 68 blocks of the Miller loop are filled as tasks once the running value at every block
+    start is known from the native pass; the parts are taken over in task order, so the recording is the same for any
+    thread count > 1 and stands for the dense matrix."""
+    _, pk, hm, sig = _bls_points()
+    jobs, _ = A.signature_jobs(pk, hm, sig)
+    dense, pis = S.trace_miller_loop(*jobs["ml1"][1])
+    seen = []
+    try:
+        for threads in (2, 5):
+            assert S.set_trace_threads(threads) in (1, 2)
+            compact, cpis = S.trace_miller_loop(*jobs["ml1"][1], compact=True)
+            expanded, conflicts = compact.expand()
+            assert conflicts == 0 and np.array_equal(expanded, dense) and np.array_equal(cpis, pis)
+            seen.append((compact.n_records, compact.nbytes))
+    finally:
+        S.set_trace_threads(1)
+    assert seen[0] == seen[1]
+    assert S.set_trace_threads(0) == 1 and S.set_trace_threads(1) == 1  # clamped to >= 1
+
+
 def test_ecc_aggregate_recorded_trace():
     from test_ecc_aggregate_cpu import pack, reference_vector
     pts, bits, _ = reference_vector()

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--small-inflight", type=int, default=0, help="contexts for the 1024-row AIRs; 0 = one pool of --inflight contexts; "
                                                                    "default for --batch > 1: 16")
     ap.add_argument("--gen-threads", type=int, default=12, help="host threads recording traces per GPU")
+    ap.add_argument("--trace-threads", type=int, default=0, help="host threads one recording generator call may use; 0 = automatic "
+                                                                  "(2 x gen-threads / jobs on the rank, at most 8)")
     ap.add_argument("--collect", action="store_true", help="N > 1: gather every proof on every rank afterwards (raw buffers) and check all signatures")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -81,7 +83,7 @@ def main():
         t0 = time.perf_counter()
         sigs = G.broadcast_operands(dist, signatures, args.batch, device=dev)
         job_args, natives = G.job_arguments(sigs, mine)
-        res, st = G.run_jobs(provers, mine, job_args, gen_threads=args.gen_threads)
+        res, st = G.run_jobs(provers, mine, job_args, gen_threads=args.gen_threads, trace_threads=args.trace_threads or None)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -124,7 +126,7 @@ def main():
             "metric": "BLS signature checks/s, end to end (operands -> trace generation -> 6 STARK proofs each)",
             "value": args.batch / el, "unit": "signatures/s", "n_gpus": world, "batch": args.batch, "steps": args.steps,
             "ms_per_step": el * 1e3, "ms_per_signature": el * 1e3 / args.batch,
-            "proofs_per_step": 6 * args.batch, "contexts_per_gpu": ({k: len(v) for k, v in provers.items()} if isinstance(provers, dict) else len(provers)), "generator_threads_per_gpu": args.gen_threads,
+            "proofs_per_step": 6 * args.batch, "contexts_per_gpu": ({k: len(v) for k, v in provers.items()} if isinstance(provers, dict) else len(provers)), "generator_threads_per_gpu": args.gen_threads, "threads_per_generator_call": S.set_trace_threads(1),
             "rank0": {"jobs": len(mine), "generate_s_sum": stats.get("generate_s"), "prove_s_sum": stats.get("prove_s"), "wall_s": stats.get("wall_s")},
             "proofs_verified_after_timing": n_verified, "signatures_checked_on_rank0": checked, "signatures_valid_on_rank0": valid,
             "proof_bytes_on_rank0": {k: v[0] for k, v in per_air.items()},

@@ -15,7 +15,7 @@
         unsigned a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 7, a3 = a0 ^ 0x55; \
         unsigned long long q0 = a0 * 77ull + 1, q1 = a1 * 99ull + 3, q2 = 5;                \
         for (int it = 0; it < ITER; it++) {                                                 \
-            asm volatile(REP32(body) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(q0), "+v"(q1), "+v"(q2)::"vcc", "s10", "s11"); \
+            asm volatile(REP32(body) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(q0), "+v"(q1), "+v"(q2)::"vcc", "scc", "s10", "s11"); \
         }                                                                                   \
         out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + (unsigned)q0 + (unsigned)q1 + (unsigned)q2; \
     }
@@ -39,6 +39,42 @@ KERNEL(k_mov_dpp, "v_mov_b32_dpp %0, %1 quad_perm:[2,2,2,2] row_mask:0xf bank_ma
 KERNEL(k_cmp_cnd_chain, "v_cmp_lt_u64 vcc, %4, %5\n v_cndmask_b32 %0, %1, %2, vcc\n")
 KERNEL(k_dot4_u8, "v_dot4_u32_u8 %0, %1, %2, %3\n")
 KERNEL(k_pk_add_u16, "v_pk_add_u16 %0, %1, %2\n")
+// which 32-bit instructions share v_add_u32's double rate
+KERNEL(k_sub_u32, "v_sub_u32 %0, %1, %2\n")
+KERNEL(k_and_b32, "v_and_b32 %0, %1, %2\n")
+KERNEL(k_xor_b32, "v_xor_b32 %0, %1, %2\n")
+KERNEL(k_lshlrev_b32, "v_lshlrev_b32 %0, 5, %1\n")
+KERNEL(k_lshrrev_b32, "v_lshrrev_b32 %0, 5, %1\n")
+KERNEL(k_ashrrev_i32, "v_ashrrev_i32 %0, 5, %1\n")
+KERNEL(k_mov_b32, "v_mov_b32 %0, %1\n")
+KERNEL(k_cndmask_s, "v_cndmask_b32_e64 %0, %1, %2, s[10:11]\n")
+KERNEL(k_bfe_u32, "v_bfe_u32 %0, %1, 5, 12\n")
+KERNEL(k_and_or_b32, "v_and_or_b32 %0, %1, %2, %3\n")
+KERNEL(k_lshl_add_u32, "v_lshl_add_u32 %0, %1, 5, %2\n")
+KERNEL(k_lshl_or_b32, "v_lshl_or_b32 %0, %1, 5, %2\n")
+KERNEL(k_perm_b32, "v_perm_b32 %0, %1, %2, %3\n")
+KERNEL(k_bfi_b32, "v_bfi_b32 %0, %1, %2, %3\n")
+KERNEL(k_min_u32, "v_min_u32 %0, %1, %2\n")
+KERNEL(k_fma_f32, "v_fma_f32 %0, %1, %2, %3\n")
+KERNEL(k_add_f32, "v_add_f32 %0, %1, %2\n")
+KERNEL(k_mul_f32, "v_mul_f32 %0, %1, %2\n")
+KERNEL(k_pk_fma_f32, "v_pk_fma_f32 %4, %5, %6, %5\n")
+KERNEL(k_fma_f64, "v_fma_f64 %4, %5, %6, %5\n")
+KERNEL(k_cvt_f32_u32, "v_cvt_f32_u32 %0, %1\n")
+KERNEL(k_add_co_e64, "v_add_co_u32_e64 %0, s[10:11], %1, %2\n")
+KERNEL(k_addc_only, "v_addc_co_u32 %0, vcc, %1, %2, vcc\n")
+KERNEL(k_mad_i64_i32, "v_mad_i64_i32 %4, s[10:11], %1, %2, %5\n")
+KERNEL(k_mul_i32_i24, "v_mul_i32_i24 %0, %1, %2\n")
+KERNEL(k_add_lshl_u32, "v_add_lshl_u32 %0, %1, %2, 3\n")
+KERNEL(k_xad_u32, "v_xad_u32 %0, %1, %2, %3\n")
+KERNEL(k_or3_b32, "v_or3_b32 %0, %1, %2, %3\n")
+KERNEL(k_sub_e64, "v_sub_u32_e64 %0, %1, %2\n")
+KERNEL(k_add_sdwa, "v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n")
+KERNEL(k_mix_add_mad, "v_add_u32 %0, %1, %2\n v_mad_u64_u32 %4, s[10:11], %1, %2, %5\n")
+KERNEL(k_mix_3add_mad, "v_add_u32 %0, %1, %2\n v_add_u32 %3, %1, %2\n v_xor_b32 %0, %1, %2\n v_mad_u64_u32 %4, s[10:11], %1, %2, %5\n")
+KERNEL(k_salu, "s_add_u32 s10, s10, 3\n")
+KERNEL(k_mix_salu_valu, "s_add_u32 s10, s10, 3\n v_mad_u32_u24 %0, %1, %2, %3\n")
+KERNEL(k_mix_salu_fast, "s_add_u32 s10, s10, 3\n v_add_u32 %0, %1, %2\n")
 
 typedef void (*kern_t)(unsigned*, unsigned);
 struct Entry {
@@ -54,7 +90,20 @@ int main() {
                    {"v_cmp_lt_u64", k_cmp_lt_u64, 1},    {"v_cmp_lt_u32", k_cmp_lt_u32, 1},    {"v_cndmask_b32", k_cndmask, 1},
                    {"v_add_co+v_addc_co", k_add_co_pair, 2}, {"v_lshlrev_b64", k_lshlrev_b64, 1}, {"v_alignbit_b32", k_alignbit, 1},
                    {"v_mov_b32_dpp", k_mov_dpp, 1},      {"v_cmp_lt_u64+v_cndmask", k_cmp_cnd_chain, 2}, {"v_dot4_u32_u8", k_dot4_u8, 1},
-                   {"v_pk_add_u16", k_pk_add_u16, 1}};
+                   {"v_pk_add_u16", k_pk_add_u16, 1},
+                   {"v_sub_u32", k_sub_u32, 1}, {"v_and_b32", k_and_b32, 1}, {"v_xor_b32", k_xor_b32, 1},
+                   {"v_lshlrev_b32", k_lshlrev_b32, 1}, {"v_lshrrev_b32", k_lshrrev_b32, 1}, {"v_ashrrev_i32", k_ashrrev_i32, 1},
+                   {"v_mov_b32", k_mov_b32, 1}, {"v_cndmask_b32 (sgpr mask)", k_cndmask_s, 1}, {"v_bfe_u32", k_bfe_u32, 1},
+                   {"v_and_or_b32", k_and_or_b32, 1}, {"v_lshl_add_u32", k_lshl_add_u32, 1}, {"v_lshl_or_b32", k_lshl_or_b32, 1},
+                   {"v_perm_b32", k_perm_b32, 1}, {"v_bfi_b32", k_bfi_b32, 1}, {"v_min_u32", k_min_u32, 1},
+                   {"v_fma_f32", k_fma_f32, 1}, {"v_add_f32", k_add_f32, 1}, {"v_mul_f32", k_mul_f32, 1},
+                   {"v_pk_fma_f32", k_pk_fma_f32, 1}, {"v_fma_f64", k_fma_f64, 1}, {"v_cvt_f32_u32", k_cvt_f32_u32, 1},
+                   {"v_add_co_u32 (sgpr carry)", k_add_co_e64, 1}, {"v_addc_co_u32", k_addc_only, 1}, {"v_mad_i64_i32", k_mad_i64_i32, 1},
+                   {"v_mul_i32_i24", k_mul_i32_i24, 1}, {"v_add_lshl_u32", k_add_lshl_u32, 1}, {"v_xad_u32", k_xad_u32, 1},
+                   {"v_or3_b32", k_or3_b32, 1}, {"v_sub_u32_e64", k_sub_e64, 1}, {"v_add_u32_sdwa", k_add_sdwa, 1},
+                   {"v_add_u32 + v_mad_u64_u32", k_mix_add_mad, 2}, {"3 simple + v_mad_u64_u32", k_mix_3add_mad, 4},
+                   {"s_add_u32", k_salu, 1}, {"s_add_u32 + v_mad_u32_u24", k_mix_salu_valu, 2}, {"s_add_u32 + v_add_u32", k_mix_salu_fast, 2}};
+    setvbuf(stdout, NULL, _IOLBF, 0);
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
