@@ -18,7 +18,7 @@ build/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
 	$(HIPCC) -O2 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude -c $< -o $@
 
 $(OUT): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrocprofiler-sdk-roctx
 
 oracle:
 	$(MAKE) -C oracle
@@ -46,7 +46,13 @@ asan-test: asan
 	STARKHIP_LIBRARY=$(CURDIR)/build/asan/libstarkhip_host_asan.so STARKHIP_ORACLE_LIBRARY=$(CURDIR)/build/asan/liboracle_asan.so \
 	python -m pytest tests/test_native_cpu.py tests/test_quotient_plan_cpu.py tests/test_toy_air_cpu.py tests/test_trace_log_cpu.py tests/test_ecc_aggregate_cpu.py -x -q -m "not gpu" -p no:cacheprovider
 
+# ThreadSanitizer on the threaded trace recording (trace_tasks.cpp): three traces recorded on 6 threads
+tsan-test: tests/tsan_trace_main.cpp $(ASAN_SRCS) $(HDRS)
+	@mkdir -p build/tsan
+	g++ -O1 -g -std=c++17 -fsanitize=thread -fno-omit-frame-pointer -Iinclude -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o build/tsan/tsan_trace tests/tsan_trace_main.cpp $(ASAN_SRCS) -lpthread
+	TSAN_OPTIONS=halt_on_error=1 build/tsan/tsan_trace
+
 clean:
 	rm -rf build $(OUT)
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean demo asan asan-test
+.PHONY: all oracle clean demo asan asan-test tsan-test

@@ -1,0 +1,295 @@
+//! FFI to `libstarkhip.so` (C ABI: `include/starkhip.h`) and a thin safe layer shaped like the calls it replaces in
+//! Electron-Labs/starky_bls12_381:
+//!
+//! | reference (src/aggregate_proof.rs)                                            | here                         |
+//! |-------------------------------------------------------------------------------|------------------------------|
+//! | `StarkConfig::standard_fast_config()` + `rate_bits` override (:32-33,155-156) | [`Config::for_air`]          |
+//! | `prove::<F, C, S, D>(stark, &config, trace, &pis, &mut timing)` (:59-65, ...) | [`Prover::prove_rows`], [`Prover::prove_recorded`] |
+//! | `verify_stark_proof(stark, proof.clone(), &config)` (:67,113,146,177)         | [`verify`]                   |
+//! | `S::generate_trace(..)` (+ public inputs built by the `*_main` drivers)       | [`record_final_exp`] etc. (or keep the reference's own generator and pass its rows) |
+//!
+//! NOT COMPILED in the image this repository is built in (no Rust toolchain there); kept in step with the header by hand.
+#![allow(non_camel_case_types)]
+
+use std::os::raw::{c_char, c_int, c_long, c_uint, c_void};
+
+// ------------------------------------------------------------------------------------------------ raw declarations
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct starkhip_config_t {
+    pub security_bits: u32,
+    pub num_challenges: u32,
+    pub rate_bits: u32,
+    pub cap_height: u32,
+    pub proof_of_work_bits: u32,
+    pub arity_bits: u32,
+    pub final_poly_bits: u32,
+    pub num_query_rounds: u32,
+}
+
+/// `starkhip_air_t`: the `S: Stark` type parameter of the reference as a value.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum Air {
+    Fp12Mul = 0,        // FP12MulStark             src/fp12_mul.rs
+    PairingPrecomp = 1, // PairingPrecompStark      src/calc_pairing_precomp.rs
+    MillerLoop = 2,     // MillerLoopStark          src/miller_loop.rs
+    FinalExp = 3,       // FinalExponentiateStark   src/final_exponentiate.rs
+    EccAggregate = 4,   // ECCAggStark              src/ecc_aggregate.rs
+}
+
+pub const STARKHIP_OK: c_int = 0;
+pub const STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE: c_int = -1;
+pub const STARKHIP_ERR_ZETA_IN_SUBGROUP: c_int = -2;
+pub const STARKHIP_ERR_BAD_SHAPE: c_int = -3;
+pub const STARKHIP_ERR_HIP: c_int = -4;
+pub const STARKHIP_ERR_OOM: c_int = -5;
+pub const STARKHIP_ERR_NO_DEVICE: c_int = -6;
+pub const STARKHIP_ERR_VERIFY: c_int = -7;
+pub const STARKHIP_ERR_BAD_AIR: c_int = -8;
+pub const STARKHIP_POW_SEARCH: u64 = u64::MAX;
+pub const STARKHIP_N_PHASES: usize = 11;
+
+/// `starkhip_proof_layout_t`: word offsets of every field of the proof blob.
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct starkhip_proof_layout_t {
+    pub n_columns: usize,
+    pub n_quotient_polys: usize,
+    pub degree_bits: usize,
+    pub rate_bits: usize,
+    pub cap_height: usize,
+    pub n_fri_layers: usize,
+    pub n_query_rounds: usize,
+    pub final_poly_len: usize,
+    pub n_public_inputs: usize,
+    pub arity_bits: usize,
+    pub off_trace_cap: usize,
+    pub off_quotient_cap: usize,
+    pub off_local_values: usize,
+    pub off_next_values: usize,
+    pub off_quotient_openings: usize,
+    pub off_fri_caps: usize,
+    pub off_query_rounds: usize,
+    pub query_round_words: usize,
+    pub off_final_poly: usize,
+    pub off_pow_witness: usize,
+    pub off_public_inputs: usize,
+    pub total_words: usize,
+    pub q_trace_leaf: usize,
+    pub q_trace_siblings: usize,
+    pub q_quotient_leaf: usize,
+    pub q_quotient_siblings: usize,
+    pub initial_sibling_count: usize,
+    pub q_step_evals: [usize; 16],
+    pub q_step_siblings: [usize; 16],
+    pub step_sibling_count: [usize; 16],
+}
+
+extern "C" {
+    pub fn starkhip_config_standard_fast(cfg: *mut starkhip_config_t);
+    pub fn starkhip_config_for_air(air: Air, cfg: *mut starkhip_config_t) -> c_int;
+    pub fn starkhip_air_columns(air: Air) -> c_int;
+    pub fn starkhip_air_public_inputs(air: Air) -> c_int;
+    pub fn starkhip_air_constraint_degree(air: Air) -> c_int;
+    pub fn starkhip_air_num_constraints(air: Air) -> c_int;
+    pub fn starkhip_air_default_rows(air: Air) -> c_int;
+
+    pub fn starkhip_trace_fp12_mul(x: *const u32, y: *const u32, trace: *mut u64, n_rows: usize, public_inputs: *mut u64) -> c_int;
+    pub fn starkhip_trace_final_exp(x: *const u32, trace: *mut u64, n_rows: usize, public_inputs: *mut u64) -> c_int;
+    pub fn starkhip_trace_miller_loop(px: *const u32, py: *const u32, qx: *const u32, qy: *const u32, qz: *const u32, trace: *mut u64,
+                                      n_rows: usize, public_inputs: *mut u64) -> c_int;
+    pub fn starkhip_trace_pairing_precomp(qx: *const u32, qy: *const u32, qz: *const u32, trace: *mut u64, n_rows: usize,
+                                          public_inputs: *mut u64) -> c_int;
+    pub fn starkhip_trace_ecc_aggregate(points: *const u32, bits: *const u8, trace: *mut u64, n_rows: usize, public_inputs: *mut u64) -> c_int;
+
+    pub fn starkhip_init(device_ordinal: c_int, ctx: *mut *mut c_void) -> c_int;
+    pub fn starkhip_shutdown(ctx: *mut c_void);
+    pub fn starkhip_set_option(ctx: *mut c_void, name: *const c_char, value: c_long) -> c_int;
+    pub fn starkhip_prove(ctx: *mut c_void, air: Air, cfg: *const starkhip_config_t, trace: *const u64, n_rows: usize, n_cols: usize,
+                          trace_layout: c_int, trace_on_device: c_int, public_inputs: *const u64, n_pis: usize, pow_witness: u64,
+                          proof: *mut *mut u64, proof_words: *mut usize) -> c_int;
+
+    pub fn starkhip_trace_log_begin(log: *mut *mut c_void) -> c_int;
+    pub fn starkhip_trace_set_threads(n: c_int) -> c_int;
+    pub fn starkhip_trace_log_end(log: *mut c_void) -> c_int;
+    pub fn starkhip_trace_log_free(log: *mut c_void);
+    pub fn starkhip_trace_log_info(log: *const c_void, n_rows: *mut usize, n_cols: *mut usize, n_records: *mut usize, n_words: *mut usize) -> c_int;
+    pub fn starkhip_prove_compact(ctx: *mut c_void, air: Air, cfg: *const starkhip_config_t, log: *const c_void, public_inputs: *const u64,
+                                  n_pis: usize, pow_witness: u64, proof: *mut *mut u64, proof_words: *mut usize) -> c_int;
+
+    pub fn starkhip_last_timings(ctx: *mut c_void, ms: *mut f32) -> c_int;
+    pub fn starkhip_host_alloc(ctx: *mut c_void, bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn starkhip_host_free(p: *mut c_void);
+
+    pub fn starkhip_verify(air: Air, cfg: *const starkhip_config_t, proof: *const u64, proof_words: usize) -> c_int;
+    pub fn starkhip_proof_layout(proof: *const u64, proof_words: usize, out: *mut starkhip_proof_layout_t) -> c_int;
+    pub fn starkhip_free(p: *mut c_void);
+    pub fn starkhip_error_string(code: c_int) -> *const c_char;
+}
+
+// ------------------------------------------------------------------------------------------------ safe layer
+/// The reference's errors: `prove` returns `anyhow::Result`; an invalid witness is "Quotient has failed, the vanishing
+/// polynomial is not divisible by Z_H", a bad challenge "Opening point is in the subgroup".
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub struct Error(pub c_int);
+
+impl std::fmt::Display for Error {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        let s = unsafe { std::ffi::CStr::from_ptr(starkhip_error_string(self.0)) };
+        write!(f, "starkhip: {} ({})", s.to_string_lossy(), self.0)
+    }
+}
+impl std::error::Error for Error {}
+
+fn check(rc: c_int) -> Result<(), Error> {
+    if rc == STARKHIP_OK { Ok(()) } else { Err(Error(rc)) }
+}
+
+pub type Config = starkhip_config_t;
+impl Config {
+    /// `StarkConfig::standard_fast_config()` with the `rate_bits` the reference's driver sets for this AIR.
+    pub fn for_air(air: Air) -> Result<Config, Error> {
+        let mut cfg = Config::default();
+        check(unsafe { starkhip_config_for_air(air, &mut cfg) })?;
+        Ok(cfg)
+    }
+}
+
+/// The proof blob (field order of `StarkProofWithPublicInputs`); `layout()` gives the offset of every field.
+pub struct Proof(pub Vec<u64>);
+impl Proof {
+    pub fn layout(&self) -> Result<starkhip_proof_layout_t, Error> {
+        let mut l = std::mem::MaybeUninit::<starkhip_proof_layout_t>::zeroed();
+        check(unsafe { starkhip_proof_layout(self.0.as_ptr(), self.0.len(), l.as_mut_ptr()) })?;
+        Ok(unsafe { l.assume_init() })
+    }
+    pub fn public_inputs(&self) -> Result<&[u64], Error> {
+        let l = self.layout()?;
+        Ok(&self.0[l.off_public_inputs..l.off_public_inputs + l.n_public_inputs])
+    }
+}
+
+/// A trace recorded as runs by one of the `record_*` functions (153 MB instead of 4.8 GB of rows for FinalExp).
+pub struct RecordedTrace {
+    log: *mut c_void,
+    pub public_inputs: Vec<u64>,
+}
+unsafe impl Send for RecordedTrace {} // immutable after recording; may be proven from any thread
+impl Drop for RecordedTrace {
+    fn drop(&mut self) {
+        unsafe { starkhip_trace_log_free(self.log) }
+    }
+}
+
+fn record(air: Air, fill: impl FnOnce(*mut u64) -> c_int) -> Result<RecordedTrace, Error> {
+    let n_pis = unsafe { starkhip_air_public_inputs(air) } as usize;
+    let mut pis = vec![0u64; n_pis];
+    let mut log = std::ptr::null_mut();
+    check(unsafe { starkhip_trace_log_begin(&mut log) })?;
+    let rc = fill(pis.as_mut_ptr());
+    let end = unsafe { starkhip_trace_log_end(log) };
+    if rc != STARKHIP_OK || end != STARKHIP_OK {
+        unsafe { starkhip_trace_log_free(log) };
+        return Err(Error(if rc != STARKHIP_OK { rc } else { end }));
+    }
+    Ok(RecordedTrace { log, public_inputs: pis })
+}
+
+/// `FinalExponentiateStark::generate_trace(x)` + the public inputs of `final_exponentiate_main` (src/aggregate_proof.rs:150-165).
+pub fn record_final_exp(x: &[u32; 144]) -> Result<RecordedTrace, Error> {
+    record(Air::FinalExp, |pis| unsafe { starkhip_trace_final_exp(x.as_ptr(), std::ptr::null_mut(), 8192, pis) })
+}
+/// `MillerLoopStark::generate_trace(..)` (src/aggregate_proof.rs:78-101).
+pub fn record_miller_loop(px: &[u32; 12], py: &[u32; 12], qx: &[u32; 24], qy: &[u32; 24], qz: &[u32; 24]) -> Result<RecordedTrace, Error> {
+    record(Air::MillerLoop, |pis| unsafe {
+        starkhip_trace_miller_loop(px.as_ptr(), py.as_ptr(), qx.as_ptr(), qy.as_ptr(), qz.as_ptr(), std::ptr::null_mut(), 1024, pis)
+    })
+}
+/// `PairingPrecompStark::generate_trace(..)` (src/aggregate_proof.rs:23-54).
+pub fn record_pairing_precomp(qx: &[u32; 24], qy: &[u32; 24], qz: &[u32; 24]) -> Result<RecordedTrace, Error> {
+    record(Air::PairingPrecomp, |pis| unsafe {
+        starkhip_trace_pairing_precomp(qx.as_ptr(), qy.as_ptr(), qz.as_ptr(), std::ptr::null_mut(), 1024, pis)
+    })
+}
+/// `FP12MulStark::generate_trace(x, y)` (src/aggregate_proof.rs:120-133).
+pub fn record_fp12_mul(x: &[u32; 144], y: &[u32; 144]) -> Result<RecordedTrace, Error> {
+    record(Air::Fp12Mul, |pis| unsafe { starkhip_trace_fp12_mul(x.as_ptr(), y.as_ptr(), std::ptr::null_mut(), 16, pis) })
+}
+
+/// One prover context = one HIP stream and its buffers on one GPU; one `prove` at a time per context, any number of contexts
+/// per GPU (four in flight per GPU is the measured optimum for FinalExp).
+pub struct Prover {
+    ctx: *mut c_void,
+}
+unsafe impl Send for Prover {}
+impl Drop for Prover {
+    fn drop(&mut self) {
+        unsafe { starkhip_shutdown(self.ctx) }
+    }
+}
+
+impl Prover {
+    pub fn new(device_ordinal: i32) -> Result<Prover, Error> {
+        let mut ctx = std::ptr::null_mut();
+        check(unsafe { starkhip_init(device_ordinal as c_int, &mut ctx) })?;
+        Ok(Prover { ctx })
+    }
+
+    unsafe fn take(p: *mut u64, words: usize) -> Proof {
+        let v = std::slice::from_raw_parts(p, words).to_vec();
+        starkhip_free(p as *mut c_void);
+        Proof(v)
+    }
+
+    /// `prove(stark, &config, trace_rows_to_poly_values(trace), &public_inputs, &mut timing)` for a trace as
+    /// `generate_trace` returns it: rows of canonical Goldilocks cells (`GoldilocksField` is `repr(transparent)` over u64:
+    /// pass `to_canonical_u64()` of every cell).
+    pub fn prove_rows<const COLUMNS: usize>(&mut self, air: Air, cfg: &Config, trace: &[[u64; COLUMNS]], public_inputs: &[u64]) -> Result<Proof, Error> {
+        let (mut p, mut w) = (std::ptr::null_mut::<u64>(), 0usize);
+        check(unsafe {
+            starkhip_prove(self.ctx, air, cfg, trace.as_ptr() as *const u64, trace.len(), COLUMNS, /* row-major */ 0, /* host */ 0,
+                           public_inputs.as_ptr(), public_inputs.len(), STARKHIP_POW_SEARCH, &mut p, &mut w)
+        })?;
+        Ok(unsafe { Prover::take(p, w) })
+    }
+
+    /// The same proof, byte for byte, from a recorded trace (expanded on the device).
+    pub fn prove_recorded(&mut self, air: Air, cfg: &Config, trace: &RecordedTrace) -> Result<Proof, Error> {
+        let (mut p, mut w) = (std::ptr::null_mut::<u64>(), 0usize);
+        check(unsafe {
+            starkhip_prove_compact(self.ctx, air, cfg, trace.log, trace.public_inputs.as_ptr(), trace.public_inputs.len(), STARKHIP_POW_SEARCH,
+                                   &mut p, &mut w)
+        })?;
+        Ok(unsafe { Prover::take(p, w) })
+    }
+
+    /// Milliseconds of the last proof's phases (upload, ifft_lde, trace_merkle, quotient, quotient_commit, openings, fri_combine,
+    /// fri_commit, pow, queries, total) -- what the reference's `TimingTree` would print.
+    pub fn last_timings(&mut self) -> Result<[f32; STARKHIP_N_PHASES], Error> {
+        let mut ms = [0f32; STARKHIP_N_PHASES];
+        check(unsafe { starkhip_last_timings(self.ctx, ms.as_mut_ptr()) })?;
+        Ok(ms)
+    }
+}
+
+/// `verify_stark_proof(stark, proof, &config)` (CPU).
+pub fn verify(air: Air, cfg: &Config, proof: &Proof) -> Result<(), Error> {
+    check(unsafe { starkhip_verify(air, cfg, proof.0.as_ptr(), proof.0.len()) })
+}
+
+/// Example: the body of `final_exponentiate_main` (src/aggregate_proof.rs:150-179) on the GPU.
+pub fn final_exponentiate_main(prover: &mut Prover, x: &[u32; 144]) -> Result<Proof, Error> {
+    let cfg = Config::for_air(Air::FinalExp)?;
+    let trace = record_final_exp(x)?;
+    let proof = prover.prove_recorded(Air::FinalExp, &cfg, &trace)?;
+    verify(Air::FinalExp, &cfg, &proof)?;
+    Ok(proof)
+}
+
+#[allow(dead_code)]
+fn _abi_sizes() {
+    // the header's structs are plain C: eight u32 / 27 + 48 size_t
+    let _ = [(); 32][std::mem::size_of::<starkhip_config_t>() - 32];
+    let _: c_uint = 0;
+}

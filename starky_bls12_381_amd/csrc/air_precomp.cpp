@@ -244,95 +244,125 @@ extern "C" int starkhip_trace_pairing_precomp(const uint32_t qx_[24], const uint
         const Fp2 x = fp2_of(qx_), y = fp2_of(qy_), z = fp2_of(qz_);
         Trace t = open_trace(trace, n_rows, PC::COLUMNS);
         const Fp2 z_inv = z.invert();
-        // the three global multiplications span ALL rows as one "12-row" gadget call (App. B.4 item 13)
-        generate_trace_fp2_mul(t, z, z_inv, 0, n_rows - 1, PC::Z_MULT_Z_INV_OFFSET);
-        generate_trace_fp2_mul(t, x, z_inv, 0, n_rows - 1, PC::X_MULT_Z_INV_OFFSET);
-        generate_trace_fp2_mul(t, y, z_inv, 0, n_rows - 1, PC::Y_MULT_Z_INV_OFFSET);
         const Fp2 qx = x * z.invert(), qy = y * z.invert(), qz = Fp2::one();  // calc_qs (native.rs:283-291)
-        for (size_t row = 0; row < n_rows; row++) {
-            t.put(row, PC::QX_OFFSET, qx);
-            t.put(row, PC::QY_OFFSET, qy);
-            t.put(row, PC::QZ_OFFSET, qz);
-        }
-        Fp2 rx = qx, ry = qy, rz = qz;
-        int bit_pos = 62;
-        bool bit1 = false;
         const size_t num_coeffs = 68;
         const Fp three = Fp::from_u32(3), two = Fp::from_u32(2), k = bls::mod_inverse_of_two();
-        for (size_t n = 0; n < n_rows / 12 + 1; n++) {
-            const size_t start_row = n * 12, end_row = (n + 1) * 12;
-            for (size_t row = start_row; row < std::min(end_row, n_rows); row++) {
-                if (n == 0) t.at(row, PC::FIRST_LOOP_SELECTOR_OFFSET) = 1;
-                t.put(row, PC::RX_OFFSET, rx);
-                t.put(row, PC::RY_OFFSET, ry);
-                t.put(row, PC::RZ_OFFSET, rz);
-                if (bit1) t.at(row, PC::BIT1_SELECTOR_OFFSET) = 1;
-                if (n < num_coeffs) t.at(row, PC::ELL_COEFFS_IDX_OFFSET + n) = 1;
-            }
-            t.at(start_row, PC::FIRST_ROW_SELECTOR_OFFSET) = 1;
-            if (end_row > n_rows) break;
-            const size_t r0 = start_row, r1 = end_row - 1;
-            auto rows_sub = [&](const Fp2& a, const Fp2& bb, size_t col) { for (size_t r = r0; r <= r1; r++) fill_trace_subtraction_with_reduction(t, a, bb, r, col); };
-            auto rows_add = [&](const Fp2& a, const Fp2& bb, size_t col) { for (size_t r = r0; r <= r1; r++) fill_trace_addition_with_reduction(t, a, bb, r, col); };
-            auto rows_neg = [&](const Fp2& a, size_t col) { for (size_t r = r0; r <= r1; r++) fill_trace_negate_fp2(t, a, r, col); };
-            if (!bit1) {
-                // v = [new_rx, new_ry, new_rz, t0, t1, x0, t2, t3, x1, t4, x3, x2, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13]
-                const std::vector<Fp2> v = bls::calc_precomp_stuff_loop0(rx, ry, rz);
-                generate_trace_fp2_mul(t, ry, ry, r0, r1, PC::T0_CALC_OFFSET);
-                generate_trace_fp2_mul(t, rz, rz, r0, r1, PC::T1_CALC_OFFSET);
-                fill_trace_fp2_fp_mul(t, v[4], three, r0, r1, PC::X0_CALC_OFFSET);
-                fill_multiply_by_b_trace(t, v[5], r0, r1, PC::T2_CALC_OFFSET);
-                fill_trace_fp2_fp_mul(t, v[6], three, r0, r1, PC::T3_CALC_OFFSET);
-                generate_trace_fp2_mul(t, ry, rz, r0, r1, PC::X1_CALC_OFFSET);
-                fill_trace_fp2_fp_mul(t, v[8], two, r0, r1, PC::T4_CALC_OFFSET);
-                rows_sub(v[6], v[3], PC::X2_CALC_OFFSET);
-                generate_trace_fp2_mul(t, rx, rx, r0, r1, PC::X3_CALC_OFFSET);
-                fill_trace_fp2_fp_mul(t, v[10], three, r0, r1, PC::X4_CALC_OFFSET);
-                rows_neg(v[9], PC::X5_CALC_OFFSET);
-                rows_sub(v[3], v[7], PC::X6_CALC_OFFSET);
-                generate_trace_fp2_mul(t, rx, ry, r0, r1, PC::X7_CALC_OFFSET);
-                generate_trace_fp2_mul(t, v[14], v[15], r0, r1, PC::X8_CALC_OFFSET);
-                rows_add(v[3], v[7], PC::X9_CALC_OFFSET);
-                fill_trace_fp2_fp_mul(t, v[17], k, r0, r1, PC::X10_CALC_OFFSET);
-                generate_trace_fp2_mul(t, v[18], v[18], r0, r1, PC::X11_CALC_OFFSET);
-                generate_trace_fp2_mul(t, v[6], v[6], r0, r1, PC::X12_CALC_OFFSET);
-                fill_trace_fp2_fp_mul(t, v[20], three, r0, r1, PC::X13_CALC_OFFSET);
-                fill_trace_fp2_fp_mul(t, v[16], k, r0, r1, PC::NEW_RX_OFFSET);
-                rows_sub(v[19], v[21], PC::NEW_RY_OFFSET);
-                generate_trace_fp2_mul(t, v[3], v[9], r0, r1, PC::NEW_RZ_OFFSET);
-                rx = v[0]; ry = v[1]; rz = v[2];
-                bit1 = (bls::BLS_X >> bit_pos) & 1;
-                bit_pos = bit1 ? bit_pos : (bit_pos > 0 ? bit_pos - 1 : 0);
-            } else {
-                // w = [new_rx, new_ry, new_rz, t0, t1, ..., t18]
-                const std::vector<Fp2> w = bls::calc_precomp_stuff_loop1(rx, ry, rz, qx, qy);
-                generate_trace_fp2_mul(t, qy, rz, r0, r1, PC::BIT1_T0_CALC_OFFSET);
-                rows_sub(ry, w[3], PC::BIT1_T1_CALC_OFFSET);
-                generate_trace_fp2_mul(t, qx, rz, r0, r1, PC::BIT1_T2_CALC_OFFSET);
-                rows_sub(rx, w[5], PC::BIT1_T3_CALC_OFFSET);
-                generate_trace_fp2_mul(t, w[4], qx, r0, r1, PC::BIT1_T4_CALC_OFFSET);
-                generate_trace_fp2_mul(t, w[6], qy, r0, r1, PC::BIT1_T5_CALC_OFFSET);
-                rows_sub(w[7], w[8], PC::BIT1_T6_CALC_OFFSET);
-                rows_neg(w[4], PC::BIT1_T7_CALC_OFFSET);
-                generate_trace_fp2_mul(t, w[6], w[6], r0, r1, PC::BIT1_T8_CALC_OFFSET);
-                generate_trace_fp2_mul(t, w[11], w[6], r0, r1, PC::BIT1_T9_CALC_OFFSET);
-                generate_trace_fp2_mul(t, w[11], rx, r0, r1, PC::BIT1_T10_CALC_OFFSET);
-                generate_trace_fp2_mul(t, w[4], w[4], r0, r1, PC::BIT1_T11_CALC_OFFSET);
-                generate_trace_fp2_mul(t, w[14], rz, r0, r1, PC::BIT1_T12_CALC_OFFSET);
-                fill_trace_fp2_fp_mul(t, w[13], two, r0, r1, PC::BIT1_T13_CALC_OFFSET);
-                rows_sub(w[12], w[16], PC::BIT1_T14_CALC_OFFSET);
-                rows_add(w[17], w[15], PC::BIT1_T15_CALC_OFFSET);
-                rows_sub(w[13], w[18], PC::BIT1_T16_CALC_OFFSET);
-                generate_trace_fp2_mul(t, w[19], w[4], r0, r1, PC::BIT1_T17_CALC_OFFSET);
-                generate_trace_fp2_mul(t, w[12], ry, r0, r1, PC::BIT1_T18_CALC_OFFSET);
-                generate_trace_fp2_mul(t, w[6], w[18], r0, r1, PC::BIT1_RX_CALC_OFFSET);
-                rows_sub(w[20], w[21], PC::BIT1_RY_CALC_OFFSET);
-                generate_trace_fp2_mul(t, rz, w[12], r0, r1, PC::BIT1_RZ_CALC_OFFSET);
-                rx = w[0]; ry = w[1]; rz = w[2];
-                bit1 = false;
-                bit_pos = bit_pos > 0 ? bit_pos - 1 : 0;
+        // The running point (rx, ry, rz) and the bit state at the start of every 12-row block come from a native pass first;
+        // after that a block's rows depend only on them, so ranges of blocks -- and the three multiplications that span all
+        // rows -- are tasks for fill_tasks (trace_tasks.cpp).
+        struct Block {
+            Fp2 rx, ry, rz;
+            bool bit1;
+        };
+        const size_t n_blocks = n_rows / 12 + 1;  // the last one is cut off by the end of the trace: header rows only
+        std::vector<Block> at(n_blocks);
+        {
+            Fp2 rx = qx, ry = qy, rz = qz;
+            int bit_pos = 62;
+            bool bit1 = false;
+            for (size_t n = 0; n < n_blocks; n++) {
+                at[n] = {rx, ry, rz, bit1};
+                if ((n + 1) * 12 > n_rows) break;
+                if (!bit1) {
+                    const std::vector<Fp2> v = bls::calc_precomp_stuff_loop0(rx, ry, rz);
+                    rx = v[0]; ry = v[1]; rz = v[2];
+                    bit1 = (bls::BLS_X >> bit_pos) & 1;
+                    bit_pos = bit1 ? bit_pos : (bit_pos > 0 ? bit_pos - 1 : 0);
+                } else {
+                    const std::vector<Fp2> w = bls::calc_precomp_stuff_loop1(rx, ry, rz, qx, qy);
+                    rx = w[0]; ry = w[1]; rz = w[2];
+                    bit1 = false;
+                    bit_pos = bit_pos > 0 ? bit_pos - 1 : 0;
+                }
             }
         }
+        const size_t per_task = t.log && trace_threads() > 1 ? 6 : n_blocks;  // blocks per task
+        const size_t n_block_tasks = (n_blocks + per_task - 1) / per_task;
+        fill_tasks(t, n_block_tasks + 1, [&](Trace& t, size_t task) {
+            if (task == n_block_tasks) {
+                // the three global multiplications span ALL rows as one "12-row" gadget call (App. B.4 item 13)
+                generate_trace_fp2_mul(t, z, z_inv, 0, n_rows - 1, PC::Z_MULT_Z_INV_OFFSET);
+                generate_trace_fp2_mul(t, x, z_inv, 0, n_rows - 1, PC::X_MULT_Z_INV_OFFSET);
+                generate_trace_fp2_mul(t, y, z_inv, 0, n_rows - 1, PC::Y_MULT_Z_INV_OFFSET);
+                for (size_t row = 0; row < n_rows; row++) {
+                    t.put(row, PC::QX_OFFSET, qx);
+                    t.put(row, PC::QY_OFFSET, qy);
+                    t.put(row, PC::QZ_OFFSET, qz);
+                }
+                return;
+            }
+            for (size_t n = task * per_task; n < std::min(n_blocks, (task + 1) * per_task); n++) {
+                const Fp2 &rx = at[n].rx, &ry = at[n].ry, &rz = at[n].rz;
+                const bool bit1 = at[n].bit1;
+                    const size_t start_row = n * 12, end_row = (n + 1) * 12;
+                    for (size_t row = start_row; row < std::min(end_row, n_rows); row++) {
+                        if (n == 0) t.at(row, PC::FIRST_LOOP_SELECTOR_OFFSET) = 1;
+                        t.put(row, PC::RX_OFFSET, rx);
+                        t.put(row, PC::RY_OFFSET, ry);
+                        t.put(row, PC::RZ_OFFSET, rz);
+                        if (bit1) t.at(row, PC::BIT1_SELECTOR_OFFSET) = 1;
+                        if (n < num_coeffs) t.at(row, PC::ELL_COEFFS_IDX_OFFSET + n) = 1;
+                    }
+                    t.at(start_row, PC::FIRST_ROW_SELECTOR_OFFSET) = 1;
+                    if (end_row > n_rows) break;  // (only the last block)
+                    const size_t r0 = start_row, r1 = end_row - 1;
+                    auto rows_sub = [&](const Fp2& a, const Fp2& bb, size_t col) { for (size_t r = r0; r <= r1; r++) fill_trace_subtraction_with_reduction(t, a, bb, r, col); };
+                    auto rows_add = [&](const Fp2& a, const Fp2& bb, size_t col) { for (size_t r = r0; r <= r1; r++) fill_trace_addition_with_reduction(t, a, bb, r, col); };
+                    auto rows_neg = [&](const Fp2& a, size_t col) { for (size_t r = r0; r <= r1; r++) fill_trace_negate_fp2(t, a, r, col); };
+                    if (!bit1) {
+                        // v = [new_rx, new_ry, new_rz, t0, t1, x0, t2, t3, x1, t4, x3, x2, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13]
+                        const std::vector<Fp2> v = bls::calc_precomp_stuff_loop0(rx, ry, rz);
+                        generate_trace_fp2_mul(t, ry, ry, r0, r1, PC::T0_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, rz, rz, r0, r1, PC::T1_CALC_OFFSET);
+                        fill_trace_fp2_fp_mul(t, v[4], three, r0, r1, PC::X0_CALC_OFFSET);
+                        fill_multiply_by_b_trace(t, v[5], r0, r1, PC::T2_CALC_OFFSET);
+                        fill_trace_fp2_fp_mul(t, v[6], three, r0, r1, PC::T3_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, ry, rz, r0, r1, PC::X1_CALC_OFFSET);
+                        fill_trace_fp2_fp_mul(t, v[8], two, r0, r1, PC::T4_CALC_OFFSET);
+                        rows_sub(v[6], v[3], PC::X2_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, rx, rx, r0, r1, PC::X3_CALC_OFFSET);
+                        fill_trace_fp2_fp_mul(t, v[10], three, r0, r1, PC::X4_CALC_OFFSET);
+                        rows_neg(v[9], PC::X5_CALC_OFFSET);
+                        rows_sub(v[3], v[7], PC::X6_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, rx, ry, r0, r1, PC::X7_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, v[14], v[15], r0, r1, PC::X8_CALC_OFFSET);
+                        rows_add(v[3], v[7], PC::X9_CALC_OFFSET);
+                        fill_trace_fp2_fp_mul(t, v[17], k, r0, r1, PC::X10_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, v[18], v[18], r0, r1, PC::X11_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, v[6], v[6], r0, r1, PC::X12_CALC_OFFSET);
+                        fill_trace_fp2_fp_mul(t, v[20], three, r0, r1, PC::X13_CALC_OFFSET);
+                        fill_trace_fp2_fp_mul(t, v[16], k, r0, r1, PC::NEW_RX_OFFSET);
+                        rows_sub(v[19], v[21], PC::NEW_RY_OFFSET);
+                        generate_trace_fp2_mul(t, v[3], v[9], r0, r1, PC::NEW_RZ_OFFSET);
+                    } else {
+                        // w = [new_rx, new_ry, new_rz, t0, t1, ..., t18]
+                        const std::vector<Fp2> w = bls::calc_precomp_stuff_loop1(rx, ry, rz, qx, qy);
+                        generate_trace_fp2_mul(t, qy, rz, r0, r1, PC::BIT1_T0_CALC_OFFSET);
+                        rows_sub(ry, w[3], PC::BIT1_T1_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, qx, rz, r0, r1, PC::BIT1_T2_CALC_OFFSET);
+                        rows_sub(rx, w[5], PC::BIT1_T3_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, w[4], qx, r0, r1, PC::BIT1_T4_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, w[6], qy, r0, r1, PC::BIT1_T5_CALC_OFFSET);
+                        rows_sub(w[7], w[8], PC::BIT1_T6_CALC_OFFSET);
+                        rows_neg(w[4], PC::BIT1_T7_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, w[6], w[6], r0, r1, PC::BIT1_T8_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, w[11], w[6], r0, r1, PC::BIT1_T9_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, w[11], rx, r0, r1, PC::BIT1_T10_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, w[4], w[4], r0, r1, PC::BIT1_T11_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, w[14], rz, r0, r1, PC::BIT1_T12_CALC_OFFSET);
+                        fill_trace_fp2_fp_mul(t, w[13], two, r0, r1, PC::BIT1_T13_CALC_OFFSET);
+                        rows_sub(w[12], w[16], PC::BIT1_T14_CALC_OFFSET);
+                        rows_add(w[17], w[15], PC::BIT1_T15_CALC_OFFSET);
+                        rows_sub(w[13], w[18], PC::BIT1_T16_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, w[19], w[4], r0, r1, PC::BIT1_T17_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, w[12], ry, r0, r1, PC::BIT1_T18_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, w[6], w[18], r0, r1, PC::BIT1_RX_CALC_OFFSET);
+                        rows_sub(w[20], w[21], PC::BIT1_RY_CALC_OFFSET);
+                        generate_trace_fp2_mul(t, rz, w[12], r0, r1, PC::BIT1_RZ_CALC_OFFSET);
+                    }
+        
+            }
+        });
         // public inputs: x, y, z (72) then 68 x 72 ell coefficients of the native precompute
         size_t p = 0;
         for (const Fp2* v : {&x, &y, &z})

@@ -720,10 +720,7 @@ hipError_t launch_quotient_eval(const QOp* ops, const uint32_t* loads, unsigned 
     if (n_slots)
         hipLaunchKernelGGL(quotient_eval_kernel<true>, dim3((unsigned)((size + 63) / 64), n_chunks), dim3(64), lds_bytes, st, P);
     else
-    {
-        static const size_t pad = [] { const char* e = getenv("STARKHIP_QUOTIENT_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
-        hipLaunchKernelGGL(quotient_eval_kernel<false>, dim3((unsigned)((size + 63) / 64), n_chunks), dim3(64), pad, st, P);
-    }
+        hipLaunchKernelGGL(quotient_eval_kernel<false>, dim3((unsigned)((size + 63) / 64), n_chunks), dim3(64), 0, st, P);
     return hipGetLastError();
 }
 

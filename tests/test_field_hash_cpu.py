@@ -76,6 +76,66 @@ def test_c_abi_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def _top_level_args(text):
+    depth, n, seen = 0, 0, False
+    for ch in text:
+        if ch in "([":
+            depth += 1
+        elif ch in ")]":
+            depth -= 1
+        elif ch == "," and depth == 0:
+            n += 1
+        if not ch.isspace():
+            seen = True
+    return n + 1 if seen and text.strip() != "void" else 0
+
+
+def test_rust_binding_matches_the_header():
+    """bindings/rust/starkhip-sys cannot be compiled here (no Rust toolchain): every `extern "C"` function it declares must
+    exist in include/starkhip.h with the same number of parameters, and its struct mirrors must have the header's fields."""
+    hdr = open(os.path.join(ROOT, "include", "starkhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    rs = open(os.path.join(ROOT, "bindings", "rust", "starkhip-sys", "src", "lib.rs")).read()
+    rs_nc = re.sub(r"//[^\n]*", "", rs)
+    c_fns = {m.group(1): _top_level_args(m.group(2)) for m in re.finditer(r"\b(starkhip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)}
+    block = rs_nc[rs_nc.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    r_fns = {m.group(1): _top_level_args(m.group(2)) for m in re.finditer(r"pub fn (starkhip_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->[^;]*)?;", block, flags=re.S)}
+    assert len(r_fns) >= 28
+    for name, n in r_fns.items():
+        assert name in c_fns, name
+        assert c_fns[name] == n, (name, c_fns[name], n)
+    for must in ("starkhip_prove", "starkhip_prove_compact", "starkhip_verify", "starkhip_proof_layout", "starkhip_trace_log_begin",
+                 "starkhip_trace_set_threads", "starkhip_config_for_air", "starkhip_init", "starkhip_shutdown", "starkhip_free"):
+        assert must in r_fns, must
+
+    def c_fields(struct_end):
+        body = hdr[:hdr.index(struct_end)]
+        body = body[body.rindex("typedef struct {") + len("typedef struct {"):]
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(",")[0:1] + decl.split(",")[1:]:
+                out.append(re.sub(r"\[.*?\]", "", part.split()[-1]))
+        return out
+
+    def r_fields(name):
+        body = rs_nc[rs_nc.index("pub struct %s {" % name):]
+        body = body[:body.index("}")]
+        return re.findall(r"pub ([a-z0-9_]+):", body)
+
+    assert r_fields("starkhip_config_t") == c_fields("} starkhip_config_t;")
+    assert r_fields("starkhip_proof_layout_t") == c_fields("} starkhip_proof_layout_t;")
+    c_codes = dict(re.findall(r"(STARKHIP_(?:OK|ERR_[A-Z_]+))\s*=\s*(-?\d+)", hdr))
+    r_codes = dict(re.findall(r"pub const (STARKHIP_(?:OK|ERR_[A-Z_]+)): c_int = (-?\d+);", rs_nc))
+    assert r_codes == c_codes
+    c_airs = {k: v for k, v in re.findall(r"STARKHIP_AIR_([A-Z0-9_]+)\s*=\s*(\d+)", hdr) if not k.startswith("TEST")}
+    r_airs = dict(re.findall(r"^\s*([A-Za-z0-9]+) = (\d+),", rs_nc[rs_nc.index("pub enum Air {"):rs_nc.index("pub const STARKHIP_OK")], flags=re.M))
+    assert sorted(r_airs.values()) == sorted(c_airs.values()) and len(r_airs) == 5
+
+
 def test_config_mirrors_standard_fast_config():
     cfg = S.StarkConfig.standard_fast_config()
     assert (cfg.security_bits, cfg.num_challenges, cfg.rate_bits, cfg.cap_height, cfg.proof_of_work_bits, cfg.arity_bits,

@@ -31,18 +31,19 @@ def test_recorded_trace_expands_to_the_dense_one(name, fn, args):
     assert compact.nbytes * 5 < dense.nbytes  # FP12Mul (16 rows) has the least repetition: 10x; the 1024-row AIRs 7-10x
 
 
-def test_miller_loop_recorded_on_several_threads():
-    """starkhip_trace_set_threads: the 68 blocks of the Miller loop are filled as tasks once the running value at every block
-    start is known from the native pass; the parts are taken over in task order, so the recording is the same for any
-    thread count > 1 and stands for the dense matrix."""
+@pytest.mark.parametrize("job,fn", [("ml1", S.trace_miller_loop), ("pp2", S.trace_pairing_precomp)])
+def test_recorded_on_several_threads(job, fn):
+    """starkhip_trace_set_threads: the 12-row blocks of the Miller loop / of the pairing precomputation are filled as tasks once
+    the running value at every block start is known from a native pass; the parts are taken over in task order, so the
+    recording is the same for any thread count > 1 and stands for the dense matrix."""
     _, pk, hm, sig = _bls_points()
     jobs, _ = A.signature_jobs(pk, hm, sig)
-    dense, pis = S.trace_miller_loop(*jobs["ml1"][1])
+    dense, pis = fn(*jobs[job][1])
     seen = []
     try:
         for threads in (2, 5):
             assert S.set_trace_threads(threads) in (1, 2)
-            compact, cpis = S.trace_miller_loop(*jobs["ml1"][1], compact=True)
+            compact, cpis = fn(*jobs[job][1], compact=True)
             expanded, conflicts = compact.expand()
             assert conflicts == 0 and np.array_equal(expanded, dense) and np.array_equal(cpis, pis)
             seen.append((compact.n_records, compact.nbytes))

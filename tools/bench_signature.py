@@ -52,6 +52,7 @@ def main():
     from starky_bls12_381_amd import signature as G
     from bls_util import native_vectors
 
+    G.tune_host_allocator()
     rank, local_rank, world = parallel.rank_info()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
