@@ -13,7 +13,7 @@ Prints ONE JSON line on rank 0.  What is measured where (DESIGN.md §6 has every
                           heavy kernels, the figures the committed rocprof summaries under profiles/ must agree with);
                           HBM-side traffic per launch from profiles/pmc_traffic_latest.json
   value_host_boundary     rank 0, untimed: host rows in page-locked memory -> H2D -> transpose -> proof (the boundary the
-                          reference has), two in flight;  value_compact: the same from recorded (compact) traces
+                          reference has), as many in flight as the timed region;  value_compact: the same from recorded (compact) traces
   cpu_baseline            rank 0 at N = 1: the CPU oracle on a bounded sample of the same workload
 """
 import argparse
@@ -266,9 +266,9 @@ def main():
             "reference_published": {"value": 1 / 92.0, "unit": "proofs/s", "hardware": "AWS r6a.8xlarge, 32-core EPYC 7R13 (reference README.md:39)"},
         }
         if not args.no_boundary and world == 1:  # per-GPU figures, taken at N = 1 (other ranks would wait in the teardown meanwhile)
-            # ---- untimed: the reference's own boundary (host rows in, proof out) and the compact-trace hand-over, two in flight
+            # ---- untimed: the reference's own boundary (host rows in, proof out) and the compact-trace hand-over
             try:
-                nb = min(2, inflight)
+                nb = inflight  # as many in flight as the timed region keeps (staging buffers: 4.8 GB more per context)
                 x0 = work[provers[0]][2]
                 _, pis0 = S.trace_final_exp(x0, out=host_rows)
                 for pv in provers[:nb]:

@@ -173,7 +173,7 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
 
     `trace_threads`: host threads ONE recording generator call may use (starkhip_trace_set_threads: the FinalExp and
     MillerLoop generators fill their gadget blocks in parallel once the native chain is known).  Default: with few jobs on
-    this rank (one signature) the generator threads would idle, so 2 x gen_threads / jobs each, at most 8; 1 for a batch.
+    this rank (one signature) 16, for a batch 1.
 
     `prove(prover, air, cfg, trace, pis)` and `generate(name, *args)` are injectable (CPU tests run the control flow without
     a GPU); defaults: Prover.prove and the compact trace generators."""
@@ -184,7 +184,9 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
         def generate(name, *a):
             return GENERATORS[name](*a, compact=True)
         if trace_threads is None:
-            trace_threads = max(1, min(8, 2 * gen_threads // max(1, len(my_jobs))))
+            # few jobs on this rank (one signature): the recording itself is the latency -- FinalExp 0.21 s on one thread,
+            # 0.025 s on 16 (EPYC 9575F, profiles/r02_c_trace_threads.txt); a batch keeps one thread per call
+            trace_threads = 16 if len(my_jobs) <= 6 else max(1, min(8, 2 * gen_threads // len(my_jobs)))
         S.set_trace_threads(trace_threads)
     pools = provers if isinstance(provers, dict) else {"big": list(provers), "small": None}
     shared = pools.get("small") is None  # one pool takes everything
@@ -197,6 +199,7 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
         ready["small"] = ready["big"]
     results, errors = {}, []
     t_gen, t_prove = [0.0], [0.0]
+    timeline = {}  # job -> [generation start, end, proof start, end] in seconds from the start of run_jobs
 
     def generator(first):
         second = "small" if first == "big" else "big"
@@ -213,6 +216,7 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
                 trace, pis = generate(job[1], *args[job])
                 with lock:
                     t_gen[0] += time.perf_counter() - t0
+                    timeline[job] = [t0 - t_begin, time.perf_counter() - t_begin, None, None]
                 ready[kind].put((job, trace, pis))
             except Exception as e:  # noqa: BLE001 -- reported to the caller below
                 with lock:
@@ -233,11 +237,12 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
                 with lock:
                     t_prove[0] += time.perf_counter() - t0
                     results[job] = (air, proof, cfg)
+                    timeline[job][2:] = [t0 - t_begin, time.perf_counter() - t_begin]
             except Exception as e:  # noqa: BLE001
                 with lock:
                     errors.append(e)
 
-    t0 = time.perf_counter()
+    t0 = t_begin = time.perf_counter()
     n_gen = max(1, min(gen_threads, len(order) or 1))
     n_big_gen = min(len(todo["big"]), max(1, n_gen // 2)) if todo["big"] else 0
     gens = [threading.Thread(target=generator, args=("big" if g < n_big_gen else "small",)) for g in range(n_gen)]
@@ -258,7 +263,7 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
     wall = time.perf_counter() - t0
     if errors:
         raise errors[0]
-    return results, {"generate_s": t_gen[0], "prove_s": t_prove[0], "wall_s": wall}
+    return results, {"generate_s": t_gen[0], "prove_s": t_prove[0], "wall_s": wall, "timeline": timeline}
 
 
 def signature_proofs(results, index):
