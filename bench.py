@@ -258,6 +258,9 @@ def main():
                          "durations": "one proof in flight (uncontended), HIP events on the library's stream, mean of 3 launches",
                          "limiter": "integer VALU issue" if dominant == "leaf_hash" else "see kernels", "valu": valu if dominant == "leaf_hash" else None},
             "kernels": kernels,
+            # the two rates the proof is governed by, from the same uncontended launches
+            "poseidon_perms_per_s": perms / (lh_ms * 1e-3) if lh_ms > 0 else None,
+            "constraint_evals_per_s": (S.air_num_constraints(air) * float(N) / (solo_ms["quotient_eval"] * 1e-3)) if solo_ms["quotient_eval"] > 0 else None,
             "latency_ms_one_in_flight": t_solo * 1e3,
             "phase_ms_one_in_flight": solo_phase,
             "phase_ms_timed_region": {k: v / steps for k, v in phase_ms.items()},

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -37,7 +38,11 @@ void fill_tasks(Trace& t, size_t n_tasks, const std::function<void(Trace&, size_
         }
     };
     std::vector<std::thread> pool;
-    for (int w = 1; w < threads && (size_t)w < n_tasks; w++) pool.emplace_back(worker);
+    try {
+        for (int w = 1; w < threads && (size_t)w < n_tasks; w++) pool.emplace_back(worker);
+    } catch (const std::system_error&) {
+        // no more threads to be had: the ones that started and this one share the tasks
+    }
     worker();
     for (std::thread& th : pool) th.join();
     if (!failure.empty()) throw std::runtime_error(failure);
