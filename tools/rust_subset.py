@@ -180,6 +180,46 @@ class Row:
         return Sym.var(i | self.flag)
 
 
+class TraceRow:
+    """One row of a TraceMatrix: `trace[row][col] = F::from_canonical_u32(..)` / `= trace[row - 1][col]`."""
+    __slots__ = ("a",)
+
+    def __init__(self, a):
+        self.a = a
+
+    def __len__(self):
+        return len(self.a)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [FieldConst(int(v)) for v in self.a[i]]
+        return FieldConst(int(self.a[i]))
+
+    def __setitem__(self, i, val):
+        if isinstance(val, FieldConst):
+            self.a[i] = val.v
+        elif isinstance(val, bool) or not isinstance(val, int):
+            raise TypeError(f"trace cell gets {type(val).__name__}")
+        else:
+            self.a[i] = val % P_GL
+
+
+class TraceMatrix:
+    """`vec![[F::ZERO; COLUMNS]; rows]` of a generate_trace function, backed by a numpy matrix of canonical field values."""
+
+    def __init__(self, rows, cols):
+        import numpy as np
+        self.m = np.zeros((rows, cols), dtype=np.uint64)
+
+    def __len__(self):
+        return self.m.shape[0]
+
+    def __getitem__(self, r):
+        if not isinstance(r, int) or not 0 <= r < self.m.shape[0]:
+            raise IndexError(f"trace row {r} out of range {self.m.shape[0]}")
+        return TraceRow(self.m[r])
+
+
 class TupleStruct:
     def __init__(self, name, fields):
         self.name, self.fields = name, fields
@@ -202,6 +242,9 @@ class Closure:
         for p, a in zip(self.params, args):
             bind_pattern(env, p, a)
         return self.interp.ev(self.body, env, self.mod)
+
+
+_MISSING = object()
 
 
 class Env:
@@ -460,14 +503,19 @@ class Parser:
         return self.range_expr(no_struct)
 
     def range_expr(self, ns):
+        enders = ("{", ")", "]", ";", ",")
         if self.at("..") or self.at("..="):
-            raise NotImplementedError("prefix range")
+            incl = self.peek().v == "..="
+            self.i += 1
+            if any(self.at(t) for t in enders):
+                return ("range", None, None, False)
+            return ("range", None, self.binary(0, ns), incl)
         lhs = self.binary(0, ns)
         if self.at("..") or self.at("..="):
             incl = self.peek().v == "..="
             self.i += 1
-            if self.at("{") or self.at(")") or self.at("]") or self.at(";") or self.at(","):
-                raise NotImplementedError("open range")
+            if any(self.at(t) for t in enders):
+                return ("range", lhs, None, False)
             rhs = self.binary(0, ns)
             return ("range", lhs, rhs, incl)
         return lhs
@@ -606,6 +654,10 @@ class Parser:
                             break
                     self.eat("|")
                 body = self.expr()
+                if self.peek().k == "op" and self.peek().v in ("=", "+=", "-=", "*="):  # |i| trace[i][c] = F::ONE
+                    op = self.peek()
+                    self.i += 1
+                    body = ("block", [("assign", op.v, body, self.expr(), op.line)], None)
                 return ("closure", params, body)
             if tk.v == "<":  # <T>::NAME
                 self.skip_generics()
@@ -666,6 +718,9 @@ class Parser:
 
 
 # ----------------------------------------------------------------------------------------------- module index
+OPERATOR_TRAITS = ("Add", "Sub", "Mul", "Div", "Neg", "AddAssign", "SubAssign", "MulAssign")
+
+
 class FnItem:
     def __init__(self, mod, name, tok_index, line, owner=None):
         self.mod, self.name, self.tok_index, self.line, self.owner = mod, name, tok_index, line, owner
@@ -682,6 +737,7 @@ class Module:
         self.const_vals = {}
         self.fns = {}         # name -> FnItem
         self.methods = {}     # (Type, name) -> FnItem
+        self.trait_methods = {}  # (Type, name) -> FnItem of an operator trait impl (Add, Sub, Mul, Div, Neg)
         self.globs = []       # glob-imported module names
         self.imports = {}     # name -> module name
         self._index()
@@ -756,6 +812,10 @@ class Module:
                     item = FnItem(self, name, i, tk.line, owner)
                     if owner is None:
                         self.fns.setdefault(name, item)
+                    elif impl_stack[-1][2] is not None and impl_stack[-1][2][0] in OPERATOR_TRAITS:
+                        # `impl Mul<U> for T { fn mul }` is what `a * b` calls for b: U; an inherent `fn mul(&self, ..)` of the
+                        # same name is what `a.mul(y)` calls (method resolution prefers inherent methods)
+                        self.trait_methods.setdefault((owner, name), {})[impl_stack[-1][2][1]] = item
                     else:
                         self.methods.setdefault((owner, name), item)
                     # skip the signature up to the body's '{' (or ';' for trait declarations)
@@ -788,6 +848,7 @@ class Module:
                     # impl<..> [Trait<..> for] Type<..> [where ..] {
                     j = i + 1
                     names = []
+                    inner = []  # identifiers one level inside <..>, with the index in `names` they follow
                     ad = 0
                     while not (t[j].v == "{" and ad <= 0):
                         v = t[j].v
@@ -800,14 +861,22 @@ class Module:
                                 ad -= 2
                         if t[j].k == "id" and ad == 0:
                             names.append(v)
+                        elif t[j].k == "id" and ad == 1:
+                            inner.append((len(names), v))
                         j += 1
                     # type name: identifier after 'for' if present, else first identifier
                     ty = None
+                    trait = None
                     if "for" in names:
-                        ty = names[names.index("for") + 1]
+                        k_for = names.index("for")
+                        ty = names[k_for + 1]
+                        trait = names[k_for - 1]
+                        # `impl Mul<Fp> for Fp2`: the operand type the impl is for (default: Self)
+                        targ = [v for pos, v in inner if pos == k_for]
+                        trait = (trait, targ[0] if targ else ty)
                     else:
                         ty = [x for x in names if x not in ("where",)][0]
-                    impl_stack.append((depth, ty))
+                    impl_stack.append((depth, ty, trait))
                     depth += 1
                     i = j + 1
                     continue
@@ -882,6 +951,8 @@ class Interp:
         self.stack_ids = {}
         self.stack_list = []
         self.fn_counts = {}        # (fn, "file:line") -> {constraints yielded by one invocation incl. nested: invocations}
+        self.const_cache = {}      # (module, NAME) -> value of a scalar `const`
+        self.fast_assign = False   # utils.rs assign_u32_* as slice stores (trace extraction of the big AIRs)
 
     # -- name resolution
     def find_const(self, mod, name):
@@ -913,10 +984,22 @@ class Interp:
                 return self.mods[g].fns[name]
         return None
 
-    def find_method(self, ty, name):
-        for m in self.mods.values():
-            if (ty, name) in m.methods:
-                return m.methods[(ty, name)]
+    def find_method(self, ty, name, operator=False, rhs=None):
+        """`a.name(..)` / `Type::name(..)`: inherent methods first; `operator`: the operator trait's impl first (a * b),
+        chosen by the right-hand operand's type (`impl Mul<Fp> for Fp2` next to `impl Mul for Fp2`)."""
+        rhs_ty = rhs.name if isinstance(rhs, TupleStruct) else ty
+        order = ("trait_methods", "methods") if operator else ("methods", "trait_methods")
+        for which in order:
+            for m in self.mods.values():
+                if (ty, name) in getattr(m, which):
+                    hit = getattr(m, which)[(ty, name)]
+                    if which == "trait_methods":
+                        if rhs_ty in hit:
+                            return hit[rhs_ty]
+                        if ty in hit and rhs is None:
+                            return hit[ty]
+                        continue
+                    return hit
         return None
 
     def parse_fn(self, item):
@@ -965,6 +1048,12 @@ class Interp:
             return self.ev(item.body, env, item.mod.name)
         except ReturnEx as r:
             return r.v
+        except (BreakEx, ContinueEx):
+            raise
+        except Exception as ex:
+            if not hasattr(ex, "rust_stack"):
+                ex.rust_stack = list(self.stack)  # where in the Rust source the failure happened
+            raise
         finally:
             self.stack.pop()
             n = len(self.records) - n0
@@ -1001,7 +1090,7 @@ class Interp:
             a, i = self.ev(e[1], env, mod), self.ev(e[2], env, mod)
             if isinstance(i, range):
                 return a[i.start:i.stop]
-            return a[i]
+            return a[i]  # an int, or a slice from an open range
         if k == "call":
             return self.ev_call(e, env, mod)
         if k == "method":
@@ -1021,7 +1110,7 @@ class Interp:
             v = self.ev(e[2], env, mod)
             if e[1] == "-":
                 if isinstance(v, TupleStruct):
-                    m = self.find_method(v.name, "neg")
+                    m = self.find_method(v.name, "neg", operator=True)
                     return self.call_fn(m, [v], f"{mod}.rs")
                 return -v
             return not v
@@ -1052,7 +1141,10 @@ class Interp:
             v, n = self.ev(e[1], env, mod), self.ev(e[2], env, mod)
             return [v for _ in range(n)]
         if k == "range":
-            a, b = self.ev(e[1], env, mod), self.ev(e[2], env, mod)
+            a = self.ev(e[1], env, mod) if e[1] is not None else None
+            b = self.ev(e[2], env, mod) if e[2] is not None else None
+            if a is None or b is None:
+                return slice(a, (b + 1 if e[3] else b) if b is not None else None)  # x[..n], x[n..], x[..]
             return range(a, b + 1 if e[3] else b)
         if k == "closure":
             return Closure(self, e[1], e[2], env, mod)
@@ -1127,7 +1219,7 @@ class Interp:
             raise TypeError(f"{mod}.rs:{line}: field op {op}")
         if isinstance(a, TupleStruct):
             name = {"+": "add", "-": "sub", "*": "mul", "/": "div"}[op]
-            m = self.find_method(a.name, name)
+            m = self.find_method(a.name, name, operator=True, rhs=b)
             return self.call_fn(m, [a, b], f"{mod}.rs:{line}")
         if op == "+":
             return a + b
@@ -1169,8 +1261,15 @@ class Interp:
         path = e[1]
         if len(path) == 1:
             name = path[0]
-            if env.has(name):
-                return env.get(name)
+            scope = env
+            while scope is not None:  # one walk instead of has() + get()
+                d = scope.v
+                if name in d:
+                    return d[name]
+                scope = scope.parent
+            hit = self.const_cache.get((mod, name), _MISSING)
+            if hit is not _MISSING:
+                return hit
             if name == "None":
                 return None
             if name == "true":
@@ -1181,7 +1280,10 @@ class Interp:
                 return env.get("self")
             m = self.find_const(mod, name)
             if m is not None:
-                return self.const_value(m, name)
+                v = self.const_value(m, name)
+                if isinstance(v, (int, bool)):
+                    self.const_cache[(mod, name)] = v  # scalars only: arrays are handed out by value
+                return v
             raise NameError(f"{mod}.rs:{e[2]}: unknown name {name}")
         head, last = path[-2], path[-1]
         if head in ("P", "FE", "F", "<T>") and last in ("ONES", "ONE"):
@@ -1223,6 +1325,15 @@ class Interp:
                 item = self.find_fn(mod, name)
                 if item is not None:
                     args = [self.ev(a, env, mod) for a in e[2]]
+                    if self.fast_assign and name in ("assign_u32_in_series", "assign_u32_12") and isinstance(args[0], TraceMatrix):
+                        # utils.rs:3-19: `for i in 0..val.len() { trace[row][start_col + i] = F::from_canonical_u32(val[i]) }`,
+                        # done as one slice store (opt-in; extract_trace_digests.py checks it against the interpreted loop)
+                        tr, row, col, val = args
+                        vals = [int(v) for v in val]
+                        if any(not 0 <= v < 2**32 for v in vals):
+                            raise OverflowError(f"{mod}.rs:{line}: from_canonical_u32 out of range")
+                        tr.m[row, col:col + len(vals)] = vals
+                        return None
                     return self.call_fn(item, args, f"{mod}.rs:{line}")
                 # tuple-struct constructor (Fp, Fp2, ...)
                 if name[0].isupper():
@@ -1230,6 +1341,8 @@ class Interp:
                 raise NameError(f"{mod}.rs:{line}: unknown function {name}")
             head = path[-2]
             args = [self.ev(a, env, mod) for a in e[2]]
+            if head in ("FE", "F") and name == "from_bool":
+                return FieldConst(1 if args[0] else 0)
             if head in ("FE", "F", "Extension") and name in ("from_canonical_u32", "from_canonical_u64", "from_canonical_usize", "from_canonical_u8", "from_canonical_u16"):
                 lim = {"from_canonical_u32": 2**32, "from_canonical_u8": 2**8, "from_canonical_u16": 2**16}.get(name, P_GL)
                 if not (0 <= args[0] < lim):
@@ -1246,6 +1359,12 @@ class Interp:
                     return int.from_bytes(bytes(args[0]), "little")
             if head in ("std", "cmp") and name in ("min", "max"):
                 return (min if name == "min" else max)(*args)
+            if head == "Vec" and name in ("with_capacity", "new"):
+                return []
+            if head in ("u32", "u64", "usize", "u128", "u8") and name in ("from", "try_from"):
+                return args[0]
+            if head == "Default" and name == "default":
+                raise NotImplementedError(f"{mod}.rs:{line}: Default::default() without a type")
             if head == "Self":
                 head = self.stack[-1] and self.current_owner()
             m = self.find_method(head, name)
@@ -1253,6 +1372,8 @@ class Interp:
                 return self.call_fn(m, args, f"{mod}.rs:{line}")
             if path[0] == "crate" and path[1] in self.mods and name in self.mods[path[1]].fns:
                 return self.call_fn(self.mods[path[1]].fns[name], args, f"{mod}.rs:{line}")
+            if head in self.mods and name in self.mods[head].fns:  # module::function
+                return self.call_fn(self.mods[head].fns[name], args, f"{mod}.rs:{line}")
             raise NameError(f"{mod}.rs:{line}: unknown function {'::'.join(path)}")
         fn = self.ev(f, env, mod)
         return fn(*[self.ev(a, env, mod) for a in e[2]])
@@ -1262,6 +1383,19 @@ class Interp:
 
     def ev_method(self, e, env, mod):
         _, recv_e, name, arg_es, line = e
+        if name in ("copy_from_slice", "clone_from_slice"):  # dst[a..b].copy_from_slice(&src): write through to dst
+            src = list(self.ev(arg_es[0], env, mod))
+            if recv_e[0] == "index":
+                base, idx = self.ev(recv_e[1], env, mod), self.ev(recv_e[2], env, mod)
+                lo, hi = (idx.start or 0), (idx.stop if idx.stop is not None else len(base))
+            else:
+                base = self.ev(recv_e, env, mod)
+                lo, hi = 0, len(base)
+            if hi - lo != len(src):
+                raise ValueError(f"{mod}.rs:{line}: copy_from_slice of {len(src)} into {hi - lo}")
+            for k, v in enumerate(src):
+                base[lo + k] = v
+            return None
         recv = self.ev(recv_e, env, mod)
         if isinstance(recv, Consumer):
             val = self.ev(arg_es[0], env, mod)
@@ -1304,6 +1438,22 @@ class Interp:
             return [args[0](x) for x in recv]
         if name == "enumerate":
             return list(enumerate(recv))
+        if name == "chunks":
+            seq = list(recv)
+            return [seq[k:k + args[0]] for k in range(0, len(seq), args[0])]
+        if name == "for_each":
+            for x in recv:
+                args[0](x)
+            return None
+        if name in ("all", "any"):
+            return (all if name == "all" else any)(bool(args[0](x)) for x in recv)
+        if name == "is_empty":
+            return len(recv) == 0
+        if name == "last":
+            return SomeV(recv[-1]) if len(recv) else None
+        if name == "extend" or name == "extend_from_slice":
+            recv.extend(list(args[0]))
+            return None
         if name == "zip":
             return list(zip(recv, args[0]))
         if name == "rev":
@@ -1342,8 +1492,12 @@ class Interp:
             return pow(recv, args[0], args[1])
         if name in ("wrapping_sub",):
             return (recv - args[0]) & 0xFFFFFFFFFFFFFFFF
+        if name == "checked_sub" and isinstance(recv, int):
+            return SomeV(recv - args[0]) if recv >= args[0] else None
+        if name == "saturating_sub" and isinstance(recv, int):
+            return max(0, recv - args[0])
         if isinstance(recv, TupleStruct):
-            m = self.find_method(recv.name, name)
+            m = self.find_method(recv.name, name, rhs=args[0] if args else None)
             if m is not None:
                 return self.call_fn(m, [recv] + args, f"{mod}.rs:{line}")
         raise NotImplementedError(f"{mod}.rs:{line}: method {name} on {type(recv).__name__}")
@@ -1360,6 +1514,10 @@ class Interp:
         if name == "vec":
             if rep is not None:
                 v, n = self.ev(items[0], env, mod), self.ev(rep, env, mod)
+                if isinstance(v, list) and len(v) >= 1000 and all(isinstance(x, FieldConst) and x.v == 0 for x in v[:4]):
+                    return TraceMatrix(n, len(v))  # vec![[F::ZERO; COLUMNS]; num_rows]
+                if isinstance(v, list):
+                    return [list(v) for _ in range(n)]  # Rust clones the element
                 return [v for _ in range(n)]
             return [self.ev(x, env, mod) for x in items]
         if name in ("assert", "assert_eq", "debug_assert", "println", "print", "debug_assert_eq"):
