@@ -81,3 +81,15 @@ def test_ecc_aggregate_trace_equals_the_reference():
     arr = np.array([limbs(x) + limbs(y) for x, y in pts], dtype=np.uint32)
     trace, _ = S.trace_ecc_aggregate(arr, np.array(bits, dtype=bool))
     check("ECCAggStark", trace)
+
+
+def test_every_public_input_is_bound_to_the_trace_by_a_constraint():
+    """The reference builds the public inputs in its drivers (src/aggregate_proof.rs:37-56,80-99,126-131,160-165,191-217), next to
+    plonky2 calls that cannot be run here.  They need no pin of their own: every public input of every AIR occurs in a constraint
+    (the constraints are pinned to the reference's text by test_constraint_schedule_cpu.py, and vanish on the product's traces with
+    the product's public inputs, test_airs_cpu.py), so with the trace fixed cell for cell the public inputs are determined."""
+    from air_blob import constraints, parse_blob
+    for air in (S.AIR_FP12_MUL, S.AIR_PAIRING_PRECOMP, S.AIR_MILLER_LOOP, S.AIR_FINAL_EXP, S.AIR_ECC_AGGREGATE):
+        prog = parse_blob(S.air_program(air))
+        used = {pi for _, _, terms in constraints(prog) for _, pi, _ in terms if pi >= 0}
+        assert used == set(range(prog["n_pis"])), S.AIR_NAMES[air]
