@@ -187,7 +187,9 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
             # few jobs on this rank (one signature): the recording itself is the latency -- FinalExp 0.21 s on one thread,
             # 0.025 s on 16 (EPYC 9575F, profiles/r02_c_trace_threads.txt); a batch keeps one thread per call
             trace_threads = 16 if len(my_jobs) <= 6 else max(1, min(8, 2 * gen_threads // len(my_jobs)))
-        S.set_trace_threads(trace_threads)
+        restore_threads = S.set_trace_threads(trace_threads)
+    else:
+        restore_threads = None
     pools = provers if isinstance(provers, dict) else {"big": list(provers), "small": None}
     shared = pools.get("small") is None  # one pool takes everything
     order = sorted(my_jobs, key=lambda j: -parallel.AIR_COST[A.JOB_AIR[j[1]]])
@@ -261,9 +263,11 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
     for t in pros:
         t.join()
     wall = time.perf_counter() - t0
+    if restore_threads is not None:
+        S.set_trace_threads(restore_threads)  # process-wide setting: leave it as it was found
     if errors:
         raise errors[0]
-    return results, {"generate_s": t_gen[0], "prove_s": t_prove[0], "wall_s": wall, "timeline": timeline}
+    return results, {"generate_s": t_gen[0], "prove_s": t_prove[0], "wall_s": wall, "timeline": timeline, "trace_threads": trace_threads}
 
 
 def signature_proofs(results, index):

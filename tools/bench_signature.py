@@ -127,7 +127,7 @@ def main():
             "metric": "BLS signature checks/s, end to end (operands -> trace generation -> 6 STARK proofs each)",
             "value": args.batch / el, "unit": "signatures/s", "n_gpus": world, "batch": args.batch, "steps": args.steps,
             "ms_per_step": el * 1e3, "ms_per_signature": el * 1e3 / args.batch,
-            "proofs_per_step": 6 * args.batch, "contexts_per_gpu": ({k: len(v) for k, v in provers.items()} if isinstance(provers, dict) else len(provers)), "generator_threads_per_gpu": args.gen_threads, "threads_per_generator_call": S.set_trace_threads(1),
+            "proofs_per_step": 6 * args.batch, "contexts_per_gpu": ({k: len(v) for k, v in provers.items()} if isinstance(provers, dict) else len(provers)), "generator_threads_per_gpu": args.gen_threads, "threads_per_generator_call": stats.get("trace_threads"),
             "rank0": {"jobs": len(mine), "generate_s_sum": stats.get("generate_s"), "prove_s_sum": stats.get("prove_s"), "wall_s": stats.get("wall_s")},
             "timeline_ms_rank0": ({f"{i}:{n}": [round(1e3 * t, 1) for t in v] for (i, n), v in sorted(stats.get("timeline", {}).items())}
                                   if args.batch == 1 else None),  # per job: generation start, end, proof start, end
