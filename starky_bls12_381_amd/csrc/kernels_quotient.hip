@@ -311,19 +311,30 @@ __device__ __forceinline__ void qt_add128(uint64_t& lo, uint64_t& hi, uint64_t x
 //   total mod p = (t1:t0) - (t4:t3) + t2 eps          (2^64 = eps, 2^96 = -1, 2^128 = -2^32)
 // with the borrow / carry settled as in gl_reduce_words (the subtrahend is < 2^42, so the same bounds hold).
 __device__ __forceinline__ gl_t qt_fold_sums(const uint64_t (&S)[6]) {
-    uint64_t ul = S[0], uh = 0, vl = S[3], vh = 0;
-    qt_add128(ul, uh, S[1] << QT_LIMB_BITS, S[1] >> (64 - QT_LIMB_BITS));
-    qt_add128(ul, uh, S[2] << (2 * QT_LIMB_BITS), S[2] >> (64 - 2 * QT_LIMB_BITS));
-    qt_add128(vl, vh, S[4] << QT_LIMB_BITS, S[4] >> (64 - QT_LIMB_BITS));
-    qt_add128(vl, vh, S[5] << (2 * QT_LIMB_BITS), S[5] >> (64 - 2 * QT_LIMB_BITS));
-    uint32_t t0 = (uint32_t)ul, t1 = (uint32_t)(ul >> 32), t2 = (uint32_t)uh, t3 = (uint32_t)(uh >> 32), t4 = (uint32_t)(vh >> 32);
-    asm("v_add_co_u32_e32 %0, vcc, %4, %0\n\t"
-        "v_addc_co_u32_e32 %1, vcc, %5, %1, vcc\n\t"
-        "v_addc_co_u32_e32 %2, vcc, %6, %2, vcc\n\t"
-        "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc"
-        : "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4)
-        : "v"((uint32_t)vl), "v"((uint32_t)(vl >> 32)), "v"((uint32_t)vh)
-        : "vcc");
+    // The five 32-bit words t0 .. t4 of the total, by word position, as chains of 32 x 32 + 64 multiply-adds (the shifts by
+    // 22, 44, 54 and 76 bits become multiplications by 2^22 / 2^12 at word offsets; every chain stays below 2^63):
+    //   position  0:  S0 + S1_lo 2^22                                            -> (x1 : t0)
+    //   position 32:  x1 + S3 + S1_hi 2^22 + S2_lo 2^12 + S4_lo 2^22               -> (y1 : t1)
+    //   position 64:  y1 + S2_hi 2^12 + S4_hi 2^22 + S5_lo 2^12                    -> (z1 : t2)
+    //   position 96:  z1 + S5_hi 2^12                                              -> (t4 : t3)
+    // eleven multiply-adds instead of twelve 64-bit shifts and twenty carry instructions.
+    uint32_t k22 = 1u << QT_LIMB_BITS, k12 = 1u << (2 * QT_LIMB_BITS - 32), k1 = 1u;
+    asm("" : "+s"(k22), "+s"(k12), "+s"(k1));  // opaque: as known powers of two the products come back as shift + carry chains
+    auto lo = [](uint64_t v) { return (uint32_t)v; };
+    auto hi = [](uint64_t v) { return (uint32_t)(v >> 32); };
+    auto mad = [](uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; };
+    const uint64_t X = mad(lo(S[1]), k22, S[0]);
+    uint64_t Y = mad(hi(S[1]), k22, S[3]);
+    Y = mad(lo(S[2]), k12, Y);
+    Y = mad(lo(S[4]), k22, Y);
+    Y = mad(hi(X), k1, Y);
+    uint64_t Z = mad(hi(S[2]), k12, 0);
+    Z = mad(hi(S[4]), k22, Z);
+    Z = mad(lo(S[5]), k12, Z);
+    Z = mad(hi(Y), k1, Z);
+    uint64_t Wd = mad(hi(S[5]), k12, 0);
+    Wd = mad(hi(Z), k1, Wd);
+    const uint32_t t0 = lo(X), t1 = lo(Y), t2 = lo(Z), t3 = lo(Wd), t4 = hi(Wd);
     // D = (t1:t0) - (t4:t3), borrow b;  r = D + t2 * eps, carry c;  result r + (c - b) * eps
     uint32_t d0, d1, t;
     uint64_t borrow_mask, carry_mask, scratch_mask, r;
