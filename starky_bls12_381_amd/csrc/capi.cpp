@@ -121,7 +121,7 @@ int starkhip_quotient_plan_check(starkhip_air_t air, unsigned want_chunks, uint6
             stats[0] = Q.n_chunks; stats[1] = Q.n_supergroups; stats[2] = Q.n_pieces; stats[3] = Q.recs.size();
             stats[4] = Q.n_cell_records; stats[5] = Q.n_direct_loads; stats[6] = Q.tile_list.size(); stats[7] = Q.contribs.size();
             if (seed == 0xBA1A) { stats[6] = Q.cost_sum_max; stats[7] = Q.cost_sum_mean; }  // balance figures (tools)
-            if (seed == 0xBA1B) { stats[5] = Q.tile_phases; stats[6] = Q.rec_sum_max; stats[7] = Q.rec_sum_total; }
+            if (seed == 0xBA1B) { stats[4] = Q.n_piece_ends; stats[5] = Q.tile_phases; stats[6] = Q.rec_sum_max; stats[7] = Q.rec_sum_total; }
         }
         if (!ok) return STARKHIP_ERR_BAD_SHAPE;
         return (want[0] == got[0] && want[1] == got[1]) ? STARKHIP_OK : STARKHIP_ERR_VERIFY;

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1)) void quotient_tiles_kernel(QTP
                 goto next_##U;                                                                                        \
             }                                                                                                         \
             if (ctl & QT_SRC_ONE) x = 1;                                                                              \
-            if (ctl & QT_SRC_GLOBAL) x = direct(__builtin_amdgcn_readfirstlane(W.a.y), ctl & QT_NEXT);                \
+            if ((ctl & QT_SRC_GLOBAL) && !(DBG & 8u)) x = direct(__builtin_amdgcn_readfirstlane(W.a.y), ctl & QT_NEXT); \
             if (ctl & QT_MULV) x = gl_mul_nc(v, x);                                                                   \
             if (ctl & QT_SETV) {                                                                                      \
                 v = x;                                                                                                \
@@ -701,6 +701,7 @@ hipError_t launch_quotient_tiles(const QTRec* recs, const QTPiece* pieces, const
         case 1: hipLaunchKernelGGL((quotient_tiles_kernel<false, 1>), grid, block, 0, st, P); break;
         case 2: hipLaunchKernelGGL((quotient_tiles_kernel<false, 2>), grid, block, 0, st, P); break;
         case 3: hipLaunchKernelGGL((quotient_tiles_kernel<false, 3>), grid, block, 0, st, P); break;
+        case 8: hipLaunchKernelGGL((quotient_tiles_kernel<false, 8>), grid, block, 0, st, P); break;  // factors outside the tile not loaded
         default: hipLaunchKernelGGL((quotient_tiles_kernel<false, 4>), grid, block, 0, st, P); break;
     }
     return hipGetLastError();

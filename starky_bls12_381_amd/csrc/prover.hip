@@ -409,7 +409,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             HIPCHK(hipEventRecord(c->kev[2], st));
             HIPCHK(launch_quotient_tiles(c->q_recs.as<QTRec>(), c->q_pieces.as<QTPiece>(), c->q_streams.as<QTStream>(),
                                          c->q_chunk_tile_off.as<uint32_t>(), c->q_tile_list.as<uint32_t>(), n_chunks, c->lde.as<gl_t>(),
-                                         c->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, (unsigned)(c->opt_quotient_debug <= 4 ? c->opt_quotient_debug : 0), st));
+                                         c->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, (unsigned)((c->opt_quotient_debug <= 4 || c->opt_quotient_debug == 8) ? c->opt_quotient_debug : 0), st));
             HIPCHK(hipEventRecord(c->kev[3], st));
             HIPCHK(launch_quotient_tiles_combine(c->partial.as<gl_t>(), n_chunks, c->qtab.as<gl_t>(), log_n, qdb, c->qvals.as<gl_t>(), st));
         } else {

@@ -92,7 +92,7 @@ struct QTPlan {
     std::vector<uint32_t> contrib_off;    // [recs.size() + 1]
     std::vector<QTContrib> contribs;
     // statistics
-    size_t n_supergroups = 0, n_pieces = 0, n_cell_records = 0, n_direct_loads = 0;
+    size_t n_supergroups = 0, n_pieces = 0, n_piece_ends = 0, n_cell_records = 0, n_direct_loads = 0;  // n_piece_ends <= n_pieces: pieces carried across a tile boundary end once
     uint64_t cost_sum_max = 0, cost_sum_mean = 0, rec_sum_max = 0, rec_sum_total = 0, tile_phases = 0;  // per tile: the busiest wave's cost / the mean over the waves (model units)
 };
 
@@ -303,18 +303,57 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         for (uint32_t t = t_lo; t < t_hi; t++) Q.tile_list.push_back(tiles[t]);
         // assignment[tile - t_lo][wave] = piece indices
         std::vector<std::vector<std::vector<uint32_t>>> assign(t_hi - t_lo, std::vector<std::vector<uint32_t>>(QT_WAVES));
+        // carry_in[tile - t_lo][wave]: the wave's first piece of this tile has the supergroup of its last piece of the previous
+        // tile and simply goes on accumulating -- no fold, no gate product, no descriptor at the tile boundary (a supergroup
+        // spans 2.4 tiles on average and a piece end costs as much as a dozen records)
+        std::vector<std::vector<uint8_t>> carry_in(t_hi - t_lo, std::vector<uint8_t>(QT_WAVES, 0));
+        std::vector<uint32_t> chain_recs(QT_WAVES, 0);  // records accumulated by the piece a wave ends the previous tile with
+        auto piece_recs = [&](uint32_t p) { return (pieces[p].cost - PIECE_COST) / REC_COST; };
         for (uint32_t t = t_lo; t < t_hi; t++) {
             std::vector<uint32_t> ps;
             for (uint32_t p = tile_first_piece[t]; p < tile_first_piece[t + 1]; p++) ps.push_back(p);
             std::stable_sort(ps.begin(), ps.end(), [&](uint32_t a, uint32_t b) { return pieces[a].cost > pieces[b].cost; });
             uint64_t load[QT_WAVES] = {0};
-            for (uint32_t p : ps) {
+            std::vector<std::vector<uint32_t>>& lists = assign[t - t_lo];
+            std::vector<uint32_t> next_chain(QT_WAVES, 0);
+            std::vector<uint8_t> taken(ps.size(), 0);
+            // first: every wave that can continue a supergroup of its previous tile gets that piece as its first one ...
+            if (t > t_lo) {
+                for (unsigned w = 0; w < QT_WAVES; w++) {
+                    std::vector<uint32_t>& prev = assign[t - 1 - t_lo][w];
+                    if (prev.empty()) continue;
+                    const bool first_pinned = carry_in[t - 1 - t_lo][w];
+                    bool done = false;
+                    for (size_t a = 0; a < ps.size() && !done; a++) {  // largest first
+                        if (taken[a]) continue;
+                        for (size_t b = 0; b < prev.size() && !done; b++) {
+                            if (pieces[ps[a]].sg != pieces[prev[b]].sg) continue;
+                            if (b == 0 && first_pinned && prev.size() > 1) continue;  // that piece must stay first
+                            const uint32_t so_far = (b == 0 && first_pinned) ? chain_recs[w] : piece_recs(prev[b]);
+                            if (so_far + piece_recs(ps[a]) > 960) continue;            // the 64-bit sums hold 1024 products
+                            std::swap(prev[b], prev.back());                          // ends the previous tile
+                            lists[w].push_back(ps[a]);                                // starts this one
+                            load[w] += pieces[ps[a]].cost - PIECE_COST;               // it has no piece end of its own
+                            taken[a] = 1;
+                            carry_in[t - t_lo][w] = 1;
+                            next_chain[w] = so_far + piece_recs(ps[a]);
+                            done = true;
+                        }
+                    }
+                }
+            }
+            // ... then the rest, largest first, to the least loaded wave
+            for (size_t a = 0; a < ps.size(); a++) {
+                if (taken[a]) continue;
                 unsigned best = 0;
                 for (unsigned w = 1; w < QT_WAVES; w++)
                     if (load[w] < load[best]) best = w;
-                load[best] += pieces[p].cost;
-                assign[t - t_lo][best].push_back(p);
+                load[best] += pieces[ps[a]].cost;
+                lists[best].push_back(ps[a]);
             }
+            // the chain a wave may continue from this tile: its last piece -- which is only known once the next tile has
+            // chosen it; a carried-in first piece that is alone in its list keeps its count
+            for (unsigned w = 0; w < QT_WAVES; w++) chain_recs[w] = (carry_in[t - t_lo][w] && assign[t - t_lo][w].size() == 1) ? next_chain[w] : 0;
             uint64_t mx = 0, sum = 0;
             for (unsigned w = 0; w < QT_WAVES; w++) {
                 mx = std::max(mx, load[w]);
@@ -325,7 +364,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
             uint64_t rmx = 0;
             for (unsigned w = 0; w < QT_WAVES; w++) {
                 uint64_t r = 0;
-                for (uint32_t p : assign[t - t_lo][w]) r += (pieces[p].cost - PIECE_COST) / REC_COST;
+                for (uint32_t p : lists[w]) r += piece_recs(p);
                 rmx = std::max(rmx, r);
                 Q.rec_sum_total += r;
             }
@@ -336,21 +375,28 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
             Q.streams.push_back({(uint32_t)Q.recs.size(), (uint32_t)Q.pieces.size()});
             for (uint32_t t = t_lo; t < t_hi; t++) {
                 const uint32_t tile = tiles[t];
-                for (uint32_t p : assign[t - t_lo][w]) {
+                const std::vector<uint32_t>& mine = assign[t - t_lo][w];
+                for (size_t pi = 0; pi < mine.size(); pi++) {
+                    const uint32_t p = mine[pi];
                     const Piece& pc = pieces[p];
                     const std::vector<uint32_t>& gates = sg_gates[pc.sg];
-                    QTPiece d = {0, {0, 0, 0, 0}, {0, 0, 0}};
-                    uint32_t compl_mask = 0;
-                    for (size_t g = 0; g < gates.size(); g++) {
-                        d.gate[g] = gates[g] & (REF_COL_MASK | REF_NEXT);
-                        if (gates[g] & REF_COMPL) compl_mask |= 1u << g;
+                    const bool continues = pi == 0 && carry_in[t - t_lo][w];                                   // no descriptor of its own
+                    const bool goes_on = pi + 1 == mine.size() && t + 1 < t_hi && carry_in[t + 1 - t_lo][w];  // no end of its own
+                    if (!continues) {
+                        QTPiece d = {0, {0, 0, 0, 0}, {0, 0, 0}};
+                        uint32_t compl_mask = 0;
+                        for (size_t g = 0; g < gates.size(); g++) {
+                            d.gate[g] = gates[g] & (REF_COL_MASK | REF_NEXT);
+                            if (gates[g] & REF_COMPL) compl_mask |= 1u << g;
+                        }
+                        d.ctl = sg_kind[pc.sg] | ((uint32_t)gates.size() << 2) | (compl_mask << 5);
+                        Q.pieces.push_back(d);
+                        Q.n_direct_loads += gates.size();
+                        Q.n_piece_ends++;
                     }
-                    d.ctl = sg_kind[pc.sg] | ((uint32_t)gates.size() << 2) | (compl_mask << 5);
-                    Q.pieces.push_back(d);
-                    Q.n_direct_loads += gates.size();
                     for (uint32_t b = pc.m_begin; b < pc.m_end; b++) {
                         const Mono& mo = monos[b];
-                        const bool last = b + 1 == pc.m_end;
+                        const bool last = b + 1 == pc.m_end && !goes_on;
                         if (mo.cells[0] == NONE) {
                             push_rec(QT_SRC_ONE | (last ? QT_END : 0u), 0, mo.c_begin, mo.c_end);
                             continue;
@@ -454,12 +500,13 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
             uint32_t ti = Q.chunk_tile_off[c];
             uint64_t S[2][6] = {{0}};
             unsigned n_in_piece = 0;
+            bool in_product = false;
             gl_t v = 1;
             for (;; rec++) {
                 const uint32_t ctl = rec->ctl;
                 if (ctl & QT_STOP) break;
                 if (ctl & QT_TILE) {
-                    if (n_in_piece) return false;  // a piece must not straddle tiles
+                    if (in_product) return false;  // a piece may go on in the next tile (same supergroup), a monomial may not
                     ti++;
                     continue;
                 }
@@ -478,9 +525,11 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
                 if (ctl & QT_MULV) x = gl_mul(v, x);
                 if (ctl & QT_SETV) {
                     v = x;
+                    in_product = true;
                     if (ctl & QT_END) return false;
                     continue;
                 }
+                in_product = false;
                 const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
                 for (int j = 0; j < 2; j++)
                     for (int l = 0; l < 3; l++) {
