@@ -58,17 +58,25 @@ def _need(name):
     return GOLD["airs"][name]["inputs"]
 
 
-def test_miller_loop_trace_equals_the_reference():
-    g = _need("MillerLoopStark")
+@pytest.mark.parametrize("name", ["MillerLoopStark", "MillerLoopStark#2"])
+def test_miller_loop_trace_equals_the_reference(name):
+    g = _need(name)
     trace, _ = S.trace_miller_loop(np.array(limbs(g["px"][0]), dtype=np.uint32), np.array(limbs(g["py"][0]), dtype=np.uint32),
                                    fp2_arr(g["qx"]), fp2_arr(g["qy"]), fp2_arr(g["qz"]))
-    check("MillerLoopStark", trace)
+    check(name, trace)
 
 
-def test_final_exp_trace_equals_the_reference():
-    g = _need("FinalExponentiateStark")
+@pytest.mark.parametrize("name", ["FinalExponentiateStark", "FinalExponentiateStark#2"])
+def test_final_exp_trace_equals_the_reference(name):
+    g = _need(name)
     trace, _ = S.trace_final_exp(fp12_arr(g["x"]))
-    check("FinalExponentiateStark", trace)
+    check(name, trace)
+
+
+def test_pairing_precomp_second_trace_equals_the_reference():
+    g = _need("PairingPrecompStark#2")
+    trace, _ = S.trace_pairing_precomp(fp2_arr(g["qx"]), fp2_arr(g["qy"]), fp2_arr(g["qz"]))
+    check("PairingPrecompStark#2", trace)
 
 
 def test_ecc_aggregate_trace_equals_the_reference():

@@ -101,7 +101,7 @@ def main():
     # The 1024- and 8192-row AIRs write 10^8 cells through utils.rs:3-19 (`assign_u32_in_series`, a loop of single stores): that
     # helper alone is replaced by a slice store (rust_subset.Interp.fast_assign).  FP12MulStark and PairingPrecompStark were
     # extracted with the interpreted loop; FP12MulStark gives the same digest both ways.
-    interp.fast_assign = bool(only & {"MillerLoopStark", "FinalExponentiateStark", "ECCAggStark"})
+    interp.fast_assign = bool({n.split("#")[0] for n in only} & {"MillerLoopStark", "FinalExponentiateStark", "ECCAggStark"}) or any("#" in n for n in only)
     doc = {"generated_by": "tools/extract_trace_digests.py (the reference's generate_trace / fill_* source text run by tools/rust_subset.py)",
            "encoding": "trace as rows x columns of canonical Goldilocks values, little-endian u64, row-major; `blocks` = first 12 hex digits "
                        "of the SHA-256 of each block of 256 columns (all rows)", "airs": {}}
@@ -141,6 +141,19 @@ def main():
                             {"points_x": [p_[0] for p_ in pts[:n_vec]], "points_y": [p_[1] for p_ in pts[:n_vec]],
                              "bits": [int(v) for v in bits[:n_vec]], "padding": ["the last point repeated with a cleared bit, up to 512 operands"]},
                             lambda: [[[fp(x), fp(y)] for x, y in pts], bits])
+    # second inputs: the signature point as Q, another generator-independent P, a seeded (invertible) Fp12 for FinalExp
+    nxt2 = splitmix(0x7ACE0002)
+    q2 = {"qx": [b["s_x1"], b["s_x2"]], "qy": [b["s_y1"], b["s_y2"]], "qz": [b["s_z1"], b["s_z2"]]}
+    cases["PairingPrecompStark#2"] = ("calc_pairing_precomp", "PairingPrecompStark", 1024, q2,
+                                      lambda: [[limbs(q2["qx"][0]), limbs(q2["qx"][1])], [limbs(q2["qy"][0]), limbs(q2["qy"][1])],
+                                               [limbs(q2["qz"][0]), limbs(q2["qz"][1])]])
+
+    def miller_args2():
+        ell = interp.call_fn(interp.mods["native"].fns["calc_pairing_precomp"], [fp2(*q2["qx"]), fp2(*q2["qy"]), fp2(*q2["qz"])], "native.rs")
+        return [fp(b["gx"]), fp(P_BLS - b["gy"]), ell]
+    cases["MillerLoopStark#2"] = ("miller_loop", "MillerLoopStark", 1024, {"px": [b["gx"]], "py": [P_BLS - b["gy"]], **q2}, miller_args2)
+    x12b = [random_fp(nxt2) for _ in range(12)]
+    cases["FinalExponentiateStark#2"] = ("final_exponentiate", "FinalExponentiateStark", 8192, {"x": x12b}, lambda: [fp12(x12b)])
     for name, (mod, ty, rows, inputs, mk) in cases.items():
         if only and name not in only:
             continue
