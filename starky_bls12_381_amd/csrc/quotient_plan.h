@@ -231,7 +231,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         }
         pieces.swap(cut);
     }
-    const uint32_t PIECE_COST = 220, REC_COST = 13, TILE_COST = 150;
+    const uint32_t PIECE_COST = 200, REC_COST = 18, TILE_COST = 150;  // vector instructions (ISA count): per piece end, per record
     for (Piece& p : pieces) {
         uint32_t recs = 0;
         for (uint32_t b = p.m_begin; b < p.m_end; b++) recs += mono_records(monos[b]);
