@@ -20,6 +20,7 @@ rocprofv3 --kernel-trace -d $OUT/prof_ov -o ov -- python3 $R/bench.py --steps 10
 cd $R
 db() { find $OUT/$1 -name "*results.db" | head -1; }
 python3 tools/rocprof_export.py stats $(db prof_kt) $OUT/${TAG}_kernel_stats.csv
+python3 tools/rocprof_export.py bygrid $(db prof_kt) $OUT/${TAG}_kernel_stats_by_grid.csv
 python3 tools/rocprof_export.py pmc $(db prof_fetch) $OUT/${TAG}_pmc_fetch_size.csv
 python3 tools/rocprof_export.py pmc $(db prof_write) $OUT/${TAG}_pmc_write_size.csv
 python3 tools/rocprof_export.py pmc $(db prof_sq) $OUT/${TAG}_pmc_sq_counters.csv
