@@ -161,7 +161,7 @@ def job_arguments(signatures, my_jobs):
 BIG = ("final_exp",)  # jobs that get their own contexts: the FinalExp leaf hash is a one-shot grid of two waves per SIMD
 
 
-def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, queue_depth=None, trace_threads=None):
+def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, queue_depth=None, trace_threads=None, big_after_small=False):
     """Generate and prove `my_jobs` on this rank: `gen_threads` host threads record compact traces into bounded queues, one
     host thread per prover context takes them and proves.  Returns ({(i, name): (air, proof, cfg)},
     {"generate_s": sum of generator time, "prove_s": sum of prover time, "wall_s": wall time}).
@@ -174,6 +174,11 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
     `trace_threads`: host threads ONE recording generator call may use (starkhip_trace_set_threads: the FinalExp and
     MillerLoop generators fill their gadget blocks in parallel once the native chain is known).  Default: with few jobs on
     this rank (one signature) 16, for a batch 1.
+
+    `big_after_small` (two pools only): the FinalExp contexts start when the last small proof is done -- scheduling by type, so
+    that a FinalExp commitment (two 176-register waves on every SIMD) and the small proofs' kernels do not wait for each other's
+    register space.  Measured for a batch of 8 on one GPU: 2.26 signatures/s against 2.61 with both
+    pools at once (the small proofs are latency chains that do not fill the chip by themselves), so it is off by default.
 
     `prove(prover, air, cfg, trace, pis)` and `generate(name, *args)` are injectable (CPU tests run the control flow without
     a GPU); defaults: Prover.prove and the compact trace generators."""
@@ -197,6 +202,8 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
     lock = threading.Lock()
     n_ctx = {"big": len(pools["big"]), "small": len(pools["big"]) if shared else len(pools["small"])}
     ready = {k: queue.Queue(maxsize=queue_depth or max(2, 2 * n_ctx[k])) for k in ("big", "small")}
+    if big_after_small and not queue_depth:
+        ready["big"] = queue.Queue(maxsize=max(2, len(todo["big"])))  # every FinalExp trace may wait recorded (150 MB each)
     if shared:
         ready["small"] = ready["big"]
     results, errors = {}, []
@@ -223,9 +230,18 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
             except Exception as e:  # noqa: BLE001 -- reported to the caller below
                 with lock:
                     errors.append(e)
+                small_done.set()
                 return
 
+    n_small = len(todo["small"])
+    small_left = [n_small]
+    small_done = threading.Event()
+    if not (big_after_small and not shared and n_small):
+        small_done.set()
+
     def prover_loop(pv, kind):
+        if kind == "big":
+            small_done.wait()
         while True:
             item = ready[kind].get()
             if item is None:
@@ -243,6 +259,12 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
             except Exception as e:  # noqa: BLE001
                 with lock:
                     errors.append(e)
+                small_done.set()  # never leave the other pool waiting
+            if job[1] not in BIG:
+                with lock:
+                    small_left[0] -= 1
+                    if small_left[0] <= 0:
+                        small_done.set()
 
     t0 = t_begin = time.perf_counter()
     n_gen = max(1, min(gen_threads, len(order) or 1))
