@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
 # VALU instructions of one permutation in the 4-lane form (ISA of poseidon_dev.h: 8 full rounds, 7 merged triples of
 # partial rounds, 1 single partial round)
-POSEIDON_QUAD_INSTRS = 8 * 261 + 7 * 309 + 152
+POSEIDON_QUAD_INSTRS = 7 * 261 + 204 + 7 * 309 + 152
 KERNELS = ("lde_columns", "leaf_hash", "quotient_eval")
 PMC_NAMES = {"lde_columns": ("lde_columns_v2_kernel",), "leaf_hash": ("leaf_hash_kernel",),
              "quotient_eval": ("quotient_tiles_kernel", "quotient_eval_kernel")}
@@ -236,8 +236,9 @@ def main():
         lh_ms = solo_ms["leaf_hash"]
         valu = {"kernel": "leaf_hash_kernel", "wave_instructions": wave_instr,
                 "achieved_Ginstr_per_s": wave_instr / (lh_ms * 1e-3) / 1e9 if lh_ms > 0 else 0.0, "peak_Ginstr_per_s": VALU_PEAK_GINSTR,
-                "basis": "8 full rounds x 261 + 7 merged triples of partial rounds x 309 + 1 partial round x 152 VALU instructions per 4-lane "
-                         "permutation (ISA count); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per integer VALU instruction "
+                "basis": "7 full rounds x 261 + the last one x 204 (capacity only: the rate outputs are overwritten by the next absorb) + 7 merged "
+                         "triples of partial rounds x 309 + 1 partial round x 152 VALU instructions per 4-lane permutation (ISA count, "
+                         "profiles/r02_isa_histograms.txt); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per integer VALU instruction "
                          "(tools/valu_rate_bench.hip, profiles/r02_valu_rates.txt)"}
         valu["frac"] = valu["achieved_Ginstr_per_s"] / VALU_PEAK_GINSTR
         out = {

@@ -12,56 +12,77 @@
 
 namespace starkhip {
 
-// ---- tables of the merged partial rounds (poseidon_dev.h), built on the host once per device
-#ifndef STARKHIP_MERGED_PARTIAL
-#define STARKHIP_MERGED_PARTIAL 1
-#endif
+// ---- per-lane tables of the quad permutation (poseidon_dev.h), built on the host once per device
 struct QuadMergedTables {
-    uint32_t coef[4][50];  // per lane: n3[3][12], n1[3], n2[3], m00 (lane 0 only), b2[3], b3[3], pad
+    uint32_t coef[4][64];  // per lane: n3[3][12], n1[3], n2[3], m00 (lane 0 only), b2[3], b3[3], pad to 50, cf[12] at 50, pad
     RcPair tk[2 * QUAD_MERGED_TRIPLES];       // k1, k2 per triple
     RcPair tk3[4][3 * QUAD_MERGED_TRIPLES];   // per lane: k3[mo] per triple
 };
 __constant__ QuadMergedTables QUAD_MERGED;
 
-// The per-lane views of poseidon_merged.h's tables: lane l's rotated operand (r, m) is state element 3((l + r) & 3) + m.
+// Lane l owns state elements l, l + 4, l + 8 (slots 0, 1, 2); its rotated operand (r, m) is element ((l + r) & 3) + 4 m.
+static inline int quad_elem(int l, int m) { return l + 4 * m; }
+static inline int quad_col(int l, int r, int m) { return ((l + r) & 3) + 4 * m; }
+
+// The per-lane views of poseidon_merged.h's tables and of the circulant MDS matrix.
 static void build_quad_merged_tables(QuadMergedTables& T) {
     static PoseidonMergedTables P;
     build_poseidon_merged_tables(P);
+    static const uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     auto split = [](gl_t v) { return RcPair{v & 0xFFFFFFFFull, v >> 32}; };
     for (int l = 0; l < 4; l++) {
         uint32_t* c = T.coef[l];
         for (int r = 0; r < 4; r++)
             for (int m = 0; m < 3; m++) {
-                const int col = 3 * ((l + r) & 3) + m;
-                for (int mo = 0; mo < 3; mo++) c[12 * mo + 3 * r + m] = (uint32_t)P.N3[3 * l + mo][col];
+                const int col = quad_col(l, r, m);
+                for (int mo = 0; mo < 3; mo++) c[12 * mo + 3 * r + m] = (uint32_t)P.N3[quad_elem(l, mo)][col];
             }
         for (int m = 0; m < 3; m++) {
-            c[36 + m] = (uint32_t)P.M[0][3 * l + m];   // the lane's own columns of row 0
-            c[39 + m] = (uint32_t)P.N2[0][3 * l + m];
+            c[36 + m] = (uint32_t)P.M[0][quad_elem(l, m)];   // the lane's own columns of row 0
+            c[39 + m] = (uint32_t)P.N2[0][quad_elem(l, m)];
         }
         c[42] = l == 0 ? (uint32_t)P.M[0][0] : 0;
         for (int mo = 0; mo < 3; mo++) {
-            c[43 + mo] = (uint32_t)P.N2[3 * l + mo][0];
-            c[46 + mo] = (uint32_t)P.M[3 * l + mo][0];
+            c[43 + mo] = (uint32_t)P.N2[quad_elem(l, mo)][0];
+            c[46 + mo] = (uint32_t)P.M[quad_elem(l, mo)][0];
         }
         c[49] = 0;
+        // cf[3 r + d]: coefficient of the operand (r, m') for the output slot m with (m' - m) mod 3 = d:
+        // CIRC[(col - out) mod 12] with col - out = ((l + r) & 3) - l + 4 d
+        for (int r = 0; r < 4; r++)
+            for (int d = 0; d < 3; d++) c[50 + 3 * r + d] = CIRC[((((l + r) & 3) - l + 4 * d) % 12 + 12) % 12];
+        c[62] = c[63] = 0;
     }
     // every lane seeds its partial sum of y1 / y2 with a quarter of the constant (4^-1 = (3p + 1) / 4 mod p)
     const gl_t quarter = (gl_t)((((unsigned __int128)3 * GL_P) + 1) / 4);
     for (int t = 0; t < QUAD_MERGED_TRIPLES; t++) {
         T.tk[2 * t] = split(gl_mul(P.k1[t], quarter));
         T.tk[2 * t + 1] = split(gl_mul(P.k2[t], quarter));
-        for (int i = 0; i < 12; i++) T.tk3[i / 3][3 * t + i % 3] = split(P.k3[t][i]);
+        for (int l = 0; l < 4; l++)
+            for (int mo = 0; mo < 3; mo++) T.tk3[l][3 * t + mo] = split(P.k3[t][quad_elem(l, mo)]);
     }
 }
 
-// Host replay of the merged formulation with exactly the tables the kernel gets (per-lane coefficient views included), against
+// Host replay of the quad formulation with exactly the tables the kernel gets (per-lane coefficient views included), against
 // the plain host permutation: a CPU-side check of build_quad_merged_tables (tests/test_field_hash_cpu.py).  Returns the
 // number of mismatching states out of `n`.
 int quad_merged_tables_selfcheck(unsigned n) {
     static QuadMergedTables T;
     build_quad_merged_tables(T);
     auto join = [](const RcPair& c) { return (gl_t)(c.lo | (c.hi << 32)); };
+    // the plain layer as the kernel computes it: per lane, twelve coefficients by rotation and slot difference
+    auto mds_lanes = [&](gl_t* s) {
+        gl_t out[12];
+        for (int l = 0; l < 4; l++)
+            for (int mo = 0; mo < 3; mo++) {
+                gl_t acc = 0;
+                for (int r = 0; r < 4; r++)
+                    for (int m = 0; m < 3; m++) acc = gl_add(acc, gl_mul(s[quad_col(l, r, m)], T.coef[l][50 + 3 * r + (m - mo + 3) % 3]));
+                if (l == 0 && mo == 0) acc = gl_add(acc, gl_mul(s[0], 8));
+                out[quad_elem(l, mo)] = acc;
+            }
+        for (int i = 0; i < 12; i++) s[i] = out[i];
+    };
     int bad = 0;
     uint64_t seed = 0x9E3779B97F4A7C15ull;
     for (unsigned it = 0; it < n; it++) {
@@ -76,7 +97,7 @@ int quad_merged_tables_selfcheck(unsigned n) {
         int r = 0;
         for (; r < 4; r++) {
             for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(gl_add(s[i], RC[12 * r + i]));
-            poseidon_mds(s);
+            mds_lanes(s);
         }
         for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], RC[12 * r + i]);
         for (int t = 0; t < QUAD_MERGED_TRIPLES; t++, r += 3) {
@@ -89,8 +110,8 @@ int quad_merged_tables_selfcheck(unsigned n) {
                 const uint32_t* c = T.coef[l];
                 gl_t a = join(T.tk[2 * t]), b = join(T.tk[2 * t + 1]);
                 for (int m = 0; m < 3; m++) {
-                    a = gl_add(a, gl_mul(u[3 * l + m], c[36 + m]));
-                    b = gl_add(b, gl_mul(u[3 * l + m], c[39 + m]));
+                    a = gl_add(a, gl_mul(u[quad_elem(l, m)], c[36 + m]));
+                    b = gl_add(b, gl_mul(u[quad_elem(l, m)], c[39 + m]));
                 }
                 y1 = gl_add(y1, a);
                 y2p = gl_add(y2p, b);
@@ -104,19 +125,22 @@ int quad_merged_tables_selfcheck(unsigned n) {
                 for (int mo = 0; mo < 3; mo++) {
                     gl_t acc = join(T.tk3[l][3 * t + mo]);
                     for (int rr = 0; rr < 4; rr++)
-                        for (int m = 0; m < 3; m++) acc = gl_add(acc, gl_mul(u[3 * ((l + rr) & 3) + m], c[12 * mo + 3 * rr + m]));
+                        for (int m = 0; m < 3; m++) acc = gl_add(acc, gl_mul(u[quad_col(l, rr, m)], c[12 * mo + 3 * rr + m]));
                     acc = gl_add(acc, gl_mul(x2, c[43 + mo]));
                     acc = gl_add(acc, gl_mul(x3, c[46 + mo]));
-                    s[3 * l + mo] = acc;
+                    s[quad_elem(l, mo)] = acc;
                 }
             }
         }
         s[0] = poseidon_sbox(s[0]);  // round 25, plain
-        poseidon_mds(s);
+        mds_lanes(s);
         r++;
+        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], RC[12 * r + i]);
         for (; r < 30; r++) {
-            for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(gl_add(s[i], RC[12 * r + i]));
-            poseidon_mds(s);
+            for (int i = 0; i < 12; i++) s[i] = poseidon_sbox(s[i]);
+            mds_lanes(s);
+            if (r + 1 < 30)
+                for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], RC[12 * (r + 1) + i]);
         }
         for (int i = 0; i < 12; i++)
             if (s[i] != want[i]) {
@@ -154,21 +178,19 @@ static hipError_t ensure_quad_merged_tables() {
 // Four lanes (one DPP quad) walk one row; adjacent quads read adjacent k => each load touches whole 128-byte runs.
 __global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
                                                          gl_t* __restrict__ digests) {
-    // lane l of the quad owns sponge state elements 3l, 3l+1, 3l+2 (poseidon_dev.h)
+    // lane l of the quad owns sponge state elements l, l + 4, l + 8 (poseidon_dev.h)
     __shared__ RcPair rcs[4][96];  // per-lane view of the round constants, split in halves, + 3 zeros ("next round" of the last round)
     for (unsigned idx = threadIdx.x; idx < 4 * 96; idx += blockDim.x) {
         const unsigned ll = idx / 96, w = idx % 96;
-        const gl_t c = w < 90 ? POSEIDON_RC_DEV[12 * (w / 3) + 3 * ll + (w % 3)] : 0;
+        const gl_t c = w < 90 ? POSEIDON_RC_DEV[12 * (w / 3) + ll + 4 * (w % 3)] : 0;
         rcs[ll][w].lo = c & 0xFFFFFFFFull;
         rcs[ll][w].hi = c >> 32;
     }
-#if STARKHIP_MERGED_PARTIAL
     __shared__ RcPair tks[2 * QUAD_MERGED_TRIPLES];
     __shared__ RcPair tk3s[4][3 * QUAD_MERGED_TRIPLES];
     for (unsigned idx = threadIdx.x; idx < 2 * QUAD_MERGED_TRIPLES; idx += blockDim.x) tks[idx] = QUAD_MERGED.tk[idx];
     for (unsigned idx = threadIdx.x; idx < 4 * 3 * QUAD_MERGED_TRIPLES; idx += blockDim.x)
         tk3s[idx / (3 * QUAD_MERGED_TRIPLES)][idx % (3 * QUAD_MERGED_TRIPLES)] = QUAD_MERGED.tk3[idx / (3 * QUAD_MERGED_TRIPLES)][idx % (3 * QUAD_MERGED_TRIPLES)];
-#endif
     __syncthreads();
     const unsigned log_N = log_n + rate_bits;
     const size_t N = (size_t)1 << log_N;
@@ -181,83 +203,60 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__
     const size_t j = gl_bitrev((uint32_t)i, log_N);
     const gl_t* col = mat + q;
     if (n_cols <= 4) {  // hash_or_noop: short leaves are copied, zero padded
-        if (l == 0) {
-#pragma unroll
-            for (unsigned e = 0; e < 3; e++) digests[4 * j + e] = e < n_cols ? col[(size_t)e * N] : 0;
-        } else if (l == 1) {
-            digests[4 * j + 3] = 3 < n_cols ? col[(size_t)3 * N] : 0;
-        }
+        digests[4 * j + l] = l < n_cols ? col[(size_t)l * N] : 0;
         return;
     }
     const uint32_t diag0 = l == 0 ? 8u : 0u;
     const RcPair* rc = rcs[l];
-#if STARKHIP_MERGED_PARTIAL
     QuadMergedCoef mc;
     {
         const uint32_t* c = QUAD_MERGED.coef[l];
 #pragma unroll
-        for (int i = 0; i < 36; i++) mc.n3[i / 12][i % 12] = c[i];
+        for (int e = 0; e < 36; e++) mc.n3[e / 12][e % 12] = c[e];
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            mc.n1[i] = c[36 + i];
-            mc.n2[i] = c[39 + i];
-            mc.b2[i] = c[43 + i];
-            mc.b3[i] = c[46 + i];
+        for (int e = 0; e < 3; e++) {
+            mc.n1[e] = c[36 + e];
+            mc.n2[e] = c[39 + e];
+            mc.b2[e] = c[43 + e];
+            mc.b3[e] = c[46 + e];
         }
         mc.m00 = c[42];
+#pragma unroll
+        for (int e = 0; e < 12; e++) mc.cf[e] = c[50 + e];
     }
     const RcPair* tk3 = tk3s[l];
     const bool even_lane = (l & 1u) == 0;
-#define PERMUTE_QUAD() poseidon_permute_quad_merged(s0, s1, s2, diag0, rc, mc, tks, tk3, l == 0, even_lane)
-#else
-#define PERMUTE_QUAD() poseidon_permute_quad(s0, s1, s2, diag0, rc, l == 0)
-#endif
     gl_t s0 = 0, s1 = 0, s2 = 0;
-    size_t off = 0;
-    // full 8-element blocks (overwrite mode): lanes 0, 1 absorb three columns, lane 2 two, lane 3 holds capacity only
-    // The next block's cells are requested before the current permutation (about 10 us of arithmetic) so that their
-    // latency -- column stride N * 8 bytes, a new page per load -- is never waited for with only two waves per SIMD.
-    const gl_t* mine = col + (size_t)(3 * l) * N;
-    gl_t n0 = 0, n1 = 0, n2 = 0;
-    if (8 <= n_cols) {
-        if (l <= 2) {
-            n0 = mine[0];
-            n1 = mine[N];
+    // Overwrite-mode sponge, rate 8: block b overwrites state elements 0 .. 7 = slots 0 and 1 of the four lanes with columns
+    // 8 b + l and 8 b + l + 4.  The next block's two cells are requested before the current permutation (about 10 us of
+    // arithmetic) so that their latency -- column stride N * 8 bytes, a new page per load -- is never waited for with only two
+    // waves per SIMD.  A permutation that is followed by another full block computes only the capacity in its last layer.
+    const gl_t* mine = col + (size_t)l * N;
+    const size_t n_full = n_cols / 8, rem = n_cols % 8;
+    gl_t n0 = 0, n1 = 0;
+    if (n_full) {
+        n0 = mine[0];
+        n1 = mine[4 * N];
+    }
+    for (size_t b = 0; b < n_full; b++) {
+        s0 = n0;
+        s1 = n1;
+        if (b + 1 < n_full) {
+            n0 = mine[(8 * (b + 1)) * N];
+            n1 = mine[(8 * (b + 1) + 4) * N];
+            poseidon_permute_quad_merged<true>(s0, s1, s2, diag0, rc, mc, tks, tk3, l == 0, even_lane);
+        } else {
+            poseidon_permute_quad_merged<false>(s0, s1, s2, diag0, rc, mc, tks, tk3, l == 0, even_lane);
         }
-        if (l <= 1) n2 = mine[2 * N];
     }
-    for (; off + 8 <= n_cols; off += 8) {
-        if (l <= 2) {
-            s0 = n0;
-            s1 = n1;
-        }
-        if (l <= 1) s2 = n2;
-        if (off + 16 <= n_cols) {
-            if (l <= 2) {
-                n0 = mine[(off + 8) * N];
-                n1 = mine[(off + 9) * N];
-            }
-            if (l <= 1) n2 = mine[(off + 10) * N];
-        }
-        PERMUTE_QUAD();
+    if (rem) {  // the last, partial block overwrites elements 0 .. rem - 1 only
+        const size_t off = 8 * n_full;
+        if (l < rem) s0 = mine[off * N];
+        if (l + 4 < rem) s1 = mine[(off + 4) * N];
+        poseidon_permute_quad_merged<false>(s0, s1, s2, diag0, rc, mc, tks, tk3, l == 0, even_lane);
     }
-    if (off < n_cols) {
-        const size_t rem = n_cols - off;
-        if (3 * l + 0 < rem) s0 = mine[off * N];
-        if (3 * l + 1 < rem) s1 = mine[(off + 1) * N];
-        if (3 * l + 2 < rem) s2 = mine[(off + 2) * N];
-        PERMUTE_QUAD();
-    }
-    // digest = state elements 0..3: lane 0's three and lane 1's first
-    if (l == 0) {
-        digests[4 * j + 0] = gl_canon(s0);
-        digests[4 * j + 1] = gl_canon(s1);
-        digests[4 * j + 2] = gl_canon(s2);
-    } else if (l == 1) {
-        digests[4 * j + 3] = gl_canon(s0);
-    }
+    digests[4 * j + l] = gl_canon(s0);  // digest = state elements 0 .. 3: slot 0 of the four lanes
 }
-#undef PERMUTE_QUAD
 
 // Leaves stored row-major and already in tree order: leaf j = rows[j][0..width)
 __global__ __launch_bounds__(64) void leaf_hash_rows_kernel(const gl_t* __restrict__ rows, size_t width, size_t n_leaves,
@@ -310,9 +309,7 @@ static inline unsigned nblocks(size_t n, unsigned bs) { return (unsigned)((n + b
 
 hipError_t launch_leaf_hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st) {
     size_t N = (size_t)1 << (log_n + rate_bits);
-#if STARKHIP_MERGED_PARTIAL
     if (hipError_t e = ensure_quad_merged_tables(); e != hipSuccess) return e;
-#endif
     hipLaunchKernelGGL(leaf_hash_kernel, dim3(nblocks(4 * N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
     return hipGetLastError();
 }

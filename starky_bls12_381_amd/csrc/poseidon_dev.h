@@ -126,10 +126,14 @@ __device__ __forceinline__ void poseidon_hash_or_noop_dev(const gl_t* in, size_t
 }
 
 // ---------------------------------------------------------------- one permutation per DPP quad
-// Lane l (= lane id & 3) owns the three CONSECUTIVE state elements 3l, 3l+1, 3l+2 in (s0, s1, s2).  Because
-// 3 * 4 = 12, rotating the quad by r lanes shifts every element index by 3r (mod 12) in all four lanes alike, so
-// the circulant MDS coefficient of a rotated operand, CIRC[(3r + m - m') mod 12], is the same compile-time
-// constant in every lane: it is an inline operand of v_mad_u64_u32, not a register.
+// Lane l (= lane id & 3) owns the three state elements l, l + 4, l + 8 in (s0, s1, s2) ("slots" 0, 1, 2).  The sponge's rate
+// (elements 0 .. 7) is then slots 0 and 1 of every lane -- each lane absorbs two columns per block -- and the capacity
+// (8 .. 11) is slot 2 of every lane, so the last linear layer of a permutation that is followed by a full absorb needs ONE
+// output per lane instead of three (the rate outputs would be overwritten): 59 instructions less per permutation.
+// A quad rotation by r lanes brings element ((l + r) & 3) + 4 m' to slot m' of lane l; the circulant coefficient of that
+// operand for output l + 4 m is CIRC[(((l + r) & 3) - l + 4 (m' - m)) mod 12] -- it depends on the lane through the wrap of
+// (l + r), so every lane holds its twelve coefficients cf[3 r + (m' - m) mod 3] in registers (the first layout, lane l owning
+// 3l .. 3l+2, had lane-uniform inline constants but no way to skip the rate outputs).
 //
 // Cost model (measured on MI355X, tools/valu_rate_bench.hip): every integer VALU instruction other than a plain
 // 32-bit add/logic op issues in 4 cycles per wave -- v_mad_u64_u32 (32 x 32 + 64) included -- so the MDS layer is
@@ -189,14 +193,13 @@ struct RcPair {
 };
 
 // MDS layer; the accumulators start from this lane's three round constants of the NEXT round.
-// diag0 = 8 on lane 0, 0 elsewhere (MDS_MATRIX_DIAG has a single non-zero entry, at element 0).
-__device__ __forceinline__ void poseidon_mds_quad(gl_t& s0, gl_t& s1, gl_t& s2, uint32_t diag0, const RcPair& c0, const RcPair& c1,
-                                                  const RcPair& c2) {
-    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    uint32_t k16 = 16, k2 = 2;
-    asm("" : "+s"(k16));
-    asm("" : "+s"(k2));
-    uint32_t lo[4][3], hi[4][3];  // [r][m]: halves of element 3((l + r) & 3) + m
+// cf: this lane's twelve circulant coefficients (above); diag0 = 8 on lane 0, 0 elsewhere (MDS_MATRIX_DIAG has a single non-zero
+// entry, at element 0 = lane 0's slot 0).  CAP_ONLY: only slot 2 (the capacity element) is computed, s0 and s1 are left as
+// they are -- for a permutation whose rate outputs the next absorb overwrites.
+template <bool CAP_ONLY>
+__device__ __forceinline__ void poseidon_mds_quad(gl_t& s0, gl_t& s1, gl_t& s2, const uint32_t (&cf)[12], uint32_t diag0, const RcPair& c0,
+                                                  const RcPair& c1, const RcPair& c2) {
+    uint32_t lo[4][3], hi[4][3];  // [r][m']: halves of element ((l + r) & 3) + 4 m'
     lo[0][0] = (uint32_t)s0; hi[0][0] = (uint32_t)(s0 >> 32);
     lo[0][1] = (uint32_t)s1; hi[0][1] = (uint32_t)(s1 >> 32);
     lo[0][2] = (uint32_t)s2; hi[0][2] = (uint32_t)(s2 >> 32);
@@ -206,20 +209,16 @@ __device__ __forceinline__ void poseidon_mds_quad(gl_t& s0, gl_t& s1, gl_t& s2, 
         lo[2][m] = mds_rot<2>(lo[0][m]); hi[2][m] = mds_rot<2>(hi[0][m]);
         lo[3][m] = mds_rot<3>(lo[0][m]); hi[3][m] = mds_rot<3>(hi[0][m]);
     }
-    gl_t out[3];
+    gl_t out[3] = {s0, s1, s2};
 #pragma unroll
-    for (int mo = 0; mo < 3; mo++) {
+    for (int mo = CAP_ONLY ? 2 : 0; mo < 3; mo++) {
         const RcPair& c = mo == 0 ? c0 : mo == 1 ? c1 : c2;
         uint64_t A = c.lo, B = c.hi;
-        // out[3l + mo] = sum_j CIRC[(j - (3l + mo)) mod 12] * x[j],  j = 3(l + r) + m
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int m = 0; m < 3; m++) {
-                // 16 and 2 from a scalar register: as literals the compiler turns these products into 64-bit shifts,
-                // which need a (value, 0) register pair, i.e. one extra move per rotated operand
-                const uint32_t kc = CIRC[(3 * r + m - mo + 12) % 12];
-                const uint32_t k = kc == 16 ? k16 : kc == 2 ? k2 : kc;
+                const uint32_t k = cf[3 * r + (m - mo + 3) % 3];
                 A = mad32(lo[r][m], k, A);
                 B = mad32(hi[r][m], k, B);
                 // keep the chain a chain: without these (empty) barriers the sum is re-associated so that the round
@@ -238,34 +237,6 @@ __device__ __forceinline__ void poseidon_mds_quad(gl_t& s0, gl_t& s1, gl_t& s2, 
     s2 = out[2];
 }
 
-// rc: this lane's view of the round constants, rc[3 r + m] = split(RC[12 r + 3 l + m]), r < 30, followed by three zeros.
-// In: canonical or not; out: any representative (canonicalise with gl_canon before it leaves the kernel).
-__device__ __forceinline__ void poseidon_permute_quad(gl_t& s0, gl_t& s1, gl_t& s2, uint32_t diag0, const RcPair* __restrict__ rc, bool lane0) {
-    s0 = gl_add_nc(s0, rc[0].lo | (rc[0].hi << 32));
-    s1 = gl_add_nc(s1, rc[1].lo | (rc[1].hi << 32));
-    s2 = gl_add_nc(s2, rc[2].lo | (rc[2].hi << 32));
-    int r = 0;
-#pragma unroll 1
-    for (; r < 4; r++) {
-        s0 = sbox_nc(s0);
-        s1 = sbox_nc(s1);
-        s2 = sbox_nc(s2);
-        poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
-    }
-#pragma unroll 1
-    for (; r < 26; r++) {
-        s0 = sbox_lane0_nc(s0, lane0);
-        poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
-    }
-#pragma unroll 1
-    for (; r < 30; r++) {
-        s0 = sbox_nc(s0);
-        s1 = sbox_nc(s1);
-        s2 = sbox_nc(s2);
-        poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
-    }
-}
-
 // ---------------------------------------------------------------- merged partial rounds
 // Only element 0 passes the S-box in a partial round, so three consecutive partial rounds are linear in the eleven other
 // elements.  With M the MDS matrix, Mz = M with row 0 zeroed, and x_k the k-th S-box output:
@@ -275,14 +246,15 @@ __device__ __forceinline__ void poseidon_permute_quad(gl_t& s0, gl_t& s1, gl_t& 
 // i.e. ONE dense 12 x 12 layer (72 multiply-adds per lane, entries of M Mz Mz < 2^21: still 32-bit multiplicands with
 // 64-bit accumulators), two 12-term dot products for the intermediate element 0, and the three S-boxes -- instead of
 // three dense layers.  The matrices are not circulant (the diagonal term and the zeroed rows break that), so each lane
-// holds its coefficients in registers: n3[mo][3r+m] = (M Mz Mz)[3l+mo][col], n1[3r+m] = M[0][col], n2[3r+m] = (M Mz)[0][col]
-// with col = 3((l + r) & 3) + m, and the columns that multiply x_2 and x_3.
+// holds its coefficients in registers: n3[mo][3r+m] = (M Mz Mz)[l + 4 mo][col], col = ((l + r) & 3) + 4 m, the lane's own
+// columns of row 0 of M and of M Mz, and the columns that multiply x_2 and x_3.
 struct QuadMergedCoef {
     uint32_t n3[3][12];
     uint32_t n1[3], n2[3];  // row 0 of M and of M Mz at this lane's OWN three columns: the two intermediate dot products
                             // are per-lane partial sums added up across the quad (6 multiply-adds + a butterfly, not 24)
     uint32_t m00;           // M[0][0] on lane 0, 0 elsewhere (the x_2 term of y2 is added once)
-    uint32_t b2[3], b3[3];  // (M Mz)[3l+mo][0], M[3l+mo][0]
+    uint32_t b2[3], b3[3];  // (M Mz)[l + 4 mo][0], M[l + 4 mo][0]
+    uint32_t cf[12];        // the circulant coefficients of the plain layers (poseidon_mds_quad)
 };
 static const int QUAD_MERGED_TRIPLES = 7;  // = POSEIDON_MERGED_TRIPLES (poseidon_merged.h): partial rounds 0..20; the 22nd stays a plain round
 
@@ -372,8 +344,11 @@ __device__ __forceinline__ void poseidon_partial3_quad(gl_t& s0, gl_t& s1, gl_t&
     s2 = out[2];
 }
 
-// poseidon_permute_quad with the partial rounds taken three at a time.  rc as there; tk[t] = {k1, k2} of triple t,
-// tk3 = this lane's k3 constants, three per triple.
+// One permutation of the quad form, the partial rounds taken three at a time.  rc: this lane's view of the round constants,
+// rc[3 r + m] = split(RC[12 r + l + 4 m]), r < 30, followed by three zeros; tk[t] = {k1, k2} of triple t, tk3 = this lane's k3
+// constants, three per triple.  In: canonical or not; out: any representative (canonicalise with gl_canon before it leaves the
+// kernel).  CAP_ONLY: the last layer leaves the rate elements (s0, s1) unspecified -- the caller overwrites them.
+template <bool CAP_ONLY>
 __device__ __forceinline__ void poseidon_permute_quad_merged(gl_t& s0, gl_t& s1, gl_t& s2, uint32_t diag0, const RcPair* __restrict__ rc,
                                                              const QuadMergedCoef& c, const RcPair* __restrict__ tk,
                                                              const RcPair* __restrict__ tk3, bool lane0, bool even_lane) {
@@ -386,21 +361,25 @@ __device__ __forceinline__ void poseidon_permute_quad_merged(gl_t& s0, gl_t& s1,
         s0 = sbox_nc(s0);
         s1 = sbox_nc(s1);
         s2 = sbox_nc(s2);
-        poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
+        poseidon_mds_quad<false>(s0, s1, s2, c.cf, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
     }
 #pragma unroll 1
     for (int t = 0; t < QUAD_MERGED_TRIPLES; t++) poseidon_partial3_quad(s0, s1, s2, c, tk[2 * t], tk[2 * t + 1], tk3 + 3 * t, lane0, even_lane);
     r = 4 + 3 * QUAD_MERGED_TRIPLES;  // 25: the last partial round
     s0 = sbox_lane0_nc(s0, lane0);
-    poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
+    poseidon_mds_quad<false>(s0, s1, s2, c.cf, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
     r++;
 #pragma unroll 1
-    for (; r < 30; r++) {
+    for (; r < 29; r++) {
         s0 = sbox_nc(s0);
         s1 = sbox_nc(s1);
         s2 = sbox_nc(s2);
-        poseidon_mds_quad(s0, s1, s2, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
+        poseidon_mds_quad<false>(s0, s1, s2, c.cf, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
     }
+    s0 = sbox_nc(s0);
+    s1 = sbox_nc(s1);
+    s2 = sbox_nc(s2);
+    poseidon_mds_quad<CAP_ONLY>(s0, s1, s2, c.cf, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
 }
 
 }  // namespace starkhip
