@@ -40,7 +40,10 @@ def test_lde_matches_oracle(prover, log_n, rate_bits, ncols):
 
 @pytest.mark.parametrize("log_N,ncols,cap_h", [(5, 60285 // 16, 4), (4, 3, 4), (8, 4, 4), (8, 5, 2), (12, 200, 4), (6, 8, 0),
                                                # many leaves, widths around the 8-element sponge blocks
-                                               (14, 21, 4), (14, 8, 4), (14, 6, 4), (14, 15, 4), (15, 9, 4), (14, 3, 4)])
+                                               (14, 21, 4), (14, 8, 4), (14, 6, 4), (14, 15, 4), (15, 9, 4), (14, 3, 4),
+                                               # the quad layout's paths: capacity-only layers before further full blocks, tails of 1..7
+                                               (10, 16, 4), (10, 24, 4), (10, 12, 4), (10, 13, 4), (10, 7, 4), (10, 17, 4), (10, 20, 4), (10, 11, 4),
+                                               (10, 10, 4), (10, 14, 4)])
 def test_merkle_cap_matches_oracle(prover, log_N, ncols, cap_h):
     rng = np.random.default_rng(log_N + ncols)
     mat = _rand(rng, (ncols, 1 << log_N))
