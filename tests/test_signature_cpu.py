@@ -74,3 +74,33 @@ def test_pipeline_reports_a_failing_job():
     args, _ = G.job_arguments(sigs, mine)
     with pytest.raises(RuntimeError):
         G.run_jobs([object()], mine, args, gen_threads=1, prove=boom)
+
+
+def test_by_type_schedule_starts_final_exp_after_the_small_proofs():
+    """`big_after_small`: with two pools the FinalExp contexts wait for the last small proof (measured slower on one GPU and off by
+    default, kept as an option); the timeline and the restored process-wide settings are part of the contract."""
+    import time
+    jobs = [(i, n) for i in range(2) for n in A.JOB_ORDER]
+    args = {j: () for j in jobs}
+    order = []
+
+    def generate(name, *a):
+        return name, np.zeros(1, dtype=np.uint64)
+
+    def prove(pv, air, cfg, trace, pis):
+        time.sleep(0.02 if trace != "final_exp" else 0.0)
+        order.append(trace)
+        return np.zeros(1, dtype=np.uint64)
+
+    before = S.set_trace_threads(1)
+    res, st = G.run_jobs({"big": [object()], "small": [object(), object()]}, jobs, args, gen_threads=4, prove=prove, generate=generate,
+                         big_after_small=True)
+    assert len(res) == 12 and set(st["timeline"]) == set(jobs)
+    first_big = order.index("final_exp")
+    assert first_big == 10 and order[10:] == ["final_exp", "final_exp"]   # every small proof came first
+    for (i, n), (g0, g1, p0, p1) in st["timeline"].items():
+        assert g0 <= g1 <= p0 <= p1
+    assert S.set_trace_threads(before) == 1  # injected generators: the setting was not touched
+    order.clear()
+    res, _ = G.run_jobs({"big": [object()], "small": [object(), object()]}, jobs, args, gen_threads=4, prove=prove, generate=generate)
+    assert len(res) == 12 and order.index("final_exp") < 10  # both pools at once: FinalExp does not wait
