@@ -3,7 +3,12 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := starky_bls12_381_amd/csrc
 OUT := starky_bls12_381_amd/libstarkhip.so
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude
+ROCM_PATH ?= /opt/rocm
+# make ROCTX=1: rocTX phase ranges inside prove() (links the profiler SDK's roctx library); make DEBUG_KNOBS=1: the profiling
+# modes of the quotient kernel that switch arithmetic off ("quotient_debug" option) -- neither is in the default library
+EXTRA_DEFS := $(if $(ROCTX),-DSTARKHIP_ROCTX) $(if $(DEBUG_KNOBS),-DSTARKHIP_DEBUG)
+EXTRA_LIBS := $(if $(ROCTX),-L$(ROCM_PATH)/lib -lrocprofiler-sdk-roctx)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude $(EXTRA_DEFS)
 SRCS := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
 OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 HDRS := $(wildcard $(CSRC)/*.h) include/starkhip.h
@@ -15,10 +20,10 @@ build/%.hip.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 build/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p build
-	$(HIPCC) -O2 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude -c $< -o $@
+	$(HIPCC) -O2 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude $(EXTRA_DEFS) -c $< -o $@
 
 $(OUT): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrocprofiler-sdk-roctx
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lpthread $(EXTRA_LIBS)
 
 oracle:
 	$(MAKE) -C oracle

@@ -154,6 +154,53 @@ int starkhip_trace_log_expand_host(const void* log, uint64_t* trace_rowmajor, si
 int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const void* log, const uint64_t* public_inputs,
                            size_t n_pis, uint64_t pow_witness, uint64_t** proof, size_t* proof_words);
 
+/* --- proof pool: submit / wait ------------------------------------------------------------------------------------
+ * The reference's caller proves one AIR after the other on one thread (src/aggregate_proof.rs:304-370: pp1, ml1, pp2, ml2,
+ * fp12_mul, final_exp; `aggregate_proof` :402-414) and lets rayon fill the cores inside each prove().  On a GPU several
+ * proofs in flight are what fills the chip, so the library schedules them itself: a pool owns `big_contexts` prover contexts
+ * for the 8192-row AIRs (FinalExp, ECCAgg: ~25 GB of buffers each) and `small_contexts` for the others, one host thread
+ * per context, `generator_threads` host threads that record traces (starkhip_pool_submit_witness), and a commitment
+ * scheduler: the trace commitments of small proofs that arrive together are hashed by ONE merged launch, and a FinalExp-class
+ * commitment (a one-shot grid that owns the chip) never shares the chip with a small one.  Proofs are byte-identical to
+ * starkhip_prove's.  submit returns at once with a ticket; wait blocks until that proof is done and hands it over
+ * (starkhip_free), exactly once per ticket, from any thread.  Inputs of submit / submit_compact (trace, log, public inputs)
+ * stay the caller's and must stay valid until the ticket has been waited for; submit_witness copies its operands. */
+typedef struct {
+    int device;
+    unsigned big_contexts;      /* 0 = default (3) */
+    unsigned small_contexts;    /* 0 = default (16) */
+    unsigned generator_threads; /* 0 = default (12) */
+    unsigned trace_threads;     /* host threads ONE recording may use; 0 = automatic (idle generator threads are lent to the running ones) */
+    unsigned commit_policy;     /* 0 = default: merged small commitments, classes never overlap; 1 = merged, classes may overlap */
+    float gather_ms;            /* how long a merged launch waits for small proofs that have started but not reached their commitment; 0 = default (25) */
+} starkhip_pool_config_t;
+typedef struct {
+    float phase_ms[11];   /* as starkhip_last_timings */
+    float kernel_ms[3];   /* as starkhip_last_kernel_timings */
+    double t_submit, t_generate_start, t_generate_end, t_prove_start, t_done; /* seconds since the pool was created */
+} starkhip_ticket_info_t;
+typedef struct {
+    unsigned long big_commit_launches, small_commit_launches, small_commit_requests, max_merged_commitments;
+} starkhip_pool_stats_t;
+int starkhip_pool_create(const starkhip_pool_config_t* cfg, void** pool);
+void starkhip_pool_destroy(void* pool); /* runs what is queued to the end first */
+/* as starkhip_prove / starkhip_prove_compact */
+int starkhip_pool_submit(void* pool, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows, size_t n_cols,
+                         int trace_layout, int trace_on_device, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness,
+                         uint64_t* ticket);
+int starkhip_pool_submit_compact(void* pool, starkhip_air_t air, const starkhip_config_t* cfg, const void* log, const uint64_t* public_inputs,
+                                 size_t n_pis, uint64_t pow_witness, uint64_t* ticket);
+/* generate_trace + prove (src/aggregate_proof.rs:23-179, one driver each) from the driver's operands as u32 limbs, packed:
+ *   FP12_MUL x[144] y[144];  FINAL_EXP x[144];  MILLER_LOOP px[12] py[12] qx[24] qy[24] qz[24];  PAIRING_PRECOMP qx[24] qy[24] qz[24];
+ *   ECC_AGGREGATE points[512][24] then 512 words of 0 / 1;  TEST_FIBONACCI x0 (lo, hi) x1 (lo, hi).
+ * The trace is recorded on a generator thread of the pool (default rows of the AIR); cfg == NULL: starkhip_config_for_air.
+ * The public inputs are the tail of the proof blob. */
+int starkhip_pool_submit_witness(void* pool, starkhip_air_t air, const starkhip_config_t* cfg, const uint32_t* operands, size_t n_limbs,
+                                 uint64_t pow_witness, uint64_t* ticket);
+/* returns the proof's status (what starkhip_prove would have returned); info may be NULL */
+int starkhip_pool_wait(void* pool, uint64_t ticket, uint64_t** proof, size_t* proof_words, starkhip_ticket_info_t* info);
+int starkhip_pool_stats(void* pool, starkhip_pool_stats_t* out);
+
 /* per-phase device timings of the last prove on this ctx, milliseconds (HIP events):
  * [0] upload/transpose [1] ifft+lde [2] trace leaf hash + merkle [3] quotient [4] quotient commit
  * [5] openings [6] fri combine [7] fri commit [8] pow [9] queries [10] total */

@@ -9,8 +9,12 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <array>
+#include <chrono>
+#include <future>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "starkhip.h"
@@ -123,6 +127,8 @@ struct SignatureProofs {
     bool linked = false; // the public-input equalities the reference's recursive aggregation enforces
 };
 
+inline void finish_links(SignatureProofs& s);  // valid / linked from the six proofs' public inputs (below)
+
 // pk = (x, y) of the aggregate public key; hm, sig = (x, y, z) of H(m) and of the signature (Fp2 limbs each).
 inline SignatureProofs prove_signature(Prover& pv, const uint32_t pk_x[12], const uint32_t pk_y[12], const uint32_t hm[3][24],
                                        const uint32_t sig[3][24]) {
@@ -137,6 +143,98 @@ inline SignatureProofs prove_signature(Prover& pv, const uint32_t pk_x[12], cons
     s.ml2 = miller_loop_main(pv, NEG_G1_X, NEG_G1_Y, sig[0], sig[1], sig[2]);
     s.fp12_mul = fp12_mul_main(pv, ml1, ml2);
     s.final_exp = final_exponentiate_main(pv, prod);
+    finish_links(s);
+    return s;
+}
+
+// ---- the same on the library's proof pool (starkhip_pool_*): every driver becomes submit + wait, so the six proofs of one
+// signature -- or of a whole batch -- are in flight together; generate_trace runs on the pool's generator threads and the
+// pool's scheduler merges the small AIRs' trace commitments (starkhip.h).
+class Pool {
+  public:
+    explicit Pool(const starkhip_pool_config_t& cfg) { check("starkhip_pool_create", starkhip_pool_create(&cfg, &pool_)); }
+    explicit Pool(int device = 0) {
+        starkhip_pool_config_t cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.device = device;
+        check("starkhip_pool_create", starkhip_pool_create(&cfg, &pool_));
+    }
+    ~Pool() { starkhip_pool_destroy(pool_); }
+    Pool(const Pool&) = delete;
+    Pool& operator=(const Pool&) = delete;
+
+    // generate_trace + prove of one driver (src/aggregate_proof.rs:23-179) from its operands; returns the ticket
+    uint64_t submit(starkhip_air_t air, const std::vector<uint32_t>& operands) {
+        uint64_t t = 0;
+        check("starkhip_pool_submit_witness", starkhip_pool_submit_witness(pool_, air, nullptr, operands.data(), operands.size(), STARKHIP_POW_SEARCH, &t));
+        return t;
+    }
+    // the finished proof of `ticket`; verify = the reference's verify_stark_proof(..).unwrap() right after prove
+    Proof wait(starkhip_air_t air, uint64_t ticket, bool verify = true, starkhip_ticket_info_t* info = nullptr) {
+        Proof p;
+        p.air = air;
+        check("starkhip_config_for_air", starkhip_config_for_air(air, &p.config));
+        uint64_t* blob = nullptr;
+        size_t words = 0;
+        check("starkhip_pool_wait", starkhip_pool_wait(pool_, ticket, &blob, &words, info));
+        p.words.assign(blob, blob + words);
+        starkhip_free(blob);
+        p.n_public_inputs = (size_t)starkhip_air_public_inputs(air);
+        if (verify) check("starkhip_verify", starkhip_verify(air, &p.config, p.words.data(), p.words.size()));
+        return p;
+    }
+    starkhip_pool_stats_t stats() {
+        starkhip_pool_stats_t s;
+        check("starkhip_pool_stats", starkhip_pool_stats(pool_, &s));
+        return s;
+    }
+
+  private:
+    void* pool_ = nullptr;
+};
+
+namespace detail {
+inline std::vector<uint32_t> pack(std::initializer_list<std::pair<const uint32_t*, size_t>> parts) {
+    std::vector<uint32_t> v;
+    for (const auto& p : parts) v.insert(v.end(), p.first, p.first + p.second);
+    return v;
+}
+}  // namespace detail
+
+// One signature's operands: aggregate public key (x, y), H(m) and signature as (x, y, z) Fp2 limbs.
+struct SignatureOperands {
+    uint32_t pk_x[12], pk_y[12], hm[3][24], sig[3][24];
+};
+
+// tickets of the six jobs of one signature, submitted in the reference's order; the two that need the native Miller-loop
+// values (fp12_mul, final_exp: src/aggregate_proof.rs:352-363) are submitted by a helper thread as soon as those are known
+struct SignatureTickets {
+    uint64_t pp1 = 0, ml1 = 0, pp2 = 0, ml2 = 0;
+    std::future<std::array<uint64_t, 2>> tail;  // fp12_mul, final_exp
+};
+
+inline SignatureTickets submit_signature(Pool& pool, const SignatureOperands& s) {
+    SignatureTickets t;
+    t.pp1 = pool.submit(STARKHIP_AIR_PAIRING_PRECOMP, detail::pack({{s.hm[0], 24}, {s.hm[1], 24}, {s.hm[2], 24}}));
+    t.ml1 = pool.submit(STARKHIP_AIR_MILLER_LOOP, detail::pack({{s.pk_x, 12}, {s.pk_y, 12}, {s.hm[0], 24}, {s.hm[1], 24}, {s.hm[2], 24}}));
+    t.pp2 = pool.submit(STARKHIP_AIR_PAIRING_PRECOMP, detail::pack({{s.sig[0], 24}, {s.sig[1], 24}, {s.sig[2], 24}}));
+    t.ml2 = pool.submit(STARKHIP_AIR_MILLER_LOOP, detail::pack({{NEG_G1_X, 12}, {NEG_G1_Y, 12}, {s.sig[0], 24}, {s.sig[1], 24}, {s.sig[2], 24}}));
+    t.tail = std::async(std::launch::async, [&pool, s]() {
+        // the two native Miller loops are independent: one on a thread of its own
+        std::vector<uint32_t> ml1(144), ml2(144), prod(144);
+        auto other = std::async(std::launch::async, [&] { return starkhip_native_miller_loop(NEG_G1_X, NEG_G1_Y, s.sig[0], s.sig[1], s.sig[2], ml2.data()); });
+        check("native_miller_loop", starkhip_native_miller_loop(s.pk_x, s.pk_y, s.hm[0], s.hm[1], s.hm[2], ml1.data()));
+        check("native_miller_loop", other.get());
+        check("native_fp12_mul", starkhip_native_fp12_mul(ml1.data(), ml2.data(), prod.data()));
+        std::array<uint64_t, 2> out;
+        out[1] = pool.submit(STARKHIP_AIR_FINAL_EXP, prod);  // the long pole first
+        out[0] = pool.submit(STARKHIP_AIR_FP12_MUL, detail::pack({{ml1.data(), 144}, {ml2.data(), 144}}));
+        return out;
+    });
+    return t;
+}
+
+inline void finish_links(SignatureProofs& s) {
     const uint64_t* fe = s.final_exp.public_inputs();
     s.valid = fe[144] == 1;
     for (int i = 1; i < 144; i++) s.valid = s.valid && fe[144 + i] == 0;
@@ -146,7 +244,51 @@ inline SignatureProofs prove_signature(Prover& pv, const uint32_t pk_x[12], cons
                same(s.ml1.public_inputs() + 24 + ELL, s.fp12_mul.public_inputs(), 144) &&
                same(s.ml2.public_inputs() + 24 + ELL, s.fp12_mul.public_inputs() + 144, 144) &&
                same(s.fp12_mul.public_inputs() + 288, s.final_exp.public_inputs(), 144);
+}
+
+// the statement: the proofs are about THESE operands -- H(m) and the signature with Z = (1, 0), the key as ml1's G1 operand
+// (the reference binds it through the ECCAggStark proof, src/aggregate_proof.rs:540-545), -G as ml2's
+inline bool statement_holds(const SignatureProofs& p, const SignatureOperands& s) {
+    auto is = [](const uint64_t* pis, const uint32_t* limbs, size_t n) {
+        for (size_t i = 0; i < n; i++)
+            if (pis[i] != limbs[i]) return false;
+        return true;
+    };
+    static const uint32_t ONE[24] = {1};
+    return is(p.pp1.public_inputs(), s.hm[0], 24) && is(p.pp1.public_inputs() + 24, s.hm[1], 24) && is(p.pp1.public_inputs() + 48, ONE, 24) &&
+           is(p.pp2.public_inputs(), s.sig[0], 24) && is(p.pp2.public_inputs() + 24, s.sig[1], 24) && is(p.pp2.public_inputs() + 48, ONE, 24) &&
+           is(p.ml1.public_inputs(), s.pk_x, 12) && is(p.ml1.public_inputs() + 12, s.pk_y, 12) && is(p.ml2.public_inputs(), NEG_G1_X, 12) &&
+           is(p.ml2.public_inputs() + 12, NEG_G1_Y, 12);
+}
+
+inline SignatureProofs wait_signature(Pool& pool, SignatureTickets& t, bool verify = true) {
+    SignatureProofs s;
+    const std::array<uint64_t, 2> tail = t.tail.get();
+    s.pp1 = pool.wait(STARKHIP_AIR_PAIRING_PRECOMP, t.pp1, verify);
+    s.ml1 = pool.wait(STARKHIP_AIR_MILLER_LOOP, t.ml1, verify);
+    s.pp2 = pool.wait(STARKHIP_AIR_PAIRING_PRECOMP, t.pp2, verify);
+    s.ml2 = pool.wait(STARKHIP_AIR_MILLER_LOOP, t.ml2, verify);
+    s.fp12_mul = pool.wait(STARKHIP_AIR_FP12_MUL, tail[0], verify);
+    s.final_exp = pool.wait(STARKHIP_AIR_FINAL_EXP, tail[1], verify);
+    finish_links(s);
     return s;
+}
+
+// the six proofs of one signature, all in flight at once
+inline SignatureProofs prove_signature(Pool& pool, const SignatureOperands& s, bool verify = true) {
+    SignatureTickets t = submit_signature(pool, s);
+    return wait_signature(pool, t, verify);
+}
+
+// BASELINE configs[4]: a batch of signatures = 6 B proofs in flight on one pool
+inline std::vector<SignatureProofs> prove_batch(Pool& pool, const std::vector<SignatureOperands>& sigs, bool verify = true) {
+    std::vector<SignatureTickets> tickets;
+    tickets.reserve(sigs.size());
+    for (const SignatureOperands& s : sigs) tickets.push_back(submit_signature(pool, s));
+    std::vector<SignatureProofs> out;
+    out.reserve(sigs.size());
+    for (SignatureTickets& t : tickets) out.push_back(wait_signature(pool, t, verify));
+    return out;
 }
 
 }  // namespace starkhip_driver

@@ -123,15 +123,28 @@ def _pis(proofs, name):
     return np.asarray(proof[-n:], dtype=np.uint64)
 
 
-def check_statement(proofs, hm, sig):
-    """The CONSTANT bindings the reference's recursive aggregation puts on the public inputs, besides the cross-proof links
-    of `check_links` (src/aggregate_proof.rs:507-520, 552-568, 576-581, 590-598): the first precompute ran on H(m) with
-    Z = (1, 0); the second on the signature point with Z = (1, 0); the second Miller loop's G1 operand is -G; the final
-    exponentiation's output is 1.  hm, sig: (x, y[, z]) Fp2 limb arrays of the points the statement is about.
-    Proofs that verify and link but attest to other points make this False."""
+def check_statement(proofs, pk, hm, sig):
+    """The bindings the reference's recursive aggregation puts on the public inputs, besides the cross-proof links of
+    `check_links` (src/aggregate_proof.rs:507-520, 540-545, 552-568, 576-581, 590-598): the first precompute ran on H(m) with
+    Z = (1, 0); the second on the signature point with Z = (1, 0); the FIRST Miller loop's G1 operand is the aggregate public
+    key -- the reference ties ml1's (PX, PY) to the key through the ECCAggStark proof's last 24 public inputs (:540-545); here
+    `pk` = (x, y) Fp limb arrays is that key, or None when an "ec" proof is in `proofs` and carries it -- the second Miller
+    loop's G1 operand is -G; the final exponentiation's output is 1.  hm, sig: (x, y[, z]) Fp2 limb arrays of the points the
+    statement is about.  Proofs that verify and link but attest to another key or other points make this False: without the
+    key binding six proofs made for any pk' with e(pk', H(m)) * e(-G, sig) = 1 would pass for (hm, sig)."""
     one = np.zeros(24, dtype=np.uint64)
     one[0] = 1
-    pp1, pp2, ml2, fe = _pis(proofs, "pp1"), _pis(proofs, "pp2"), _pis(proofs, "ml2"), _pis(proofs, "final_exp")
+    pp1, pp2, ml1, ml2, fe = _pis(proofs, "pp1"), _pis(proofs, "pp2"), _pis(proofs, "ml1"), _pis(proofs, "ml2"), _pis(proofs, "final_exp")
+    if pk is None:
+        if "ec" not in proofs:
+            raise ValueError("check_statement needs the public key: pass pk, or include the 'ec' (ECCAggStark) proof that publishes it")
+        key = _pis(proofs, "ec")[-24:]
+    else:
+        key = np.concatenate([np.asarray(pk[0], dtype=np.uint64), np.asarray(pk[1], dtype=np.uint64)])
+        if "ec" in proofs and not np.array_equal(_pis(proofs, "ec")[-24:], key):
+            return False
+    if not np.array_equal(ml1[0:24], key):
+        return False
     ok = bool(np.array_equal(pp1[0:24], np.asarray(hm[0], dtype=np.uint64)) and np.array_equal(pp1[24:48], np.asarray(hm[1], dtype=np.uint64)))
     ok &= bool(np.array_equal(pp1[48:72], one))
     ok &= bool(np.array_equal(pp2[0:24], np.asarray(sig[0], dtype=np.uint64)) and np.array_equal(pp2[24:48], np.asarray(sig[1], dtype=np.uint64)))

@@ -489,6 +489,139 @@ class Prover:
         return s
 
 
+# ----------------------------------------------------------------------------- proof pool (submit / wait)
+class PoolConfig(C.Structure):
+    """starkhip_pool_config_t (0 = the library's default)."""
+    _fields_ = [("device", C.c_int), ("big_contexts", C.c_uint), ("small_contexts", C.c_uint), ("generator_threads", C.c_uint),
+                ("trace_threads", C.c_uint), ("commit_policy", C.c_uint), ("gather_ms", C.c_float)]
+
+
+class TicketInfo(C.Structure):
+    _fields_ = [("phase_ms", C.c_float * N_PHASES), ("kernel_ms", C.c_float * 3), ("t_submit", C.c_double), ("t_generate_start", C.c_double),
+                ("t_generate_end", C.c_double), ("t_prove_start", C.c_double), ("t_done", C.c_double)]
+
+
+class PoolStats(C.Structure):
+    _fields_ = [(n, C.c_ulong) for n in ("big_commit_launches", "small_commit_launches", "small_commit_requests", "max_merged_commitments")]
+
+
+lib.starkhip_pool_create.argtypes = [C.POINTER(PoolConfig), C.POINTER(C.c_void_p)]
+lib.starkhip_pool_destroy.argtypes = [C.c_void_p]
+lib.starkhip_pool_destroy.restype = None
+lib.starkhip_pool_submit.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _u64p,
+                                     C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)]
+lib.starkhip_pool_submit_compact.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), C.c_void_p, _u64p, C.c_size_t, C.c_uint64,
+                                             C.POINTER(C.c_uint64)]
+lib.starkhip_pool_submit_witness.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), _u32p, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)]
+lib.starkhip_pool_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_u64p), C.POINTER(C.c_size_t), C.POINTER(TicketInfo)]
+lib.starkhip_pool_stats.argtypes = [C.c_void_p, C.POINTER(PoolStats)]
+
+
+def witness_operands(air, *args):
+    """The packed u32 operand vector `starkhip_pool_submit_witness` takes for `air` from the arguments of its `trace_*`
+    generator (starkhip.h has the layouts)."""
+    if air == AIR_FP12_MUL:
+        parts = [_limbs(args[0], 144), _limbs(args[1], 144)]
+    elif air == AIR_FINAL_EXP:
+        parts = [_limbs(args[0], 144)]
+    elif air == AIR_MILLER_LOOP:
+        parts = [_limbs(args[0], 12), _limbs(args[1], 12), _limbs(args[2], 24), _limbs(args[3], 24), _limbs(args[4], 24)]
+    elif air == AIR_PAIRING_PRECOMP:
+        parts = [_limbs(args[0], 24), _limbs(args[1], 24), _limbs(args[2], 24)]
+    elif air == AIR_ECC_AGGREGATE:
+        pts, b = _ecc_inputs(args[0], args[1])
+        parts = [pts, b.astype(np.uint32)]
+    elif air == AIR_TEST_FIBONACCI:
+        x0, x1 = int(args[0]), int(args[1])
+        parts = [np.array([x0 & 0xFFFFFFFF, x0 >> 32, x1 & 0xFFFFFFFF, x1 >> 32], dtype=np.uint32)]
+    else:
+        raise StarkhipError(ERR_BAD_AIR)
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.uint32)
+
+
+class ProofPool:
+    """starkhip_pool_*: the library's own scheduler of many proofs on one GPU -- prover contexts with a host thread each,
+    generator threads, merged trace commitments for the small AIRs.  The caller side of the reference's six-proof sequence
+    (src/aggregate_proof.rs:304-370) only submits and waits:
+
+        t = pool.submit_witness(AIR_MILLER_LOOP, px, py, qx, qy, qz)     # generate_trace + prove, both inside the pool
+        proof, info = pool.wait(t)
+    """
+
+    def __init__(self, device=0, big_contexts=0, small_contexts=0, generator_threads=0, trace_threads=0, commit_policy=0, gather_ms=0.0):
+        cfg = PoolConfig(device, big_contexts, small_contexts, generator_threads, trace_threads, commit_policy, gather_ms)
+        self._h = C.c_void_p()
+        _chk(lib.starkhip_pool_create(C.byref(cfg), C.byref(self._h)))
+        self._keep = {}  # ticket -> inputs that must outlive the proof
+
+    def close(self):
+        if self._h:
+            lib.starkhip_pool_destroy(self._h)
+            self._h = C.c_void_p()
+            self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, air, config, trace, public_inputs, pow_witness=POW_SEARCH, layout=0):
+        """As Prover.prove, asynchronously: `trace` a host array or a CompactTrace.  Returns the ticket."""
+        pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        cfg = StarkConfig.from_buffer_copy(config)
+        t = C.c_uint64()
+        if isinstance(trace, CompactTrace):
+            _chk(lib.starkhip_pool_submit_compact(self._h, air, C.byref(cfg), trace._h, _p64(pis), pis.size, pow_witness, C.byref(t)))
+        else:
+            trace = np.ascontiguousarray(trace, dtype=np.uint64)
+            if trace.ndim != 2 or layout not in (0, 1):
+                raise StarkhipError(ERR_BAD_SHAPE)
+            n_rows, n_cols = trace.shape if layout == 0 else trace.shape[::-1]
+            _chk(lib.starkhip_pool_submit(self._h, air, C.byref(cfg), trace.ctypes.data_as(C.c_void_p), n_rows, n_cols, layout, 0, _p64(pis), pis.size,
+                                          pow_witness, C.byref(t)))
+        self._keep[t.value] = (trace, pis, cfg)
+        return t.value
+
+    def submit_device(self, air, config, trace_ptr, n_rows, public_inputs, pow_witness=POW_SEARCH, layout=1):
+        """`trace_ptr`: device address of a uint64 trace already resident in HBM (benchmark path)."""
+        pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        cfg = StarkConfig.from_buffer_copy(config)
+        t = C.c_uint64()
+        _chk(lib.starkhip_pool_submit(self._h, air, C.byref(cfg), C.c_void_p(trace_ptr), n_rows, air_columns(air), layout, 1, _p64(pis), pis.size,
+                                      pow_witness, C.byref(t)))
+        self._keep[t.value] = (pis, cfg)
+        return t.value
+
+    def submit_witness(self, air, *generator_args, config=None, pow_witness=POW_SEARCH):
+        """generate_trace + prove inside the pool, from the arguments of `trace_<air>`."""
+        ops = witness_operands(air, *generator_args)
+        t = C.c_uint64()
+        cfgp = C.byref(StarkConfig.from_buffer_copy(config)) if config is not None else None
+        _chk(lib.starkhip_pool_submit_witness(self._h, air, cfgp, _p32(ops), ops.size, pow_witness, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket, keep=True):
+        """(proof, info) of `ticket`; raises StarkhipError with the proof's status if it failed.  info: phase_ms / kernel_ms
+        dicts and the job's timeline in seconds since the pool was created."""
+        out = _u64p()
+        words = C.c_size_t()
+        info = TicketInfo()
+        rc = lib.starkhip_pool_wait(self._h, ticket, C.byref(out), C.byref(words), C.byref(info))
+        self._keep.pop(ticket, None)
+        _chk(rc)
+        proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy() if keep else None
+        lib.starkhip_free(out)
+        return proof, {"phase_ms": dict(zip(PHASE_NAMES, [float(x) for x in info.phase_ms])),
+                       "kernel_ms": {"lde_columns": float(info.kernel_ms[0]), "leaf_hash": float(info.kernel_ms[1]), "quotient_eval": float(info.kernel_ms[2])},
+                       "timeline_s": [info.t_submit, info.t_generate_start, info.t_generate_end, info.t_prove_start, info.t_done]}
+
+    def stats(self):
+        s = PoolStats()
+        _chk(lib.starkhip_pool_stats(self._h, C.byref(s)))
+        return {n: int(getattr(s, n)) for n, _ in PoolStats._fields_}
+
+
 def verify_stark_proof(air, config, proof):
     """Mirror of starky::verifier::verify_stark_proof; raises StarkhipError on rejection."""
     p = np.ascontiguousarray(proof, dtype=np.uint64)

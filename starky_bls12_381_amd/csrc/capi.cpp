@@ -23,7 +23,9 @@ TraceLog*& armed_trace_log() {
     return armed;
 }
 static std::atomic<int> g_trace_threads(1);
-int trace_threads() { return g_trace_threads.load(); }
+static thread_local int tl_trace_threads = 0;  // a pool's generator thread sets its own share (scheduler.cpp)
+int trace_threads() { return tl_trace_threads > 0 ? tl_trace_threads : g_trace_threads.load(); }
+void set_thread_trace_threads(int n) { tl_trace_threads = n < 0 ? 0 : n > 64 ? 64 : n; }
 }  // namespace starkhip
 
 extern "C" {
@@ -266,6 +268,55 @@ int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_
     } catch (const std::exception&) {
         return STARKHIP_ERR_BAD_SHAPE;
     }
+}
+
+// ---- proof pool (scheduler.cpp)
+int starkhip_pool_create(const starkhip_pool_config_t* cfg, void** pool) {
+    if (!cfg || !pool) return STARKHIP_ERR_BAD_SHAPE;
+    *pool = nullptr;
+    // one hardware queue per in-flight proof where the runtime has not been initialised yet: with HIP's default of 4, streams
+    // share queues and kernels of different proofs serialise behind each other
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    Pool* p = nullptr;
+    try {
+        const int rc = pool_create(*cfg, &p);
+        *pool = p;
+        return rc;
+    } catch (const std::bad_alloc&) {
+        return STARKHIP_ERR_OOM;
+    } catch (const std::exception&) {
+        return STARKHIP_ERR_HIP;
+    }
+}
+void starkhip_pool_destroy(void* pool) { pool_destroy((Pool*)pool); }
+int starkhip_pool_submit(void* pool, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows, size_t n_cols,
+                         int trace_layout, int trace_on_device, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness,
+                         uint64_t* ticket) {
+    if (!pool) return STARKHIP_ERR_NO_DEVICE;
+    return pool_submit((Pool*)pool, air, cfg, trace, n_rows, n_cols, trace_layout, trace_on_device, public_inputs, n_pis, pow_witness, ticket);
+}
+int starkhip_pool_submit_compact(void* pool, starkhip_air_t air, const starkhip_config_t* cfg, const void* log, const uint64_t* public_inputs,
+                                 size_t n_pis, uint64_t pow_witness, uint64_t* ticket) {
+    if (!pool) return STARKHIP_ERR_NO_DEVICE;
+    if (log && armed_trace_log() == (const TraceLog*)log) return STARKHIP_ERR_BAD_SHAPE;
+    return pool_submit_compact((Pool*)pool, air, cfg, log, public_inputs, n_pis, pow_witness, ticket);
+}
+int starkhip_pool_submit_witness(void* pool, starkhip_air_t air, const starkhip_config_t* cfg, const uint32_t* operands, size_t n_limbs,
+                                 uint64_t pow_witness, uint64_t* ticket) {
+    if (!pool) return STARKHIP_ERR_NO_DEVICE;
+    try {
+        return pool_submit_witness((Pool*)pool, air, cfg, operands, n_limbs, pow_witness, ticket);
+    } catch (const std::bad_alloc&) {
+        return STARKHIP_ERR_OOM;
+    }
+}
+int starkhip_pool_wait(void* pool, uint64_t ticket, uint64_t** proof, size_t* proof_words, starkhip_ticket_info_t* info) {
+    if (!pool) return STARKHIP_ERR_NO_DEVICE;
+    return pool_wait((Pool*)pool, ticket, proof, proof_words, info);
+}
+int starkhip_pool_stats(void* pool, starkhip_pool_stats_t* out) {
+    if (!pool || !out) return STARKHIP_ERR_BAD_SHAPE;
+    return pool_stats((Pool*)pool, out);
 }
 
 int starkhip_last_timings(void* ctx, float ms[STARKHIP_N_PHASES]) {

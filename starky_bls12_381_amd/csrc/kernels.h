@@ -38,6 +38,13 @@ hipError_t launch_ntt_global(gl_t* data, size_t n_vecs, size_t vec_stride, unsig
                              const gl_t* pre_scale, const gl_t* post_scale, gl_t final_mul, hipStream_t st);
 
 // kernels_hash.hip
+// up to LEAF_HASH_MAX_BATCH matrices of one shape hashed by one launch (the trace commitments of proofs of the same AIR)
+static const unsigned LEAF_HASH_MAX_BATCH = 64;
+struct LeafHashBatch {
+    const gl_t* mat[LEAF_HASH_MAX_BATCH];
+    gl_t* digests[LEAF_HASH_MAX_BATCH];
+};
+hipError_t launch_leaf_hash_multi(const LeafHashBatch& B, unsigned count, size_t n_cols, unsigned log_n, unsigned rate_bits, hipStream_t st);
 hipError_t launch_leaf_hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st);
 hipError_t launch_leaf_hash_rows(const gl_t* rows, size_t width, size_t n_leaves, gl_t* digests, hipStream_t st);
 hipError_t launch_merkle_levels(gl_t* digests, unsigned log_leaves, unsigned cap_h, hipStream_t st);

@@ -176,8 +176,8 @@ static hipError_t ensure_quad_merged_tables() {
 // Leaf position j in the tree holds natural row bitrev_logN(j) (plonky2 reverse_index_bits_in_place),
 // so the thread that owns physical point q writes digest slot j = bitrev(i).
 // Four lanes (one DPP quad) walk one row; adjacent quads read adjacent k => each load touches whole 128-byte runs.
-__global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
-                                                         gl_t* __restrict__ digests) {
+__device__ __forceinline__ void leaf_hash_body(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                                               gl_t* __restrict__ digests) {
     // lane l of the quad owns sponge state elements l, l + 4, l + 8 (poseidon_dev.h)
     __shared__ RcPair rcs[4][96];  // per-lane view of the round constants, split in halves, + 3 zeros ("next round" of the last round)
     for (unsigned idx = threadIdx.x; idx < 4 * 96; idx += blockDim.x) {
@@ -258,6 +258,18 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__
     digests[4 * j + l] = gl_canon(s0);  // digest = state elements 0 .. 3: slot 0 of the four lanes
 }
 
+__global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                                                         gl_t* __restrict__ digests) {
+    leaf_hash_body(mat, n_cols, log_n, rate_bits, digests);
+}
+
+// The same over K matrices of ONE shape in one launch (grid.y = matrix): the commitments of K proofs of the same AIR.  A
+// 1024-row AIR has 2048 .. 4096 leaves, i.e. 128 .. 256 waves of up to 12 167 sequential permutations each -- a latency chain
+// that leaves 7/8 of the chip idle; K of them side by side fill it (scheduler.hip gathers them).
+__global__ __launch_bounds__(256) void leaf_hash_multi_kernel(LeafHashBatch B, size_t n_cols, unsigned log_n, unsigned rate_bits) {
+    leaf_hash_body(B.mat[blockIdx.y], n_cols, log_n, rate_bits, B.digests[blockIdx.y]);
+}
+
 // Leaves stored row-major and already in tree order: leaf j = rows[j][0..width)
 __global__ __launch_bounds__(64) void leaf_hash_rows_kernel(const gl_t* __restrict__ rows, size_t width, size_t n_leaves,
                                                              gl_t* __restrict__ digests) {
@@ -311,6 +323,14 @@ hipError_t launch_leaf_hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsi
     size_t N = (size_t)1 << (log_n + rate_bits);
     if (hipError_t e = ensure_quad_merged_tables(); e != hipSuccess) return e;
     hipLaunchKernelGGL(leaf_hash_kernel, dim3(nblocks(4 * N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
+    return hipGetLastError();
+}
+hipError_t launch_leaf_hash_multi(const LeafHashBatch& B, unsigned count, size_t n_cols, unsigned log_n, unsigned rate_bits, hipStream_t st) {
+    if (count == 0 || count > LEAF_HASH_MAX_BATCH) return hipErrorInvalidValue;
+    size_t N = (size_t)1 << (log_n + rate_bits);
+    if (hipError_t e = ensure_quad_merged_tables(); e != hipSuccess) return e;
+    if (count == 1) hipLaunchKernelGGL(leaf_hash_kernel, dim3(nblocks(4 * N, 256)), dim3(256), 0, st, B.mat[0], n_cols, log_n, rate_bits, B.digests[0]);
+    else hipLaunchKernelGGL(leaf_hash_multi_kernel, dim3(nblocks(4 * N, 256), count), dim3(256), 0, st, B, n_cols, log_n, rate_bits);
     return hipGetLastError();
 }
 hipError_t launch_leaf_hash_rows(const gl_t* rows, size_t width, size_t n_leaves, gl_t* digests, hipStream_t st) {

@@ -306,13 +306,14 @@ __device__ __forceinline__ void qt_add128(uint64_t& lo, uint64_t& hi, uint64_t x
     hi = ((uint64_t)h1 << 32) | h0;
 }
 
-// sum_l 2^(22 l) * (S[l] + 2^32 S[3 + l]) mod p, any representative.  Every S < 2^61 (at most QT_MAX_PIECE products < 2^54).
+// sum_l 2^(22 l) * (S[l] + 2^32 S[3 + l]) mod p, any representative.  Every S < QT_MAX_CHAIN * 2^54 = 0.9375 * 2^64
+// (a chain carried across tiles holds up to QT_MAX_CHAIN = 960 products < 2^54; quotient_plan.h has the derivation).
 //   U = S0 + S1 2^22 + S2 2^44,  V = S3 + S4 2^22 + S5 2^44  (both < 2^106),  total = U + V 2^32 = sum_k t_k 2^(32 k), k < 5
 //   total mod p = (t1:t0) - (t4:t3) + t2 eps          (2^64 = eps, 2^96 = -1, 2^128 = -2^32)
 // with the borrow / carry settled as in gl_reduce_words (the subtrahend is < 2^42, so the same bounds hold).
 __device__ __forceinline__ gl_t qt_fold_sums(const uint64_t (&S)[6]) {
     // The five 32-bit words t0 .. t4 of the total, by word position, as chains of 32 x 32 + 64 multiply-adds (the shifts by
-    // 22, 44, 54 and 76 bits become multiplications by 2^22 / 2^12 at word offsets; every chain stays below 2^63):
+    // 22, 44, 54 and 76 bits become multiplications by 2^22 / 2^12 at word offsets; every chain stays below (0.9375 + 2^-9) 2^64):
     //   position  0:  S0 + S1_lo 2^22                                            -> (x1 : t0)
     //   position 32:  x1 + S3 + S1_hi 2^22 + S2_lo 2^12 + S4_lo 2^22               -> (y1 : t1)
     //   position 64:  y1 + S2_hi 2^12 + S4_hi 2^22 + S5_lo 2^12                    -> (z1 : t2)
@@ -693,17 +694,20 @@ hipError_t launch_quotient_tiles(const QTRec* recs, const QTPiece* pieces, const
     const size_t size = (size_t)1 << (log_n + qdb);
     const dim3 grid((unsigned)((size + 63) / 64), n_chunks), block(64 * (QT_WAVES + 1));
     const bool small = log_n < 6 || size < 64;
-    switch (dbg) {  // 1..4: profiling variants with parts switched off (1 tile loads, 2 arithmetic, 3 both, 4 piece ends)
-        case 0:
-            if (small) hipLaunchKernelGGL((quotient_tiles_kernel<true, 0>), grid, block, 0, st, P);
-            else hipLaunchKernelGGL((quotient_tiles_kernel<false, 0>), grid, block, 0, st, P);
-            break;
-        case 1: hipLaunchKernelGGL((quotient_tiles_kernel<false, 1>), grid, block, 0, st, P); break;
-        case 2: hipLaunchKernelGGL((quotient_tiles_kernel<false, 2>), grid, block, 0, st, P); break;
-        case 3: hipLaunchKernelGGL((quotient_tiles_kernel<false, 3>), grid, block, 0, st, P); break;
-        case 8: hipLaunchKernelGGL((quotient_tiles_kernel<false, 8>), grid, block, 0, st, P); break;  // factors outside the tile not loaded
-        default: hipLaunchKernelGGL((quotient_tiles_kernel<false, 4>), grid, block, 0, st, P); break;
+#ifdef STARKHIP_DEBUG  // make DEBUG_KNOBS=1: profiling variants with parts switched off (results are garbage); not in the release library
+    switch (dbg) {  // 1 tile loads, 2 arithmetic, 3 both, 4 piece ends, 8 factors outside the tile not loaded
+        case 0: break;
+        case 1: hipLaunchKernelGGL((quotient_tiles_kernel<false, 1>), grid, block, 0, st, P); return hipGetLastError();
+        case 2: hipLaunchKernelGGL((quotient_tiles_kernel<false, 2>), grid, block, 0, st, P); return hipGetLastError();
+        case 3: hipLaunchKernelGGL((quotient_tiles_kernel<false, 3>), grid, block, 0, st, P); return hipGetLastError();
+        case 8: hipLaunchKernelGGL((quotient_tiles_kernel<false, 8>), grid, block, 0, st, P); return hipGetLastError();
+        default: hipLaunchKernelGGL((quotient_tiles_kernel<false, 4>), grid, block, 0, st, P); return hipGetLastError();
     }
+#else
+    if (dbg) return hipErrorInvalidValue;
+#endif
+    if (small) hipLaunchKernelGGL((quotient_tiles_kernel<true, 0>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((quotient_tiles_kernel<false, 0>), grid, block, 0, st, P);
     return hipGetLastError();
 }
 

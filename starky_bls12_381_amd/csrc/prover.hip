@@ -19,13 +19,17 @@
 #include "quotient_ops.h"
 #include "quotient_plan.h"
 #include "prover.h"
+#include "scheduler.h"
 
+#ifdef STARKHIP_ROCTX  // make ROCTX=1: phase ranges for rocprofv3 --marker-trace; the default build has no profiler-SDK dependency
 #include <rocprofiler-sdk-roctx/roctx.h>
+#endif
 
 namespace starkhip {
 
-// One open rocTX range at a time on the calling thread; closed on every way out of prove().
+// One open rocTX range at a time on the calling thread; closed on every way out of prove().  Without STARKHIP_ROCTX: nothing.
 struct PhaseRanges {
+#ifdef STARKHIP_ROCTX
     bool open = false;
     void next(const char* name) {
         if (open) roctxRangePop();
@@ -35,6 +39,9 @@ struct PhaseRanges {
     ~PhaseRanges() {
         if (open) roctxRangePop();
     }
+#else
+    void next(const char*) {}
+#endif
 };
 
 
@@ -76,6 +83,9 @@ struct Ctx {
     float timings[STARKHIP_N_PHASES] = {0};
     hipEvent_t kev[6];            // the three heavy kernels bracketed on their own: leaf hash, quotient evaluation, trace LDE
     float ktimings[3] = {0};      // lde_columns, leaf_hash (trace), quotient_eval
+    HashService* hs = nullptr;    // a pooled context's trace commitments are launched by the pool's scheduler (scheduler.h)
+    hipEvent_t hash_ready = nullptr, hash_done = nullptr;
+    bool hash_requested = false;
     // tuning (starkhip_set_option; defaults are the measured best)
     long opt_quotient_impl = 0;   // 0: tiled evaluator (quotient_plan.h), 1: op-stream interpreter (quotient_ops.h)
     long opt_quotient_waves = 65536, opt_quotient_slots = 0, opt_quotient_chunks = 0, opt_quotient_debug = 0;
@@ -211,7 +221,11 @@ int ctx_create(int device, Ctx** out) {
     bool ok = hipStreamCreate(&c->st) == hipSuccess;
     for (auto& e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     for (auto& e : c->kev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->hash_ready, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->hash_done, hipEventDisableTiming) == hipSuccess;
     if (!ok) {  // release whatever was created
+        if (c->hash_ready) (void)hipEventDestroy(c->hash_ready);
+        if (c->hash_done) (void)hipEventDestroy(c->hash_done);
         for (auto& e : c->ev)
             if (e) (void)hipEventDestroy(e);
         for (auto& e : c->kev)
@@ -239,9 +253,14 @@ void ctx_destroy(Ctx* c) {
     for (auto& b : c->fri_digests) b.release();
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& e : c->kev) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c->hash_ready);
+    (void)hipEventDestroy(c->hash_done);
     (void)hipStreamDestroy(c->st);
     delete c;
 }
+void ctx_attach_hash_service(Ctx* c, HashService* hs) { c->hs = hs; }
+void ctx_hash_request_reset(Ctx* c) { c->hash_requested = false; }
+bool ctx_hash_requested(Ctx* c) { return c->hash_requested; }
 
 hipStream_t ctx_stream(Ctx* c) { return c->st; }
 int ctx_set_option(Ctx* c, const char* name, long value) {
@@ -250,7 +269,10 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
     if (k == "quotient_impl" && (value == 0 || value == 1)) c->opt_quotient_impl = value;
     else if (k == "quotient_waves" && value >= 64) { c->opt_quotient_waves = value; c->prog_air = -1; }
     else if (k == "quotient_slots" && value >= 0 && value <= 64) { c->opt_quotient_slots = value; c->prog_air = -1; }
-    else if (k == "quotient_debug" && value >= 0 && value <= 9) c->opt_quotient_debug = value;  // profiling: wrong results
+#ifdef STARKHIP_DEBUG  // make DEBUG_KNOBS=1 only: modes 1..4, 8 switch arithmetic off (timing decomposition; the proof is then WRONG and
+                       // prove() refuses to return it), 9 compares the two evaluators point by point on stderr
+    else if (k == "quotient_debug" && value >= 0 && value <= 9) c->opt_quotient_debug = value;
+#endif
     else if (k == "quotient_chunks" && value >= 0 && value <= 4096) { c->opt_quotient_chunks = value; c->plan_air = -1; }
     else return STARKHIP_ERR_BAD_SHAPE;
     return STARKHIP_OK;
@@ -386,7 +408,12 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
 
     // ---- phase 2: Merkle tree over bit-reversed LDE rows
     HIPCHK(hipEventRecord(c->kev[0], st));
-    HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
+    if (c->hs) {  // pooled: the scheduler decides when this commitment runs and which others share its launch
+        c->hash_requested = true;
+        HIPCHK(c->hs->hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st, c->hash_ready, c->hash_done, !HashService::is_big(log_n, r)));
+    } else {
+        HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
+    }
     HIPCHK(hipEventRecord(c->kev[1], st));
     HIPCHK(launch_merkle_levels(c->digests.as<gl_t>(), log_N, cap_h, st));
     std::vector<gl_t> trace_cap(4 * ncap), quot_cap(4 * ncap);
@@ -676,6 +703,12 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         return STARKHIP_ERR_HIP;
     }
     for (int i = 0; i < STARKHIP_N_PHASES - 1; i++) (void)hipEventElapsedTime(&c->timings[i], c->ev[i], c->ev[i + 1]);
+    if (c->opt_quotient_debug >= 1 && c->opt_quotient_debug <= 8) {  // profiling build only: timings are valid, the proof is not
+        free(out);
+        (void)hipEventElapsedTime(&c->timings[STARKHIP_N_PHASES - 1], c->ev[0], c->ev[STARKHIP_N_PHASES - 1]);
+        (void)hipEventElapsedTime(&c->ktimings[2], c->kev[2], c->kev[3]);
+        return STARKHIP_ERR_VERIFY;
+    }
     (void)hipEventElapsedTime(&c->timings[STARKHIP_N_PHASES - 1], c->ev[0], c->ev[STARKHIP_N_PHASES - 1]);
     (void)hipEventElapsedTime(&c->ktimings[0], c->kev[4], c->kev[5]);
     (void)hipEventElapsedTime(&c->ktimings[1], c->kev[0], c->kev[1]);

@@ -38,7 +38,13 @@ static const unsigned QT_TILE_COLS = 64;    // columns per LDS tile
 static const unsigned QT_TILE_ROWS = 66;    // 64 points + the successor of the last one (next-row reads are "lane + 1") + 8 bytes so
                                             // that every column starts on a 16-byte boundary (direct-to-LDS loads write 16 bytes per lane)
 static const unsigned QT_WAVES = 7;         // evaluating waves per workgroup (an eighth wave stages the tiles)
-static const unsigned QT_MAX_PIECE = 192;   // records per piece after splitting (the 64-bit sums hold 1024 products of 54 bits)
+static const unsigned QT_MAX_PIECE = 192;   // records per piece after splitting
+// Records one accumulation chain may hold before its fold: a piece, or the pieces of one supergroup a wave carries across tile
+// boundaries.  Each record adds a (32-bit half) x (22-bit limb) product < 2^54 to six 64-bit sums, so S < 960 * 2^54 =
+// 0.9375 * 2^64; qt_fold_sums' word chains add at most 2 * 2^54 + 2^44 + 2^32 to one S (X = S0 + lo(S1) 2^22,
+// Y = S3 + hi(S1) 2^22 + lo(S2) 2^12 + lo(S4) 2^22 + hi(X)), i.e. < (0.9375 + 2^-9) * 2^64: no wrap.  At 1024 records the sums
+// themselves still fit but X and Y can wrap -- planner, host replay and kernel all use THIS bound.
+static const unsigned QT_MAX_CHAIN = 960;
 static const unsigned QT_LIMB_BITS = 22;    // weights are split into three limbs of 22 bits
 
 // record control word
@@ -330,7 +336,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                             if (pieces[ps[a]].sg != pieces[prev[b]].sg) continue;
                             if (b == 0 && first_pinned && prev.size() > 1) continue;  // that piece must stay first
                             const uint32_t so_far = (b == 0 && first_pinned) ? chain_recs[w] : piece_recs(prev[b]);
-                            if (so_far + piece_recs(ps[a]) > 960) continue;            // the 64-bit sums hold 1024 products
+                            if (so_far + piece_recs(ps[a]) > QT_MAX_CHAIN) continue;   // the fold's 64-bit chains (QT_MAX_CHAIN)
                             std::swap(prev[b], prev.back());                          // ends the previous tile
                             lists[w].push_back(ps[a]);                                // starts this one
                             load[w] += pieces[ps[a]].cost - PIECE_COST;               // it has no piece end of its own
@@ -537,7 +543,7 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
                         S[j][l] += (uint64_t)x0 * rec->w[3 * j + l];
                         S[j][3 + l] += (uint64_t)x1 * rec->w[3 * j + l];
                     }
-                if (++n_in_piece > 1024) return false;  // 2^54 * 2^10: the 64-bit sums would wrap
+                if (++n_in_piece > QT_MAX_CHAIN) return false;  // the device fold's chains would wrap (see QT_MAX_CHAIN)
                 if (ctl & QT_END) {
                     const uint32_t kind = pc->ctl & 3u, ng = (pc->ctl >> 2) & 7u, cm = pc->ctl >> 5;
                     gl_t G = masks[kind];

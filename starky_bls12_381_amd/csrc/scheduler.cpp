@@ -1,0 +1,536 @@
+// Proof pool (starkhip_pool_* of include/starkhip.h) and the commitment scheduler it owns (scheduler.h).
+//
+// What the reference's caller does on one thread -- generate_trace, prove, verify, six times per signature
+// (/root/reference/src/aggregate_proof.rs:23-179, :304-370) -- becomes jobs of a pool: generator threads record compact
+// traces (trace_log.h), one host thread per prover context proves them, and a caller only submits and waits.
+#include "scheduler.h"
+
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <memory>
+#include <new>
+#include <unordered_map>
+
+#include "kernels.h"
+#include "prover.h"
+#include "trace_log.h"
+
+namespace starkhip {
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ------------------------------------------------------------------------------------------------ HashService
+HashService::HashService(int device) : device_(device) { th_ = std::thread([this] { run(); }); }
+
+HashService::~HashService() {
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        stop_ = true;
+    }
+    cv_.notify_all();
+    th_.join();
+}
+
+void HashService::announce_small() {
+    std::lock_guard<std::mutex> g(mu_);
+    announced_++;
+}
+void HashService::abandon_small() {
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        if (announced_ > 0) announced_--;
+    }
+    cv_.notify_all();
+}
+
+HashService::Stats HashService::stats() {
+    std::lock_guard<std::mutex> g(mu_);
+    return stats_;
+}
+
+hipError_t HashService::hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st, hipEvent_t ready,
+                             hipEvent_t done, bool announced) {
+    hipError_t e = hipEventRecord(ready, st);
+    Req r;
+    r.mat = mat; r.digests = digests; r.n_cols = n_cols; r.log_n = log_n; r.rate_bits = rate_bits; r.ready = ready; r.done = done;
+    r.big = is_big(log_n, rate_bits);
+    r.t_arrive = now_s();
+    std::unique_lock<std::mutex> lk(mu_);
+    if (announced && announced_ > 0) announced_--;
+    if (e != hipSuccess) {
+        lk.unlock();
+        cv_.notify_all();
+        return e;
+    }
+    (r.big ? big_ : small_).push_back(&r);
+    cv_.notify_all();
+    cv_done_.wait(lk, [&] { return r.state != 0; });
+    lk.unlock();
+    if (r.state == 2) return r.err;
+    return hipStreamWaitEvent(st, done, 0);
+}
+
+void HashService::drain(std::vector<hipEvent_t>& evs) {
+    for (hipEvent_t ev : evs) (void)hipEventSynchronize(ev);
+    evs.clear();
+}
+
+void HashService::launch_big(Req* r) {
+    hipError_t e = hipStreamWaitEvent(st_, r->ready, 0);
+    if (e == hipSuccess) e = launch_leaf_hash(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, st_);
+    if (e == hipSuccess) e = hipEventRecord(r->done, st_);
+    r->err = e;
+    if (e == hipSuccess) running_big_.push_back(r->done);
+}
+
+// all pending small commitments, merged by shape: one launch per (columns, rows, rate), each on a stream of its own so that
+// different AIRs' windows overlap
+void HashService::launch_small(std::vector<Req*>& reqs) {
+    std::map<std::tuple<size_t, unsigned, unsigned>, std::vector<Req*>> groups;
+    for (Req* r : reqs) groups[std::make_tuple(r->n_cols, r->log_n, r->rate_bits)].push_back(r);
+    int si = 0;
+    for (auto& kv : groups) {
+        std::vector<Req*>& g = kv.second;
+        for (size_t at = 0; at < g.size(); at += LEAF_HASH_MAX_BATCH, si++) {
+            const size_t cnt = std::min<size_t>(LEAF_HASH_MAX_BATCH, g.size() - at);
+            hipStream_t& s = small_st_[si % N_SMALL_STREAMS];
+            hipError_t e = hipSuccess;
+            if (!s) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            LeafHashBatch B;
+            for (size_t i = 0; i < cnt && e == hipSuccess; i++) {
+                B.mat[i] = g[at + i]->mat;
+                B.digests[i] = g[at + i]->digests;
+                e = hipStreamWaitEvent(s, g[at + i]->ready, 0);
+            }
+            if (e == hipSuccess) e = launch_leaf_hash_multi(B, (unsigned)cnt, g[0]->n_cols, g[0]->log_n, g[0]->rate_bits, s);
+            for (size_t i = 0; i < cnt; i++) {
+                Req* r = g[at + i];
+                if (e == hipSuccess) e = hipEventRecord(r->done, s);
+                r->err = e;
+                if (e == hipSuccess) running_small_.push_back(r->done);
+            }
+            std::lock_guard<std::mutex> lock(mu_);
+            stats_.small_launches++;
+            stats_.max_merged = std::max<unsigned long>(stats_.max_merged, cnt);
+        }
+    }
+}
+
+void HashService::run() {
+    (void)hipSetDevice(device_);
+    if (hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) != hipSuccess) st_ = nullptr;
+    std::unique_lock<std::mutex> lk(mu_);
+    while (true) {
+        cv_.wait(lk, [&] { return stop_ || !big_.empty() || !small_.empty(); });
+        if (stop_ && big_.empty() && small_.empty()) break;
+        // small window: ready when every announced small proof has arrived, or the oldest request has waited long enough
+        bool small_ready = false;
+        if (!small_.empty()) {
+            const double waited = (now_s() - small_.front()->t_arrive) * 1e3;
+            small_ready = announced_ <= 0 || waited >= gather_ms || stop_;
+        }
+        const bool take_big = !big_.empty() && (!small_ready || !last_was_big_);
+        if (take_big) {
+            Req* r = big_.front();
+            big_.pop_front();
+            std::vector<hipEvent_t> wait_for;
+            wait_for.swap(running_small_);
+            lk.unlock();
+            if (policy == 0) drain(wait_for);  // the small window has left the chip
+            launch_big(r);
+            lk.lock();
+            r->state = r->err == hipSuccess ? 1 : 2;
+            stats_.big_launches++;
+            last_was_big_ = true;
+            cv_done_.notify_all();
+            continue;
+        }
+        if (small_ready) {
+            std::vector<Req*> reqs(small_.begin(), small_.end());
+            small_.clear();
+            std::vector<hipEvent_t> wait_for;
+            wait_for.swap(running_big_);
+            lk.unlock();
+            if (policy == 0) drain(wait_for);
+            lk.lock();
+            // whatever arrived while the big commitment drained joins the window
+            reqs.insert(reqs.end(), small_.begin(), small_.end());
+            small_.clear();
+            lk.unlock();
+            launch_small(reqs);
+            lk.lock();
+            for (Req* r : reqs) r->state = r->err == hipSuccess ? 1 : 2;
+            stats_.small_requests += reqs.size();
+            last_was_big_ = false;
+            cv_done_.notify_all();
+            continue;
+        }
+        // small requests are pending but the window is still gathering: wake up when something arrives or its time is up
+        const double left_ms = gather_ms - (now_s() - small_.front()->t_arrive) * 1e3;
+        cv_.wait_for(lk, std::chrono::microseconds((long)(std::max(0.1, left_ms) * 1e3)));
+    }
+    lk.unlock();
+    if (st_) {
+        (void)hipStreamSynchronize(st_);
+        (void)hipStreamDestroy(st_);
+    }
+    for (hipStream_t& s : small_st_)
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ pool
+extern void set_thread_trace_threads(int n);  // capi.cpp: trace_threads() of the calling thread (0 = the process-wide setting)
+
+namespace {
+
+enum JobKind { JOB_DENSE, JOB_COMPACT, JOB_WITNESS };
+
+struct Job {
+    uint64_t id = 0;
+    int air = 0;
+    starkhip_config_t cfg;
+    JobKind kind = JOB_DENSE;
+    const uint64_t* trace = nullptr;  // dense: caller's matrix; compact: a TraceLog*
+    size_t n_rows = 0, n_cols = 0;
+    int layout = 0, on_device = 0;
+    const uint64_t* pis = nullptr;
+    size_t n_pis = 0;
+    uint64_t pow = 0;
+    std::vector<uint32_t> operands;   // witness jobs
+    void* own_log = nullptr;          // witness jobs: the recording, freed when proven
+    std::vector<uint64_t> own_pis;
+    bool big = false;
+    // result
+    int state = 0;  // 0 queued for generation / proving, 1 running, 2 done
+    int rc = STARKHIP_OK;
+    uint64_t* proof = nullptr;
+    size_t words = 0;
+    float phase_ms[STARKHIP_N_PHASES] = {0};
+    float kernel_ms[3] = {0};
+    double t[5] = {0, 0, 0, 0, 0};  // submit, generation start / end, proof start / end (seconds since the pool was created)
+};
+
+int witness_limbs(int air) {
+    switch (air) {
+        case STARKHIP_AIR_FP12_MUL: return 288;
+        case STARKHIP_AIR_FINAL_EXP: return 144;
+        case STARKHIP_AIR_MILLER_LOOP: return 96;
+        case STARKHIP_AIR_PAIRING_PRECOMP: return 72;
+        case STARKHIP_AIR_ECC_AGGREGATE: return 512 * 24 + 512;
+        case STARKHIP_AIR_TEST_FIBONACCI: return 4;
+        default: return -1;
+    }
+}
+
+// the ONE starkhip_trace_* call of `air` on packed operands (layouts: starkhip_pool_submit_witness in starkhip.h)
+int run_generator(int air, const uint32_t* w, size_t n_rows, uint64_t* pis) {
+    switch (air) {
+        case STARKHIP_AIR_FP12_MUL: return starkhip_trace_fp12_mul(w, w + 144, nullptr, n_rows, pis);
+        case STARKHIP_AIR_FINAL_EXP: return starkhip_trace_final_exp(w, nullptr, n_rows, pis);
+        case STARKHIP_AIR_MILLER_LOOP: return starkhip_trace_miller_loop(w, w + 12, w + 24, w + 48, w + 72, nullptr, n_rows, pis);
+        case STARKHIP_AIR_PAIRING_PRECOMP: return starkhip_trace_pairing_precomp(w, w + 24, w + 48, nullptr, n_rows, pis);
+        case STARKHIP_AIR_ECC_AGGREGATE: {
+            std::vector<uint8_t> bits(512);
+            for (int i = 0; i < 512; i++) bits[i] = (uint8_t)(w[512 * 24 + i] != 0);
+            return starkhip_trace_ecc_aggregate(w, bits.data(), nullptr, n_rows, pis);
+        }
+        case STARKHIP_AIR_TEST_FIBONACCI:
+            return starkhip_trace_fibonacci((uint64_t)w[0] | ((uint64_t)w[1] << 32), (uint64_t)w[2] | ((uint64_t)w[3] << 32), nullptr, n_rows, pis);
+        default: return STARKHIP_ERR_BAD_AIR;
+    }
+}
+
+}  // namespace
+
+struct Pool {
+    int device = 0;
+    double t0 = 0;
+    std::unique_ptr<HashService> hs;
+    std::vector<Ctx*> big_ctx, small_ctx;
+    std::mutex mu;
+    std::condition_variable cv_gen, cv_big, cv_small, cv_done;
+    std::deque<Job*> q_gen, q_big, q_small;
+    std::unordered_map<uint64_t, Job*> jobs;
+    uint64_t next_id = 1;
+    bool stop = false;
+    unsigned gen_threads = 0, trace_threads_cfg = 0, gen_running = 0;
+    std::vector<std::thread> threads;
+
+    double now() const { return now_s() - t0; }
+
+    void finish(Job* j, int rc) {
+        std::lock_guard<std::mutex> g(mu);
+        j->rc = rc;
+        j->state = 2;
+        j->t[4] = now();
+        cv_done.notify_all();
+    }
+
+    // threads one recording may use: the generator threads that have nothing else to do are lent to the calls that run
+    int trace_threads_for_call() {
+        if (trace_threads_cfg) return (int)trace_threads_cfg;
+        const unsigned busy = std::max(1u, gen_running + (unsigned)q_gen.size());  // under mu
+        const unsigned share = std::max(1u, 2 * gen_threads / busy);
+        return (int)std::min(16u, share);
+    }
+
+    void generator_loop() {
+        while (true) {
+            Job* j;
+            int tt;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_gen.wait(lk, [&] { return stop || !q_gen.empty(); });
+                if (q_gen.empty()) return;
+                // FinalExp-class recordings first: they are the long pole of a signature
+                auto it = q_gen.begin();
+                for (auto k = q_gen.begin(); k != q_gen.end(); ++k)
+                    if ((*k)->big) { it = k; break; }
+                j = *it;
+                q_gen.erase(it);
+                tt = trace_threads_for_call();
+                gen_running++;
+                j->t[1] = now();
+            }
+            int rc = STARKHIP_OK;
+            try {
+                set_thread_trace_threads(tt);
+                const AirInfo* a = air_get(j->air);
+                j->own_pis.assign(a->pis, 0);
+                rc = starkhip_trace_log_begin(&j->own_log);
+                if (rc == STARKHIP_OK) {
+                    rc = run_generator(j->air, j->operands.data(), a->default_rows, j->own_pis.data());
+                    const int rc_end = starkhip_trace_log_end(j->own_log);
+                    if (rc == STARKHIP_OK) rc = rc_end;
+                }
+                set_thread_trace_threads(0);
+            } catch (const std::bad_alloc&) {
+                rc = STARKHIP_ERR_OOM;
+            } catch (const std::exception&) {
+                rc = STARKHIP_ERR_BAD_SHAPE;
+            }
+            if (rc != STARKHIP_OK) {
+                if (j->own_log) starkhip_trace_log_free(j->own_log);
+                j->own_log = nullptr;
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    gen_running--;
+                    j->t[2] = now();
+                }
+                finish(j, rc);
+                continue;
+            }
+            std::lock_guard<std::mutex> g(mu);
+            gen_running--;
+            j->t[2] = now();
+            j->kind = JOB_COMPACT;
+            j->trace = (const uint64_t*)j->own_log;
+            j->n_rows = ((const TraceLog*)j->own_log)->rows;
+            j->pis = j->own_pis.data();
+            j->n_pis = j->own_pis.size();
+            (j->big ? q_big : q_small).push_back(j);
+            (j->big ? cv_big : cv_small).notify_one();
+        }
+    }
+
+    void prover_loop(Ctx* c, bool big) {
+        std::deque<Job*>& q = big ? q_big : q_small;
+        std::condition_variable& cv = big ? cv_big : cv_small;
+        while (true) {
+            Job* j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                j = q.front();
+                q.pop_front();
+                j->state = 1;
+                j->t[3] = now();
+            }
+            int rc;
+            const bool announce = !big;
+            if (announce) hs->announce_small();
+            ctx_hash_request_reset(c);
+            try {
+                const AirInfo* a = air_get(j->air);
+                rc = prove(c, *a, j->cfg, j->trace, j->n_rows, j->kind == JOB_COMPACT ? 2 : j->layout, j->on_device, j->pis, j->n_pis, j->pow, &j->proof,
+                           &j->words);
+            } catch (const std::bad_alloc&) {
+                rc = STARKHIP_ERR_OOM;
+            } catch (const std::exception&) {
+                rc = STARKHIP_ERR_BAD_SHAPE;
+            }
+            if (announce && !ctx_hash_requested(c)) hs->abandon_small();  // failed before its commitment: do not hold the window open
+            memcpy(j->phase_ms, ctx_timings(c), sizeof j->phase_ms);
+            memcpy(j->kernel_ms, ctx_kernel_timings(c), sizeof j->kernel_ms);
+            if (j->own_log) {
+                starkhip_trace_log_free(j->own_log);
+                j->own_log = nullptr;
+                j->trace = nullptr;
+            }
+            finish(j, rc);
+        }
+    }
+};
+
+int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
+    std::unique_ptr<Pool> p(new Pool());
+    p->device = cfg.device;
+    p->t0 = now_s();
+    const unsigned n_big = cfg.big_contexts ? cfg.big_contexts : 3, n_small = cfg.small_contexts ? cfg.small_contexts : 16;
+    p->gen_threads = cfg.generator_threads ? cfg.generator_threads : 12;
+    p->trace_threads_cfg = cfg.trace_threads;
+    int rc = STARKHIP_OK;
+    for (unsigned i = 0; i < n_big + n_small && rc == STARKHIP_OK; i++) {
+        Ctx* c = nullptr;
+        rc = ctx_create(cfg.device, &c);
+        if (rc == STARKHIP_OK) (i < n_big ? p->big_ctx : p->small_ctx).push_back(c);
+    }
+    if (rc != STARKHIP_OK) {
+        for (Ctx* c : p->big_ctx) ctx_destroy(c);
+        for (Ctx* c : p->small_ctx) ctx_destroy(c);
+        return rc;
+    }
+    p->hs.reset(new HashService(cfg.device));
+    if (cfg.gather_ms > 0) p->hs->gather_ms = cfg.gather_ms;
+    p->hs->policy = (int)cfg.commit_policy;
+    for (Ctx* c : p->big_ctx) ctx_attach_hash_service(c, p->hs.get());
+    for (Ctx* c : p->small_ctx) ctx_attach_hash_service(c, p->hs.get());
+    Pool* raw = p.get();
+    for (unsigned i = 0; i < p->gen_threads; i++) p->threads.emplace_back([raw] { raw->generator_loop(); });
+    for (Ctx* c : p->big_ctx) p->threads.emplace_back([raw, c] { raw->prover_loop(c, true); });
+    for (Ctx* c : p->small_ctx) p->threads.emplace_back([raw, c] { raw->prover_loop(c, false); });
+    *out = p.release();
+    return STARKHIP_OK;
+}
+
+void pool_destroy(Pool* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(p->mu);
+        p->stop = true;
+    }
+    p->cv_gen.notify_all();
+    p->cv_big.notify_all();
+    p->cv_small.notify_all();
+    for (std::thread& t : p->threads) t.join();  // queued jobs are still run to completion: their callers may be waiting
+    for (Ctx* c : p->big_ctx) ctx_destroy(c);
+    for (Ctx* c : p->small_ctx) ctx_destroy(c);
+    p->hs.reset();
+    for (auto& kv : p->jobs) {
+        free(kv.second->proof);
+        if (kv.second->own_log) starkhip_trace_log_free(kv.second->own_log);
+        delete kv.second;
+    }
+    delete p;
+}
+
+static int pool_enqueue(Pool* p, Job* j, uint64_t* ticket) {
+    const AirInfo* a = air_get(j->air);
+    unsigned log_n = 0;
+    const size_t rows = j->kind == JOB_WITNESS ? a->default_rows : j->n_rows;
+    while (((size_t)1 << log_n) < rows) log_n++;
+    j->big = HashService::is_big(log_n, j->cfg.rate_bits);
+    std::lock_guard<std::mutex> g(p->mu);
+    if (p->stop) {
+        delete j;
+        return STARKHIP_ERR_BAD_SHAPE;
+    }
+    j->id = p->next_id++;
+    j->t[0] = p->now();
+    p->jobs[j->id] = j;
+    *ticket = j->id;
+    if (j->kind == JOB_WITNESS) {
+        p->q_gen.push_back(j);
+        p->cv_gen.notify_one();
+    } else {
+        (j->big ? p->q_big : p->q_small).push_back(j);
+        (j->big ? p->cv_big : p->cv_small).notify_one();
+    }
+    return STARKHIP_OK;
+}
+
+int pool_submit(Pool* p, int air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows, size_t n_cols, int layout, int on_device,
+                const uint64_t* pis, size_t n_pis, uint64_t pow, uint64_t* ticket) {
+    const AirInfo* a = air_get(air);
+    if (!a) return STARKHIP_ERR_BAD_AIR;
+    if (!cfg || !trace || !ticket || (n_pis && !pis) || (layout != 0 && layout != 1) || n_cols != a->cols) return STARKHIP_ERR_BAD_SHAPE;
+    Job* j = new (std::nothrow) Job();
+    if (!j) return STARKHIP_ERR_OOM;
+    j->air = air; j->cfg = *cfg; j->kind = JOB_DENSE; j->trace = trace; j->n_rows = n_rows; j->n_cols = n_cols; j->layout = layout;
+    j->on_device = on_device; j->pis = pis; j->n_pis = n_pis; j->pow = pow;
+    return pool_enqueue(p, j, ticket);
+}
+
+int pool_submit_compact(Pool* p, int air, const starkhip_config_t* cfg, const void* log, const uint64_t* pis, size_t n_pis, uint64_t pow,
+                        uint64_t* ticket) {
+    const AirInfo* a = air_get(air);
+    if (!a) return STARKHIP_ERR_BAD_AIR;
+    const TraceLog* l = (const TraceLog*)log;
+    if (!cfg || !l || !ticket || (n_pis && !pis) || l->cols != a->cols || !l->rows) return STARKHIP_ERR_BAD_SHAPE;
+    Job* j = new (std::nothrow) Job();
+    if (!j) return STARKHIP_ERR_OOM;
+    j->air = air; j->cfg = *cfg; j->kind = JOB_COMPACT; j->trace = (const uint64_t*)l; j->n_rows = l->rows; j->n_cols = l->cols;
+    j->pis = pis; j->n_pis = n_pis; j->pow = pow;
+    return pool_enqueue(p, j, ticket);
+}
+
+int pool_submit_witness(Pool* p, int air, const starkhip_config_t* cfg, const uint32_t* operands, size_t n_limbs, uint64_t pow, uint64_t* ticket) {
+    const AirInfo* a = air_get(air);
+    if (!a) return STARKHIP_ERR_BAD_AIR;
+    if (!operands || !ticket || witness_limbs(air) < 0 || (size_t)witness_limbs(air) != n_limbs) return STARKHIP_ERR_BAD_SHAPE;
+    Job* j = new (std::nothrow) Job();
+    if (!j) return STARKHIP_ERR_OOM;
+    j->air = air;
+    if (cfg) j->cfg = *cfg;
+    else if (int rc = starkhip_config_for_air((starkhip_air_t)air, &j->cfg)) { delete j; return rc; }
+    j->kind = JOB_WITNESS; j->pow = pow;
+    j->operands.assign(operands, operands + n_limbs);
+    return pool_enqueue(p, j, ticket);
+}
+
+int pool_wait(Pool* p, uint64_t ticket, uint64_t** proof, size_t* words, starkhip_ticket_info_t* info) {
+    Job* j;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        auto it = p->jobs.find(ticket);
+        if (it == p->jobs.end()) return STARKHIP_ERR_BAD_SHAPE;
+        j = it->second;
+        p->cv_done.wait(lk, [&] { return j->state == 2; });
+        p->jobs.erase(it);
+    }
+    const int rc = j->rc;
+    if (info) {
+        memcpy(info->phase_ms, j->phase_ms, sizeof info->phase_ms);
+        memcpy(info->kernel_ms, j->kernel_ms, sizeof info->kernel_ms);
+        info->t_submit = j->t[0]; info->t_generate_start = j->t[1]; info->t_generate_end = j->t[2]; info->t_prove_start = j->t[3];
+        info->t_done = j->t[4];
+    }
+    if (rc == STARKHIP_OK && proof && words) {
+        *proof = j->proof;
+        *words = j->words;
+    } else {
+        free(j->proof);
+        if (proof) *proof = nullptr;
+        if (words) *words = 0;
+    }
+    delete j;
+    return rc;
+}
+
+int pool_stats(Pool* p, starkhip_pool_stats_t* out) {
+    const HashService::Stats s = p->hs->stats();
+    out->big_commit_launches = s.big_launches;
+    out->small_commit_launches = s.small_launches;
+    out->small_commit_requests = s.small_requests;
+    out->max_merged_commitments = s.max_merged;
+    return STARKHIP_OK;
+}
+
+}  // namespace starkhip

@@ -1,0 +1,85 @@
+// In-library scheduling of many proofs on one GPU (starkhip_pool_*, include/starkhip.h).
+//
+// The reference's caller issues its proves one after the other on one thread (/root/reference/src/aggregate_proof.rs:304-370)
+// and leaves all parallelism to rayon inside prove().  On a GPU the proofs of one or many signature checks are what fills the
+// chip, so the library itself keeps several in flight: a pool of prover contexts with one host thread each, generator threads
+// that record traces, and ONE place that decides when a Merkle commitment -- the kernel that owns the chip -- is launched:
+//
+//  * HashService: every trace commitment of a pooled context goes through it.  The FinalExp-class commitment is a one-shot
+//    grid of exactly two 188-register waves per SIMD (kernels_hash.hip): a foreign long-lived wave on a SIMD pushes one of
+//    them into a second round and doubles the launch.  The 1024-row AIRs' commitments are the opposite: 128 .. 256 waves of
+//    up to 12 167 sequential permutations, 7/8 of the chip idle.  So: commitments of the small class that arrive together are
+//    launched as ONE merged grid (leaf_hash_multi_kernel, grid.y = proof), and the two classes never overlap -- a big
+//    commitment starts when the small window has drained and vice versa.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "gl.h"
+
+namespace starkhip {
+
+class HashService {
+  public:
+    explicit HashService(int device);
+    ~HashService();
+    HashService(const HashService&) = delete;
+    HashService& operator=(const HashService&) = delete;
+
+    // A pooled proof of the small class announces itself when it starts and calls hash() (or abandon()) exactly once: the
+    // service holds a small window open while announced proofs have not arrived yet (bounded by `gather_ms`).
+    void announce_small();
+    void abandon_small();
+    // Leaf digests of the coset-major LDE `mat` (kernels_hash.hip: launch_leaf_hash) into `digests`, ordered after everything
+    // enqueued on `st` so far; when this returns, `st` has been made to wait for the launch (the caller goes on enqueueing).
+    // `ready` / `done` are events owned by the caller's context.
+    hipError_t hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st, hipEvent_t ready,
+                    hipEvent_t done, bool announced);
+
+    static bool is_big(unsigned log_n, unsigned rate_bits) { return log_n + rate_bits >= 15; }  // >= 2048 waves: fills every SIMD twice
+    double gather_ms = 25.0;  // how long a small window waits for announced proofs that have not reached their commitment
+    // 0: the two classes never overlap (default); 1: small commitments are merged but a big one starts whenever it arrives
+    int policy = 0;
+
+    struct Stats {
+        unsigned long big_launches = 0, small_launches = 0, small_requests = 0, max_merged = 0;
+    };
+    Stats stats();
+
+  private:
+    struct Req {
+        const gl_t* mat;
+        gl_t* digests;
+        size_t n_cols;
+        unsigned log_n, rate_bits;
+        hipEvent_t ready, done;
+        bool big;
+        int state = 0;  // 0 queued, 1 launched, 2 failed
+        hipError_t err = hipSuccess;
+        double t_arrive = 0;
+    };
+    void run();
+    void launch_big(Req* r);
+    void launch_small(std::vector<Req*>& reqs);
+    void drain(std::vector<hipEvent_t>& evs);
+
+    int device_;
+    hipStream_t st_ = nullptr;
+    static const int N_SMALL_STREAMS = 4;  // one merged launch per AIR shape, side by side
+    hipStream_t small_st_[N_SMALL_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+    std::mutex mu_;
+    std::condition_variable cv_, cv_done_;
+    std::deque<Req*> big_, small_;
+    int announced_ = 0;  // small proofs that have started and not yet asked for their commitment
+    bool stop_ = false, last_was_big_ = false;
+    std::vector<hipEvent_t> running_big_, running_small_;  // done events of launches that may still be executing
+    Stats stats_;
+    std::thread th_;
+};
+
+}  // namespace starkhip

@@ -202,8 +202,10 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
     lock = threading.Lock()
     n_ctx = {"big": len(pools["big"]), "small": len(pools["big"]) if shared else len(pools["small"])}
     ready = {k: queue.Queue(maxsize=queue_depth or max(2, 2 * n_ctx[k])) for k in ("big", "small")}
-    if big_after_small and not queue_depth:
-        ready["big"] = queue.Queue(maxsize=max(2, len(todo["big"])))  # every FinalExp trace may wait recorded (150 MB each)
+    if big_after_small:
+        # every FinalExp trace may wait recorded (150 MB each).  Whatever `queue_depth` says: a "big"-first generator that blocked
+        # on a full queue here would never record the small traces the FinalExp provers are waiting for
+        ready["big"] = queue.Queue(maxsize=max(2, len(todo["big"])))
     if shared:
         ready["small"] = ready["big"]
     results, errors = {}, []
@@ -295,3 +297,49 @@ def run_jobs(provers, my_jobs, args, gen_threads=6, prove=None, generate=None, q
 def signature_proofs(results, index):
     """The six proofs of signature `index` out of `run_jobs` / collected results, keyed by job name."""
     return {name: results[(index, name)] for name in A.JOB_ORDER if (index, name) in results}
+
+
+# ------------------------------------------------------------------------------------------------ one step, all ranks
+def one_step(dist, batch, provers, mine, signatures, device="cpu", sync=None, **run_kw):
+    """ONE step of the signature pipeline on this rank, exactly what `tools/bench_signature.py` times and what the gloo tests
+    drive: barrier, [t0] operand broadcast from rank 0 (`signatures` is None on the other ranks), natives for this rank's jobs,
+    `run_jobs` (trace generation overlapped with proving), barrier, [t1], max over ranks of t1 - t0.
+    `sync()` (e.g. torch.cuda.synchronize) runs right before each barrier so that the region brackets finished GPU work.
+    Returns (elapsed_s, results, stats, sigs, natives); `run_kw` goes to `run_jobs`."""
+    if sync is not None:
+        sync()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    sigs = broadcast_operands(dist, signatures, batch, device=device)
+    job_args, natives = job_arguments(sigs, mine)
+    results, stats = run_jobs(provers, mine, job_args, **run_kw)
+    if sync is not None:
+        sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = parallel.max_over_ranks(dist, time.perf_counter() - t0, device=device)
+    return elapsed, results, stats, sigs, natives
+
+
+def collect_results(dist, results, device="cpu"):
+    """`run_jobs` results {(i, name): (air, proof, cfg)} of every rank merged on every rank (`aggregate.collect_proofs`)."""
+    if dist is None:
+        return dict(results)
+    flat = {f"{i}:{name}": v for (i, name), v in results.items()}
+    return {(int(k.split(":")[0]), k.split(":")[1]): v for k, v in A.collect_proofs(dist, flat, device=device).items()}
+
+
+def check_signatures(merged, sigs, natives, batch):
+    """Per signature whose six proofs are in `merged`: the links between them, the statement (key, H(m), signature, -G, output 1)
+    and, where this rank computed the natives, that the proven output is the native one.  Returns {index: bool}."""
+    verdicts = {}
+    for i in range(batch):
+        six = signature_proofs(merged, i)
+        if len(six) != 6:
+            continue
+        ok = A.check_links(six) and A.check_statement(six, sigs[i][0], sigs[i][1], sigs[i][2])
+        if i in natives:
+            ok = ok and A.signature_is_valid(natives[i], six)
+        verdicts[i] = bool(ok)
+    return verdicts

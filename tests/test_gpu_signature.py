@@ -78,9 +78,10 @@ def test_batch_of_eight_different_signatures_end_to_end():
     digests = set()
     for i in range(batch):
         six = G.signature_proofs(results, i)
-        assert A.check_links(six) and A.check_statement(six, sigs[i][1], sigs[i][2])
+        assert A.check_links(six) and A.check_statement(six, sigs[i][0], sigs[i][1], sigs[i][2])
         assert A.signature_is_valid(natives[i], six)
-        assert not A.check_statement(six, sigs[(i + 1) % batch][1], sigs[(i + 1) % batch][2])
+        assert not A.check_statement(six, sigs[i][0], sigs[(i + 1) % batch][1], sigs[(i + 1) % batch][2])
+        assert not A.check_statement(six, sigs[(i + 1) % batch][0], sigs[i][1], sigs[i][2])   # another key: not this statement
         digests.add(bytes(six["final_exp"][1][16:80]))
     assert len(digests) == batch   # eight different FinalExp proofs (different trace caps)
     assert stats["wall_s"] < stats["generate_s"] + stats["prove_s"]   # generation overlapped proving

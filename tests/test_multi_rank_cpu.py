@@ -159,25 +159,14 @@ def _signature_worker(rank, world, port, batch, q):
     from starky_bls12_381_amd import signature as G
     from bls_util import native_vectors
     dist = P.init_distributed("gloo")
-    # exactly the control flow of tools/bench_signature.py's one_step()
+    # the step tools/bench_signature.py times (signature.one_step), with an injected prove
     signatures = G.synthetic_signatures(batch, native_vectors()["bls_signature"], 0x2000) if rank == 0 else None
-    dist.barrier()
-    sigs = G.broadcast_operands(dist, signatures, batch)
-    plan = G.plan_batch(batch, world)
-    mine = plan[rank]
-    job_args, natives = G.job_arguments(sigs, mine)
-    results, stats = G.run_jobs([object(), object()], mine, job_args, gen_threads=3, prove=_fake_prove)
-    dist.barrier()
-    slowest = P.max_over_ranks(dist, stats["wall_s"])
-    flat = {f"{i}:{name}": v for (i, name), v in results.items()}
-    merged = {(int(k.split(":")[0]), k.split(":")[1]): v for k, v in A.collect_proofs(dist, flat).items()}
-    verdicts = []
-    for i in range(batch):
-        six = G.signature_proofs(merged, i)
-        ok = len(six) == 6 and A.check_links(six) and A.check_statement(six, sigs[i][1], sigs[i][2])
-        if i in natives:
-            ok = ok and A.signature_is_valid(natives[i], six)
-        verdicts.append(bool(ok))
+    mine = G.plan_batch(batch, world)[rank]
+    elapsed, results, stats, sigs, natives = G.one_step(dist, batch, [object(), object()], mine, signatures, gen_threads=3, prove=_fake_prove)
+    slowest = elapsed + 1e-9
+    merged = G.collect_results(dist, results)
+    checked = G.check_signatures(merged, sigs, natives, batch)
+    verdicts = [checked.get(i, False) for i in range(batch)]
     digest = int(np.bitwise_xor.reduce(G.pack_operands(sigs).reshape(-1)))
     q.put((rank, sorted(mine), verdicts, digest, slowest >= stats["wall_s"]))
     dist.barrier()

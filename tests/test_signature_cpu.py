@@ -49,19 +49,25 @@ def test_pipeline_generates_on_threads_and_links_hold_on_what_was_proven():
     assert sorted(results) == sorted(mine)
     six = G.signature_proofs(results, 0)
     assert A.check_links(six)
-    assert A.check_statement(six, sigs[0][1], sigs[0][2])
+    assert A.check_statement(six, sigs[0][0], sigs[0][1], sigs[0][2])
     assert A.signature_is_valid(natives[0], six)
     assert stats["generate_s"] > stats["wall_s"] * 0.5 or stats["wall_s"] < 2.0   # generation ran on several threads
     # the statement check is about the POINTS: proofs of another signature verify and link, but are not this statement
     other = G.synthetic_signatures(2, _vector(), seed=9)[1]
-    assert not A.check_statement(six, other[1], other[2])
+    assert not A.check_statement(six, sigs[0][0], other[1], other[2])
+    # ... and about the KEY: six proofs made for another key pk' that also satisfies e(pk', H(m)) e(-G, sig) = 1 would verify and
+    # link; what makes them a different statement is ml1's G1 operand (src/aggregate_proof.rs:540-545)
+    assert not A.check_statement(six, other[0], sigs[0][1], sigs[0][2])
+    import pytest
+    with pytest.raises(ValueError):
+        A.check_statement(six, None, sigs[0][1], sigs[0][2])   # no key and no ECCAggStark proof that publishes it
     # ... and a final_exp proof that attests to something else than 1 is not a valid signature
     bad = dict(six)
     air, blob, cfg = bad["final_exp"]
     blob = blob.copy()
     blob[-1] ^= np.uint64(1)
     bad["final_exp"] = (air, blob, cfg)
-    assert not A.check_statement(bad, sigs[0][1], sigs[0][2])
+    assert not A.check_statement(bad, sigs[0][0], sigs[0][1], sigs[0][2])
 
 
 def test_pipeline_reports_a_failing_job():

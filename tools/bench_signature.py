@@ -81,19 +81,8 @@ def main():
 
     def one_step(seed):
         signatures = G.synthetic_signatures(args.batch, native_vectors()["bls_signature"], seed) if rank == 0 else None
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        sigs = G.broadcast_operands(dist, signatures, args.batch, device=dev)
-        job_args, natives = G.job_arguments(sigs, mine)
-        res, st = G.run_jobs(provers, mine, job_args, gen_threads=args.gen_threads, trace_threads=args.trace_threads or None,
-                             big_after_small=bool(args.by_type))
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        el = parallel.max_over_ranks(dist, time.perf_counter() - t0, device=dev)
-        return el, res, st, sigs, natives
+        return G.one_step(dist, args.batch, provers, mine, signatures, device=dev, sync=torch.cuda.synchronize, gen_threads=args.gen_threads,
+                          trace_threads=args.trace_threads or None, big_after_small=bool(args.by_type))
 
     for w in range(args.warmup):
         one_step(0x1000 + w)
@@ -109,19 +98,9 @@ def main():
         for (_, name), (air, proof, cfg) in results.items():
             S.verify_stark_proof(air, cfg, proof)
             verified += 1
-    merged = results
-    if dist is not None and args.collect:
-        flat = {f"{i}:{name}": v for (i, name), v in results.items()}
-        merged = {(int(k.split(":")[0]), k.split(":")[1]): v for k, v in A.collect_proofs(dist, flat, device=dev).items()}
-    checked = valid = 0
-    for i in range(args.batch):
-        six = G.signature_proofs(merged, i)
-        if len(six) == 6:
-            ok = A.check_links(six) and A.check_statement(six, sigs[i][1], sigs[i][2])
-            if i in natives:
-                ok = ok and A.signature_is_valid(natives[i], six)
-            checked += 1
-            valid += bool(ok)
+    merged = G.collect_results(dist, results, device=dev) if (dist is not None and args.collect) else results
+    verdicts = G.check_signatures(merged, sigs, natives, args.batch)
+    checked, valid = len(verdicts), sum(verdicts.values())
     n_verified = int(parallel.sum_over_ranks(dist, verified, device=dev))
     if rank == 0:
         per_air = {}
