@@ -130,7 +130,9 @@ int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, 
 
 /* Tuning knobs of a context (defaults are the measured best; tests and profiling tools use them to reach the other code
  * paths): "quotient_impl" 0 = tiled evaluator / 1 = op-stream interpreter, "quotient_chunks" (0 = automatic),
- * "quotient_waves", "quotient_slots".  Unknown name or value out of range: STARKHIP_ERR_BAD_SHAPE. */
+ * "quotient_waves", "quotient_slots", "lde_closed_forms" (1 = constant and unit-vector trace columns take their closed-form LDE
+ * instead of five transforms, 0 = every column is transformed; same bytes either way).  Unknown name or value out of range:
+ * STARKHIP_ERR_BAD_SHAPE. */
 int starkhip_set_option(void* ctx, const char* name, long value);
 
 /* --- compact traces: on-device trace expansion -----------------------------------------------
@@ -169,9 +171,10 @@ typedef struct {
     int device;
     unsigned big_contexts;      /* 0 = default (3) */
     unsigned small_contexts;    /* 0 = default (16) */
-    unsigned generator_threads; /* 0 = default (12) */
+    unsigned generator_threads; /* recordings under way at once; 0 = default (hardware threads / 16, 4 .. 12) */
     unsigned trace_threads;     /* host threads ONE recording may use; 0 = automatic (idle generator threads are lent to the running ones) */
-    unsigned commit_policy;     /* 0 = default: merged small commitments, classes never overlap; 1 = merged, classes may overlap */
+    unsigned commit_policy;     /* 0 = default: merged small commitments, classes never overlap; 1 = merged, classes may overlap;
+                                   2 = no commitment scheduling (every context launches its own; for A/B measurements) */
     float gather_ms;            /* how long a merged launch waits for small proofs that have started but not reached their commitment; 0 = default (25) */
 } starkhip_pool_config_t;
 typedef struct {

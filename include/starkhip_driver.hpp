@@ -9,6 +9,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <malloc.h>
+
 #include <array>
 #include <chrono>
 #include <future>
@@ -20,6 +22,17 @@
 #include "starkhip.h"
 
 namespace starkhip_driver {
+
+// For a DRIVER process that proves all the time: keep glibc from handing every large buffer (150 MB trace recordings, 50 MB
+// proofs) back to the kernel, so that the next one does not start with page faults on fresh memory -- in a process with dozens
+// of threads those serialise on the address-space lock.  Process-wide, so a driver's choice, not the library's.
+inline void tune_host_allocator() {
+#ifdef __GLIBC__
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 1 << 28);
+#endif
+}
 
 struct Error : std::runtime_error {
     int code;
@@ -35,12 +48,43 @@ static const uint32_t NEG_G1_X[12] = {0xdb22c6bb, 0xfb3af00a, 0xf97a1aef, 0x6c55
 static const uint32_t NEG_G1_Y[12] = {0xb939c2ca, 0xad54dcd6, 0x0ecb751b, 0x4e6f38ba, 0xcaac4236, 0x6655b9d5,
                                       0x1db507c9, 0x67816aef, 0xcf2e21f2, 0xaa7d76c8, 0x55d545a8, 0x114d1d68};
 
+// A proof blob as the library hands it over (starkhip.h): owned, released with starkhip_free -- never copied (a FinalExp proof
+// is 52 MB; copying 48 of them into fresh host memory costs more than proving one).
+class Words {
+  public:
+    Words() = default;
+    Words(uint64_t* p, size_t n) : p_(p), n_(n) {}
+    Words(Words&& o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    Words& operator=(Words&& o) noexcept {
+        if (this != &o) {
+            starkhip_free(p_);
+            p_ = o.p_; n_ = o.n_;
+            o.p_ = nullptr; o.n_ = 0;
+        }
+        return *this;
+    }
+    Words(const Words&) = delete;
+    Words& operator=(const Words&) = delete;
+    ~Words() { starkhip_free(p_); }
+    const uint64_t* data() const { return p_; }
+    size_t size() const { return n_; }
+    uint64_t operator[](size_t i) const { return p_[i]; }
+
+  private:
+    uint64_t* p_ = nullptr;
+    size_t n_ = 0;
+};
+
 struct Proof {
     starkhip_air_t air;
     starkhip_config_t config;
-    std::vector<uint64_t> words;  // blob of starkhip.h
+    Words words;  // blob of starkhip.h
     size_t n_public_inputs = 0;
+    starkhip_ticket_info_t info{};  // pool proofs: phase times and the job's timeline (starkhip_pool_wait)
     const uint64_t* public_inputs() const { return words.data() + words.size() - n_public_inputs; }
+    Proof() = default;
+    Proof(Proof&&) = default;
+    Proof& operator=(Proof&&) = default;
 };
 
 class Prover {
@@ -60,8 +104,7 @@ class Prover {
         size_t words = 0;
         check("starkhip_prove_compact",
               starkhip_prove_compact(ctx_, air, &p.config, trace_log, pis.data(), pis.size(), STARKHIP_POW_SEARCH, &blob, &words));
-        p.words.assign(blob, blob + words);
-        starkhip_free(blob);
+        p.words = Words(blob, words);
         p.n_public_inputs = pis.size();
         check("starkhip_verify", starkhip_verify(air, &p.config, p.words.data(), p.words.size()));
         return p;
@@ -176,9 +219,9 @@ class Pool {
         check("starkhip_config_for_air", starkhip_config_for_air(air, &p.config));
         uint64_t* blob = nullptr;
         size_t words = 0;
-        check("starkhip_pool_wait", starkhip_pool_wait(pool_, ticket, &blob, &words, info));
-        p.words.assign(blob, blob + words);
-        starkhip_free(blob);
+        check("starkhip_pool_wait", starkhip_pool_wait(pool_, ticket, &blob, &words, &p.info));
+        if (info) *info = p.info;
+        p.words = Words(blob, words);
         p.n_public_inputs = (size_t)starkhip_air_public_inputs(air);
         if (verify) check("starkhip_verify", starkhip_verify(air, &p.config, p.words.data(), p.words.size()));
         return p;

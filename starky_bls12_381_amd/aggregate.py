@@ -77,6 +77,35 @@ def ec_aggregate_main(prover, points, bits):
     return _prove_and_verify(prover, S.AIR_ECC_AGGREGATE, trace, pis)
 
 
+def signature_natives(pk, hm, sig):
+    """The native values that link the six proofs (src/aggregate_proof.rs:352-363): the two Miller-loop values, their product
+    and its final exponentiation, as Fp12 limbs."""
+    neg_g = (fp_limbs(NEG_G1_X), fp_limbs(NEG_G1_Y))
+    ml1 = S.native_miller_loop(pk[0], pk[1], hm[0], hm[1], hm[2])
+    ml2 = S.native_miller_loop(neg_g[0], neg_g[1], sig[0], sig[1], sig[2])
+    product = S.native_fp12_mul(ml1, ml2)
+    return {"ml1": ml1, "ml2": ml2, "product": product, "final": S.native_final_exponentiate(product)}
+
+
+def job_operands(name, pk, hm, sig, natives=None):
+    """Generator arguments of job `name` of one signature (the operands `ProofPool.submit_witness` packs); the fp12_mul and
+    final_exp jobs need `natives`."""
+    neg_g = (fp_limbs(NEG_G1_X), fp_limbs(NEG_G1_Y))
+    if name == "pp1":
+        return (hm[0], hm[1], hm[2])
+    if name == "pp2":
+        return (sig[0], sig[1], sig[2])
+    if name == "ml1":
+        return (pk[0], pk[1], hm[0], hm[1], hm[2])
+    if name == "ml2":
+        return (neg_g[0], neg_g[1], sig[0], sig[1], sig[2])
+    if name == "fp12_mul":
+        return (natives["ml1"], natives["ml2"])
+    if name == "final_exp":
+        return (natives["product"],)
+    raise KeyError(name)
+
+
 def signature_jobs(pk, hm, sig):
     """The six proof jobs of one signature check, in the reference's order, with the natives that link them.
 
@@ -85,9 +114,8 @@ def signature_jobs(pk, hm, sig):
     The Miller-loop values are computed natively first, as the reference does at :352-353, so that all six jobs are
     independent and can be proven on different GPUs."""
     neg_g = (fp_limbs(NEG_G1_X), fp_limbs(NEG_G1_Y))
-    ml1 = S.native_miller_loop(pk[0], pk[1], hm[0], hm[1], hm[2])
-    ml2 = S.native_miller_loop(neg_g[0], neg_g[1], sig[0], sig[1], sig[2])
-    product = S.native_fp12_mul(ml1, ml2)
+    natives = signature_natives(pk, hm, sig)
+    ml1, ml2, product = natives["ml1"], natives["ml2"], natives["product"]
     jobs = {
         "pp1": (calc_pairing_precomp, (hm[0], hm[1], hm[2])),
         "ml1": (miller_loop_main, (pk[0], pk[1], hm[0], hm[1], hm[2])),
@@ -96,7 +124,6 @@ def signature_jobs(pk, hm, sig):
         "fp12_mul": (fp12_mul_main, (ml1, ml2)),
         "final_exp": (final_exponentiate_main, (product,)),
     }
-    natives = {"ml1": ml1, "ml2": ml2, "product": product, "final": S.native_final_exponentiate(product)}
     return jobs, natives
 
 

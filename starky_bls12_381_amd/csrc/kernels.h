@@ -31,9 +31,10 @@ hipError_t launch_lde_columns(const gl_t* values, gl_t* coeffs, gl_t* lde, size_
 // 2^8 .. 2^13 rows (register radix-16 Stockham passes, kernels_lde.hip) with its own host-built tables
 bool lde_v2_supported(unsigned log_n);
 size_t lde_v2_tw_words(unsigned log_n);
-hipError_t lde_v2_upload_tables(unsigned log_n, unsigned rate_bits, gl_t* d_tw_fwd, gl_t* d_tw_inv, gl_t* d_cs, hipStream_t st);
+size_t lde_v2_oh_words(unsigned log_n, unsigned rate_bits);  // closed-form tables of unit-vector columns (0: shape without them)
+hipError_t lde_v2_upload_tables(unsigned log_n, unsigned rate_bits, gl_t* d_tw_fwd, gl_t* d_tw_inv, gl_t* d_cs, gl_t* d_oh, hipStream_t st);
 hipError_t launch_lde_columns_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, size_t n_cols, unsigned log_n, unsigned rate_bits,
-                                 const gl_t* tw_fwd, const gl_t* tw_inv, const gl_t* cs, int from_coeffs, hipStream_t st);
+                                 const gl_t* tw_fwd, const gl_t* tw_inv, const gl_t* cs, const gl_t* oh, int from_coeffs, hipStream_t st);
 hipError_t launch_ntt_global(gl_t* data, size_t n_vecs, size_t vec_stride, unsigned log_n, const gl_t* tw, unsigned tw_log,
                              const gl_t* pre_scale, const gl_t* post_scale, gl_t final_mul, hipStream_t st);
 

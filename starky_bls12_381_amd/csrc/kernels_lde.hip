@@ -158,10 +158,14 @@ __global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kern
                                                                                     gl_t* __restrict__ lde, unsigned n_cols, unsigned rate_bits,
                                                                                     const gl_t* __restrict__ tw_fwd,
                                                                                     const gl_t* __restrict__ tw_inv, const gl_t* __restrict__ cs,
-                                                                                    int from_coeffs) {
+                                                                                    const gl_t* __restrict__ oh, int from_coeffs) {
     using PL = LdePlan<LOGN>;
     constexpr int T = PL::T, n = PL::N;
     extern __shared__ gl_t lds_all[];
+    __shared__ unsigned cls[3];  // closed-form classes (below): [0] flags, [1] number of ones, [2] row of a one
+    if constexpr (PL::CPB == 1) {
+        if (threadIdx.x == 0) cls[0] = cls[1] = 0;
+    }
     const int cib_raw = threadIdx.x / T, t = threadIdx.x % T;
     const unsigned col0 = blockIdx.x * PL::CPB;           // first column of this workgroup (always < n_cols)
     const bool live = col0 + cib_raw < n_cols;            // idle columns of the last workgroup shadow col0 and store nothing
@@ -177,6 +181,68 @@ __global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kern
     if (!from_coeffs) {
 #pragma unroll
         for (int i = 0; i < 16; i++) v[i] = *(const gl_t*)(in_base + in_off + (uint32_t)(i * T * 8));
+        if constexpr (PL::CPB == 1) {
+            // Columns whose transforms have a closed form skip all five of them.  A FinalExp trace repeats every intermediate
+            // Fp12 of its 32 operations on all 8192 rows (/root/reference/src/final_exponentiate.rs:137-228: constant columns) and
+            // carries a one-hot row selector per row (:242-245, :931-956): 17.6 % of its 73 527 columns.
+            //   constant c:   coefficients (c, 0, ..., 0), LDE = c everywhere;
+            //   unit vector e_r (one 1 in row r, zeros elsewhere): coefficients n^-1 w_n^(-r j) = oh[(r j) mod n], and its LDE is
+            //   the LDE of e_0 rotated by r inside every coset: lde_r[s][k] = lde_0[s][(k - r) mod n] = oh[n + s n + ((k - r) mod n)].
+            // Both are the exact field values the transforms would produce (canonical), so the proof bytes do not change.  The
+            // class is found from the values themselves (one barrier per column); one workgroup = one column here.
+            if (oh != nullptr) {
+                const gl_t first = *(const gl_t*)in_base;  // uniform
+                unsigned flags = 0, ones = 0, row = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    flags |= v[i] != first ? 1u : 0u;
+                    flags |= v[i] > 1 ? 2u : 0u;
+                    if (v[i] == 1) {
+                        ones++;
+                        row = (unsigned)(t + i * T);
+                    }
+                }
+                __syncthreads();  // cls[] cleared
+                if (flags) atomicOr(&cls[0], flags);
+                if (ones) {
+                    atomicAdd(&cls[1], ones);
+                    cls[2] = row;
+                }
+                __syncthreads();
+                const unsigned all_flags = cls[0], all_ones = cls[1];
+                const bool is_const = (all_flags & 1u) == 0, is_unit = (all_flags & 2u) == 0 && all_ones == 1;
+                if (is_const || is_unit) {  // uniform over the workgroup
+                    const unsigned n_cosets = 1u << rate_bits;
+                    char* cf_out = (char*)(coeffs + (size_t)col0 * n);
+                    char* out_base = (char*)(lde + (size_t)col0 * n_cosets * n);
+                    if (is_const) {
+                        const gl_t c = gl_canon(first);
+#pragma unroll
+                        for (int i = 0; i < 16; i++) *(gl_t*)(cf_out + in_off + (uint32_t)(i * T * 8)) = (t == 0 && i == 0) ? c : 0;
+                        for (unsigned s = 0; s < n_cosets; s++) {
+                            const uint32_t out_off = (uint32_t)(s * n + t) * 8u;
+#pragma unroll
+                            for (int i = 0; i < 16; i++) *(gl_t*)(out_base + out_off + (uint32_t)(i * T * 8)) = c;
+                        }
+                    } else {
+                        const unsigned r = cls[2];
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const unsigned j = (unsigned)(t + i * T);
+                            *(gl_t*)(cf_out + in_off + (uint32_t)(i * T * 8)) = oh[(r * j) & (unsigned)(n - 1)];
+                        }
+                        for (unsigned s = 0; s < n_cosets; s++) {
+                            const gl_t* e0 = oh + n + (size_t)s * n;
+                            const uint32_t out_off = (uint32_t)(s * n + t) * 8u;
+#pragma unroll
+                            for (int i = 0; i < 16; i++)
+                                *(gl_t*)(out_base + out_off + (uint32_t)(i * T * 8)) = e0[((unsigned)(t + i * T) - r) & (unsigned)(n - 1)];
+                        }
+                    }
+                    return;
+                }
+            }
+        }
         LdePasses<LOGN, 0, true>::run(v, lds, tw_inv, t);
         char* cf_out = (char*)(coeffs + (size_t)col0 * n);
         if (live) {
@@ -230,7 +296,7 @@ static void fill_tw(std::vector<gl_t>& out, bool inv) {
 
 template <int LOGN>
 static hipError_t launch_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, size_t n_cols, unsigned rate_bits, const gl_t* tw_fwd,
-                            const gl_t* tw_inv, const gl_t* cs, int from_coeffs, hipStream_t st) {
+                            const gl_t* tw_inv, const gl_t* cs, const gl_t* oh, int from_coeffs, hipStream_t st) {
     using PL = LdePlan<LOGN>;
     const size_t lds_bytes = (size_t)PL::CPB * PL::LDS_COL * sizeof(gl_t);
     if (lds_bytes > 64 * 1024) {  // per device, so not cached in a static
@@ -239,7 +305,7 @@ static hipError_t launch_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, size_t 
     }
     const unsigned blocks = (unsigned)((n_cols + PL::CPB - 1) / PL::CPB);
     hipLaunchKernelGGL(lde_columns_v2_kernel<LOGN>, dim3(blocks), dim3(PL::THREADS), lds_bytes, st, values, coeffs, lde, (unsigned)n_cols,
-                       rate_bits, tw_fwd, tw_inv, cs, from_coeffs);
+                       rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs);
     return hipGetLastError();
 }
 
@@ -259,7 +325,11 @@ size_t lde_v2_tw_words(unsigned log_n) {
 
 // Host-built tables: forward / inverse inter-pass twiddles, and cs[s][k] = (7 * w_N^s)^k (the coset shift of
 // coset s; N = n * 2^rate_bits).  The three device buffers must hold lde_v2_tw_words(log_n) (x2) and N words.
-hipError_t lde_v2_upload_tables(unsigned log_n, unsigned rate_bits, gl_t* d_tw_fwd, gl_t* d_tw_inv, gl_t* d_cs, hipStream_t st) {
+// d_oh (n + N words, used when one workgroup owns one column: log_n >= 12): the closed forms of a unit-vector column --
+// oh[i] = n^-1 w_n^(-i) for i < n, then the LDE of e_0, coset-major: oh[n + s n + k] = n^-1 (x^n - 1) / (x - 1) at x = 7 w_N^(4 k + s).
+size_t lde_v2_oh_words(unsigned log_n, unsigned rate_bits) { return log_n >= 12 ? ((size_t)1 << log_n) + ((size_t)1 << (log_n + rate_bits)) : 0; }
+
+hipError_t lde_v2_upload_tables(unsigned log_n, unsigned rate_bits, gl_t* d_tw_fwd, gl_t* d_tw_inv, gl_t* d_cs, gl_t* d_oh, hipStream_t st) {
     std::vector<gl_t> fwd, inv;
     switch (log_n) {
         case 8: fill_tw<8>(fwd, false); fill_tw<8>(inv, true); break;
@@ -282,6 +352,28 @@ hipError_t lde_v2_upload_tables(unsigned log_n, unsigned rate_bits, gl_t* d_tw_f
         }
     }
     hipError_t e;
+    std::vector<gl_t> oh;
+    if (d_oh && lde_v2_oh_words(log_n, rate_bits)) {
+        oh.resize(lde_v2_oh_words(log_n, rate_bits));
+        const gl_t ninv = gl_inv((gl_t)n), wn_inv = gl_inv(gl_root_of_unity(log_n));
+        gl_t acc = ninv;
+        for (size_t i = 0; i < n; i++) {
+            oh[i] = acc;
+            acc = gl_mul(acc, wn_inv);
+        }
+        // x^n = 7^n w_N^(s n) (w_N^(4 k n) = 1); geometric sum n^-1 (x^n - 1) / (x - 1); x - 1 != 0 on the coset
+        const gl_t g_n = gl_pow(GL_GENERATOR, n);
+        for (size_t s = 0; s < n_cosets; s++) {
+            const gl_t num = gl_mul(ninv, gl_sub(gl_mul(g_n, gl_pow(wN, s * n)), 1));
+            const gl_t step = gl_pow(wN, n_cosets);  // w_n
+            gl_t x = gl_mul(GL_GENERATOR, gl_pow(wN, s));
+            for (size_t k = 0; k < n; k++) {
+                oh[n + s * n + k] = gl_mul(num, gl_inv(gl_sub(x, 1)));
+                x = gl_mul(x, step);
+            }
+        }
+        if ((e = hipMemcpyAsync(d_oh, oh.data(), oh.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    }
     if ((e = hipMemcpyAsync(d_tw_fwd, fwd.data(), fwd.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(d_tw_inv, inv.data(), inv.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(d_cs, cs.data(), cs.size() * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
@@ -289,16 +381,16 @@ hipError_t lde_v2_upload_tables(unsigned log_n, unsigned rate_bits, gl_t* d_tw_f
 }
 
 hipError_t launch_lde_columns_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, size_t n_cols, unsigned log_n, unsigned rate_bits,
-                                 const gl_t* tw_fwd, const gl_t* tw_inv, const gl_t* cs, int from_coeffs, hipStream_t st) {
+                                 const gl_t* tw_fwd, const gl_t* tw_inv, const gl_t* cs, const gl_t* oh, int from_coeffs, hipStream_t st) {
     if (!from_coeffs && !coeffs) return hipErrorInvalidValue;  // the coset transforms read the coefficients back from `coeffs`
     if (n_cols == 0) return hipSuccess;
     switch (log_n) {
-        case 8: return launch_v2<8>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, from_coeffs, st);
-        case 9: return launch_v2<9>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, from_coeffs, st);
-        case 10: return launch_v2<10>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, from_coeffs, st);
-        case 11: return launch_v2<11>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, from_coeffs, st);
-        case 12: return launch_v2<12>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, from_coeffs, st);
-        case 13: return launch_v2<13>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, from_coeffs, st);
+        case 8: return launch_v2<8>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs, st);
+        case 9: return launch_v2<9>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs, st);
+        case 10: return launch_v2<10>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs, st);
+        case 11: return launch_v2<11>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs, st);
+        case 12: return launch_v2<12>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs, st);
+        case 13: return launch_v2<13>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -15,6 +15,7 @@ const float* ctx_kernel_timings(Ctx* c);
 int ctx_set_option(Ctx* c, const char* name, long value);
 class HashService;  // scheduler.h
 void ctx_attach_hash_service(Ctx* c, HashService* hs);  // trace commitments of this context go through the pool's scheduler
+bool ctx_has_hash_service(Ctx* c);
 void ctx_hash_request_reset(Ctx* c);
 bool ctx_hash_requested(Ctx* c);  // the current / last prove() reached its trace commitment
 

@@ -92,7 +92,8 @@ struct Ctx {
     // shape-dependent tables
     int tab_log_n = -1, tab_rate = -1, tab_qdb = -1;
     DevBuf tw_fwd, tw_inv, coset_scale, qtab, qshift_inv;
-    DevBuf lde2_fwd, lde2_inv, lde2_cs;  // kernels_lde.hip tables (log_n >= 8)
+    DevBuf lde2_fwd, lde2_inv, lde2_cs, lde2_oh;  // kernels_lde.hip tables (log_n >= 8)
+    long opt_lde_closed_forms = 1;   // constant / unit-vector columns skip their transforms (kernels_lde.hip); 0: every column is transformed
     // program
     int prog_air = -1;
     unsigned prog_chunks = 0;
@@ -129,7 +130,8 @@ static int ensure_tables(Ctx* c, unsigned log_n, unsigned rate, unsigned qdb) {
         HIPCHK(c->lde2_fwd.ensure(lde_v2_tw_words(log_n) * 8));
         HIPCHK(c->lde2_inv.ensure(lde_v2_tw_words(log_n) * 8));
         HIPCHK(c->lde2_cs.ensure(N * 8));
-        HIPCHK(lde_v2_upload_tables(log_n, rate, c->lde2_fwd.as<gl_t>(), c->lde2_inv.as<gl_t>(), c->lde2_cs.as<gl_t>(), c->st));
+        HIPCHK(c->lde2_oh.ensure(std::max<size_t>(1, lde_v2_oh_words(log_n, rate)) * 8));
+        HIPCHK(lde_v2_upload_tables(log_n, rate, c->lde2_fwd.as<gl_t>(), c->lde2_inv.as<gl_t>(), c->lde2_cs.as<gl_t>(), c->lde2_oh.as<gl_t>(), c->st));
     }
     c->tab_log_n = log_n;
     c->tab_rate = rate;
@@ -141,7 +143,8 @@ static int ensure_tables(Ctx* c, unsigned log_n, unsigned rate, unsigned qdb) {
 static hipError_t run_lde(Ctx* c, const gl_t* values, gl_t* coeffs, gl_t* lde, size_t cols, unsigned log_n, unsigned rate, int from_coeffs) {
     if (lde_v2_supported(log_n))
         return launch_lde_columns_v2(values, coeffs, lde, cols, log_n, rate, c->lde2_fwd.as<gl_t>(), c->lde2_inv.as<gl_t>(),
-                                     c->lde2_cs.as<gl_t>(), from_coeffs, c->st);
+                                     c->lde2_cs.as<gl_t>(), (c->opt_lde_closed_forms && lde_v2_oh_words(log_n, rate)) ? c->lde2_oh.as<gl_t>() : nullptr,
+                                     from_coeffs, c->st);
     return launch_lde_columns(values, coeffs, lde, cols, log_n, rate, c->tw_fwd.as<gl_t>(), c->tw_inv.as<gl_t>(), log_n + rate,
                               c->coset_scale.as<gl_t>(), from_coeffs, c->st);
 }
@@ -242,7 +245,7 @@ void ctx_destroy(Ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
-    DevBuf* bufs[] = {&c->tw_fwd, &c->tw_inv, &c->coset_scale, &c->qtab, &c->qshift_inv, &c->lde2_fwd, &c->lde2_inv, &c->lde2_cs, &c->d_ops, &c->d_loads, &c->d_chunk_off, &c->q_recs, &c->q_pieces, &c->q_streams, &c->q_chunk_tile_off, &c->q_tile_list,
+    DevBuf* bufs[] = {&c->tw_fwd, &c->tw_inv, &c->coset_scale, &c->qtab, &c->qshift_inv, &c->lde2_fwd, &c->lde2_inv, &c->lde2_cs, &c->lde2_oh, &c->d_ops, &c->d_loads, &c->d_chunk_off, &c->q_recs, &c->q_pieces, &c->q_streams, &c->q_chunk_tile_off, &c->q_tile_list,
                       &c->q_contrib_off, &c->q_contribs, &c->q_consts, &c->q_apow, &c->staging,
                       &c->values, &c->coeffs, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial, &c->qvals, &c->qcoef,
                       &c->qlde, &c->qdigests, &c->zpow, &c->gzpow, &c->open_local, &c->open_next, &c->open_q, &c->ext_apow, &c->comb_partial,
@@ -259,6 +262,7 @@ void ctx_destroy(Ctx* c) {
     delete c;
 }
 void ctx_attach_hash_service(Ctx* c, HashService* hs) { c->hs = hs; }
+bool ctx_has_hash_service(Ctx* c) { return c->hs != nullptr; }
 void ctx_hash_request_reset(Ctx* c) { c->hash_requested = false; }
 bool ctx_hash_requested(Ctx* c) { return c->hash_requested; }
 
@@ -273,6 +277,7 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
                        // prove() refuses to return it), 9 compares the two evaluators point by point on stderr
     else if (k == "quotient_debug" && value >= 0 && value <= 9) c->opt_quotient_debug = value;
 #endif
+    else if (k == "lde_closed_forms" && (value == 0 || value == 1)) c->opt_lde_closed_forms = value;
     else if (k == "quotient_chunks" && value >= 0 && value <= 4096) { c->opt_quotient_chunks = value; c->plan_air = -1; }
     else return STARKHIP_ERR_BAD_SHAPE;
     return STARKHIP_OK;

@@ -86,19 +86,40 @@ void HashService::launch_big(Req* r) {
     if (e == hipSuccess) running_big_.push_back(r->done);
 }
 
+// A stream with nothing pending (a merged launch must not wait in stream order behind an earlier window's latency chain); all
+// busy: the next one in turn.
+hipStream_t HashService::pick_small_stream(hipError_t* err) {
+    *err = hipSuccess;
+    for (int k = 0; k < N_SMALL_STREAMS; k++) {
+        hipStream_t& s = small_st_[(next_small_st_ + k) % N_SMALL_STREAMS];
+        if (!s) {
+            *err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            next_small_st_ = (next_small_st_ + k + 1) % N_SMALL_STREAMS;
+            return s;
+        }
+        const bool idle = hipStreamQuery(s) == hipSuccess;
+        (void)hipGetLastError();  // hipErrorNotReady from a query is not an error (and must not surface at the next launch)
+        if (idle) {
+            next_small_st_ = (next_small_st_ + k + 1) % N_SMALL_STREAMS;
+            return s;
+        }
+    }
+    hipStream_t s = small_st_[next_small_st_];
+    next_small_st_ = (next_small_st_ + 1) % N_SMALL_STREAMS;
+    return s;
+}
+
 // all pending small commitments, merged by shape: one launch per (columns, rows, rate), each on a stream of its own so that
 // different AIRs' windows overlap
 void HashService::launch_small(std::vector<Req*>& reqs) {
     std::map<std::tuple<size_t, unsigned, unsigned>, std::vector<Req*>> groups;
     for (Req* r : reqs) groups[std::make_tuple(r->n_cols, r->log_n, r->rate_bits)].push_back(r);
-    int si = 0;
     for (auto& kv : groups) {
         std::vector<Req*>& g = kv.second;
-        for (size_t at = 0; at < g.size(); at += LEAF_HASH_MAX_BATCH, si++) {
+        for (size_t at = 0; at < g.size(); at += LEAF_HASH_MAX_BATCH) {
             const size_t cnt = std::min<size_t>(LEAF_HASH_MAX_BATCH, g.size() - at);
-            hipStream_t& s = small_st_[si % N_SMALL_STREAMS];
             hipError_t e = hipSuccess;
-            if (!s) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            hipStream_t s = pick_small_stream(&e);
             LeafHashBatch B;
             for (size_t i = 0; i < cnt && e == hipSuccess; i++) {
                 B.mat[i] = g[at + i]->mat;
@@ -204,7 +225,7 @@ struct Job {
     uint64_t pow = 0;
     std::vector<uint32_t> operands;   // witness jobs
     void* own_log = nullptr;          // witness jobs: the recording, freed when proven
-    std::vector<uint64_t> own_pis;
+    std::vector<uint64_t> own_pis, own_rows;  // own_rows: the toy AIR's generator writes plain rows (it does not record)
     bool big = false;
     // result
     int state = 0;  // 0 queued for generation / proving, 1 running, 2 done
@@ -229,7 +250,7 @@ int witness_limbs(int air) {
 }
 
 // the ONE starkhip_trace_* call of `air` on packed operands (layouts: starkhip_pool_submit_witness in starkhip.h)
-int run_generator(int air, const uint32_t* w, size_t n_rows, uint64_t* pis) {
+int run_generator(int air, const uint32_t* w, size_t n_rows, uint64_t* pis, uint64_t* rows) {
     switch (air) {
         case STARKHIP_AIR_FP12_MUL: return starkhip_trace_fp12_mul(w, w + 144, nullptr, n_rows, pis);
         case STARKHIP_AIR_FINAL_EXP: return starkhip_trace_final_exp(w, nullptr, n_rows, pis);
@@ -241,7 +262,7 @@ int run_generator(int air, const uint32_t* w, size_t n_rows, uint64_t* pis) {
             return starkhip_trace_ecc_aggregate(w, bits.data(), nullptr, n_rows, pis);
         }
         case STARKHIP_AIR_TEST_FIBONACCI:
-            return starkhip_trace_fibonacci((uint64_t)w[0] | ((uint64_t)w[1] << 32), (uint64_t)w[2] | ((uint64_t)w[3] << 32), nullptr, n_rows, pis);
+            return starkhip_trace_fibonacci((uint64_t)w[0] | ((uint64_t)w[1] << 32), (uint64_t)w[2] | ((uint64_t)w[3] << 32), rows, n_rows, pis);
         default: return STARKHIP_ERR_BAD_AIR;
     }
 }
@@ -260,6 +281,7 @@ struct Pool {
     uint64_t next_id = 1;
     bool stop = false;
     unsigned gen_threads = 0, trace_threads_cfg = 0, gen_running = 0;
+    size_t big_recordings_started = 0, big_proofs_done = 0;  // under mu
     std::vector<std::thread> threads;
 
     double now() const { return now_s() - t0; }
@@ -276,7 +298,9 @@ struct Pool {
     int trace_threads_for_call() {
         if (trace_threads_cfg) return (int)trace_threads_cfg;
         const unsigned busy = std::max(1u, gen_running + (unsigned)q_gen.size());  // under mu
-        const unsigned share = std::max(1u, 2 * gen_threads / busy);
+        const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+        const unsigned running = std::min(busy, std::max(1u, gen_threads));
+        const unsigned share = std::max(1u, hw / (2 * running));  // half the hardware threads, split over the recordings that run at once
         return (int)std::min(16u, share);
     }
 
@@ -288,12 +312,19 @@ struct Pool {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_gen.wait(lk, [&] { return stop || !q_gen.empty(); });
                 if (q_gen.empty()) return;
-                // FinalExp-class recordings first: they are the long pole of a signature
-                auto it = q_gen.begin();
+                // Order by need, not by arrival.  FinalExp-class recordings are the long pole of a signature, so the first ones
+                // go first -- as many as there are contexts to prove them, plus one in reserve -- then the small AIRs' (their
+                // proofs fill the chip beside the first FinalExp proofs), then the FinalExp traces that will wait for a context
+                // anyway.  Few recordings run at once, each on many threads (trace_threads_for_call): the FIRST trace of each
+                // class is ready after tens of milliseconds instead of all of them after hundreds.
+                auto it = q_gen.end();
+                const bool want_big = big_recordings_started < big_ctx.size() + 1;
                 for (auto k = q_gen.begin(); k != q_gen.end(); ++k)
-                    if ((*k)->big) { it = k; break; }
+                    if ((*k)->big == want_big) { it = k; break; }
+                if (it == q_gen.end()) it = q_gen.begin();
                 j = *it;
                 q_gen.erase(it);
+                if (j->big) big_recordings_started++;
                 tt = trace_threads_for_call();
                 gen_running++;
                 j->t[1] = now();
@@ -303,11 +334,16 @@ struct Pool {
                 set_thread_trace_threads(tt);
                 const AirInfo* a = air_get(j->air);
                 j->own_pis.assign(a->pis, 0);
-                rc = starkhip_trace_log_begin(&j->own_log);
-                if (rc == STARKHIP_OK) {
-                    rc = run_generator(j->air, j->operands.data(), a->default_rows, j->own_pis.data());
-                    const int rc_end = starkhip_trace_log_end(j->own_log);
-                    if (rc == STARKHIP_OK) rc = rc_end;
+                if (j->air == STARKHIP_AIR_TEST_FIBONACCI) {  // plain rows
+                    j->own_rows.assign((size_t)a->default_rows * a->cols, 0);
+                    rc = run_generator(j->air, j->operands.data(), a->default_rows, j->own_pis.data(), j->own_rows.data());
+                } else {
+                    rc = starkhip_trace_log_begin(&j->own_log);
+                    if (rc == STARKHIP_OK) {
+                        rc = run_generator(j->air, j->operands.data(), a->default_rows, j->own_pis.data(), nullptr);
+                        const int rc_end = starkhip_trace_log_end(j->own_log);
+                        if (rc == STARKHIP_OK) rc = rc_end;
+                    }
                 }
                 set_thread_trace_threads(0);
             } catch (const std::bad_alloc&) {
@@ -329,9 +365,17 @@ struct Pool {
             std::lock_guard<std::mutex> g(mu);
             gen_running--;
             j->t[2] = now();
-            j->kind = JOB_COMPACT;
-            j->trace = (const uint64_t*)j->own_log;
-            j->n_rows = ((const TraceLog*)j->own_log)->rows;
+            if (j->own_log) {
+                j->kind = JOB_COMPACT;
+                j->trace = (const uint64_t*)j->own_log;
+                j->n_rows = ((const TraceLog*)j->own_log)->rows;
+            } else {
+                j->kind = JOB_DENSE;
+                j->trace = j->own_rows.data();
+                j->n_rows = air_get(j->air)->default_rows;
+                j->layout = 0;
+                j->on_device = 0;
+            }
             j->pis = j->own_pis.data();
             j->n_pis = j->own_pis.size();
             (j->big ? q_big : q_small).push_back(j);
@@ -342,19 +386,24 @@ struct Pool {
     void prover_loop(Ctx* c, bool big) {
         std::deque<Job*>& q = big ? q_big : q_small;
         std::condition_variable& cv = big ? cv_big : cv_small;
+        int last_air = -1;  // a context keeps the tables and the constraint plan of the AIR it proved last: take that AIR again if one waits
         while (true) {
             Job* j;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return stop || !q.empty(); });
                 if (q.empty()) return;
-                j = q.front();
-                q.pop_front();
+                auto it = q.begin();
+                for (auto k = q.begin(); k != q.end(); ++k)
+                    if ((*k)->air == last_air) { it = k; break; }
+                j = *it;
+                q.erase(it);
+                last_air = j->air;
                 j->state = 1;
                 j->t[3] = now();
             }
             int rc;
-            const bool announce = !big;
+            const bool announce = !big && ctx_has_hash_service(c);
             if (announce) hs->announce_small();
             ctx_hash_request_reset(c);
             try {
@@ -367,6 +416,10 @@ struct Pool {
                 rc = STARKHIP_ERR_BAD_SHAPE;
             }
             if (announce && !ctx_hash_requested(c)) hs->abandon_small();  // failed before its commitment: do not hold the window open
+            if (big) {
+                std::lock_guard<std::mutex> g(mu);
+                if (big_recordings_started > 0) big_recordings_started--;  // a context is free again: the next FinalExp-class recording moves up
+            }
             memcpy(j->phase_ms, ctx_timings(c), sizeof j->phase_ms);
             memcpy(j->kernel_ms, ctx_kernel_timings(c), sizeof j->kernel_ms);
             if (j->own_log) {
@@ -384,7 +437,10 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
     p->device = cfg.device;
     p->t0 = now_s();
     const unsigned n_big = cfg.big_contexts ? cfg.big_contexts : 3, n_small = cfg.small_contexts ? cfg.small_contexts : 16;
-    p->gen_threads = cfg.generator_threads ? cfg.generator_threads : 12;
+    // recording is host work the GPU waits for: few recordings at once (hardware threads / 16, 4 .. 12), each on several
+    // threads (trace_threads_for_call: half the hardware threads split over the running recordings, at most 16 each)
+    const unsigned hw = std::max(4u, std::thread::hardware_concurrency());
+    p->gen_threads = cfg.generator_threads ? cfg.generator_threads : std::min(12u, std::max(4u, hw / 16));
     p->trace_threads_cfg = cfg.trace_threads;
     int rc = STARKHIP_OK;
     for (unsigned i = 0; i < n_big + n_small && rc == STARKHIP_OK; i++) {
@@ -400,8 +456,10 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
     p->hs.reset(new HashService(cfg.device));
     if (cfg.gather_ms > 0) p->hs->gather_ms = cfg.gather_ms;
     p->hs->policy = (int)cfg.commit_policy;
-    for (Ctx* c : p->big_ctx) ctx_attach_hash_service(c, p->hs.get());
-    for (Ctx* c : p->small_ctx) ctx_attach_hash_service(c, p->hs.get());
+    if (cfg.commit_policy != 2) {  // 2: no commitment scheduling at all -- every context launches its own (A/B measurements)
+        for (Ctx* c : p->big_ctx) ctx_attach_hash_service(c, p->hs.get());
+        for (Ctx* c : p->small_ctx) ctx_attach_hash_service(c, p->hs.get());
+    }
     Pool* raw = p.get();
     for (unsigned i = 0; i < p->gen_threads; i++) p->threads.emplace_back([raw] { raw->generator_loop(); });
     for (Ctx* c : p->big_ctx) p->threads.emplace_back([raw, c] { raw->prover_loop(c, true); });

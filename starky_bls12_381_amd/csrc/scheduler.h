@@ -70,8 +70,11 @@ class HashService {
 
     int device_;
     hipStream_t st_ = nullptr;
-    static const int N_SMALL_STREAMS = 4;  // one merged launch per AIR shape, side by side
-    hipStream_t small_st_[N_SMALL_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+    // merged launches run side by side: each goes to a stream that is idle, so a window never queues behind an earlier one
+    static const int N_SMALL_STREAMS = 12;
+    hipStream_t small_st_[N_SMALL_STREAMS] = {};
+    unsigned next_small_st_ = 0;
+    hipStream_t pick_small_stream(hipError_t* err);
     std::mutex mu_;
     std::condition_variable cv_, cv_done_;
     std::deque<Req*> big_, small_;

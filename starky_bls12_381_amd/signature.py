@@ -299,12 +299,69 @@ def signature_proofs(results, index):
     return {name: results[(index, name)] for name in A.JOB_ORDER if (index, name) in results}
 
 
+# ------------------------------------------------------------------------------------------------ execution on the library's pool
+NEEDS_NATIVES = ("fp12_mul", "final_exp")
+
+
+def run_jobs_pool(pool, my_jobs, signatures):
+    """`my_jobs` of this rank on a `ProofPool` (starkhip_pool_*): trace generation, the in-flight scheduling and the merged
+    commitments all happen inside the library; here the jobs are only submitted and waited for.  Jobs that need no natives
+    (the precomputations and Miller loops) are submitted at once; per signature with an fp12_mul / final_exp job here, the natives
+    are computed on a host thread (ctypes releases the GIL) and those jobs follow, FinalExp first.
+    Returns (results, stats, natives) as `run_jobs` + `job_arguments` do."""
+    from concurrent.futures import ThreadPoolExecutor
+    t_begin = time.perf_counter()
+    tickets, natives = {}, {}
+    lock = threading.Lock()
+    mine = set(my_jobs)
+    need = sorted({i for i, name in mine if name in NEEDS_NATIVES})
+
+    def with_natives(i):
+        nat = A.signature_natives(*signatures[i])
+        with lock:
+            natives[i] = nat
+        for name in ("final_exp", "fp12_mul"):
+            if (i, name) in mine:
+                t = pool.submit_witness(A.JOB_AIR[name], *A.job_operands(name, *signatures[i], natives=nat))
+                with lock:
+                    tickets[(i, name)] = t
+
+    ex = ThreadPoolExecutor(max_workers=max(1, min(16, len(need)))) if need else None
+    futs = [ex.submit(with_natives, i) for i in need] if ex else []
+    for i, name in sorted(mine, key=lambda j: -parallel.AIR_COST[A.JOB_AIR[j[1]]]):
+        if name not in NEEDS_NATIVES:
+            t = pool.submit_witness(A.JOB_AIR[name], *A.job_operands(name, *signatures[i]))
+            with lock:
+                tickets[(i, name)] = t
+    for f in futs:
+        f.result()
+    if ex:
+        ex.shutdown()
+    results, timeline = {}, {}
+    t_gen = t_prove = 0.0
+    for job, t in tickets.items():
+        air = A.JOB_AIR[job[1]]
+        proof, info = pool.wait(t)
+        results[job] = (air, proof, S.StarkConfig.for_air(air))
+        tl = info["timeline_s"]
+        timeline[job] = tl
+        t_gen += tl[2] - tl[1]
+        t_prove += tl[4] - tl[3]
+    if timeline:  # relative to the first submit of this step
+        t0 = min(v[0] for v in timeline.values())
+        timeline = {k: [x - t0 for x in v[1:]] for k, v in timeline.items()}
+    return results, {"generate_s": t_gen, "prove_s": t_prove, "wall_s": time.perf_counter() - t_begin, "timeline": timeline,
+                     "trace_threads": "automatic (pool)", "pool": pool.stats()}, natives
+
+
 # ------------------------------------------------------------------------------------------------ one step, all ranks
 def one_step(dist, batch, provers, mine, signatures, device="cpu", sync=None, **run_kw):
     """ONE step of the signature pipeline on this rank, exactly what `tools/bench_signature.py` times and what the gloo tests
     drive: barrier, [t0] operand broadcast from rank 0 (`signatures` is None on the other ranks), natives for this rank's jobs,
     `run_jobs` (trace generation overlapped with proving), barrier, [t1], max over ranks of t1 - t0.
     `sync()` (e.g. torch.cuda.synchronize) runs right before each barrier so that the region brackets finished GPU work.
+    `provers`: a `ProofPool` (the product path: scheduling inside the library, `run_jobs_pool`) or contexts for the Python
+    driver `run_jobs` (kept for the CPU tests, which inject prove / generate, and for A/B measurements).
     Returns (elapsed_s, results, stats, sigs, natives); `run_kw` goes to `run_jobs`."""
     if sync is not None:
         sync()
@@ -312,8 +369,11 @@ def one_step(dist, batch, provers, mine, signatures, device="cpu", sync=None, **
         dist.barrier()
     t0 = time.perf_counter()
     sigs = broadcast_operands(dist, signatures, batch, device=device)
-    job_args, natives = job_arguments(sigs, mine)
-    results, stats = run_jobs(provers, mine, job_args, **run_kw)
+    if isinstance(provers, S.ProofPool):
+        results, stats, natives = run_jobs_pool(provers, mine, sigs)
+    else:
+        job_args, natives = job_arguments(sigs, mine)
+        results, stats = run_jobs(provers, mine, job_args, **run_kw)
     if sync is not None:
         sync()
     if dist is not None:

@@ -270,3 +270,32 @@ def test_both_constraint_evaluators_give_the_same_proof():
             pv.set_option("no_such_option", 1)
     finally:
         pv.close()
+
+
+@pytest.mark.parametrize("air_name", ["fp12_mul", "pairing_precomp"])
+def test_handoff_round_trip_of_gpu_proofs(prover, air_name):
+    """Proof hand-off on what the GPU path produces: the blob of a real AIR's proof -> the nested
+    StarkProofWithPublicInputs value (the shape src/aggregate_proof.rs:435-439 consumes) -> JSON -> blob is lossless, the value has
+    the AIR's column / quotient / FRI-layer counts, and the round-tripped blob is still accepted by the verifier."""
+    from starky_bls12_381_amd import handoff as H
+    if air_name == "fp12_mul":
+        air = S.AIR_FP12_MUL
+        t, pis = S.trace_fp12_mul(random_fp12(0x5EED5000), random_fp12(0x5EED5001), compact=True)
+    else:
+        from test_gpu_pool import _precomp_args
+        air = S.AIR_PAIRING_PRECOMP
+        t, pis = S.trace_pairing_precomp(*_precomp_args(0x5EED5010), compact=True)
+    cfg = S.StarkConfig.for_air(air)
+    proof = prover.prove(air, cfg, t, pis)
+    lay = S.proof_layout(proof)
+    v = H.proof_to_value(proof)
+    assert v["public_inputs"] == [int(x) for x in pis]
+    r0 = v["proof"]["opening_proof"]["query_round_proofs"][0]
+    leaf, path = r0["initial_trees_proof"]["evals_proofs"][0]
+    assert len(leaf) == S.air_columns(air) == lay.n_columns and len(path["siblings"]) == lay.initial_sibling_count
+    assert len(r0["initial_trees_proof"]["evals_proofs"][1][0]) == lay.n_quotient_polys
+    assert len(v["proof"]["openings"]["local_values"]) == lay.n_columns and len(v["proof"]["openings"]["quotient_polys"]) == lay.n_quotient_polys
+    assert len(v["proof"]["opening_proof"]["commit_phase_merkle_caps"]) == lay.n_fri_layers
+    back = H.loads(H.dumps(proof), degree_bits=lay.degree_bits, rate_bits=cfg.rate_bits, arity_bits=cfg.arity_bits, num_challenges=cfg.num_challenges)
+    assert np.array_equal(back, proof)
+    S.verify_stark_proof(air, cfg, back)

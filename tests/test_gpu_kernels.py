@@ -38,6 +38,39 @@ def test_lde_matches_oracle(prover, log_n, rate_bits, ncols):
     assert np.array_equal(lde, olde_rows.T)
 
 
+@pytest.mark.parametrize("log_n,rate_bits", [(13, 2), (12, 2), (12, 1), (13, 1)])
+def test_lde_closed_forms_match_oracle(prover, log_n, rate_bits):
+    """Columns the LDE kernel does NOT transform (kernels_lde.hip: one workgroup per column, 2^12 and 2^13 rows): constant
+    columns and unit vectors -- FinalExp's replicated Fp12 blocks and its one-hot row selectors -- take closed forms; next to them
+    the near misses that must still go through the transforms (two ones, a single 2, a one among other values, all ones but one).
+    Coefficients and LDE equal the oracle's for every column, with the closed forms on and off."""
+    n = 1 << log_n
+    rng = np.random.default_rng(99 + log_n + rate_bits)
+    cols = []
+    for c in (0, 1, 7, P - 1, 1 << 32, (1 << 32) - 1):                       # constants
+        cols.append(np.full(n, c, dtype=np.uint64))
+    for r in (0, 1, 5, n // 2, n - 2, n - 1, int(rng.integers(0, n))):       # unit vectors e_r
+        v = np.zeros(n, dtype=np.uint64)
+        v[r] = 1
+        cols.append(v)
+    two = np.zeros(n, dtype=np.uint64); two[3] = two[n - 7] = 1; cols.append(two)          # two ones
+    big = np.zeros(n, dtype=np.uint64); big[9] = 2; cols.append(big)                        # a single 2
+    mix = _rand(rng, n); mix[11] = 1; cols.append(mix)                                      # a one among other values
+    hole = np.ones(n, dtype=np.uint64); hole[n - 1] = 0; cols.append(hole)                  # all ones but one
+    same16 = np.zeros(n, dtype=np.uint64); same16[::n // 16] = 1; cols.append(same16)       # sixteen ones, one per thread slot
+    cols.append(_rand(rng, n))
+    vals = np.stack(cols)
+    ocoeffs, olde_rows = O.lde_rows(vals, rate_bits)
+    for on in (1, 0):
+        prover.set_option("lde_closed_forms", on)
+        try:
+            coeffs, lde = prover.lde_batch(vals, rate_bits)
+        finally:
+            prover.set_option("lde_closed_forms", 1)
+        assert np.array_equal(coeffs, ocoeffs), on
+        assert np.array_equal(lde, olde_rows.T), on
+
+
 @pytest.mark.parametrize("log_N,ncols,cap_h", [(5, 60285 // 16, 4), (4, 3, 4), (8, 4, 4), (8, 5, 2), (12, 200, 4), (6, 8, 0),
                                                # many leaves, widths around the 8-element sponge blocks
                                                (14, 21, 4), (14, 8, 4), (14, 6, 4), (14, 15, 4), (15, 9, 4), (14, 3, 4),

@@ -1,0 +1,150 @@
+"""The library's proof pool (starkhip_pool_*: submit / wait, merged trace commitments) on the GPU: proofs from the pool are
+byte-identical to the ones from a plain context -- and so to the CPU oracle's -- whatever shares the chip with them."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import starky_bls12_381_amd as S
+from bls_util import GOLDEN, random_fp, random_fp12, splitmix64
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fp2(gen):
+    return np.concatenate([np.array([(random_fp(gen) >> (32 * i)) & 0xFFFFFFFF for i in range(12)], dtype=np.uint32) for _ in range(2)])
+
+
+def _precomp_args(seed):
+    g = splitmix64(seed)
+    one = np.zeros(24, dtype=np.uint32)
+    one[0] = 1
+    return _fp2(g), _fp2(g), one
+
+
+def test_merged_commitments_give_the_same_proofs_as_one_context(prover):
+    """Seven small proofs of three AIRs submitted at once: the FP12Mul ones share one merged leaf-hash launch, the
+    PairingPrecomp ones another, the toy AIR a third; every proof equals the single-context proof byte for byte (FP12Mul also
+    the oracle's)."""
+    pool = S.ProofPool(0, big_contexts=1, small_contexts=7, generator_threads=4)
+    try:
+        jobs = []
+        for k in range(3):
+            x, y = random_fp12(0x5EED3000 + 2 * k), random_fp12(0x5EED3001 + 2 * k)
+            jobs.append((S.AIR_FP12_MUL, S.trace_fp12_mul(x, y)))
+        for k in range(2):
+            jobs.append((S.AIR_PAIRING_PRECOMP, S.trace_pairing_precomp(*_precomp_args(0x5EED3100 + k))))
+        for k in range(2):
+            jobs.append((S.AIR_TEST_FIBONACCI, S.trace_fibonacci(3 + k, 5, 256)))
+        tickets = [pool.submit(air, S.StarkConfig.for_air(air), t, pis) for air, (t, pis) in jobs]
+        got = [pool.wait(t)[0] for t in tickets]
+        stats = pool.stats()
+    finally:
+        pool.close()
+    assert stats["small_commit_requests"] == 7 and stats["big_commit_launches"] == 0
+    assert stats["small_commit_launches"] < 7 and stats["max_merged_commitments"] >= 2   # some commitments shared a launch
+    for (air, (t, pis)), proof in zip(jobs, got):
+        cfg = S.StarkConfig.for_air(air)
+        S.verify_stark_proof(air, cfg, proof)
+        assert np.array_equal(proof, prover.prove(air, cfg, t, pis))
+    air, (t, pis) = jobs[0]
+    assert np.array_equal(got[0], O.prove(S.air_program(air), S.StarkConfig.for_air(air), S.trace_rows_to_poly_values(t), pis))
+
+
+def test_witness_jobs_generate_inside_the_pool():
+    """starkhip_pool_submit_witness: generate_trace + prove from the driver's operands, as src/aggregate_proof.rs:23-179 does in
+    one function each; same bytes as recording the trace here and proving it on a context."""
+    x, y = random_fp12(0x5EED3200), random_fp12(0x5EED3201)
+    args = _precomp_args(0x5EED3210)
+    pool = S.ProofPool(0, big_contexts=1, small_contexts=3, generator_threads=3)
+    pv = S.Prover(0)
+    try:
+        t1 = pool.submit_witness(S.AIR_FP12_MUL, x, y)
+        t2 = pool.submit_witness(S.AIR_PAIRING_PRECOMP, *args)
+        t3 = pool.submit_witness(S.AIR_TEST_FIBONACCI, 3, 5)
+        p1, info1 = pool.wait(t1)
+        p2, _ = pool.wait(t2)
+        p3, _ = pool.wait(t3)
+        for air, proof, gen in ((S.AIR_FP12_MUL, p1, lambda: S.trace_fp12_mul(x, y, compact=True)),
+                                (S.AIR_PAIRING_PRECOMP, p2, lambda: S.trace_pairing_precomp(*args, compact=True))):
+            cfg = S.StarkConfig.for_air(air)
+            trace, pis = gen()
+            assert np.array_equal(proof[-pis.size:], pis)
+            assert np.array_equal(proof, pv.prove(air, cfg, trace, pis))
+        t, pis = S.trace_fibonacci(3, 5)
+        assert np.array_equal(p3, pv.prove(S.AIR_TEST_FIBONACCI, S.StarkConfig.for_air(S.AIR_TEST_FIBONACCI), t, pis))
+        tl = info1["timeline_s"]
+        assert tl[0] <= tl[1] <= tl[2] <= tl[3] <= tl[4] and info1["phase_ms"]["total"] > 0
+    finally:
+        pv.close()
+        pool.close()
+
+
+def test_a_failing_job_reports_its_code_and_the_pool_goes_on():
+    """A witness that does not satisfy the AIR (a trace cell changed) fails with the prover's own error code at wait();
+    proofs submitted with it and after it are unaffected (a failed small proof must not hold the merged window open)."""
+    air = S.AIR_PAIRING_PRECOMP   # degree 4 at blow-up 4: a broken constraint shows in the quotient's zero chunk ("Quotient has failed")
+    cfg = S.StarkConfig.for_air(air)
+    t, pis = S.trace_pairing_precomp(*_precomp_args(0x5EED3300))
+    bad = t.copy()
+    bad[200, 15000] = (int(bad[200, 15000]) + 1) % S.P
+    pool = S.ProofPool(0, big_contexts=1, small_contexts=2, generator_threads=1)
+    try:
+        tb, tg = pool.submit(air, cfg, bad, pis), pool.submit(air, cfg, t, pis)
+        with pytest.raises(S.StarkhipError) as e:
+            pool.wait(tb)
+        assert e.value.code == S.ERR_QUOTIENT_NOT_DIVISIBLE
+        good, _ = pool.wait(tg)
+        S.verify_stark_proof(air, cfg, good)
+        with pytest.raises(S.StarkhipError) as e:
+            pool.submit(air, cfg, t[:, :-1], pis)   # wrong shape: refused at submit
+        assert e.value.code == S.ERR_BAD_SHAPE
+        pis_bad = pis.copy()
+        pis_bad[0] = np.uint64(S.P)                   # not canonical: refused by prove() before any GPU work, before the commitment
+        t_early = pool.submit(air, cfg, t, pis_bad)
+        again = pool.submit(air, cfg, t, pis)
+        with pytest.raises(S.StarkhipError) as e:
+            pool.wait(t_early)
+        assert e.value.code == S.ERR_BAD_SHAPE
+        assert np.array_equal(pool.wait(again)[0], good)
+        with pytest.raises(S.StarkhipError):
+            pool.wait(again)                          # a ticket is waited for once
+    finally:
+        pool.close()
+
+
+def test_final_exp_four_in_flight_match_the_oracle_digest():
+    """The regime bench.py times: FOUR FinalExp proofs in flight on one GPU.  All four prove the benchmark's first seeded
+    input (0x5EED0001); every proof's SHA-256 equals the CPU oracle's (tests/golden/final_exp_seed_5eed0001_proof.sha256, made by
+    tests/make_final_exp_golden.py --seed 0x5EED0001 on the GPU box's host) -- contention changes nothing in the bytes."""
+    air = S.AIR_FINAL_EXP
+    cfg = S.StarkConfig.for_air(air)
+    want = open(os.path.join(GOLDEN, "final_exp_seed_5eed0001_proof.sha256")).read().split()[0]
+    trace, pis = S.trace_final_exp(random_fp12(0x5EED0001))
+    cols = S.trace_rows_to_poly_values(trace)   # what the reference hands to prove(): column vectors
+    del trace
+    pool = S.ProofPool(0, big_contexts=4, small_contexts=1, generator_threads=1)
+    try:
+        tickets = [pool.submit(air, cfg, cols, pis, layout=1) for _ in range(4)]
+        digests = [hashlib.sha256(pool.wait(t)[0].tobytes()).hexdigest() for t in tickets]
+        stats = pool.stats()
+    finally:
+        pool.close()
+    assert digests == [want] * 4
+    assert stats["big_commit_launches"] == 4
+
+
+def test_cpp_demo_proves_a_batch_on_the_pool():
+    """tools/signature_demo.cpp --batch 2: compiled host code above the C ABI only; 12 proofs in flight, all verified, linked and
+    bound to their statements (exit code 0)."""
+    exe = os.path.join(ROOT, "build", "signature_demo")
+    ops = os.path.join(GOLDEN, "signature_operands_8.bin")
+    if not os.path.exists(exe):
+        pytest.skip("build/signature_demo not built (make demo)")
+    r = subprocess.run([exe, "--batch", "2", "--operands", ops, "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert '"proofs_verified_after_timing": 12' in r.stdout and '"signatures_valid_linked_bound": 2' in r.stdout

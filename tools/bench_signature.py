@@ -44,6 +44,11 @@ def main():
     ap.add_argument("--by-type", type=int, default=0, help="1: the FinalExp contexts start when the small proofs are done (two pools); "
                                                            "0 (default): both pools at once -- measured for a batch of 8: 2.61 against "
                                                            "2.26 signatures/s by type")
+    ap.add_argument("--driver", choices=("pool", "python"), default="pool",
+                    help="pool (default): the library's proof pool (starkhip_pool_*: generator threads, contexts, merged commitments inside "
+                         "libstarkhip.so); python: the round-2 driver (signature.run_jobs: Python threads over plain contexts)")
+    ap.add_argument("--policy", type=int, default=0, help="pool: commit policy (0: commitment classes never overlap, 1: they may)")
+    ap.add_argument("--gather-ms", type=float, default=0.0, help="pool: how long a merged commitment waits for stragglers (0 = default)")
     ap.add_argument("--collect", action="store_true", help="N > 1: gather every proof on every rank afterwards (raw buffers) and check all signatures")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -68,7 +73,13 @@ def main():
 
     if args.small_inflight == 0 and args.batch > 1:
         args.small_inflight = 16
-    if args.small_inflight > 0:
+    if args.driver == "pool":
+        big = max(1, args.big_inflight if args.batch > 1 else 1)
+        small = args.small_inflight if args.small_inflight > 0 else 5
+        provers = S.ProofPool(local_rank, big_contexts=big, small_contexts=small, generator_threads=args.gen_threads,
+                              trace_threads=args.trace_threads, commit_policy=args.policy, gather_ms=args.gather_ms)
+        all_provers = [provers]
+    elif args.small_inflight > 0:
         provers = {"big": [S.Prover(local_rank) for _ in range(max(1, args.big_inflight))],
                    "small": [S.Prover(local_rank) for _ in range(args.small_inflight)]}
         all_provers = provers["big"] + provers["small"]
@@ -110,7 +121,7 @@ def main():
             "metric": "BLS signature checks/s, end to end (operands -> trace generation -> 6 STARK proofs each)",
             "value": args.batch / el, "unit": "signatures/s", "n_gpus": world, "batch": args.batch, "steps": args.steps,
             "ms_per_step": el * 1e3, "ms_per_signature": el * 1e3 / args.batch,
-            "proofs_per_step": 6 * args.batch, "contexts_per_gpu": ({k: len(v) for k, v in provers.items()} if isinstance(provers, dict) else len(provers)), "generator_threads_per_gpu": args.gen_threads, "threads_per_generator_call": stats.get("trace_threads"), "final_exp_after_small_proofs": bool(args.by_type),
+            "proofs_per_step": 6 * args.batch, "driver": args.driver, "contexts_per_gpu": ({"big": big, "small": small} if args.driver == "pool" else {k: len(v) for k, v in provers.items()} if isinstance(provers, dict) else len(provers)), "pool_commit_stats": stats.get("pool"), "generator_threads_per_gpu": args.gen_threads, "threads_per_generator_call": stats.get("trace_threads"), "final_exp_after_small_proofs": bool(args.by_type),
             "rank0": {"jobs": len(mine), "generate_s_sum": stats.get("generate_s"), "prove_s_sum": stats.get("prove_s"), "wall_s": stats.get("wall_s")},
             "timeline_ms_rank0": ({f"{i}:{n}": [round(1e3 * t, 1) for t in v] for (i, n), v in sorted(stats.get("timeline", {}).items())}
                                   if args.batch == 1 else None),  # per job: generation start, end, proof start, end

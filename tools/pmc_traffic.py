@@ -4,8 +4,12 @@
 kernels, trace-commitment launches only.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.
 usage: pmc_traffic.py <fetch_results.db> <write_results.db> <out.json>"""
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_fingerprint import KERNEL_SOURCES, kernel_fingerprint  # noqa: E402
 
 
 def main():
@@ -27,7 +31,8 @@ def main():
         fetch = v["FETCH_SIZE"][0] * 1024 * 2  # gfx950: 128-byte requests are tallied as 64 bytes
         write = v["WRITE_SIZE"][0] * 1024
         out[k] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "traffic_bytes": fetch + write, "fetch_size_raw_KB": v["FETCH_SIZE"][0],
-                  "write_size_raw_KB": v["WRITE_SIZE"][0], "launches_averaged": v["FETCH_SIZE"][1], "avg_ms_under_pmc": v["FETCH_SIZE"][2]}
+                  "write_size_raw_KB": v["WRITE_SIZE"][0], "launches_averaged": v["FETCH_SIZE"][1], "avg_ms_under_pmc": v["FETCH_SIZE"][2],
+                  "source_sha256": kernel_fingerprint(k) if k in KERNEL_SOURCES else None}
     out["_source"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "
                       "--inflight 1`, trace-commitment launches only; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-byte requests "
                       "as 64 bytes); Infinity-Cache hits are included in these memory-side counters")

@@ -1,9 +1,21 @@
-// The six STARK proofs of one BLS signature check through the C++ drivers of include/starkhip_driver.hpp, on the
-// reference's own vector (/root/reference/src/native.rs:1480-1498: public key, H(m), signature; the generator is
-// negated instead of the signature, as src/aggregate_proof.rs:336-337 does).  Exit code 0 = every proof verified, the
-// public inputs chain, and final_exponentiate(ml1 * ml2) == 1.  Build: make demo
+// BLS signature checks as STARK proofs through the C++ drivers of include/starkhip_driver.hpp -- compiled host code above the
+// C ABI only, as a Rust caller of the reference's src/aggregate_proof.rs:304-370 would drive it.
+//
+//   signature_demo                      the six proofs of the reference's own vector (src/native.rs:1480-1498), one at a time on
+//                                       one context (generate_trace + prove + verify each, as the reference does)
+//   signature_demo --pool               the same six proofs in flight together on the library's proof pool
+//   signature_demo --batch 8 [--operands tests/golden/signature_operands_8.bin] [--steps K] [--warmup W]
+//                                       BASELINE configs[4]: B different signatures = 6 B proofs per step on the pool; prints
+//                                       signatures/s with trace generation and natives INSIDE the timed region; afterwards every
+//                                       proof of the last step is verified and checked against its statement
+// Exit code 0 = every proof verified, the public inputs chain, and final_exponentiate(ml1 * ml2) == 1 for every signature.
+// Operand file: B records of 120 little-endian u32 limbs -- pk x, y (12 each), H(m) x, y (24 each), signature x, y (24 each);
+// Z = (1, 0) is implied (tools/make_signature_operands.py derives them from the reference vector).  Build: make demo
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
 
 #include "starkhip_driver.hpp"
 
@@ -16,17 +28,137 @@ static const uint32_t SIG[3][24] = {{0x7d9b6c52, 0xc8cab074, 0xf71a1b2d, 0xe67cd
                                     {0x47a7da5f, 0x951e4254, 0xbe6fbfc5, 0x48df24e8, 0x6d2b0652, 0xd8fd26d4, 0x42d22a2d, 0x33d38215, 0x3cedad7f, 0x7783a6f0, 0xb45a176f, 0x1099e699, 0x51e1e62d, 0xcc1047c0, 0xe57f924a, 0x47cb3632, 0xaadbc63, 0x7e1c66ab, 0xf075e068, 0x3083c45d, 0xe5d1379, 0xc3cb36f8, 0xcfb8185e, 0x4880abf},
                                     {0x1, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0, 0x0}};
 
-int main() {
+using starkhip_driver::SignatureOperands;
+using starkhip_driver::SignatureProofs;
+
+static SignatureOperands reference_vector() {
+    SignatureOperands s;
+    memcpy(s.pk_x, PK_X, sizeof PK_X);
+    memcpy(s.pk_y, PK_Y, sizeof PK_Y);
+    memcpy(s.hm, HM, sizeof HM);
+    memcpy(s.sig, SIG, sizeof SIG);
+    return s;
+}
+
+static std::vector<SignatureOperands> load_operands(const char* path, size_t want) {
+    std::vector<SignatureOperands> out;
+    FILE* f = fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+    uint32_t rec[120];
+    while (out.size() < want && fread(rec, sizeof rec, 1, f) == 1) {
+        SignatureOperands s;
+        memset(&s, 0, sizeof s);
+        memcpy(s.pk_x, rec, 48);
+        memcpy(s.pk_y, rec + 12, 48);
+        memcpy(s.hm[0], rec + 24, 96);
+        memcpy(s.hm[1], rec + 48, 96);
+        memcpy(s.sig[0], rec + 72, 96);
+        memcpy(s.sig[1], rec + 96, 96);
+        s.hm[2][0] = 1;
+        s.sig[2][0] = 1;
+        out.push_back(s);
+    }
+    fclose(f);
+    if (out.size() < want) throw std::runtime_error(std::string(path) + ": fewer signatures than --batch asks for");
+    return out;
+}
+
+static double seconds_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+
+int main(int argc, char** argv) {
+    size_t batch = 0, steps = 3, warmup = 1;
+    bool use_pool = false, timeline = false;
+    const char* operands = nullptr;
+    starkhip_pool_config_t cfg;
+    memset(&cfg, 0, sizeof cfg);
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
+        if (a == "--batch") batch = strtoul(val(), nullptr, 0), use_pool = true;
+        else if (a == "--steps") steps = strtoul(val(), nullptr, 0);
+        else if (a == "--warmup") warmup = strtoul(val(), nullptr, 0);
+        else if (a == "--operands") operands = val();
+        else if (a == "--pool") use_pool = true;
+        else if (a == "--timeline") timeline = true;  // per proof of the last step: submit, generation, proof (ms since the step began) on stderr
+        else if (a == "--big") cfg.big_contexts = (unsigned)strtoul(val(), nullptr, 0);
+        else if (a == "--small") cfg.small_contexts = (unsigned)strtoul(val(), nullptr, 0);
+        else if (a == "--gen") cfg.generator_threads = (unsigned)strtoul(val(), nullptr, 0);
+        else if (a == "--trace-threads") cfg.trace_threads = (unsigned)strtoul(val(), nullptr, 0);
+        else if (a == "--policy") cfg.commit_policy = (unsigned)strtoul(val(), nullptr, 0);
+        else if (a == "--gather-ms") cfg.gather_ms = (float)atof(val());
+        else if (a == "--device") cfg.device = atoi(val());
+        else {
+            fprintf(stderr, "signature_demo: unknown option %s\n", a.c_str());
+            return 2;
+        }
+    }
     try {
-        starkhip_driver::Prover prover(0);
-        const auto t0 = std::chrono::steady_clock::now();
-        const starkhip_driver::SignatureProofs s = starkhip_driver::prove_signature(prover, PK_X, PK_Y, HM, SIG);
-        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        const size_t words = s.pp1.words.size() + s.ml1.words.size() + s.pp2.words.size() + s.ml2.words.size() + s.fp12_mul.words.size() +
-                             s.final_exp.words.size();
-        printf("six proofs (trace generation + prove + verify, one at a time): %.2f s, %.1f MB, valid=%d linked=%d\n", sec, words * 8 / 1e6,
-               (int)s.valid, (int)s.linked);
-        return s.valid && s.linked ? 0 : 1;
+        if (!use_pool) {
+            starkhip_driver::Prover prover(cfg.device);
+            const auto t0 = std::chrono::steady_clock::now();
+            const SignatureProofs s = starkhip_driver::prove_signature(prover, PK_X, PK_Y, HM, SIG);
+            const double sec = seconds_since(t0);
+            const size_t words = s.pp1.words.size() + s.ml1.words.size() + s.pp2.words.size() + s.ml2.words.size() + s.fp12_mul.words.size() +
+                                 s.final_exp.words.size();
+            printf("six proofs (trace generation + prove + verify, one at a time): %.2f s, %.1f MB, valid=%d linked=%d\n", sec, words * 8 / 1e6,
+                   (int)s.valid, (int)s.linked);
+            return s.valid && s.linked ? 0 : 1;
+        }
+        if (batch == 0) batch = 1;
+        std::vector<SignatureOperands> sigs;
+        if (operands) sigs = load_operands(operands, batch);
+        else sigs.assign(batch, reference_vector());  // the reference's vector (B copies of it when no operand file is given)
+        if (batch == 1) {  // latency: everything of one signature in flight -- one context per proof is all it can use
+            if (!cfg.big_contexts) cfg.big_contexts = 1;
+            if (!cfg.small_contexts) cfg.small_contexts = 5;
+            if (!cfg.generator_threads) cfg.generator_threads = 6;
+        }
+        starkhip_driver::tune_host_allocator();
+        starkhip_driver::Pool pool(cfg);
+        std::vector<SignatureProofs> proofs;
+        double total = 0, best = 1e30;
+        for (size_t k = 0; k < warmup + steps; k++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            proofs = starkhip_driver::prove_batch(pool, sigs, /*verify=*/false);
+            const double sec = seconds_since(t0);
+            if (k >= warmup) {
+                total += sec;
+                best = std::min(best, sec);
+            }
+        }
+        const double per_step = total / (steps ? steps : 1);
+        // untimed: what the reference does after each prove (verify_stark_proof) and what its recursion enforces on the public inputs
+        size_t verified = 0, ok = 0;
+        const auto tv = std::chrono::steady_clock::now();
+        std::vector<std::future<int>> checks;
+        for (const SignatureProofs& s : proofs)
+            for (const starkhip_driver::Proof* p : {&s.pp1, &s.ml1, &s.pp2, &s.ml2, &s.fp12_mul, &s.final_exp})
+                checks.push_back(std::async(std::launch::async, [p] { return starkhip_verify(p->air, &p->config, p->words.data(), p->words.size()); }));
+        for (auto& c : checks) verified += c.get() == STARKHIP_OK;
+        for (size_t i = 0; i < proofs.size(); i++) ok += proofs[i].valid && proofs[i].linked && starkhip_driver::statement_holds(proofs[i], sigs[i]);
+        if (timeline) {
+            double t0 = 1e300;
+            for (const SignatureProofs& s : proofs)
+                for (const starkhip_driver::Proof* p : {&s.pp1, &s.ml1, &s.pp2, &s.ml2, &s.fp12_mul, &s.final_exp}) t0 = std::min(t0, p->info.t_submit);
+            static const char* names[] = {"pp1", "ml1", "pp2", "ml2", "fp12_mul", "final_exp"};
+            for (size_t i = 0; i < proofs.size(); i++) {
+                const starkhip_driver::Proof* ps[] = {&proofs[i].pp1, &proofs[i].ml1, &proofs[i].pp2, &proofs[i].ml2, &proofs[i].fp12_mul, &proofs[i].final_exp};
+                for (int k = 0; k < 6; k++) {
+                    const starkhip_ticket_info_t& f = ps[k]->info;
+                    fprintf(stderr, "%zu:%-9s submit %7.1f gen %7.1f..%7.1f prove %7.1f..%7.1f | lde %5.1f merkle %6.1f quot %5.1f fri_comb %5.1f total %6.1f\n", i, names[k],
+                            (f.t_submit - t0) * 1e3, (f.t_generate_start - t0) * 1e3, (f.t_generate_end - t0) * 1e3, (f.t_prove_start - t0) * 1e3,
+                            (f.t_done - t0) * 1e3, f.phase_ms[1], f.phase_ms[2], f.phase_ms[3], f.phase_ms[6], f.phase_ms[10]);
+                }
+            }
+        }
+        const starkhip_pool_stats_t st = pool.stats();
+        printf("{\"metric\": \"BLS signature checks/s, end to end from compiled host code (operands -> natives -> trace generation -> 6 STARK proofs each)\", "
+               "\"value\": %.4f, \"unit\": \"signatures/s\", \"batch\": %zu, \"steps\": %zu, \"warmup\": %zu, \"ms_per_step\": %.1f, \"best_ms\": %.1f, "
+               "\"proofs_per_step\": %zu, \"proofs_verified_after_timing\": %zu, \"verify_s\": %.2f, \"signatures_valid_linked_bound\": %zu, "
+               "\"commit_launches\": {\"big\": %lu, \"small_merged\": %lu, \"small_requests\": %lu, \"max_merged\": %lu}, \"operands\": \"%s\"}\n",
+               batch / per_step, batch, steps, warmup, per_step * 1e3, best * 1e3, 6 * batch, verified, seconds_since(tv), ok, st.big_commit_launches,
+               st.small_commit_launches, st.small_commit_requests, st.max_merged_commitments, operands ? operands : "reference vector (src/native.rs:1480-1498)");
+        return verified == 6 * batch && ok == batch ? 0 : 1;
     } catch (const std::exception& e) {
         fprintf(stderr, "signature_demo: %s\n", e.what());
         return 2;
