@@ -86,6 +86,33 @@ pub struct starkhip_proof_layout_t {
     pub step_sibling_count: [usize; 16],
 }
 
+/// `starkhip_pool_config_t` (0 = the library's default).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct starkhip_pool_config_t {
+    pub device: c_int,
+    pub big_contexts: c_uint,
+    pub small_contexts: c_uint,
+    pub generator_threads: c_uint,
+    pub trace_threads: c_uint,
+    pub commit_policy: c_uint,
+    pub stream_priority: c_uint,
+    pub gather_ms: f32,
+}
+
+/// `starkhip_ticket_info_t`: phase times of a pool proof and the job's timeline (seconds since the pool was created).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct starkhip_ticket_info_t {
+    pub phase_ms: [f32; 11],
+    pub kernel_ms: [f32; 3],
+    pub t_submit: f64,
+    pub t_generate_start: f64,
+    pub t_generate_end: f64,
+    pub t_prove_start: f64,
+    pub t_done: f64,
+}
+
 extern "C" {
     pub fn starkhip_config_standard_fast(cfg: *mut starkhip_config_t);
     pub fn starkhip_config_for_air(air: Air, cfg: *mut starkhip_config_t) -> c_int;
@@ -117,6 +144,17 @@ extern "C" {
     pub fn starkhip_trace_log_info(log: *const c_void, n_rows: *mut usize, n_cols: *mut usize, n_records: *mut usize, n_words: *mut usize) -> c_int;
     pub fn starkhip_prove_compact(ctx: *mut c_void, air: Air, cfg: *const starkhip_config_t, log: *const c_void, public_inputs: *const u64,
                                   n_pis: usize, pow_witness: u64, proof: *mut *mut u64, proof_words: *mut usize) -> c_int;
+
+    pub fn starkhip_pool_create(cfg: *const starkhip_pool_config_t, pool: *mut *mut c_void) -> c_int;
+    pub fn starkhip_pool_destroy(pool: *mut c_void);
+    pub fn starkhip_pool_submit(pool: *mut c_void, air: Air, cfg: *const starkhip_config_t, trace: *const u64, n_rows: usize, n_cols: usize,
+                                trace_layout: c_int, trace_on_device: c_int, public_inputs: *const u64, n_pis: usize, pow_witness: u64,
+                                ticket: *mut u64) -> c_int;
+    pub fn starkhip_pool_submit_compact(pool: *mut c_void, air: Air, cfg: *const starkhip_config_t, log: *const c_void, public_inputs: *const u64,
+                                        n_pis: usize, pow_witness: u64, ticket: *mut u64) -> c_int;
+    pub fn starkhip_pool_submit_witness(pool: *mut c_void, air: Air, cfg: *const starkhip_config_t, operands: *const u32, n_limbs: usize,
+                                        pow_witness: u64, ticket: *mut u64) -> c_int;
+    pub fn starkhip_pool_wait(pool: *mut c_void, ticket: u64, proof: *mut *mut u64, proof_words: *mut usize, info: *mut starkhip_ticket_info_t) -> c_int;
 
     pub fn starkhip_last_timings(ctx: *mut c_void, ms: *mut f32) -> c_int;
     pub fn starkhip_host_alloc(ctx: *mut c_void, bytes: usize, out: *mut *mut c_void) -> c_int;
@@ -273,6 +311,53 @@ impl Prover {
     }
 }
 
+/// The library's proof pool (`starkhip_pool_*`): what replaces the six back-to-back `prove` calls of
+/// `generate_aggregate_proof` (src/aggregate_proof.rs:304-370).  `submit_*` returns at once with a ticket; the proofs of one
+/// signature -- or of many -- are in flight together, traces are generated on the pool's threads, and the library decides
+/// which Merkle commitments share a launch.
+pub struct Pool {
+    pool: *mut c_void,
+}
+unsafe impl Send for Pool {}
+unsafe impl Sync for Pool {} // submit / wait are thread-safe
+impl Drop for Pool {
+    fn drop(&mut self) {
+        unsafe { starkhip_pool_destroy(self.pool) }
+    }
+}
+pub struct Ticket(pub Air, pub u64);
+
+impl Pool {
+    pub fn new(cfg: &starkhip_pool_config_t) -> Result<Pool, Error> {
+        let mut pool = std::ptr::null_mut();
+        check(unsafe { starkhip_pool_create(cfg, &mut pool) })?;
+        Ok(Pool { pool })
+    }
+    /// generate_trace + prove of one of the reference's drivers (src/aggregate_proof.rs:23-179) from its operands as u32 limbs,
+    /// packed as `starkhip.h` says (e.g. MillerLoop: px, py, qx, qy, qz).
+    pub fn submit(&self, air: Air, operands: &[u32]) -> Result<Ticket, Error> {
+        let mut t = 0u64;
+        check(unsafe { starkhip_pool_submit_witness(self.pool, air, std::ptr::null(), operands.as_ptr(), operands.len(), STARKHIP_POW_SEARCH, &mut t) })?;
+        Ok(Ticket(air, t))
+    }
+    /// The reference's own generator stays: hand over the rows `generate_trace` returned.  `trace` and `public_inputs` must
+    /// outlive the ticket (they are borrowed until `wait` returns).
+    pub fn submit_rows<'a, const COLUMNS: usize>(&'a self, air: Air, cfg: &Config, trace: &'a [[u64; COLUMNS]], public_inputs: &'a [u64]) -> Result<Ticket, Error> {
+        let mut t = 0u64;
+        check(unsafe {
+            starkhip_pool_submit(self.pool, air, cfg, trace.as_ptr() as *const u64, trace.len(), COLUMNS, 0, 0, public_inputs.as_ptr(),
+                                 public_inputs.len(), STARKHIP_POW_SEARCH, &mut t)
+        })?;
+        Ok(Ticket(air, t))
+    }
+    /// Blocks until the proof is done; the `Err` is what `prove` would have returned.
+    pub fn wait(&self, ticket: Ticket) -> Result<Proof, Error> {
+        let (mut p, mut w) = (std::ptr::null_mut::<u64>(), 0usize);
+        check(unsafe { starkhip_pool_wait(self.pool, ticket.1, &mut p, &mut w, std::ptr::null_mut()) })?;
+        Ok(unsafe { Prover::take(p, w) })
+    }
+}
+
 /// `verify_stark_proof(stark, proof, &config)` (CPU).
 pub fn verify(air: Air, cfg: &Config, proof: &Proof) -> Result<(), Error> {
     check(unsafe { starkhip_verify(air, cfg, proof.0.as_ptr(), proof.0.len()) })
@@ -292,4 +377,89 @@ fn _abi_sizes() {
     // the header's structs are plain C: eight u32 / 27 + 48 size_t
     let _ = [(); 32][std::mem::size_of::<starkhip_config_t>() - 32];
     let _: c_uint = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ hand-off to the recursion
+/// `StarkProofWithPublicInputs<F, C, D>` filled FIELD BY FIELD from the blob, for
+/// `starky::recursive_verifier::set_stark_proof_with_pis_target` in `recursive_proof` (src/aggregate_proof.rs:435-439) -- no
+/// serde names involved.  Compiled only with `--features plonky2` next to the reference's own plonky2 / starky git dependencies
+/// (Cargo.toml of the reference, :9-10); this repository's image has neither the crates nor a Rust toolchain, so the struct and
+/// field names below are restated from memory of starky 0.1.x @ 666f3151 and are UNPINNED (COMPAT.md section 6.2): a maintainer
+/// compiles this module once against the real crates and fixes whatever name differs -- the offsets come from
+/// `starkhip_proof_layout` and do not depend on names.
+#[cfg(feature = "plonky2")]
+pub mod handoff {
+    use super::{Error, Proof};
+    use plonky2::field::extension::quadratic::QuadraticExtension;
+    use plonky2::field::goldilocks_field::GoldilocksField;
+    use plonky2::field::polynomial::PolynomialCoeffs;
+    use plonky2::field::types::Field;
+    use plonky2::fri::proof::{FriInitialTreeProof, FriProof, FriQueryRound, FriQueryStep};
+    use plonky2::hash::hash_types::HashOut;
+    use plonky2::hash::merkle_proofs::MerkleProof;
+    use plonky2::hash::merkle_tree::MerkleCap;
+    use plonky2::hash::poseidon::PoseidonHash;
+    use plonky2::plonk::config::PoseidonGoldilocksConfig;
+    use starky::proof::{StarkOpeningSet, StarkProof, StarkProofWithPublicInputs};
+
+    type F = GoldilocksField;
+    type FE = QuadraticExtension<F>;
+    type C = PoseidonGoldilocksConfig;
+    const D: usize = 2;
+
+    fn f(w: u64) -> F { F::from_canonical_u64(w) }
+    fn ext(w: &[u64]) -> FE { FE::from_basefield_array([f(w[0]), f(w[1])]) }
+    fn exts(w: &[u64]) -> Vec<FE> { w.chunks_exact(2).map(ext).collect() }
+    fn hash(w: &[u64]) -> HashOut<F> { HashOut { elements: [f(w[0]), f(w[1]), f(w[2]), f(w[3])] } }
+    fn cap(w: &[u64]) -> MerkleCap<F, PoseidonHash> { MerkleCap(w.chunks_exact(4).map(hash).collect()) }
+    fn path(w: &[u64]) -> MerkleProof<F, PoseidonHash> { MerkleProof { siblings: w.chunks_exact(4).map(hash).collect() } }
+
+    pub fn stark_proof_with_public_inputs(proof: &Proof) -> Result<StarkProofWithPublicInputs<F, C, D>, Error> {
+        let l = proof.layout()?;
+        let b = &proof.0[..];
+        let ncap = 4usize << l.cap_height; // words per cap
+        let openings = StarkOpeningSet {
+            local_values: exts(&b[l.off_local_values..l.off_local_values + 2 * l.n_columns]),
+            next_values: exts(&b[l.off_next_values..l.off_next_values + 2 * l.n_columns]),
+            permutation_zs: None,       // none of the five AIRs uses permutation arguments
+            permutation_zs_next: None,
+            quotient_polys: exts(&b[l.off_quotient_openings..l.off_quotient_openings + 2 * l.n_quotient_polys]),
+        };
+        let commit_phase_merkle_caps = (0..l.n_fri_layers).map(|i| cap(&b[l.off_fri_caps + i * ncap..l.off_fri_caps + (i + 1) * ncap])).collect();
+        let query_round_proofs = (0..l.n_query_rounds)
+            .map(|r| {
+                let q = &b[l.off_query_rounds + r * l.query_round_words..l.off_query_rounds + (r + 1) * l.query_round_words];
+                let d0 = 4 * l.initial_sibling_count;
+                // oracle 0 = trace, oracle 1 = quotient polynomials (the order PolynomialBatch commitments are passed to prove_openings)
+                let evals_proofs = vec![
+                    (q[l.q_trace_leaf..l.q_trace_leaf + l.n_columns].iter().map(|&w| f(w)).collect(), path(&q[l.q_trace_siblings..l.q_trace_siblings + d0])),
+                    (q[l.q_quotient_leaf..l.q_quotient_leaf + l.n_quotient_polys].iter().map(|&w| f(w)).collect(),
+                     path(&q[l.q_quotient_siblings..l.q_quotient_siblings + d0])),
+                ];
+                let steps = (0..l.n_fri_layers)
+                    .map(|s| FriQueryStep {
+                        evals: exts(&q[l.q_step_evals[s]..l.q_step_evals[s] + (2usize << l.arity_bits)]),
+                        merkle_proof: path(&q[l.q_step_siblings[s]..l.q_step_siblings[s] + 4 * l.step_sibling_count[s]]),
+                    })
+                    .collect();
+                FriQueryRound { initial_trees_proof: FriInitialTreeProof { evals_proofs }, steps }
+            })
+            .collect();
+        let opening_proof = FriProof {
+            commit_phase_merkle_caps,
+            query_round_proofs,
+            final_poly: PolynomialCoeffs::new(exts(&b[l.off_final_poly..l.off_final_poly + 2 * l.final_poly_len])),
+            pow_witness: f(b[l.off_pow_witness]),
+        };
+        Ok(StarkProofWithPublicInputs {
+            proof: StarkProof {
+                trace_cap: cap(&b[l.off_trace_cap..l.off_trace_cap + ncap]),
+                permutation_zs_cap: None,
+                quotient_polys_cap: cap(&b[l.off_quotient_cap..l.off_quotient_cap + ncap]),
+                openings,
+                opening_proof,
+            },
+            public_inputs: b[l.off_public_inputs..l.off_public_inputs + l.n_public_inputs].iter().map(|&w| f(w)).collect(),
+        })
+    }
 }

@@ -162,8 +162,8 @@ int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_
  * proofs in flight are what fills the chip, so the library schedules them itself: a pool owns `big_contexts` prover contexts
  * for the 8192-row AIRs (FinalExp, ECCAgg: ~25 GB of buffers each) and `small_contexts` for the others, one host thread
  * per context, `generator_threads` host threads that record traces (starkhip_pool_submit_witness), and a commitment
- * scheduler: the trace commitments of small proofs that arrive together are hashed by ONE merged launch, and a FinalExp-class
- * commitment (a one-shot grid that owns the chip) never shares the chip with a small one.  Proofs are byte-identical to
+ * scheduler: the trace commitments of small proofs that arrive together are hashed by ONE merged launch (and, by option, a
+ * FinalExp-class commitment -- a one-shot grid that owns the chip -- never shares the chip with a small one).  Proofs are byte-identical to
  * starkhip_prove's.  submit returns at once with a ticket; wait blocks until that proof is done and hands it over
  * (starkhip_free), exactly once per ticket, from any thread.  Inputs of submit / submit_compact (trace, log, public inputs)
  * stay the caller's and must stay valid until the ticket has been waited for; submit_witness copies its operands. */
@@ -171,10 +171,15 @@ typedef struct {
     int device;
     unsigned big_contexts;      /* 0 = default (3) */
     unsigned small_contexts;    /* 0 = default (16) */
-    unsigned generator_threads; /* recordings under way at once; 0 = default (hardware threads / 16, 4 .. 12) */
-    unsigned trace_threads;     /* host threads ONE recording may use; 0 = automatic (idle generator threads are lent to the running ones) */
-    unsigned commit_policy;     /* 0 = default: merged small commitments, classes never overlap; 1 = merged, classes may overlap;
-                                   2 = no commitment scheduling (every context launches its own; for A/B measurements) */
+    unsigned generator_threads; /* recordings under way at once; 0 = default (a quarter of the CPUs the process may use -- its
+                                   cgroup quota or affinity mask --, 3 .. 12) */
+    unsigned trace_threads;     /* host threads ONE recording may use; 0 = automatic (FinalExp-class: 3/4 of the CPU budget, at most 16;
+                                   the others at most 4) */
+    unsigned commit_policy;     /* 0 = default: small commitments that arrive together share one launch; 1 = in addition a FinalExp-class
+                                   commitment never shares the chip with a small one; 2 = no commitment scheduling (every context
+                                   launches its own; for A/B measurements) */
+    unsigned stream_priority;   /* 0 = all contexts alike; 1 = FinalExp-class contexts (and their commitments) on high-priority streams;
+                                   2 = the small contexts */
     float gather_ms;            /* how long a merged launch waits for small proofs that have started but not reached their commitment; 0 = default (25) */
 } starkhip_pool_config_t;
 typedef struct {

@@ -8,7 +8,7 @@
 namespace starkhip {
 
 struct Ctx;
-int ctx_create(int device, Ctx** out);
+int ctx_create(int device, Ctx** out, int priority = 0);
 void ctx_destroy(Ctx* c);
 const float* ctx_timings(Ctx* c);
 const float* ctx_kernel_timings(Ctx* c);

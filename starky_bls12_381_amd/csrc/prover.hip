@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -89,22 +90,31 @@ struct Ctx {
     // tuning (starkhip_set_option; defaults are the measured best)
     long opt_quotient_impl = 0;   // 0: tiled evaluator (quotient_plan.h), 1: op-stream interpreter (quotient_ops.h)
     long opt_quotient_waves = 65536, opt_quotient_slots = 0, opt_quotient_chunks = 0, opt_quotient_debug = 0;
-    // shape-dependent tables
-    int tab_log_n = -1, tab_rate = -1, tab_qdb = -1;
-    DevBuf tw_fwd, tw_inv, coset_scale, qtab, qshift_inv;
-    DevBuf lde2_fwd, lde2_inv, lde2_cs, lde2_oh;  // kernels_lde.hip tables (log_n >= 8)
+    // Shape-dependent tables and the per-AIR constraint plan are CACHED per context: a pooled context that alternates between
+    // AIRs (a PairingPrecomp proof, then an FP12Mul one) finds both again instead of rebuilding the plan on the host and
+    // re-allocating device buffers -- hipFree synchronises the whole device, i.e. waits for every other proof's kernels.
+    struct Tables {
+        int log_n = -1, rate = -1, qdb = -1;
+        DevBuf tw_fwd, tw_inv, coset_scale, qtab, qshift_inv;
+        DevBuf lde2_fwd, lde2_inv, lde2_cs, lde2_oh;  // kernels_lde.hip tables (log_n >= 8)
+    };
+    struct PlanDev {  // tiled plan (quotient_plan.h) of one AIR on the device
+        int air = -1;
+        unsigned chunks = 0, want = 0;
+        uint32_t recs = 0;
+        DevBuf q_recs, q_pieces, q_streams, q_chunk_tile_off, q_tile_list, q_contrib_off, q_contribs, q_consts, q_apow;
+    };
+    std::vector<std::unique_ptr<Tables>> table_cache;
+    std::vector<std::unique_ptr<PlanDev>> plan_cache;
+    Tables* tab = nullptr;    // the current shape's (ensure_tables)
+    PlanDev* plan = nullptr;  // the current AIR's (ensure_plan)
     long opt_lde_closed_forms = 1;   // constant / unit-vector columns skip their transforms (kernels_lde.hip); 0: every column is transformed
-    // program
+    // op-stream program (quotient_impl = 1; kept as the cross-check)
     int prog_air = -1;
     unsigned prog_chunks = 0;
     DevBuf d_ops, d_loads, d_chunk_off;  // compile_quotient_ops() + attach_cell_cache() output for prog_air
     unsigned prog_slots = 0;
     std::vector<uint32_t> chunk_k_after;
-    // tiled plan (quotient_plan.h) for plan_air
-    int plan_air = -1;
-    unsigned plan_chunks = 0, plan_want = 0;
-    uint32_t plan_recs = 0;
-    DevBuf q_recs, q_pieces, q_streams, q_chunk_tile_off, q_tile_list, q_contrib_off, q_contribs, q_consts, q_apow;
     // work buffers
     DevBuf staging, values, coeffs, lde, digests, pis, apow, chunk_scale, partial, qvals, qcoef, qlde, qdigests, zpow, gzpow, open_local,
         open_next, open_q, ext_apow, comb_partial, comb_out, fri_coef, fri_vals, fri_rows[16], fri_digests[16], scale_tab, pow_state,
@@ -112,41 +122,57 @@ struct Ctx {
 };
 
 static int ensure_tables(Ctx* c, unsigned log_n, unsigned rate, unsigned qdb) {
-    if (c->tab_log_n == (int)log_n && c->tab_rate == (int)rate && c->tab_qdb == (int)qdb) return 0;
+    for (auto& t : c->table_cache)
+        if (t->log_n == (int)log_n && t->rate == (int)rate && t->qdb == (int)qdb) {
+            c->tab = t.get();
+            return 0;
+        }
+    std::unique_ptr<Ctx::Tables> fresh(new Ctx::Tables());
+    Ctx::Tables* T = fresh.get();
+    struct Release {  // a half-built set of tables is not kept
+        Ctx::Tables* t;
+        ~Release() {
+            if (!t) return;
+            for (DevBuf* b : {&t->tw_fwd, &t->tw_inv, &t->coset_scale, &t->qtab, &t->qshift_inv, &t->lde2_fwd, &t->lde2_inv, &t->lde2_cs, &t->lde2_oh}) b->release();
+        }
+    } guard{T};
     const unsigned log_N = log_n + rate;
     const size_t N = (size_t)1 << log_N, size = (size_t)1 << (log_n + qdb);
-    HIPCHK(c->tw_fwd.ensure(N / 2 * 8 + 8));
-    HIPCHK(c->tw_inv.ensure(N / 2 * 8 + 8));
-    HIPCHK(c->coset_scale.ensure(N * 8));
-    HIPCHK(c->qtab.ensure(4 * size * 8));
-    HIPCHK(c->qshift_inv.ensure(size * 8));
+    HIPCHK(T->tw_fwd.ensure(N / 2 * 8 + 8));
+    HIPCHK(T->tw_inv.ensure(N / 2 * 8 + 8));
+    HIPCHK(T->coset_scale.ensure(N * 8));
+    HIPCHK(T->qtab.ensure(4 * size * 8));
+    HIPCHK(T->qshift_inv.ensure(size * 8));
     gl_t w = gl_root_of_unity(log_N);
-    HIPCHK(launch_fill_powers(c->tw_fwd.as<gl_t>(), 1, w, N / 2, c->st));
-    HIPCHK(launch_fill_powers(c->tw_inv.as<gl_t>(), 1, gl_inv(w), N / 2, c->st));
-    HIPCHK(launch_fill_coset_scale(c->coset_scale.as<gl_t>(), log_n, rate, c->st));
-    HIPCHK(launch_quotient_tables(c->qtab.as<gl_t>(), log_n, qdb, c->st));
-    HIPCHK(launch_fill_powers(c->qshift_inv.as<gl_t>(), 1, gl_inv(GL_GENERATOR), size, c->st));
+    HIPCHK(launch_fill_powers(T->tw_fwd.as<gl_t>(), 1, w, N / 2, c->st));
+    HIPCHK(launch_fill_powers(T->tw_inv.as<gl_t>(), 1, gl_inv(w), N / 2, c->st));
+    HIPCHK(launch_fill_coset_scale(T->coset_scale.as<gl_t>(), log_n, rate, c->st));
+    HIPCHK(launch_quotient_tables(T->qtab.as<gl_t>(), log_n, qdb, c->st));
+    HIPCHK(launch_fill_powers(T->qshift_inv.as<gl_t>(), 1, gl_inv(GL_GENERATOR), size, c->st));
     if (lde_v2_supported(log_n)) {
-        HIPCHK(c->lde2_fwd.ensure(lde_v2_tw_words(log_n) * 8));
-        HIPCHK(c->lde2_inv.ensure(lde_v2_tw_words(log_n) * 8));
-        HIPCHK(c->lde2_cs.ensure(N * 8));
-        HIPCHK(c->lde2_oh.ensure(std::max<size_t>(1, lde_v2_oh_words(log_n, rate)) * 8));
-        HIPCHK(lde_v2_upload_tables(log_n, rate, c->lde2_fwd.as<gl_t>(), c->lde2_inv.as<gl_t>(), c->lde2_cs.as<gl_t>(), c->lde2_oh.as<gl_t>(), c->st));
+        HIPCHK(T->lde2_fwd.ensure(lde_v2_tw_words(log_n) * 8));
+        HIPCHK(T->lde2_inv.ensure(lde_v2_tw_words(log_n) * 8));
+        HIPCHK(T->lde2_cs.ensure(N * 8));
+        HIPCHK(T->lde2_oh.ensure(std::max<size_t>(1, lde_v2_oh_words(log_n, rate)) * 8));
+        HIPCHK(lde_v2_upload_tables(log_n, rate, T->lde2_fwd.as<gl_t>(), T->lde2_inv.as<gl_t>(), T->lde2_cs.as<gl_t>(), T->lde2_oh.as<gl_t>(), c->st));
     }
-    c->tab_log_n = log_n;
-    c->tab_rate = rate;
-    c->tab_qdb = qdb;
+    T->log_n = log_n;
+    T->rate = rate;
+    T->qdb = qdb;
+    guard.t = nullptr;
+    c->table_cache.push_back(std::move(fresh));
+    c->tab = T;
     return 0;
 }
 
 // IFFT + coset LDE of `cols` columns with the tables of ensure_tables(log_n, rate, .)
 static hipError_t run_lde(Ctx* c, const gl_t* values, gl_t* coeffs, gl_t* lde, size_t cols, unsigned log_n, unsigned rate, int from_coeffs) {
     if (lde_v2_supported(log_n))
-        return launch_lde_columns_v2(values, coeffs, lde, cols, log_n, rate, c->lde2_fwd.as<gl_t>(), c->lde2_inv.as<gl_t>(),
-                                     c->lde2_cs.as<gl_t>(), (c->opt_lde_closed_forms && lde_v2_oh_words(log_n, rate)) ? c->lde2_oh.as<gl_t>() : nullptr,
-                                     from_coeffs, c->st);
-    return launch_lde_columns(values, coeffs, lde, cols, log_n, rate, c->tw_fwd.as<gl_t>(), c->tw_inv.as<gl_t>(), log_n + rate,
-                              c->coset_scale.as<gl_t>(), from_coeffs, c->st);
+        return launch_lde_columns_v2(values, coeffs, lde, cols, log_n, rate, c->tab->lde2_fwd.as<gl_t>(), c->tab->lde2_inv.as<gl_t>(),
+                                     c->tab->lde2_cs.as<gl_t>(),
+                                     (c->opt_lde_closed_forms && lde_v2_oh_words(log_n, rate)) ? c->tab->lde2_oh.as<gl_t>() : nullptr, from_coeffs, c->st);
+    return launch_lde_columns(values, coeffs, lde, cols, log_n, rate, c->tab->tw_fwd.as<gl_t>(), c->tab->tw_inv.as<gl_t>(), log_n + rate,
+                              c->tab->coset_scale.as<gl_t>(), from_coeffs, c->st);
 }
 
 static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
@@ -182,29 +208,45 @@ static int ensure_plan(Ctx* c, const AirInfo& air, size_t quotient_points) {
     const size_t blocks = (quotient_points + 63) / 64;
     unsigned want = (unsigned)std::min<size_t>(512, std::max<size_t>(1, (8192 + blocks - 1) / blocks));  // FinalExp: 4 chunks 29.8 ms, 8: 29.4, 16: 29.0, 32: 28.9
     if (c->opt_quotient_chunks > 0) want = (unsigned)c->opt_quotient_chunks;
-    if (c->plan_air == air.id && c->plan_want == want) return 0;
+    for (auto& pd : c->plan_cache)
+        if (pd->air == air.id && pd->want == want) {
+            c->plan = pd.get();
+            return 0;
+        }
     const QTPlan Q = build_quotient_plan(air.prog, want);
+    std::unique_ptr<Ctx::PlanDev> fresh(new Ctx::PlanDev());
+    Ctx::PlanDev* D = fresh.get();
+    struct Release {
+        Ctx::PlanDev* d;
+        ~Release() {
+            if (!d) return;
+            for (DevBuf* b : {&d->q_recs, &d->q_pieces, &d->q_streams, &d->q_chunk_tile_off, &d->q_tile_list, &d->q_contrib_off, &d->q_contribs, &d->q_consts, &d->q_apow}) b->release();
+        }
+    } guard{D};
     struct Up { DevBuf* b; const void* src; size_t bytes; };
     const std::vector<gl_t>& consts = air.prog.consts;
     const gl_t zero = 0;
-    const Up ups[] = {{&c->q_recs, Q.recs.data(), Q.recs.size() * sizeof(QTRec)},
-                      {&c->q_pieces, Q.pieces.data(), Q.pieces.size() * sizeof(QTPiece)},
-                      {&c->q_streams, Q.streams.data(), Q.streams.size() * sizeof(QTStream)},
-                      {&c->q_chunk_tile_off, Q.chunk_tile_off.data(), Q.chunk_tile_off.size() * 4},
-                      {&c->q_tile_list, Q.tile_list.empty() ? (const void*)&zero : (const void*)Q.tile_list.data(), std::max<size_t>(1, Q.tile_list.size()) * 4},
-                      {&c->q_contrib_off, Q.contrib_off.data(), Q.contrib_off.size() * 4},
-                      {&c->q_contribs, Q.contribs.empty() ? (const void*)&zero : (const void*)Q.contribs.data(), std::max<size_t>(1, Q.contribs.size()) * sizeof(QTContrib)},
-                      {&c->q_consts, consts.empty() ? (const void*)&zero : (const void*)consts.data(), std::max<size_t>(1, consts.size()) * 8}};
+    const Up ups[] = {{&D->q_recs, Q.recs.data(), Q.recs.size() * sizeof(QTRec)},
+                      {&D->q_pieces, Q.pieces.data(), Q.pieces.size() * sizeof(QTPiece)},
+                      {&D->q_streams, Q.streams.data(), Q.streams.size() * sizeof(QTStream)},
+                      {&D->q_chunk_tile_off, Q.chunk_tile_off.data(), Q.chunk_tile_off.size() * 4},
+                      {&D->q_tile_list, Q.tile_list.empty() ? (const void*)&zero : (const void*)Q.tile_list.data(), std::max<size_t>(1, Q.tile_list.size()) * 4},
+                      {&D->q_contrib_off, Q.contrib_off.data(), Q.contrib_off.size() * 4},
+                      {&D->q_contribs, Q.contribs.empty() ? (const void*)&zero : (const void*)Q.contribs.data(), std::max<size_t>(1, Q.contribs.size()) * sizeof(QTContrib)},
+                      {&D->q_consts, consts.empty() ? (const void*)&zero : (const void*)consts.data(), std::max<size_t>(1, consts.size()) * 8}};
     for (const Up& u : ups) {
         HIPCHK(u.b->ensure(u.bytes));
         HIPCHK(hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, c->st));
     }
-    HIPCHK(c->q_apow.ensure(std::max<size_t>(1, air.prog.n_constraints) * 16));
+    HIPCHK(D->q_apow.ensure(std::max<size_t>(1, air.prog.n_constraints) * 16));
     HIPCHK(hipStreamSynchronize(c->st));  // Q goes out of scope
-    c->plan_air = air.id;
-    c->plan_want = want;
-    c->plan_chunks = Q.n_chunks;
-    c->plan_recs = (uint32_t)Q.recs.size();
+    D->air = air.id;
+    D->want = want;
+    D->chunks = Q.n_chunks;
+    D->recs = (uint32_t)Q.recs.size();
+    guard.d = nullptr;
+    c->plan_cache.push_back(std::move(fresh));
+    c->plan = D;
     return 0;
 }
 
@@ -212,16 +254,28 @@ static int ensure_plan(Ctx* c, const AirInfo& air, size_t quotient_points) {
 static inline size_t level_off(size_t n_leaves, unsigned l) { return 2 * n_leaves - (2 * n_leaves >> l); }
 static inline size_t digest_words(size_t n_leaves) { return 8 * n_leaves; }
 
-int ctx_create(int device, Ctx** out) {
+int ctx_create(int device, Ctx** out, int priority) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return STARKHIP_ERR_NO_DEVICE;
     if (device < 0 || device >= count) return STARKHIP_ERR_NO_DEVICE;
     HIPCHK(hipSetDevice(device));
+    // A host thread that waits for its stream SLEEPS (interrupt-driven wait) instead of spinning: with several proofs in flight
+    // every context has a thread in hipStreamSynchronize most of the time, and spinning ones eat the CPUs -- in a container with
+    // a CPU quota, the quota -- that trace generation and the Fiat-Shamir hashing of the other proofs need.  Best effort: the
+    // flag cannot be changed once another library has activated the device.
+    if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
     Ctx* c = new Ctx();
     c->device = device;
     for (auto& e : c->ev) e = nullptr;
     for (auto& e : c->kev) e = nullptr;
-    bool ok = hipStreamCreate(&c->st) == hipSuccess;
+    bool ok;
+    if (priority) {  // +1: the highest stream priority of the device, -1: the lowest (pooled contexts, starkhip_pool_config_t)
+        int least = 0, greatest = 0;
+        ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+             hipStreamCreateWithPriority(&c->st, hipStreamDefault, priority > 0 ? greatest : least) == hipSuccess;
+    } else {
+        ok = hipStreamCreate(&c->st) == hipSuccess;
+    }
     for (auto& e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     for (auto& e : c->kev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->hash_ready, hipEventDisableTiming) == hipSuccess;
@@ -245,8 +299,11 @@ void ctx_destroy(Ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
-    DevBuf* bufs[] = {&c->tw_fwd, &c->tw_inv, &c->coset_scale, &c->qtab, &c->qshift_inv, &c->lde2_fwd, &c->lde2_inv, &c->lde2_cs, &c->lde2_oh, &c->d_ops, &c->d_loads, &c->d_chunk_off, &c->q_recs, &c->q_pieces, &c->q_streams, &c->q_chunk_tile_off, &c->q_tile_list,
-                      &c->q_contrib_off, &c->q_contribs, &c->q_consts, &c->q_apow, &c->staging,
+    for (auto& t : c->table_cache)
+        for (DevBuf* b : {&t->tw_fwd, &t->tw_inv, &t->coset_scale, &t->qtab, &t->qshift_inv, &t->lde2_fwd, &t->lde2_inv, &t->lde2_cs, &t->lde2_oh}) b->release();
+    for (auto& d : c->plan_cache)
+        for (DevBuf* b : {&d->q_recs, &d->q_pieces, &d->q_streams, &d->q_chunk_tile_off, &d->q_tile_list, &d->q_contrib_off, &d->q_contribs, &d->q_consts, &d->q_apow}) b->release();
+    DevBuf* bufs[] = {&c->d_ops, &c->d_loads, &c->d_chunk_off, &c->staging,
                       &c->values, &c->coeffs, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial, &c->qvals, &c->qcoef,
                       &c->qlde, &c->qdigests, &c->zpow, &c->gzpow, &c->open_local, &c->open_next, &c->open_q, &c->ext_apow, &c->comb_partial,
                       &c->comb_out, &c->fri_coef, &c->fri_vals, &c->scale_tab, &c->pow_state, &c->pow_best, &c->qidx, &c->gather_t,
@@ -278,7 +335,7 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
     else if (k == "quotient_debug" && value >= 0 && value <= 9) c->opt_quotient_debug = value;
 #endif
     else if (k == "lde_closed_forms" && (value == 0 || value == 1)) c->opt_lde_closed_forms = value;
-    else if (k == "quotient_chunks" && value >= 0 && value <= 4096) { c->opt_quotient_chunks = value; c->plan_air = -1; }
+    else if (k == "quotient_chunks" && value >= 0 && value <= 4096) c->opt_quotient_chunks = value;  // plans are cached by (AIR, chunks)
     else return STARKHIP_ERR_BAD_SHAPE;
     return STARKHIP_OK;
 }
@@ -318,7 +375,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     if ((rc = ensure_tables(c, log_n, r, qdb))) return rc;
     const bool tiled = c->opt_quotient_impl == 0;
     if ((rc = tiled ? ensure_plan(c, air, size) : ensure_program(c, air, size))) return rc;
-    const unsigned n_chunks = tiled ? c->plan_chunks : c->prog_chunks;
+    const unsigned n_chunks = tiled ? c->plan->chunks : c->prog_chunks;
 
     // ---- buffers
     HIPCHK(c->coeffs.ensure(C * n * 8));
@@ -436,14 +493,14 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         if (n_pis) HIPCHK(hipMemcpyAsync(c->pis.p, pis_host, n_pis * 8, hipMemcpyHostToDevice, st));
         if (tiled) {
             // per-proof weights of the plan's records, then one pass over the LDE in LDS-staged column tiles
-            HIPCHK(launch_quotient_weights(c->q_recs.as<QTRec>(), c->q_contrib_off.as<uint32_t>(), c->q_contribs.as<QTContrib>(), c->plan_recs,
-                                           c->q_apow.as<gl_t>(), P.n_constraints, c->q_consts.as<gl_t>(), c->pis.as<gl_t>(), alphas[0], alphas[1], st));
+            HIPCHK(launch_quotient_weights(c->plan->q_recs.as<QTRec>(), c->plan->q_contrib_off.as<uint32_t>(), c->plan->q_contribs.as<QTContrib>(), c->plan->recs,
+                                           c->plan->q_apow.as<gl_t>(), P.n_constraints, c->plan->q_consts.as<gl_t>(), c->pis.as<gl_t>(), alphas[0], alphas[1], st));
             HIPCHK(hipEventRecord(c->kev[2], st));
-            HIPCHK(launch_quotient_tiles(c->q_recs.as<QTRec>(), c->q_pieces.as<QTPiece>(), c->q_streams.as<QTStream>(),
-                                         c->q_chunk_tile_off.as<uint32_t>(), c->q_tile_list.as<uint32_t>(), n_chunks, c->lde.as<gl_t>(),
-                                         c->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, (unsigned)((c->opt_quotient_debug <= 4 || c->opt_quotient_debug == 8) ? c->opt_quotient_debug : 0), st));
+            HIPCHK(launch_quotient_tiles(c->plan->q_recs.as<QTRec>(), c->plan->q_pieces.as<QTPiece>(), c->plan->q_streams.as<QTStream>(),
+                                         c->plan->q_chunk_tile_off.as<uint32_t>(), c->plan->q_tile_list.as<uint32_t>(), n_chunks, c->lde.as<gl_t>(),
+                                         c->tab->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, (unsigned)((c->opt_quotient_debug <= 4 || c->opt_quotient_debug == 8) ? c->opt_quotient_debug : 0), st));
             HIPCHK(hipEventRecord(c->kev[3], st));
-            HIPCHK(launch_quotient_tiles_combine(c->partial.as<gl_t>(), n_chunks, c->qtab.as<gl_t>(), log_n, qdb, c->qvals.as<gl_t>(), st));
+            HIPCHK(launch_quotient_tiles_combine(c->partial.as<gl_t>(), n_chunks, c->tab->qtab.as<gl_t>(), log_n, qdb, c->qvals.as<gl_t>(), st));
         } else {
             std::vector<gl_t> apow(2 * (AIR_MAX_GROUP + 1)), cscale(2 * n_chunks);
             for (int j = 0; j < 2; j++) {
@@ -455,10 +512,10 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             HIPCHK(hipMemcpyAsync(c->chunk_scale.p, cscale.data(), cscale.size() * 8, hipMemcpyHostToDevice, st));
             HIPCHK(hipEventRecord(c->kev[2], st));
             HIPCHK(launch_quotient_eval(c->d_ops.as<QOp>(), c->d_loads.as<uint32_t>(), c->prog_slots, c->d_chunk_off.as<uint32_t>(), n_chunks,
-                                        c->pis.as<gl_t>(), c->lde.as<gl_t>(), c->qtab.as<gl_t>(), c->apow.as<gl_t>(), alphas[0], alphas[1],
+                                        c->pis.as<gl_t>(), c->lde.as<gl_t>(), c->tab->qtab.as<gl_t>(), c->apow.as<gl_t>(), alphas[0], alphas[1],
                                         c->partial.as<gl_t>(), log_n, r, qdb, st));
             HIPCHK(hipEventRecord(c->kev[3], st));
-            HIPCHK(launch_quotient_combine(c->partial.as<gl_t>(), c->chunk_scale.as<gl_t>(), n_chunks, c->qtab.as<gl_t>(), log_n, qdb,
+            HIPCHK(launch_quotient_combine(c->partial.as<gl_t>(), c->chunk_scale.as<gl_t>(), n_chunks, c->tab->qtab.as<gl_t>(), log_n, qdb,
                                            c->qvals.as<gl_t>(), st));
             HIPCHK(hipStreamSynchronize(st));  // apow / cscale go out of scope
         }
@@ -468,13 +525,13 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             if ((rc2 = ensure_plan(c, air, size))) return rc2;
             std::vector<gl_t> ref(2 * size), got(2 * size);
             HIPCHK(hipMemcpyAsync(ref.data(), c->qvals.p, 2 * size * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(c->partial.ensure((size_t)std::max(n_chunks, c->plan_chunks) * 2 * size * 8));
-            HIPCHK(launch_quotient_weights(c->q_recs.as<QTRec>(), c->q_contrib_off.as<uint32_t>(), c->q_contribs.as<QTContrib>(), c->plan_recs,
-                                           c->q_apow.as<gl_t>(), P.n_constraints, c->q_consts.as<gl_t>(), c->pis.as<gl_t>(), alphas[0], alphas[1], st));
-            HIPCHK(launch_quotient_tiles(c->q_recs.as<QTRec>(), c->q_pieces.as<QTPiece>(), c->q_streams.as<QTStream>(),
-                                         c->q_chunk_tile_off.as<uint32_t>(), c->q_tile_list.as<uint32_t>(), c->plan_chunks, c->lde.as<gl_t>(),
-                                         c->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, 0, st));
-            HIPCHK(launch_quotient_tiles_combine(c->partial.as<gl_t>(), c->plan_chunks, c->qtab.as<gl_t>(), log_n, qdb, c->comb_partial.as<gl_t>(), st));
+            HIPCHK(c->partial.ensure((size_t)std::max(n_chunks, c->plan->chunks) * 2 * size * 8));
+            HIPCHK(launch_quotient_weights(c->plan->q_recs.as<QTRec>(), c->plan->q_contrib_off.as<uint32_t>(), c->plan->q_contribs.as<QTContrib>(), c->plan->recs,
+                                           c->plan->q_apow.as<gl_t>(), P.n_constraints, c->plan->q_consts.as<gl_t>(), c->pis.as<gl_t>(), alphas[0], alphas[1], st));
+            HIPCHK(launch_quotient_tiles(c->plan->q_recs.as<QTRec>(), c->plan->q_pieces.as<QTPiece>(), c->plan->q_streams.as<QTStream>(),
+                                         c->plan->q_chunk_tile_off.as<uint32_t>(), c->plan->q_tile_list.as<uint32_t>(), c->plan->chunks, c->lde.as<gl_t>(),
+                                         c->tab->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, 0, st));
+            HIPCHK(launch_quotient_tiles_combine(c->partial.as<gl_t>(), c->plan->chunks, c->tab->qtab.as<gl_t>(), log_n, qdb, c->comb_partial.as<gl_t>(), st));
             HIPCHK(hipMemcpyAsync(got.data(), c->comb_partial.p, 2 * size * 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             size_t bad = 0;
@@ -489,7 +546,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             fprintf(stderr, "quotient compare: %zu of %zu values differ\n", bad, 2 * size);
         }
         // coset_ifft(7): inverse transform, scale by size^-1 and by 7^-i
-        HIPCHK(launch_ntt_global(c->qvals.as<gl_t>(), 2, size, log_n + qdb, c->tw_inv.as<gl_t>(), log_N, nullptr, c->qshift_inv.as<gl_t>(),
+        HIPCHK(launch_ntt_global(c->qvals.as<gl_t>(), 2, size, log_n + qdb, c->tab->tw_inv.as<gl_t>(), log_N, nullptr, c->tab->qshift_inv.as<gl_t>(),
                                  gl_inv((gl_t)size), st));
         // trim_to_len(n * factor) must succeed, then chunks of n: [alpha0: c0..cf-1, alpha1: c0..cf-1]
         std::vector<gl_t> tail;
@@ -584,7 +641,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             HIPCHK(hipMemcpyAsync(vals, coef, len * 8, hipMemcpyDeviceToDevice, st));
             HIPCHK(hipMemcpyAsync(vals + len, coef + len, len * 8, hipMemcpyDeviceToDevice, st));
             HIPCHK(launch_fill_powers(c->scale_tab.as<gl_t>(), 1, shift, len, st));
-            HIPCHK(launch_ntt_global(vals, 2, len, log_len, c->tw_fwd.as<gl_t>(), log_N, c->scale_tab.as<gl_t>(), nullptr, 1, st));
+            HIPCHK(launch_ntt_global(vals, 2, len, log_len, c->tab->tw_fwd.as<gl_t>(), log_N, c->scale_tab.as<gl_t>(), nullptr, 1, st));
             const unsigned ab = geo.arities[l];
             const size_t n_leaves = len >> ab, width = 2 << ab;
             HIPCHK(c->fri_rows[l].ensure(len * 2 * 8));

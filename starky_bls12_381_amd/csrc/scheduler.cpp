@@ -5,6 +5,9 @@
 // traces (trace_log.h), one host thread per prover context proves them, and a caller only submits and waits.
 #include "scheduler.h"
 
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -20,10 +23,33 @@
 
 namespace starkhip {
 
+// CPUs this process may actually use: the cgroup's quota where there is one (a container that sees 256 hardware threads may be
+// entitled to 16 of them -- threads beyond the quota are not slower, they are THROTTLED, kernel launches included), else the
+// affinity mask.
+unsigned cpu_budget() {
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) hw = std::max(1, CPU_COUNT(&set));
+    double quota = 0, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char q[64];
+        if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+        fclose(f);
+    } else {
+        FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+        FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (fq && fp && fscanf(fq, "%lf", &quota) == 1 && fscanf(fp, "%lf", &period) == 1 && quota <= 0) quota = 0;
+        if (fq) fclose(fq);
+        if (fp) fclose(fp);
+    }
+    if (quota > 0 && period > 0) hw = std::min(hw, std::max(1u, (unsigned)(quota / period + 0.5)));
+    return hw;
+}
+
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ------------------------------------------------------------------------------------------------ HashService
-HashService::HashService(int device) : device_(device) { th_ = std::thread([this] { run(); }); }
+HashService::HashService(int device, int big_priority) : device_(device), big_priority_(big_priority) { th_ = std::thread([this] { run(); }); }
 
 HashService::~HashService() {
     {
@@ -142,7 +168,12 @@ void HashService::launch_small(std::vector<Req*>& reqs) {
 
 void HashService::run() {
     (void)hipSetDevice(device_);
-    if (hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) != hipSuccess) st_ = nullptr;
+    int least = 0, greatest = 0;
+    if (big_priority_ && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) {
+        if (hipStreamCreateWithPriority(&st_, hipStreamNonBlocking, greatest) != hipSuccess) st_ = nullptr;
+    } else if (hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) != hipSuccess) {
+        st_ = nullptr;
+    }
     std::unique_lock<std::mutex> lk(mu_);
     while (true) {
         cv_.wait(lk, [&] { return stop_ || !big_.empty() || !small_.empty(); });
@@ -160,7 +191,7 @@ void HashService::run() {
             std::vector<hipEvent_t> wait_for;
             wait_for.swap(running_small_);
             lk.unlock();
-            if (policy == 0) drain(wait_for);  // the small window has left the chip
+            if (policy == 1) drain(wait_for);  // exclusive classes: the small window has left the chip
             launch_big(r);
             lk.lock();
             r->state = r->err == hipSuccess ? 1 : 2;
@@ -175,7 +206,7 @@ void HashService::run() {
             std::vector<hipEvent_t> wait_for;
             wait_for.swap(running_big_);
             lk.unlock();
-            if (policy == 0) drain(wait_for);
+            if (policy == 1) drain(wait_for);
             lk.lock();
             // whatever arrived while the big commitment drained joins the window
             reqs.insert(reqs.end(), small_.begin(), small_.end());
@@ -280,7 +311,7 @@ struct Pool {
     std::unordered_map<uint64_t, Job*> jobs;
     uint64_t next_id = 1;
     bool stop = false;
-    unsigned gen_threads = 0, trace_threads_cfg = 0, gen_running = 0;
+    unsigned gen_threads = 0, trace_threads_cfg = 0, gen_running = 0, cpus = 1;
     size_t big_recordings_started = 0, big_proofs_done = 0;  // under mu
     std::vector<std::thread> threads;
 
@@ -294,14 +325,13 @@ struct Pool {
         cv_done.notify_all();
     }
 
-    // threads one recording may use: the generator threads that have nothing else to do are lent to the calls that run
-    int trace_threads_for_call() {
+    // Threads one recording may use.  The long pole -- a FinalExp-class recording -- gets three quarters of the CPU budget (its
+    // 53 tasks scale to 16 threads: 212 ms on one, 25 on 16), a small AIR's a quarter of it split over the small recordings
+    // under way; the prover threads' Fiat-Shamir hashing and the natives need the rest.
+    int trace_threads_for_call(bool big_job) {
         if (trace_threads_cfg) return (int)trace_threads_cfg;
-        const unsigned busy = std::max(1u, gen_running + (unsigned)q_gen.size());  // under mu
-        const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-        const unsigned running = std::min(busy, std::max(1u, gen_threads));
-        const unsigned share = std::max(1u, hw / (2 * running));  // half the hardware threads, split over the recordings that run at once
-        return (int)std::min(16u, share);
+        if (big_job) return (int)std::min(16u, std::max(1u, cpus * 3 / 4));
+        return (int)std::min(4u, std::max(1u, cpus / 4));
     }
 
     void generator_loop() {
@@ -325,7 +355,7 @@ struct Pool {
                 j = *it;
                 q_gen.erase(it);
                 if (j->big) big_recordings_started++;
-                tt = trace_threads_for_call();
+                tt = trace_threads_for_call(j->big);
                 gen_running++;
                 j->t[1] = now();
             }
@@ -437,15 +467,17 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
     p->device = cfg.device;
     p->t0 = now_s();
     const unsigned n_big = cfg.big_contexts ? cfg.big_contexts : 3, n_small = cfg.small_contexts ? cfg.small_contexts : 16;
-    // recording is host work the GPU waits for: few recordings at once (hardware threads / 16, 4 .. 12), each on several
-    // threads (trace_threads_for_call: half the hardware threads split over the running recordings, at most 16 each)
-    const unsigned hw = std::max(4u, std::thread::hardware_concurrency());
-    p->gen_threads = cfg.generator_threads ? cfg.generator_threads : std::min(12u, std::max(4u, hw / 16));
+    // recording is host work the GPU waits for, but the CPU budget is shared with the prover threads (Fiat-Shamir hashing, kernel
+    // launches): a quarter of the budget in recordings at once (at least 3), each on a few threads (trace_threads_for_call)
+    p->cpus = cpu_budget();
+    p->gen_threads = cfg.generator_threads ? cfg.generator_threads : std::min(12u, std::max(3u, p->cpus / 4));
     p->trace_threads_cfg = cfg.trace_threads;
     int rc = STARKHIP_OK;
     for (unsigned i = 0; i < n_big + n_small && rc == STARKHIP_OK; i++) {
         Ctx* c = nullptr;
-        rc = ctx_create(cfg.device, &c);
+        const bool is_big = i < n_big;
+        const int prio = cfg.stream_priority == 1 ? (is_big ? 1 : 0) : cfg.stream_priority == 2 ? (is_big ? 0 : 1) : 0;
+        rc = ctx_create(cfg.device, &c, prio);
         if (rc == STARKHIP_OK) (i < n_big ? p->big_ctx : p->small_ctx).push_back(c);
     }
     if (rc != STARKHIP_OK) {
@@ -453,7 +485,7 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
         for (Ctx* c : p->small_ctx) ctx_destroy(c);
         return rc;
     }
-    p->hs.reset(new HashService(cfg.device));
+    p->hs.reset(new HashService(cfg.device, cfg.stream_priority == 1 ? 1 : 0));
     if (cfg.gather_ms > 0) p->hs->gather_ms = cfg.gather_ms;
     p->hs->policy = (int)cfg.commit_policy;
     if (cfg.commit_policy != 2) {  // 2: no commitment scheduling at all -- every context launches its own (A/B measurements)

@@ -9,8 +9,8 @@
 //    grid of exactly two 188-register waves per SIMD (kernels_hash.hip): a foreign long-lived wave on a SIMD pushes one of
 //    them into a second round and doubles the launch.  The 1024-row AIRs' commitments are the opposite: 128 .. 256 waves of
 //    up to 12 167 sequential permutations, 7/8 of the chip idle.  So: commitments of the small class that arrive together are
-//    launched as ONE merged grid (leaf_hash_multi_kernel, grid.y = proof), and the two classes never overlap -- a big
-//    commitment starts when the small window has drained and vice versa.
+//    launched as ONE merged grid (leaf_hash_multi_kernel, grid.y = proof); optionally (policy 1) the two classes never
+//    overlap -- a big commitment then starts when the small window has drained and vice versa.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,7 +26,7 @@ namespace starkhip {
 
 class HashService {
   public:
-    explicit HashService(int device);
+    explicit HashService(int device, int big_priority = 0);
     ~HashService();
     HashService(const HashService&) = delete;
     HashService& operator=(const HashService&) = delete;
@@ -43,7 +43,11 @@ class HashService {
 
     static bool is_big(unsigned log_n, unsigned rate_bits) { return log_n + rate_bits >= 15; }  // >= 2048 waves: fills every SIMD twice
     double gather_ms = 25.0;  // how long a small window waits for announced proofs that have not reached their commitment
-    // 0: the two classes never overlap (default); 1: small commitments are merged but a big one starts whenever it arrives
+    // 0 (default): small commitments that arrive together share a launch, and a big one starts whenever it arrives;
+    // 1: in addition the two classes never overlap (a big commitment waits for the small window to drain and vice versa).
+    // Measured on one MI355X: a batch of 8 signatures 3.5 against 3.2 signatures/s, one signature 0.42
+    // against 0.47 s -- a lone wave on a SIMD runs about twice as fast as one of two, so a FinalExp commitment that starts
+    // beside a MillerLoop latency chain loses less than it would by waiting for it.
     int policy = 0;
 
     struct Stats {
@@ -68,7 +72,7 @@ class HashService {
     void launch_small(std::vector<Req*>& reqs);
     void drain(std::vector<hipEvent_t>& evs);
 
-    int device_;
+    int device_, big_priority_ = 0;
     hipStream_t st_ = nullptr;
     // merged launches run side by side: each goes to a stream that is idle, so a window never queues behind an earlier one
     static const int N_SMALL_STREAMS = 12;

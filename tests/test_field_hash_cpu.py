@@ -128,6 +128,16 @@ def test_rust_binding_matches_the_header():
 
     assert r_fields("starkhip_config_t") == c_fields("} starkhip_config_t;")
     assert r_fields("starkhip_proof_layout_t") == c_fields("} starkhip_proof_layout_t;")
+    assert r_fields("starkhip_pool_config_t") == c_fields("} starkhip_pool_config_t;")
+    assert r_fields("starkhip_ticket_info_t") == c_fields("} starkhip_ticket_info_t;")
+    for must in ("starkhip_pool_create", "starkhip_pool_submit_witness", "starkhip_pool_wait", "starkhip_pool_destroy"):
+        assert must in r_fns, must
+    # the field-by-field hand-off to the recursion stage reads every offset the layout struct offers
+    handoff = rs[rs.index("pub mod handoff"):]
+    for field in ("off_trace_cap", "off_quotient_cap", "off_local_values", "off_next_values", "off_quotient_openings", "off_fri_caps",
+                  "off_query_rounds", "query_round_words", "off_final_poly", "off_pow_witness", "off_public_inputs", "q_trace_leaf",
+                  "q_trace_siblings", "q_quotient_leaf", "q_quotient_siblings", "q_step_evals", "q_step_siblings", "step_sibling_count"):
+        assert "l." + field in handoff, field
     c_codes = dict(re.findall(r"(STARKHIP_(?:OK|ERR_[A-Z_]+))\s*=\s*(-?\d+)", hdr))
     r_codes = dict(re.findall(r"pub const (STARKHIP_(?:OK|ERR_[A-Z_]+)): c_int = (-?\d+);", rs_nc))
     assert r_codes == c_codes

@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--driver", choices=("pool", "python"), default="pool",
                     help="pool (default): the library's proof pool (starkhip_pool_*: generator threads, contexts, merged commitments inside "
                          "libstarkhip.so); python: the round-2 driver (signature.run_jobs: Python threads over plain contexts)")
-    ap.add_argument("--policy", type=int, default=0, help="pool: commit policy (0: commitment classes never overlap, 1: they may)")
+    ap.add_argument("--policy", type=int, default=0, help="pool: commit policy (0: merged small commitments, 1: also keep the two classes apart, 2: no scheduling)")
     ap.add_argument("--gather-ms", type=float, default=0.0, help="pool: how long a merged commitment waits for stragglers (0 = default)")
     ap.add_argument("--collect", action="store_true", help="N > 1: gather every proof on every rank afterwards (raw buffers) and check all signatures")
     ap.add_argument("--no-verify", action="store_true")

@@ -85,6 +85,7 @@ int main(int argc, char** argv) {
         else if (a == "--gen") cfg.generator_threads = (unsigned)strtoul(val(), nullptr, 0);
         else if (a == "--trace-threads") cfg.trace_threads = (unsigned)strtoul(val(), nullptr, 0);
         else if (a == "--policy") cfg.commit_policy = (unsigned)strtoul(val(), nullptr, 0);
+        else if (a == "--priority") cfg.stream_priority = (unsigned)strtoul(val(), nullptr, 0);
         else if (a == "--gather-ms") cfg.gather_ms = (float)atof(val());
         else if (a == "--device") cfg.device = atoi(val());
         else {
@@ -117,6 +118,7 @@ int main(int argc, char** argv) {
         starkhip_driver::Pool pool(cfg);
         std::vector<SignatureProofs> proofs;
         double total = 0, best = 1e30;
+        std::string step_ms;
         for (size_t k = 0; k < warmup + steps; k++) {
             const auto t0 = std::chrono::steady_clock::now();
             proofs = starkhip_driver::prove_batch(pool, sigs, /*verify=*/false);
@@ -124,6 +126,9 @@ int main(int argc, char** argv) {
             if (k >= warmup) {
                 total += sec;
                 best = std::min(best, sec);
+                char buf[32];
+                snprintf(buf, sizeof buf, "%s%.1f", step_ms.empty() ? "" : ", ", sec * 1e3);
+                step_ms += buf;
             }
         }
         const double per_step = total / (steps ? steps : 1);
@@ -153,10 +158,10 @@ int main(int argc, char** argv) {
         }
         const starkhip_pool_stats_t st = pool.stats();
         printf("{\"metric\": \"BLS signature checks/s, end to end from compiled host code (operands -> natives -> trace generation -> 6 STARK proofs each)\", "
-               "\"value\": %.4f, \"unit\": \"signatures/s\", \"batch\": %zu, \"steps\": %zu, \"warmup\": %zu, \"ms_per_step\": %.1f, \"best_ms\": %.1f, "
+               "\"value\": %.4f, \"unit\": \"signatures/s\", \"batch\": %zu, \"steps\": %zu, \"warmup\": %zu, \"ms_per_step\": %.1f, \"best_ms\": %.1f, \"step_ms\": [%s], "
                "\"proofs_per_step\": %zu, \"proofs_verified_after_timing\": %zu, \"verify_s\": %.2f, \"signatures_valid_linked_bound\": %zu, "
                "\"commit_launches\": {\"big\": %lu, \"small_merged\": %lu, \"small_requests\": %lu, \"max_merged\": %lu}, \"operands\": \"%s\"}\n",
-               batch / per_step, batch, steps, warmup, per_step * 1e3, best * 1e3, 6 * batch, verified, seconds_since(tv), ok, st.big_commit_launches,
+               batch / per_step, batch, steps, warmup, per_step * 1e3, best * 1e3, step_ms.c_str(), 6 * batch, verified, seconds_since(tv), ok, st.big_commit_launches,
                st.small_commit_launches, st.small_commit_requests, st.max_merged_commitments, operands ? operands : "reference vector (src/native.rs:1480-1498)");
         return verified == 6 * batch && ok == batch ? 0 : 1;
     } catch (const std::exception& e) {
