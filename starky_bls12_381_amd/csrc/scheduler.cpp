@@ -313,6 +313,7 @@ struct Pool {
     bool stop = false;
     unsigned gen_threads = 0, trace_threads_cfg = 0, gen_running = 0, cpus = 1;
     size_t big_recordings_started = 0, big_proofs_done = 0;  // under mu
+    std::map<int, int> idle_big, idle_small;                 // idle contexts by the AIR they proved last (under mu)
     std::vector<std::thread> threads;
 
     double now() const { return now_s() - t0; }
@@ -409,25 +410,47 @@ struct Pool {
             j->pis = j->own_pis.data();
             j->n_pis = j->own_pis.size();
             (j->big ? q_big : q_small).push_back(j);
-            (j->big ? cv_big : cv_small).notify_one();
+            (j->big ? cv_big : cv_small).notify_all();
         }
     }
 
     void prover_loop(Ctx* c, bool big) {
         std::deque<Job*>& q = big ? q_big : q_small;
         std::condition_variable& cv = big ? cv_big : cv_small;
-        int last_air = -1;  // a context keeps the tables and the constraint plan of the AIR it proved last: take that AIR again if one waits
+        std::map<int, int>& idle = big ? idle_big : idle_small;
+        // A context keeps the tables, the constraint plan and -- above all -- device buffers sized for the AIRs it has proven
+        // (growing them means hipFree + hipMalloc, and hipFree waits for every kernel on the device).  So a waiting job goes to
+        // a context that proved its AIR last if one is idle; a context takes another AIR only when no idle one matches it.
+        int last_air = -1;
         while (true) {
-            Job* j;
+            Job* j = nullptr;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || !q.empty(); });
-                if (q.empty()) return;
-                auto it = q.begin();
-                for (auto k = q.begin(); k != q.end(); ++k)
-                    if ((*k)->air == last_air) { it = k; break; }
-                j = *it;
-                q.erase(it);
+                idle[last_air]++;
+                while (true) {
+                    if (!q.empty()) {
+                        auto it = q.end();
+                        for (auto k = q.begin(); k != q.end(); ++k)
+                            if ((*k)->air == last_air) { it = k; break; }
+                        if (it == q.end())
+                            for (auto k = q.begin(); k != q.end(); ++k) {
+                                auto f = idle.find((*k)->air);
+                                if (f == idle.end() || f->second == 0) { it = k; break; }  // nobody idle knows this AIR better
+                            }
+                        if (it != q.end()) {
+                            j = *it;
+                            q.erase(it);
+                            break;
+                        }
+                    } else if (stop) {
+                        idle[last_air]--;
+                        return;
+                    }
+                    // shutting down: the queue may drain through other contexts without another notification
+                    if (stop) cv.wait_for(lk, std::chrono::milliseconds(20));
+                    else cv.wait(lk);
+                }
+                idle[last_air]--;
                 last_air = j->air;
                 j->state = 1;
                 j->t[3] = now();
@@ -541,7 +564,7 @@ static int pool_enqueue(Pool* p, Job* j, uint64_t* ticket) {
         p->cv_gen.notify_one();
     } else {
         (j->big ? p->q_big : p->q_small).push_back(j);
-        (j->big ? p->cv_big : p->cv_small).notify_one();
+        (j->big ? p->cv_big : p->cv_small).notify_all();
     }
     return STARKHIP_OK;
 }

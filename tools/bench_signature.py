@@ -35,10 +35,12 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--inflight", type=int, default=6, help="prover contexts per GPU when --small-inflight is 0 (one pool)")
-    ap.add_argument("--big-inflight", type=int, default=3, help="contexts for FinalExp proofs (two pools)")
+    ap.add_argument("--big-inflight", type=int, default=4, help="contexts for FinalExp proofs (two pools)")
+    ap.add_argument("--priority", type=int, default=1, help="pool: 1 = FinalExp-class contexts on high-priority streams, 0 = all alike")
     ap.add_argument("--small-inflight", type=int, default=0, help="contexts for the 1024-row AIRs; 0 = one pool of --inflight contexts; "
                                                                    "default for --batch > 1: 16")
-    ap.add_argument("--gen-threads", type=int, default=12, help="host threads recording traces per GPU")
+    ap.add_argument("--gen-threads", type=int, default=0, help="recordings under way at once per GPU (0 = the pool's default: a quarter of the CPU budget; "
+                                                               "the python driver uses 12 when 0)")
     ap.add_argument("--trace-threads", type=int, default=0, help="host threads one recording generator call may use; 0 = automatic "
                                                                   "(2 x gen-threads / jobs on the rank, at most 8)")
     ap.add_argument("--by-type", type=int, default=0, help="1: the FinalExp contexts start when the small proofs are done (two pools); "
@@ -77,7 +79,7 @@ def main():
         big = max(1, args.big_inflight if args.batch > 1 else 1)
         small = args.small_inflight if args.small_inflight > 0 else 5
         provers = S.ProofPool(local_rank, big_contexts=big, small_contexts=small, generator_threads=args.gen_threads,
-                              trace_threads=args.trace_threads, commit_policy=args.policy, gather_ms=args.gather_ms)
+                              trace_threads=args.trace_threads, commit_policy=args.policy, gather_ms=args.gather_ms, stream_priority=args.priority)
         all_provers = [provers]
     elif args.small_inflight > 0:
         provers = {"big": [S.Prover(local_rank) for _ in range(max(1, args.big_inflight))],
@@ -92,7 +94,7 @@ def main():
 
     def one_step(seed):
         signatures = G.synthetic_signatures(args.batch, native_vectors()["bls_signature"], seed) if rank == 0 else None
-        return G.one_step(dist, args.batch, provers, mine, signatures, device=dev, sync=torch.cuda.synchronize, gen_threads=args.gen_threads,
+        return G.one_step(dist, args.batch, provers, mine, signatures, device=dev, sync=torch.cuda.synchronize, gen_threads=args.gen_threads or 12,
                           trace_threads=args.trace_threads or None, big_after_small=bool(args.by_type))
 
     for w in range(args.warmup):

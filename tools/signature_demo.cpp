@@ -71,6 +71,7 @@ int main(int argc, char** argv) {
     const char* operands = nullptr;
     starkhip_pool_config_t cfg;
     memset(&cfg, 0, sizeof cfg);
+    cfg.stream_priority = 1;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
@@ -113,6 +114,10 @@ int main(int argc, char** argv) {
             if (!cfg.big_contexts) cfg.big_contexts = 1;
             if (!cfg.small_contexts) cfg.small_contexts = 5;
             if (!cfg.generator_threads) cfg.generator_threads = 6;
+        }
+        if (batch > 1) {  // measured on one MI355X: four FinalExp contexts on high-priority streams, 16 small ones
+            if (!cfg.big_contexts) cfg.big_contexts = 4;
+            if (!cfg.small_contexts) cfg.small_contexts = 16;
         }
         starkhip_driver::tune_host_allocator();
         starkhip_driver::Pool pool(cfg);
