@@ -208,6 +208,7 @@ def main():
         # ---- untimed: the same proof with the GPU to itself (one in flight): uncontended kernel and phase durations
         solo_ms = {k: 0.0 for k in KERNELS}
         solo_phase = {k: 0.0 for k in S.PHASE_NAMES}
+        solo_host = {"fiat_shamir": 0.0, "other": 0.0}
         n_solo = 3
         t_solo = time.perf_counter()
         for _ in range(n_solo):
@@ -216,6 +217,8 @@ def main():
                 solo_ms[k] += v / n_solo
             for k, v in info["phase_ms"].items():
                 solo_phase[k] += v / n_solo
+            for k, v in info["host_ms"].items():
+                solo_host[k] += v / n_solo
         t_solo = (time.perf_counter() - t_solo) / n_solo
         # algorithmic bytes per launch: u64 cells, dense, minimum traffic of the decomposition
         alg = {"lde_columns": 8.0 * C * (n + n + N),  # read values, write coeffs + LDE (IFFT and LDE fused in one kernel)
@@ -286,6 +289,8 @@ def main():
             "oracle_digest_match": oracle_match,
             "latency_ms_one_in_flight": t_solo * 1e3,
             "phase_ms_one_in_flight": solo_phase,
+            "host_ms_one_in_flight": dict(solo_host, note="wall time of host work inside prove(): the challenger's sequential Poseidon sponge (inside the "
+                                                            "device phases fri_combine / fri_commit), and the FRI batches' divisions by X - z"),
             "phase_ms_timed_region": {k: v / steps for k, v in phase_ms.items()},
             "note": ("roofline / kernels: durations with ONE proof in flight; phase_ms_timed_region: HIP-event phase durations inside the timed "
                      "region, which include the time a kernel shares the CUs with the other contexts' kernels"),

@@ -106,6 +106,7 @@ pub struct starkhip_pool_config_t {
 pub struct starkhip_ticket_info_t {
     pub phase_ms: [f32; 11],
     pub kernel_ms: [f32; 3],
+    pub host_ms: [f32; 2],
     pub t_submit: f64,
     pub t_generate_start: f64,
     pub t_generate_end: f64,

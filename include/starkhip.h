@@ -185,6 +185,7 @@ typedef struct {
 typedef struct {
     float phase_ms[11];   /* as starkhip_last_timings */
     float kernel_ms[3];   /* as starkhip_last_kernel_timings */
+    float host_ms[2];     /* as starkhip_last_host_timings */
     double t_submit, t_generate_start, t_generate_end, t_prove_start, t_done; /* seconds since the pool was created */
 } starkhip_ticket_info_t;
 typedef struct {
@@ -217,6 +218,10 @@ int starkhip_last_timings(void* ctx, float ms[STARKHIP_N_PHASES]);
 /* durations (ms, HIP events on the launch stream) of the three heavy kernels of the last prove:
  * [0] lde_columns_kernel (trace) [1] leaf_hash_kernel (trace) [2] quotient_eval_kernel */
 int starkhip_last_kernel_timings(void* ctx, float ms[3]);
+/* host time (ms, wall) inside the last prove: [0] Fiat-Shamir hashing -- the challenger's sequential Poseidon sponge over the
+ * caps, the 2 (2 C + Q) opening words and the FRI data, on the proof's critical path (it falls inside the device phases
+ * "fri_combine" and "fri_commit" above) -- [1] the other host arithmetic (the two divisions by X - z of the FRI batches) */
+int starkhip_last_host_timings(void* ctx, float ms[2]);
 
 /* Page-locked, reusable host memory for traces (starkhip_trace_* take any pointer).  Measured on FinalExp (4.8 GB of
  * rows): the upload itself already runs at link speed from pageable memory (86 ms, 56 GB/s) and stays there; what a

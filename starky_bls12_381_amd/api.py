@@ -82,6 +82,7 @@ lib.starkhip_prove.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), C.c_
                                C.c_uint64, C.POINTER(_u64p), C.POINTER(C.c_size_t)]
 lib.starkhip_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
 lib.starkhip_last_kernel_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+lib.starkhip_last_host_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
 lib.starkhip_lde_batch.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_uint, C.c_uint, _u64p, _u64p]
 lib.starkhip_merkle_cap.argtypes = [C.c_void_p, _u64p, C.c_size_t, C.c_uint, C.c_uint, _u64p]
 lib.starkhip_poseidon_permute_batch.argtypes = [C.c_void_p, _u64p, C.c_size_t]
@@ -453,6 +454,11 @@ class Prover:
         _chk(lib.starkhip_last_timings(self._ctx, ms))
         return dict(zip(PHASE_NAMES, [float(x) for x in ms]))
 
+    def last_host_timings(self):
+        ms = (C.c_float * 2)()
+        _chk(lib.starkhip_last_host_timings(self._ctx, ms))
+        return {"fiat_shamir": float(ms[0]), "other": float(ms[1])}
+
     def last_kernel_timings(self):
         ms = (C.c_float * 3)()
         _chk(lib.starkhip_last_kernel_timings(self._ctx, ms))
@@ -497,7 +503,7 @@ class PoolConfig(C.Structure):
 
 
 class TicketInfo(C.Structure):
-    _fields_ = [("phase_ms", C.c_float * N_PHASES), ("kernel_ms", C.c_float * 3), ("t_submit", C.c_double), ("t_generate_start", C.c_double),
+    _fields_ = [("phase_ms", C.c_float * N_PHASES), ("kernel_ms", C.c_float * 3), ("host_ms", C.c_float * 2), ("t_submit", C.c_double), ("t_generate_start", C.c_double),
                 ("t_generate_end", C.c_double), ("t_prove_start", C.c_double), ("t_done", C.c_double)]
 
 
@@ -615,6 +621,7 @@ class ProofPool:
         lib.starkhip_free(out)
         return proof, {"phase_ms": dict(zip(PHASE_NAMES, [float(x) for x in info.phase_ms])),
                        "kernel_ms": {"lde_columns": float(info.kernel_ms[0]), "leaf_hash": float(info.kernel_ms[1]), "quotient_eval": float(info.kernel_ms[2])},
+                       "host_ms": {"fiat_shamir": float(info.host_ms[0]), "other": float(info.host_ms[1])},
                        "timeline_s": [info.t_submit, info.t_generate_start, info.t_generate_end, info.t_prove_start, info.t_done]}
 
     def stats(self):

@@ -331,6 +331,12 @@ int starkhip_last_kernel_timings(void* ctx, float ms[3]) {
     return STARKHIP_OK;
 }
 
+int starkhip_last_host_timings(void* ctx, float ms[2]) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    memcpy(ms, ctx_host_timings((Ctx*)ctx), sizeof(float) * 2);
+    return STARKHIP_OK;
+}
+
 int starkhip_host_alloc(void* ctx, size_t bytes, void** out) {
     if (!out) return STARKHIP_ERR_BAD_SHAPE;
     *out = nullptr;

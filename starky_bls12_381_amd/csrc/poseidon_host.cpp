@@ -31,15 +31,40 @@ struct V12 {  // 12 x u64: elements 0..7 and 8..11
 
 const uint64_t EPS = 0xFFFFFFFFull;
 
+// ---- scalar, lazy: any 64-bit representative in and out (the partial rounds' S-boxes are one dependent chain)
+inline gl_t reduce128_nc(uint64_t hi, uint64_t lo) {
+    const uint64_t hi_hi = hi >> 32, hi_lo = hi & EPS;
+    uint64_t t0 = lo - hi_hi;
+    t0 -= (uint64_t)(0 - (uint64_t)(lo < hi_hi)) & EPS;
+    const uint64_t t1 = (hi_lo << 32) - hi_lo;
+    uint64_t r = t0 + t1;
+    r += (uint64_t)(0 - (uint64_t)(r < t1)) & EPS;
+    return r;
+}
+inline gl_t mul_nc(gl_t a, gl_t b) {
+    const unsigned __int128 m = (unsigned __int128)a * b;
+    return reduce128_nc((uint64_t)(m >> 64), (uint64_t)m);
+}
+inline gl_t sbox_nc(gl_t x) {
+    const gl_t x2 = mul_nc(x, x), x4 = mul_nc(x2, x2), x3 = mul_nc(x2, x);
+    return mul_nc(x3, x4);
+}
+
 // ---- 8 lanes
-AVX512_TARGET inline __m512i reduce128_8(__m512i hi, __m512i lo) {  // canonical result
-    const __m512i eps = _mm512_set1_epi64((long long)EPS), p = _mm512_set1_epi64((long long)GL_P);
+// Values between the layers of one permutation are ANY 64-bit representative of their class (lazy reduction): a product's
+// operands may be arbitrary, and so may the addends of the sums below; the state is canonicalised once, when it leaves
+// permute_avx512.  That removes a compare + masked subtract (4 cycles of latency) from every reduction of the sequential chain.
+AVX512_TARGET inline __m512i reduce128_8(__m512i hi, __m512i lo) {  // any representative
+    const __m512i eps = _mm512_set1_epi64((long long)EPS);
     const __m512i hh = _mm512_srli_epi64(hi, 32), hl = _mm512_and_si512(hi, eps);
     __m512i t0 = _mm512_sub_epi64(lo, hh);
     t0 = _mm512_mask_sub_epi64(t0, _mm512_cmplt_epu64_mask(lo, hh), t0, eps);  // borrowed: - eps
     const __m512i t1 = _mm512_sub_epi64(_mm512_slli_epi64(hl, 32), hl);          // hl * eps < p
     __m512i r = _mm512_add_epi64(t0, t1);
-    r = _mm512_mask_add_epi64(r, _mm512_cmplt_epu64_mask(r, t1), r, eps);         // wrapped: + eps
+    return _mm512_mask_add_epi64(r, _mm512_cmplt_epu64_mask(r, t1), r, eps);      // wrapped: + eps (t1 < p, so no second wrap)
+}
+AVX512_TARGET inline __m512i canon_8(__m512i r) {
+    const __m512i p = _mm512_set1_epi64((long long)GL_P);
     return _mm512_mask_sub_epi64(r, _mm512_cmpge_epu64_mask(r, p), r, p);
 }
 AVX512_TARGET inline __m512i mul_8(__m512i x, __m512i y) {
@@ -52,12 +77,10 @@ AVX512_TARGET inline __m512i mul_8(__m512i x, __m512i y) {
     const __m512i hi = _mm512_add_epi64(p11, _mm512_add_epi64(_mm512_srli_epi64(mid, 32), _mm512_srli_epi64(mid2, 32)));
     return reduce128_8(hi, lo);
 }
-AVX512_TARGET inline __m512i add_8(__m512i x, __m512i y) {  // canonical inputs, canonical result
-    const __m512i p = _mm512_set1_epi64((long long)GL_P);
+AVX512_TARGET inline __m512i add_8(__m512i x, __m512i y) {  // x any representative, y canonical (a constant); any representative out
+    const __m512i eps = _mm512_set1_epi64((long long)EPS);
     const __m512i s = _mm512_add_epi64(x, y);
-    const __mmask8 wrap = _mm512_cmplt_epu64_mask(s, x);
-    const __mmask8 big = _mm512_cmpge_epu64_mask(s, p);
-    return _mm512_mask_sub_epi64(s, (__mmask8)(wrap | big), s, p);  // s - p == s + eps (mod 2^64) when wrapped
+    return _mm512_mask_add_epi64(s, _mm512_cmplt_epu64_mask(s, x), s, eps);  // wrapped: s <= p - 2, + eps cannot wrap again
 }
 AVX512_TARGET inline __m512i sbox_8(__m512i x) {
     const __m512i x2 = mul_8(x, x), x4 = mul_8(x2, x2), x3 = mul_8(x2, x);
@@ -66,13 +89,16 @@ AVX512_TARGET inline __m512i sbox_8(__m512i x) {
 
 // ---- 4 lanes (same code on 256-bit vectors)
 AVX512_TARGET inline __m256i reduce128_4(__m256i hi, __m256i lo) {
-    const __m256i eps = _mm256_set1_epi64x((long long)EPS), p = _mm256_set1_epi64x((long long)GL_P);
+    const __m256i eps = _mm256_set1_epi64x((long long)EPS);
     const __m256i hh = _mm256_srli_epi64(hi, 32), hl = _mm256_and_si256(hi, eps);
     __m256i t0 = _mm256_sub_epi64(lo, hh);
     t0 = _mm256_mask_sub_epi64(t0, _mm256_cmplt_epu64_mask(lo, hh), t0, eps);
     const __m256i t1 = _mm256_sub_epi64(_mm256_slli_epi64(hl, 32), hl);
     __m256i r = _mm256_add_epi64(t0, t1);
-    r = _mm256_mask_add_epi64(r, _mm256_cmplt_epu64_mask(r, t1), r, eps);
+    return _mm256_mask_add_epi64(r, _mm256_cmplt_epu64_mask(r, t1), r, eps);
+}
+AVX512_TARGET inline __m256i canon_4(__m256i r) {
+    const __m256i p = _mm256_set1_epi64x((long long)GL_P);
     return _mm256_mask_sub_epi64(r, _mm256_cmpge_epu64_mask(r, p), r, p);
 }
 AVX512_TARGET inline __m256i mul_4(__m256i x, __m256i y) {
@@ -86,11 +112,9 @@ AVX512_TARGET inline __m256i mul_4(__m256i x, __m256i y) {
     return reduce128_4(hi, lo);
 }
 AVX512_TARGET inline __m256i add_4(__m256i x, __m256i y) {
-    const __m256i p = _mm256_set1_epi64x((long long)GL_P);
+    const __m256i eps = _mm256_set1_epi64x((long long)EPS);
     const __m256i s = _mm256_add_epi64(x, y);
-    const __mmask8 wrap = _mm256_cmplt_epu64_mask(s, x);
-    const __mmask8 big = _mm256_cmpge_epu64_mask(s, p);
-    return _mm256_mask_sub_epi64(s, (__mmask8)(wrap | big), s, p);
+    return _mm256_mask_add_epi64(s, _mm256_cmplt_epu64_mask(s, x), s, eps);
 }
 AVX512_TARGET inline __m256i sbox_4(__m256i x) {
     const __m256i x2 = mul_4(x, x), x4 = mul_4(x2, x2), x3 = mul_4(x2, x);
@@ -197,27 +221,30 @@ const MergedVectors& merged_vectors() {
 #define MV_A(x) _mm512_load_si512((const void*)(x))
 #define MV_B(x) _mm256_load_si256((const __m256i*)((x) + 8))
 
-// (sum over the 12 lanes of lo * row) + (sum of hi * row) * 2^32 + extra, mod p; the sums stay below 2^48
-AVX512_TARGET inline gl_t dot_row(__m512i alo, __m512i ahi, __m256i blo, __m256i bhi, __m512i ra, __m256i rb, unsigned __int128 extra) {
+// (sum over the 12 lanes of lo * row) + (sum of hi * row) * 2^32 as an integer (the sums stay below 2^48, the value below 2^81)
+AVX512_TARGET inline unsigned __int128 dot_row(__m512i alo, __m512i ahi, __m256i blo, __m256i bhi, __m512i ra, __m256i rb) {
     const uint64_t L = (uint64_t)_mm512_reduce_add_epi64(_mm512_mul_epu32(alo, ra)) +
                        (uint64_t)_mm512_reduce_add_epi64(_mm512_zextsi256_si512(_mm256_mul_epu32(blo, rb)));
     const uint64_t H = (uint64_t)_mm512_reduce_add_epi64(_mm512_mul_epu32(ahi, ra)) +
                        (uint64_t)_mm512_reduce_add_epi64(_mm512_zextsi256_si512(_mm256_mul_epu32(bhi, rb)));
-    const unsigned __int128 v = (unsigned __int128)L + ((unsigned __int128)H << 32) + extra;
-    return gl_reduce128((uint64_t)(v >> 64), (uint64_t)v);
+    return (unsigned __int128)L + ((unsigned __int128)H << 32);
 }
 
-// s: the state at the start of a partial round (constants added); on return the state three rounds later (constants added)
+// s: the state at the start of a partial round (constants added); on return the state three rounds later (constants added).
+// The three S-boxes are ONE dependent chain (x1 -> y1 -> x2 -> y2 -> x3), and a sequential sponge is bound by it: everything
+// that does not depend on them -- the dot products and the dense layer over elements 1 .. 11 -- is computed from the state
+// with element 0 zeroed, beside the chain; each link then costs one scalar multiply-add and a reduction
+// (y1 = P1 + M00 x1 + k1, y2 = P2 + N2_00 x1 + M00 x2 + k2), and x1, x2, x3 enter the dense layer as three last terms.
 AVX512_TARGET inline void partial3(V12& s, const MergedVectors& V, int t) {
     const __m512i m32 = _mm512_set1_epi64((long long)EPS);
     const __m256i m32h = _mm256_set1_epi64x((long long)EPS);
-    const gl_t x1 = poseidon_sbox((gl_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(s.a)));
-    const __m512i ua = _mm512_mask_set1_epi64(s.a, 1, (long long)x1);
-    const __m512i alo = _mm512_and_si512(ua, m32), ahi = _mm512_srli_epi64(ua, 32);
+    const gl_t x1 = sbox_nc((gl_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(s.a)));  // the chain starts at once
+    const __m512i uz = _mm512_maskz_mov_epi64(0xFE, s.a);  // element 0 zeroed
+    const __m512i alo = _mm512_and_si512(uz, m32), ahi = _mm512_srli_epi64(uz, 32);
     const __m256i blo = _mm256_and_si256(s.b, m32h), bhi = _mm256_srli_epi64(s.b, 32);
-    const gl_t x2 = poseidon_sbox(dot_row(alo, ahi, blo, bhi, MV_A(V.r1), MV_B(V.r1), V.k1[t]));
-    const gl_t x3 = poseidon_sbox(dot_row(alo, ahi, blo, bhi, MV_A(V.r2), MV_B(V.r2), (unsigned __int128)V.m00 * x2 + V.k2[t]));
-    // out = N3 ut + N2[:,0] x2 + M[:,0] x3 + k3
+    const unsigned __int128 P1 = dot_row(alo, ahi, blo, bhi, MV_A(V.r1), MV_B(V.r1)) + V.k1[t];
+    const unsigned __int128 P2 = dot_row(alo, ahi, blo, bhi, MV_A(V.r2), MV_B(V.r2)) + V.k2[t];
+    // the dense layer over elements 1 .. 11: out = N3 ut + N2[:,0] x2 + M[:,0] x3 + k3, column 0 of N3 (times x1) added below
     alignas(64) uint64_t lo[12], hi[12];
     _mm512_store_si512((void*)lo, alo);
     _mm256_store_si256((__m256i*)(lo + 8), blo);
@@ -225,7 +252,7 @@ AVX512_TARGET inline void partial3(V12& s, const MergedVectors& V, int t) {
     _mm256_store_si256((__m256i*)(hi + 8), bhi);
     __m512i La = _mm512_setzero_si512(), Ha = _mm512_setzero_si512();
     __m256i Lb = _mm256_setzero_si256(), Hb = _mm256_setzero_si256();
-    for (int j = 0; j < 12; j++) {
+    for (int j = 1; j < 12; j++) {
         const __m512i l8 = _mm512_set1_epi64((long long)lo[j]), h8 = _mm512_set1_epi64((long long)hi[j]);
         const __m256i l4 = _mm256_set1_epi64x((long long)lo[j]), h4 = _mm256_set1_epi64x((long long)hi[j]);
         const __m512i ca = MV_A(V.n3[j]);
@@ -235,15 +262,23 @@ AVX512_TARGET inline void partial3(V12& s, const MergedVectors& V, int t) {
         Lb = _mm256_add_epi64(Lb, _mm256_mul_epu32(l4, cb));
         Hb = _mm256_add_epi64(Hb, _mm256_mul_epu32(h4, cb));
     }
-    const long long x2l = (long long)(x2 & EPS), x2h = (long long)(x2 >> 32), x3l = (long long)(x3 & EPS), x3h = (long long)(x3 >> 32);
-    La = _mm512_add_epi64(La, _mm512_mul_epu32(_mm512_set1_epi64(x2l), MV_A(V.b2)));
-    Ha = _mm512_add_epi64(Ha, _mm512_mul_epu32(_mm512_set1_epi64(x2h), MV_A(V.b2)));
-    Lb = _mm256_add_epi64(Lb, _mm256_mul_epu32(_mm256_set1_epi64x(x2l), MV_B(V.b2)));
-    Hb = _mm256_add_epi64(Hb, _mm256_mul_epu32(_mm256_set1_epi64x(x2h), MV_B(V.b2)));
-    La = _mm512_add_epi64(La, _mm512_mul_epu32(_mm512_set1_epi64(x3l), MV_A(V.b3)));
-    Ha = _mm512_add_epi64(Ha, _mm512_mul_epu32(_mm512_set1_epi64(x3h), MV_A(V.b3)));
-    Lb = _mm256_add_epi64(Lb, _mm256_mul_epu32(_mm256_set1_epi64x(x3l), MV_B(V.b3)));
-    Hb = _mm256_add_epi64(Hb, _mm256_mul_epu32(_mm256_set1_epi64x(x3h), MV_B(V.b3)));
+#define ADD_TERM(x, col)                                                                          /* += (column) * x, x any 64-bit value */ \
+    {                                                                                                                                    \
+        const long long xl = (long long)((x) & EPS), xh = (long long)((x) >> 32);                                                        \
+        La = _mm512_add_epi64(La, _mm512_mul_epu32(_mm512_set1_epi64(xl), MV_A(col)));                                                   \
+        Ha = _mm512_add_epi64(Ha, _mm512_mul_epu32(_mm512_set1_epi64(xh), MV_A(col)));                                                   \
+        Lb = _mm256_add_epi64(Lb, _mm256_mul_epu32(_mm256_set1_epi64x(xl), MV_B(col)));                                                  \
+        Hb = _mm256_add_epi64(Hb, _mm256_mul_epu32(_mm256_set1_epi64x(xh), MV_B(col)));                                                  \
+    }
+    ADD_TERM(x1, V.n3[0]);
+    // the chain: entries of M, N2 are < 2^21, so every sum below is < 2^81 + 2 * 2^85
+    const unsigned __int128 v1 = P1 + (unsigned __int128)V.r1[0] * x1;
+    const gl_t x2 = sbox_nc(reduce128_nc((uint64_t)(v1 >> 64), (uint64_t)v1));
+    ADD_TERM(x2, V.b2);
+    const unsigned __int128 v2 = P2 + (unsigned __int128)V.r2[0] * x1 + (unsigned __int128)V.m00 * x2;
+    const gl_t x3 = sbox_nc(reduce128_nc((uint64_t)(v2 >> 64), (uint64_t)v2));
+    ADD_TERM(x3, V.b3);
+#undef ADD_TERM
     {  // value = L + H * 2^32 (L, H < 2^58), then + k3 (canonical)
         const __m512i l = _mm512_add_epi64(La, _mm512_slli_epi64(Ha, 32));
         const __m512i h = _mm512_mask_add_epi64(_mm512_srli_epi64(Ha, 32), _mm512_cmplt_epu64_mask(l, La), _mm512_srli_epi64(Ha, 32),
@@ -276,7 +311,7 @@ AVX512_TARGET void permute_avx512(gl_t* st) {
     for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++) partial3(s, V, t);
     rc += 12 * 3 * POSEIDON_MERGED_TRIPLES;  // the constants of this round are already in s
     {
-        const gl_t x0 = poseidon_sbox((gl_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(s.a)));  // element 0, scalar
+        const gl_t x0 = sbox_nc((gl_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(s.a)));  // element 0, scalar
         s.a = _mm512_maskz_mov_epi64(0xFE, s.a);  // the vector part does not wait for x0
         mds_t<true>(s, x0);
         rc += 12;
@@ -286,8 +321,8 @@ AVX512_TARGET void permute_avx512(gl_t* st) {
         s.b = sbox_4(add_4(s.b, _mm256_loadu_si256((const __m256i*)(RC + rc + 8))));
         mds(s);
     }
-    _mm512_storeu_si512((void*)st, s.a);
-    _mm256_storeu_si256((__m256i*)(st + 8), s.b);
+    _mm512_storeu_si512((void*)st, canon_8(s.a));
+    _mm256_storeu_si256((__m256i*)(st + 8), canon_4(s.b));
 }
 
 bool have_avx512() {

@@ -12,6 +12,7 @@ int ctx_create(int device, Ctx** out, int priority = 0);
 void ctx_destroy(Ctx* c);
 const float* ctx_timings(Ctx* c);
 const float* ctx_kernel_timings(Ctx* c);
+const float* ctx_host_timings(Ctx* c);
 int ctx_set_option(Ctx* c, const char* name, long value);
 class HashService;  // scheduler.h
 void ctx_attach_hash_service(Ctx* c, HashService* hs);  // trace commitments of this context go through the pool's scheduler

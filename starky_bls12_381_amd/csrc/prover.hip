@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include <string>
 #include <vector>
@@ -84,8 +85,10 @@ struct Ctx {
     float timings[STARKHIP_N_PHASES] = {0};
     hipEvent_t kev[6];            // the three heavy kernels bracketed on their own: leaf hash, quotient evaluation, trace LDE
     float ktimings[3] = {0};      // lde_columns, leaf_hash (trace), quotient_eval
+    float htimings[2] = {0};      // host time inside the last prove: Fiat-Shamir hashing (the challenger's sequential sponge), other host arithmetic
     HashService* hs = nullptr;    // a pooled context's trace commitments are launched by the pool's scheduler (scheduler.h)
     hipEvent_t hash_ready = nullptr, hash_done = nullptr;
+    hipEvent_t wait_ev = nullptr;  // hipEventBlockingSync: see stream_wait()
     bool hash_requested = false;
     // tuning (starkhip_set_option; defaults are the measured best)
     long opt_quotient_impl = 0;   // 0: tiled evaluator (quotient_plan.h), 1: op-stream interpreter (quotient_ops.h)
@@ -120,6 +123,17 @@ struct Ctx {
         open_next, open_q, ext_apow, comb_partial, comb_out, fri_coef, fri_vals, fri_rows[16], fri_digests[16], scale_tab, pow_state,
         pow_best, qidx, gather_t, gather_q;
 };
+
+// Wait for everything enqueued on the context's stream -- SLEEPING, not spinning: the wait goes through an event created with
+// hipEventBlockingSync (an interrupt-driven wait).  With several proofs in flight every context has a host thread waiting for
+// its stream most of the time; hipStreamSynchronize spins by default (hipDeviceScheduleAuto on a many-core host), and spinning
+// threads eat the CPUs -- in a container with a CPU quota, the quota -- that trace generation and the other proofs' Fiat-Shamir
+// hashing need.  Per event, so nothing about the device's scheduling flags changes for other libraries in the process (RCCL).
+static hipError_t stream_wait(Ctx* c) {
+    hipError_t e = hipEventRecord(c->wait_ev, c->st);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(c->wait_ev);
+}
 
 static int ensure_tables(Ctx* c, unsigned log_n, unsigned rate, unsigned qdb) {
     for (auto& t : c->table_cache)
@@ -197,7 +211,7 @@ static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
     HIPCHK(hipMemcpyAsync(c->d_ops.p, Q.ops.data(), Q.ops.size() * sizeof(QOp), hipMemcpyHostToDevice, c->st));
     HIPCHK(c->d_chunk_off.ensure(Q.chunk_batch.size() * 4));
     HIPCHK(hipMemcpyAsync(c->d_chunk_off.p, Q.chunk_batch.data(), Q.chunk_batch.size() * 4, hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));  // Q goes out of scope
+    HIPCHK(stream_wait(c));  // Q goes out of scope
     c->prog_air = air.id;
     c->prog_chunks = want;
     return 0;
@@ -239,7 +253,7 @@ static int ensure_plan(Ctx* c, const AirInfo& air, size_t quotient_points) {
         HIPCHK(hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, c->st));
     }
     HIPCHK(D->q_apow.ensure(std::max<size_t>(1, air.prog.n_constraints) * 16));
-    HIPCHK(hipStreamSynchronize(c->st));  // Q goes out of scope
+    HIPCHK(stream_wait(c));  // Q goes out of scope
     D->air = air.id;
     D->want = want;
     D->chunks = Q.n_chunks;
@@ -259,11 +273,6 @@ int ctx_create(int device, Ctx** out, int priority) {
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return STARKHIP_ERR_NO_DEVICE;
     if (device < 0 || device >= count) return STARKHIP_ERR_NO_DEVICE;
     HIPCHK(hipSetDevice(device));
-    // A host thread that waits for its stream SLEEPS (interrupt-driven wait) instead of spinning: with several proofs in flight
-    // every context has a thread in hipStreamSynchronize most of the time, and spinning ones eat the CPUs -- in a container with
-    // a CPU quota, the quota -- that trace generation and the Fiat-Shamir hashing of the other proofs need.  Best effort: the
-    // flag cannot be changed once another library has activated the device.
-    if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
     Ctx* c = new Ctx();
     c->device = device;
     for (auto& e : c->ev) e = nullptr;
@@ -279,10 +288,12 @@ int ctx_create(int device, Ctx** out, int priority) {
     for (auto& e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     for (auto& e : c->kev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->hash_ready, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->hash_done, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->hash_done, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
     if (!ok) {  // release whatever was created
         if (c->hash_ready) (void)hipEventDestroy(c->hash_ready);
         if (c->hash_done) (void)hipEventDestroy(c->hash_done);
+        if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
         for (auto& e : c->ev)
             if (e) (void)hipEventDestroy(e);
         for (auto& e : c->kev)
@@ -315,6 +326,7 @@ void ctx_destroy(Ctx* c) {
     for (auto& e : c->kev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->hash_ready);
     (void)hipEventDestroy(c->hash_done);
+    (void)hipEventDestroy(c->wait_ev);
     (void)hipStreamDestroy(c->st);
     delete c;
 }
@@ -341,6 +353,7 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
 }
 const float* ctx_timings(Ctx* c) { return c->timings; }
 const float* ctx_kernel_timings(Ctx* c) { return c->ktimings; }
+const float* ctx_host_timings(Ctx* c) { return c->htimings; }
 
 // (F(X) - F(z)) / (X - z), padded with one zero coefficient back to length n (plonky2 divide_by_linear + push(0))
 static void divide_by_linear(const gl2_t* F, size_t n, gl2_t z, gl2_t* q) {
@@ -351,6 +364,15 @@ static void divide_by_linear(const gl2_t* F, size_t n, gl2_t z, gl2_t* q) {
         q[k - 1] = carry;
     }
 }
+
+namespace {
+struct HostWatch {  // accumulates wall time of the host-side stretches of prove()
+    double ms = 0;
+    std::chrono::steady_clock::time_point t0;
+    void start() { t0 = std::chrono::steady_clock::now(); }
+    void stop() { ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
 
 int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64_t* trace, size_t n_rows, int layout, int on_device,
           const uint64_t* pis_host, size_t n_pis, uint64_t pow_witness, uint64_t** proof_out, size_t* proof_words) {
@@ -482,11 +504,14 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(hipMemcpyAsync(trace_cap.data(), c->digests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), 4 * ncap * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
     ranges.next("starkhip:quotient");
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(stream_wait(c));
 
+    HostWatch fs, host_other;  // Fiat-Shamir hashing / other host arithmetic of this proof
     Challenger ch;
+    fs.start();
     ch.observe_many(trace_cap.data(), trace_cap.size());  // public inputs are NOT observed (App. A.5)
     gl_t alphas[2] = {ch.get(), ch.get()};
+    fs.stop();
 
     // ---- phase 3: quotient polynomials (App. A.6)
     {
@@ -517,7 +542,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             HIPCHK(hipEventRecord(c->kev[3], st));
             HIPCHK(launch_quotient_combine(c->partial.as<gl_t>(), c->chunk_scale.as<gl_t>(), n_chunks, c->tab->qtab.as<gl_t>(), log_n, qdb,
                                            c->qvals.as<gl_t>(), st));
-            HIPCHK(hipStreamSynchronize(st));  // apow / cscale go out of scope
+            HIPCHK(stream_wait(c));  // apow / cscale go out of scope
         }
         if (c->opt_quotient_debug == 9 && !tiled) {
             // development aid: the tiled evaluator's values against the interpreter's on this very proof (stderr)
@@ -533,7 +558,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
                                          c->tab->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, 0, st));
             HIPCHK(launch_quotient_tiles_combine(c->partial.as<gl_t>(), c->plan->chunks, c->tab->qtab.as<gl_t>(), log_n, qdb, c->comb_partial.as<gl_t>(), st));
             HIPCHK(hipMemcpyAsync(got.data(), c->comb_partial.p, 2 * size * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(stream_wait(c));
             size_t bad = 0;
             size_t last_blk = (size_t)-1;
             for (size_t i = 0; i < 2 * size; i++)
@@ -561,7 +586,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
                                   hipMemcpyDeviceToDevice, st));
         HIPCHK(hipEventRecord(c->ev[evi++], st));
         ranges.next("starkhip:quotient_commit");
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(stream_wait(c));
         for (gl_t v : tail)
             if (v != 0) return STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE;
     }
@@ -573,9 +598,11 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(hipMemcpyAsync(quot_cap.data(), c->qdigests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), 4 * ncap * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
     ranges.next("starkhip:openings");
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(stream_wait(c));
+    fs.start();
     ch.observe_many(quot_cap.data(), quot_cap.size());
     gl2_t zeta = ch.get_ext();
+    fs.stop();
     if (gl2_eq(gl2_pow(zeta, n), gl2_one())) return STARKHIP_ERR_ZETA_IN_SUBGROUP;
     gl2_t gzeta = gl2_mul_base(zeta, gl_root_of_unity(log_n));
 
@@ -591,13 +618,15 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(hipMemcpyAsync(op_q.data(), c->open_q.p, Q * 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
     ranges.next("starkhip:fri_combine");
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(stream_wait(c));
+    fs.start();  // 2 (2 C + Q) field elements through the sponge, one permutation per 8: the longest host stretch of a proof
     for (size_t i = 0; i < C; i++) ch.observe_ext(op_local[i]);
     for (size_t i = 0; i < Q; i++) ch.observe_ext(op_q[i]);
     for (size_t i = 0; i < C; i++) ch.observe_ext(op_next[i]);
 
     // ---- phase 6: FRI batch combination (prove_openings, App. A.8)
     gl2_t fri_alpha = ch.get_ext();
+    fs.stop();
     std::vector<gl2_t> fin(n);
     {
         HIPCHK(launch_ext_powers(c->ext_apow.as<gl2_t>(), fri_alpha, C + Q, st));
@@ -608,7 +637,8 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         std::vector<gl2_t> F1(n), tailq(n), F0(n), q0(n), q1(n);
         HIPCHK(hipMemcpyAsync(F1.data(), comb, n * 16, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(tailq.data(), comb + n, n * 16, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(stream_wait(c));
+        host_other.start();
         for (size_t k = 0; k < n; k++) F0[k] = gl2_add(F1[k], tailq[k]);
         divide_by_linear(F0.data(), n, zeta, q0.data());   // batch 0: trace ++ quotient at zeta
         divide_by_linear(F1.data(), n, gzeta, q1.data());  // batch 1: trace at g*zeta
@@ -620,8 +650,9 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             soa[k] = fin[k].a0;
             soa[N + k] = fin[k].a1;
         }
+        host_other.stop();
         HIPCHK(hipMemcpyAsync(c->fri_coef.p, soa.data(), 2 * N * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(stream_wait(c));
     }
     HIPCHK(hipEventRecord(c->ev[evi++], st));
     ranges.next("starkhip:fri_commit");
@@ -653,9 +684,11 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             gl_t* cap = fri_caps.data() + l * 4 * ncap;
             HIPCHK(hipMemcpyAsync(cap, c->fri_digests[l].as<gl_t>() + 4 * level_off(n_leaves, log_len - ab - cap_h), 4 * ncap * 8,
                                   hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(stream_wait(c));
+            fs.start();
             ch.observe_many(cap, 4 * ncap);
             gl2_t beta = ch.get_ext();
+            fs.stop();
             // fold coefficients; output goes to the other half of fri_vals' sibling buffer: reuse coef in place via temp
             HIPCHK(launch_fri_fold(coef, len, ab, beta, vals, st));  // vals now holds folded coefficients SoA [2][len >> ab]
             std::swap(coef, vals);
@@ -667,13 +700,15 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         std::vector<gl_t> fc(2 * len);
         HIPCHK(hipMemcpyAsync(fc.data(), coef, len * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(fc.data() + len, coef + len, len * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(stream_wait(c));
         if ((len >> r) != geo.final_poly_len) return STARKHIP_ERR_BAD_SHAPE;
         for (size_t k = 0; k < len; k++) {
             if (k < geo.final_poly_len) final_poly[k] = gl2_make(fc[k], fc[len + k]);
             else if (fc[k] || fc[len + k]) return STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE;
         }
+        fs.start();
         for (auto& e : final_poly) ch.observe_ext(e);
+        fs.stop();
     }
     HIPCHK(hipEventRecord(c->ev[evi++], st));
     ranges.next("starkhip:pow");
@@ -694,7 +729,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
                 HIPCHK(hipMemcpyAsync(c->pow_best.p, &best, 8, hipMemcpyHostToDevice, st));
                 HIPCHK(launch_pow_grind(c->pow_state.as<gl_t>(), ch.n_in, cfg.proof_of_work_bits, start, batch, c->pow_best.as<unsigned long long>(), st));
                 HIPCHK(hipMemcpyAsync(&best, c->pow_best.p, 8, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
+                HIPCHK(stream_wait(c));
             }
             pow_witness = best;
         }
@@ -750,7 +785,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         memcpy(out + pl.off_next, op_next.data(), C * 16);
         memcpy(out + pl.off_quot_open, op_q.data(), Q * 16);
         if (L) memcpy(out + pl.off_fri_caps, fri_caps.data(), L * 4 * ncap * 8);
-        HIPCHK_FREE(hipStreamSynchronize(st));
+        HIPCHK_FREE(stream_wait(c));
 #undef HIPCHK_FREE
         if (err || off != stride) {
             free(out);
@@ -760,7 +795,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         out[pl.off_pow] = pow_witness;
         if (n_pis) memcpy(out + pl.off_pis, pis_host, n_pis * 8);
     }
-    if (hipEventRecord(c->ev[evi++], st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    if (hipEventRecord(c->ev[evi++], st) != hipSuccess || stream_wait(c) != hipSuccess) {
         free(out);
         return STARKHIP_ERR_HIP;
     }
@@ -772,6 +807,8 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         return STARKHIP_ERR_VERIFY;
     }
     (void)hipEventElapsedTime(&c->timings[STARKHIP_N_PHASES - 1], c->ev[0], c->ev[STARKHIP_N_PHASES - 1]);
+    c->htimings[0] = (float)fs.ms;
+    c->htimings[1] = (float)host_other.ms;
     (void)hipEventElapsedTime(&c->ktimings[0], c->kev[4], c->kev[5]);
     (void)hipEventElapsedTime(&c->ktimings[1], c->kev[0], c->kev[1]);
     (void)hipEventElapsedTime(&c->ktimings[2], c->kev[2], c->kev[3]);
@@ -793,7 +830,7 @@ int lde_batch(Ctx* c, const uint64_t* values, size_t n_cols, unsigned log_n, uns
     HIPCHK(hipMemcpyAsync(c->values.p, values, n_cols * n * 8, hipMemcpyHostToDevice, c->st));
     HIPCHK(run_lde(c, c->values.as<gl_t>(), c->coeffs.as<gl_t>(), c->lde.as<gl_t>(), n_cols, log_n, rate_bits, 0));
     if (coeffs_out) HIPCHK(hipMemcpyAsync(coeffs_out, c->coeffs.p, n_cols * n * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(stream_wait(c));
     if (lde_out) {
         // device layout is coset-major; hand back NATURAL point order i = k * R + s
         std::vector<gl_t> tmp(n_cols * N);
@@ -817,7 +854,7 @@ int merkle_cap(Ctx* c, const uint64_t* lde_natural, size_t n_cols, unsigned log_
     HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
     HIPCHK(launch_merkle_levels(c->digests.as<gl_t>(), log_N, cap_h, c->st));
     HIPCHK(hipMemcpyAsync(cap_out, c->digests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), ((size_t)4 << cap_h) * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(stream_wait(c));
     return STARKHIP_OK;
 }
 
@@ -827,7 +864,7 @@ int permute_batch(Ctx* c, uint64_t* states, size_t n) {
     HIPCHK(hipMemcpyAsync(c->staging.p, states, n * 96, hipMemcpyHostToDevice, c->st));
     HIPCHK(launch_permute_batch(c->staging.as<gl_t>(), n, c->st));
     HIPCHK(hipMemcpyAsync(states, c->staging.p, n * 96, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(stream_wait(c));
     return STARKHIP_OK;
 }
 
@@ -839,7 +876,7 @@ int field_ops(Ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* ou
     HIPCHK(hipMemcpyAsync(d + n, b, n * 8, hipMemcpyHostToDevice, c->st));
     HIPCHK(launch_field_ops(op, d, d + n, d + 2 * n, n, c->st));
     HIPCHK(hipMemcpyAsync(out, d + 2 * n, n * 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(stream_wait(c));
     return STARKHIP_OK;
 }
 

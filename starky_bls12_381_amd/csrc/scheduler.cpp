@@ -265,6 +265,7 @@ struct Job {
     size_t words = 0;
     float phase_ms[STARKHIP_N_PHASES] = {0};
     float kernel_ms[3] = {0};
+    float host_ms[2] = {0};
     double t[5] = {0, 0, 0, 0, 0};  // submit, generation start / end, proof start / end (seconds since the pool was created)
 };
 
@@ -475,6 +476,7 @@ struct Pool {
             }
             memcpy(j->phase_ms, ctx_timings(c), sizeof j->phase_ms);
             memcpy(j->kernel_ms, ctx_kernel_timings(c), sizeof j->kernel_ms);
+            memcpy(j->host_ms, ctx_host_timings(c), sizeof j->host_ms);
             if (j->own_log) {
                 starkhip_trace_log_free(j->own_log);
                 j->own_log = nullptr;
@@ -622,6 +624,7 @@ int pool_wait(Pool* p, uint64_t ticket, uint64_t** proof, size_t* words, starkhi
     if (info) {
         memcpy(info->phase_ms, j->phase_ms, sizeof info->phase_ms);
         memcpy(info->kernel_ms, j->kernel_ms, sizeof info->kernel_ms);
+        memcpy(info->host_ms, j->host_ms, sizeof info->host_ms);
         info->t_submit = j->t[0]; info->t_generate_start = j->t[1]; info->t_generate_end = j->t[2]; info->t_prove_start = j->t[3];
         info->t_done = j->t[4];
     }

@@ -5,11 +5,14 @@
 #   the SQ instruction counters, the kernel-overlap figure of the default four-in-flight run, the integer-VALU issue
 #   rates behind the "4 cycles per instruction" peak, and the default bench line.
 # rocprofv3 gets `python3 ...` directly after `--` (no wrapper that would exec after the GPU is initialised).
+# usage: profile_round.sh TAG [prof|sig|all]   (prof: rocprofv3 passes + bench line; sig: the signature-path measurements)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
+PART=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
+if [ "$PART" != "sig" ]; then
 cd /tmp && export TMPDIR=/tmp
 ONE="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-boundary --inflight 1"
 rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -o kt -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-boundary --inflight 1 > $OUT/prof_kt.log 2>&1
@@ -31,3 +34,15 @@ rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq $OUT/prof_ov
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rate_bench tools/valu_rate_bench.hip && /tmp/valu_rate_bench > $OUT/${TAG}_valu_rates.txt 2>&1 || true
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 head -8 $OUT/${TAG}_kernel_stats.csv; cat $OUT/${TAG}_kernel_overlap.txt; cat $OUT/${TAG}_pmc_traffic.json | head -40; tail -c 3000 $OUT/${TAG}_bench.json
+fi
+if [ "$PART" != "prof" ]; then
+cd $R
+# the signature path from compiled host code (tools/signature_demo.cpp on the library's proof pool) and from the Python harness
+OPS=tests/golden/signature_operands_8.bin
+build/signature_demo --batch 8 --operands $OPS --steps 5 --warmup 1 --timeline > $OUT/${TAG}_demo_batch8.json 2> $OUT/${TAG}_demo_batch8_timeline.txt || true
+build/signature_demo --batch 1 --steps 10 --warmup 2 --timeline > $OUT/${TAG}_demo_batch1.json 2> $OUT/${TAG}_demo_batch1_timeline.txt || true
+python3 tools/bench_signature.py --batch 8 --steps 3 > $OUT/${TAG}_bench_signature_batch8.json 2> /dev/null || true
+python3 tools/bench_signature.py --batch 1 --steps 5 > $OUT/${TAG}_bench_signature.json 2> /dev/null || true
+python3 tools/air_latency.py > $OUT/${TAG}_air_latency.json 2> /dev/null || true
+cut -c1-400 $OUT/${TAG}_demo_batch8.json; cut -c1-400 $OUT/${TAG}_demo_batch1.json; cut -c1-300 $OUT/${TAG}_bench_signature_batch8.json; cut -c1-300 $OUT/${TAG}_bench_signature.json
+fi

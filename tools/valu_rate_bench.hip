@@ -76,6 +76,16 @@ KERNEL(k_salu, "s_add_u32 s10, s10, 3\n")
 KERNEL(k_mix_salu_valu, "s_add_u32 s10, s10, 3\n v_mad_u32_u24 %0, %1, %2, %3\n")
 KERNEL(k_mix_salu_fast, "s_add_u32 s10, s10, 3\n v_add_u32 %0, %1, %2\n")
 
+// DEPENDENT chains: every instruction reads the previous one's result -- one wave alone then shows the result latency, which is
+// what a latency chain (a lone wave walking a sponge) pays per instruction
+KERNEL(k_dep_mad_u64_acc, "v_mad_u64_u32 %4, s[10:11], %1, %2, %4\n")
+KERNEL(k_dep_lshl_add_u64, "v_lshl_add_u64 %4, %4, 0, %5\n")
+KERNEL(k_dep_add_u32, "v_add_u32 %0, %0, %1\n")
+KERNEL(k_dep_mul_lo_u32, "v_mul_lo_u32 %0, %0, %1\n")
+KERNEL(k_dep_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %2\n")
+KERNEL(k_dep_mov_dpp, "v_mov_b32_dpp %0, %0 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf\n")
+KERNEL(k_dep_two_chains, "v_mad_u64_u32 %4, s[10:11], %1, %2, %4\n v_mad_u64_u32 %5, s[10:11], %1, %3, %5\n")
+
 typedef void (*kern_t)(unsigned*, unsigned);
 struct Entry {
     const char* name;
@@ -102,6 +112,9 @@ int main() {
                    {"v_mul_i32_i24", k_mul_i32_i24, 1}, {"v_add_lshl_u32", k_add_lshl_u32, 1}, {"v_xad_u32", k_xad_u32, 1},
                    {"v_or3_b32", k_or3_b32, 1}, {"v_sub_u32_e64", k_sub_e64, 1}, {"v_add_u32_sdwa", k_add_sdwa, 1},
                    {"v_add_u32 + v_mad_u64_u32", k_mix_add_mad, 2}, {"3 simple + v_mad_u64_u32", k_mix_3add_mad, 4},
+                   {"dep: v_mad_u64_u32 (acc)", k_dep_mad_u64_acc, 1}, {"dep: v_lshl_add_u64", k_dep_lshl_add_u64, 1}, {"dep: v_add_u32", k_dep_add_u32, 1},
+                   {"dep: v_mul_lo_u32", k_dep_mul_lo_u32, 1}, {"dep: v_mad_u32_u24", k_dep_mad_u32_u24, 1}, {"dep: v_mov_b32_dpp", k_dep_mov_dpp, 1},
+                   {"dep: 2 chains of mad_u64", k_dep_two_chains, 2},
                    {"s_add_u32", k_salu, 1}, {"s_add_u32 + v_mad_u32_u24", k_mix_salu_valu, 2}, {"s_add_u32 + v_add_u32", k_mix_salu_fast, 2}};
     setvbuf(stdout, NULL, _IOLBF, 0);
     hipDeviceProp_t prop;
