@@ -44,8 +44,23 @@ struct Dif {
         for (int i = 0; i < H; i++) {
             const int e = (E * i) % 192;
             const gl_t a = v[BASE + STRIDE * i], b = v[BASE + STRIDE * (i + H)];
+#ifdef STARKHIP_LDE_NN_BUTTERFLY  // the round-2 form: both operands arbitrary representatives, two wrap corrections per sum and difference
             v[BASE + STRIDE * i] = gl_add_nn(a, b);
             v[BASE + STRIDE * (i + H)] = e < 96 ? gl_mul_pow2_nn(gl_sub_nn(a, b), e) : gl_mul_pow2_nn(gl_sub_nn(b, a), e - 96);
+#else
+            // One operand canonical (3 instructions) makes both the sum and the difference single-correction forms (4 + 5
+            // instead of 7 + 8): the second wrap of a + b or a - b needs BOTH operands >= p - 1 (gl_dev.h).  The subtrahend is
+            // the canonical one: b for (a - b) 2^e, a for the negated form (b - a) 2^(e - 96).
+            if (e < 96) {
+                const gl_t bc = gl_canon(b);
+                v[BASE + STRIDE * i] = gl_add_nc(a, bc);
+                v[BASE + STRIDE * (i + H)] = gl_mul_pow2_nn(gl_sub_nc(a, bc), e);
+            } else {
+                const gl_t ac = gl_canon(a);
+                v[BASE + STRIDE * i] = gl_add_nc(b, ac);
+                v[BASE + STRIDE * (i + H)] = gl_mul_pow2_nn(gl_sub_nc(b, ac), e - 96);
+            }
+#endif
         }
         Dif<H, INV, BASE, STRIDE>::run(v);
         Dif<H, INV, BASE + STRIDE * H, STRIDE>::run(v);
