@@ -97,6 +97,7 @@ pub struct starkhip_pool_config_t {
     pub trace_threads: c_uint,
     pub commit_policy: c_uint,
     pub stream_priority: c_uint,
+    pub warm_up: c_uint,
     pub gather_ms: f32,
 }
 

@@ -178,8 +178,11 @@ typedef struct {
     unsigned commit_policy;     /* 0 = default: small commitments that arrive together share one launch; 1 = in addition a FinalExp-class
                                    commitment never shares the chip with a small one; 2 = no commitment scheduling (every context
                                    launches its own; for A/B measurements) */
-    unsigned stream_priority;   /* 0 = all contexts alike; 1 = FinalExp-class contexts (and their commitments) on high-priority streams;
-                                   2 = the small contexts */
+    unsigned stream_priority;   /* 0 = all contexts alike; 1 = the last wave of FinalExp-class proofs (no more of them waiting than there are
+                                   contexts) on high-priority streams; 2 = the small contexts, 3 = all FinalExp-class proofs (measurements) */
+    unsigned warm_up;           /* != 0: starkhip_pool_create returns when every context has allocated what the BLS pipeline's AIRs of its class
+                                   need (FinalExp on the big contexts; MillerLoop, PairingPrecomp, FP12Mul on the small ones: tables, constraint
+                                   plans, buffers, upload staging), so that no proof pays for -- or stalls the device with -- allocations */
     float gather_ms;            /* how long a merged launch waits for small proofs that have started but not reached their commitment; 0 = default (25) */
 } starkhip_pool_config_t;
 typedef struct {

@@ -499,7 +499,7 @@ class Prover:
 class PoolConfig(C.Structure):
     """starkhip_pool_config_t (0 = the library's default)."""
     _fields_ = [("device", C.c_int), ("big_contexts", C.c_uint), ("small_contexts", C.c_uint), ("generator_threads", C.c_uint),
-                ("trace_threads", C.c_uint), ("commit_policy", C.c_uint), ("stream_priority", C.c_uint), ("gather_ms", C.c_float)]
+                ("trace_threads", C.c_uint), ("commit_policy", C.c_uint), ("stream_priority", C.c_uint), ("warm_up", C.c_uint), ("gather_ms", C.c_float)]
 
 
 class TicketInfo(C.Structure):
@@ -555,8 +555,8 @@ class ProofPool:
     """
 
     def __init__(self, device=0, big_contexts=0, small_contexts=0, generator_threads=0, trace_threads=0, commit_policy=0, gather_ms=0.0,
-                 stream_priority=0):
-        cfg = PoolConfig(device, big_contexts, small_contexts, generator_threads, trace_threads, commit_policy, stream_priority, gather_ms)
+                 stream_priority=0, warm_up=0):
+        cfg = PoolConfig(device, big_contexts, small_contexts, generator_threads, trace_threads, commit_policy, stream_priority, warm_up, gather_ms)
         self._h = C.c_void_p()
         _chk(lib.starkhip_pool_create(C.byref(cfg), C.byref(self._h)))
         self._keep = {}  # ticket -> inputs that must outlive the proof

@@ -80,7 +80,8 @@ struct DevBuf {
 
 struct Ctx {
     int device = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;       // the stream of the current proof: st_normal, or st_high for a proof the pool marks urgent
+    hipStream_t st_normal = nullptr, st_high = nullptr;
     hipEvent_t ev[STARKHIP_N_PHASES + 1];
     float timings[STARKHIP_N_PHASES] = {0};
     hipEvent_t kev[6];            // the three heavy kernels bracketed on their own: leaf hash, quotient evaluation, trace LDE
@@ -89,7 +90,10 @@ struct Ctx {
     HashService* hs = nullptr;    // a pooled context's trace commitments are launched by the pool's scheduler (scheduler.h)
     hipEvent_t hash_ready = nullptr, hash_done = nullptr;
     hipEvent_t wait_ev = nullptr;  // hipEventBlockingSync: see stream_wait()
+    void* host_staging = nullptr;  // page-locked: a recording's parts gathered for one upload (prove(), layout 2)
+    size_t host_staging_cap = 0;
     bool hash_requested = false;
+    bool urgent = false;  // ctx_set_urgent
     // tuning (starkhip_set_option; defaults are the measured best)
     long opt_quotient_impl = 0;   // 0: tiled evaluator (quotient_plan.h), 1: op-stream interpreter (quotient_ops.h)
     long opt_quotient_waves = 65536, opt_quotient_slots = 0, opt_quotient_chunks = 0, opt_quotient_debug = 0;
@@ -281,10 +285,11 @@ int ctx_create(int device, Ctx** out, int priority) {
     if (priority) {  // +1: the highest stream priority of the device, -1: the lowest (pooled contexts, starkhip_pool_config_t)
         int least = 0, greatest = 0;
         ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
-             hipStreamCreateWithPriority(&c->st, hipStreamDefault, priority > 0 ? greatest : least) == hipSuccess;
+             hipStreamCreateWithPriority(&c->st_normal, hipStreamDefault, priority > 0 ? greatest : least) == hipSuccess;
     } else {
-        ok = hipStreamCreate(&c->st) == hipSuccess;
+        ok = hipStreamCreate(&c->st_normal) == hipSuccess;
     }
+    c->st = c->st_normal;
     for (auto& e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     for (auto& e : c->kev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->hash_ready, hipEventDisableTiming) == hipSuccess;
@@ -298,7 +303,7 @@ int ctx_create(int device, Ctx** out, int priority) {
             if (e) (void)hipEventDestroy(e);
         for (auto& e : c->kev)
             if (e) (void)hipEventDestroy(e);
-        if (c->st) (void)hipStreamDestroy(c->st);
+        if (c->st_normal) (void)hipStreamDestroy(c->st_normal);
         delete c;
         return STARKHIP_ERR_HIP;
     }
@@ -327,10 +332,25 @@ void ctx_destroy(Ctx* c) {
     (void)hipEventDestroy(c->hash_ready);
     (void)hipEventDestroy(c->hash_done);
     (void)hipEventDestroy(c->wait_ev);
-    (void)hipStreamDestroy(c->st);
+    if (c->host_staging) (void)hipHostFree(c->host_staging);
+    (void)hipStreamDestroy(c->st_normal);
+    if (c->st_high) (void)hipStreamDestroy(c->st_high);
     delete c;
 }
 void ctx_attach_hash_service(Ctx* c, HashService* hs) { c->hs = hs; }
+// The next proofs of this context run on a high-priority stream (urgent = true) or on its ordinary one.  Between proofs only:
+// a context's stream is idle then.
+int ctx_set_urgent(Ctx* c, bool urgent) {
+    if (urgent && !c->st_high) {
+        HIPCHK(hipSetDevice(c->device));
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&c->st_high, hipStreamDefault, greatest));
+    }
+    c->st = urgent ? c->st_high : c->st_normal;
+    c->urgent = urgent;
+    return STARKHIP_OK;
+}
 bool ctx_has_hash_service(Ctx* c) { return c->hs != nullptr; }
 void ctx_hash_request_reset(Ctx* c) { c->hash_requested = false; }
 bool ctx_hash_requested(Ctx* c) { return c->hash_requested; }
@@ -444,21 +464,30 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         uint32_t* d_offsets = d_words + nw;
         uint32_t* d_zeros = d_offsets + nr;
         HIPCHK(hipMemsetAsync(c->values.p, 0, C * n * 8, st));
-        {  // a log recorded by several threads comes in parts (trace_log.h): each part's words land at its base, its offsets
-           // (already shifted by that base) and late zeros back to back
+        {  // A log recorded by several threads comes in parts (trace_log.h): each part's words land at its base, its offsets
+           // (already shifted by that base) and late zeros back to back.  The parts are gathered into ONE page-locked staging
+           // buffer of the context and go up as ONE copy: a FinalExp recording has 53 parts x 3 arrays, and on a GPU that other
+           // proofs keep busy every one of 160 dependent stream operations waits its turn (measured: 0.9 - 1.6 s of "upload" for a
+           // proof whose copies queued behind other proofs' commitments, against 6 ms alone).
+            const size_t total = nw + nr + nz;
+            if (c->host_staging_cap < total * 4) {
+                if (c->host_staging) (void)hipHostFree(c->host_staging);
+                c->host_staging = nullptr;
+                c->host_staging_cap = 0;
+                const size_t want = total * 4 + total;  // + 25 %: the next recording of this AIR is about as long
+                HIPCHK(hipHostMalloc(&c->host_staging, want, hipHostMallocDefault));
+                c->host_staging_cap = want;
+            }
+            uint32_t* h = (uint32_t*)c->host_staging;
             size_t at_r = 0, at_z = 0;
-            hipError_t up = hipSuccess;
             log->for_each_part([&](const TraceLog& part) {
-                if (up != hipSuccess) return;
-                if (!part.words.empty()) up = hipMemcpyAsync(d_words + part.base, part.words.data(), part.words.size() * 4, hipMemcpyHostToDevice, st);
-                if (up == hipSuccess && !part.offsets.empty())
-                    up = hipMemcpyAsync(d_offsets + at_r, part.offsets.data(), part.offsets.size() * 4, hipMemcpyHostToDevice, st);
-                if (up == hipSuccess && !part.late_zeros.empty())
-                    up = hipMemcpyAsync(d_zeros + at_z, part.late_zeros.data(), part.late_zeros.size() * 4, hipMemcpyHostToDevice, st);
+                if (!part.words.empty()) memcpy(h + part.base, part.words.data(), part.words.size() * 4);
+                if (!part.offsets.empty()) memcpy(h + nw + at_r, part.offsets.data(), part.offsets.size() * 4);
+                if (!part.late_zeros.empty()) memcpy(h + nw + nr + at_z, part.late_zeros.data(), part.late_zeros.size() * 4);
                 at_r += part.offsets.size();
                 at_z += part.late_zeros.size();
             });
-            HIPCHK(up);
+            if (total) HIPCHK(hipMemcpyAsync(d_words, h, total * 4, hipMemcpyHostToDevice, st));
         }
         if (nr) HIPCHK(launch_expand_trace(d_words, d_offsets, nr, c->values.as<gl_t>(), n, st));
         if (nz) HIPCHK(launch_zero_cells(d_zeros, nz / 2, c->values.as<gl_t>(), n, st));
@@ -494,7 +523,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(hipEventRecord(c->kev[0], st));
     if (c->hs) {  // pooled: the scheduler decides when this commitment runs and which others share its launch
         c->hash_requested = true;
-        HIPCHK(c->hs->hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st, c->hash_ready, c->hash_done, !HashService::is_big(log_n, r)));
+        HIPCHK(c->hs->hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st, c->hash_ready, c->hash_done, !HashService::is_big(log_n, r), c->urgent));
     } else {
         HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
     }
@@ -815,6 +844,61 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     *proof_out = out;
     *proof_words = pl.total;
     return STARKHIP_OK;
+}
+
+// Everything a proof of `air` (default rows, config `cfg`) will ask of this context, allocated NOW: shape tables, the constraint
+// plan, every work buffer, the page-locked staging of a recording of `log_bytes`.  A pool warms its contexts with this before the
+// first job: growing a buffer later means hipFree + hipMalloc (or hipHostFree + hipHostMalloc), and those wait for EVERY stream of
+// the device -- measured in a batch of 8 signatures: a PairingPrecomp proof with 212 ms of device time held its context for 2.3 s
+// because its buffers grew while four FinalExp proofs kept the device busy.
+int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t log_bytes) {
+    const AirProgram& P = air.prog;
+    const size_t n = air.default_rows;
+    unsigned log_n = 0;
+    while (((size_t)1 << log_n) < n) log_n++;
+    FriGeometry geo;
+    if (!FriGeometry::make(cfg, log_n, &geo)) return STARKHIP_ERR_BAD_SHAPE;
+    const unsigned r = cfg.rate_bits;
+    const unsigned factor = P.degree > 1 ? P.degree - 1 : 1;
+    unsigned qdb = 0;
+    while ((1u << qdb) < factor) qdb++;
+    if (qdb > r) return STARKHIP_ERR_BAD_SHAPE;
+    const size_t N = n << r, C = P.n_cols, Q = (size_t)factor * 2, size = n << qdb, L = geo.arities.size();
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_tables(c, log_n, r, qdb))) return rc;
+    if ((rc = ensure_plan(c, air, size))) return rc;
+    const unsigned n_chunks = c->plan->chunks;
+    const size_t comb_chunks = (C + 255) / 256;
+    ProofLayout pl;
+    pl.C = C; pl.Q = Q; pl.log_n = log_n; pl.rate_bits = r; pl.cap_h = cfg.cap_height; pl.L = L; pl.n_queries = cfg.num_query_rounds;
+    pl.final_len = geo.final_poly_len; pl.n_pis = P.n_pis; pl.arity_bits = cfg.arity_bits; pl.n_challenges = 2;
+    pl.compute();
+    struct Want { DevBuf* b; size_t bytes; };
+    const Want wants[] = {{&c->values, C * n * 8}, {&c->coeffs, C * n * 8}, {&c->lde, C * N * 8}, {&c->digests, digest_words(N) * 8},
+                          {&c->pis, std::max<size_t>(1, P.n_pis) * 8}, {&c->apow, 2 * (AIR_MAX_GROUP + 1) * 8}, {&c->chunk_scale, 2 * (size_t)n_chunks * 8},
+                          {&c->partial, (size_t)n_chunks * 2 * size * 8}, {&c->qvals, 2 * size * 8}, {&c->qcoef, Q * n * 8}, {&c->qlde, Q * N * 8},
+                          {&c->qdigests, digest_words(N) * 8}, {&c->zpow, n * 16}, {&c->gzpow, n * 16}, {&c->open_local, C * 16}, {&c->open_next, C * 16},
+                          {&c->open_q, Q * 16}, {&c->ext_apow, (C + Q) * 16}, {&c->comb_partial, comb_chunks * n * 16}, {&c->comb_out, 2 * n * 16},
+                          {&c->fri_coef, 2 * N * 8}, {&c->fri_vals, 2 * N * 8}, {&c->scale_tab, N * 8}, {&c->pow_state, 12 * 8}, {&c->pow_best, 8},
+                          {&c->qidx, cfg.num_query_rounds * 4}, {&c->gather_t, cfg.num_query_rounds * pl.query_words * 8},
+                          {&c->staging, log_bytes + 64}};
+    for (const Want& w : wants) HIPCHK(w.b->ensure(w.bytes));
+    size_t len = N;
+    for (size_t l = 0; l < L; l++) {
+        const unsigned ab = geo.arities[l];
+        HIPCHK(c->fri_rows[l].ensure(len * 2 * 8));
+        HIPCHK(c->fri_digests[l].ensure(digest_words(len >> ab) * 8));
+        len >>= ab;
+    }
+    if (log_bytes && c->host_staging_cap < log_bytes) {
+        if (c->host_staging) (void)hipHostFree(c->host_staging);
+        c->host_staging = nullptr;
+        c->host_staging_cap = 0;
+        HIPCHK(hipHostMalloc(&c->host_staging, log_bytes, hipHostMallocDefault));
+        c->host_staging_cap = log_bytes;
+    }
+    return stream_wait(c) == hipSuccess ? STARKHIP_OK : STARKHIP_ERR_HIP;
 }
 
 // ---------------------------------------------------------------- kernel-level entry points (tests)

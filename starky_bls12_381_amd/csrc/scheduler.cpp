@@ -49,7 +49,7 @@ unsigned cpu_budget() {
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ------------------------------------------------------------------------------------------------ HashService
-HashService::HashService(int device, int big_priority) : device_(device), big_priority_(big_priority) { th_ = std::thread([this] { run(); }); }
+HashService::HashService(int device) : device_(device) { th_ = std::thread([this] { run(); }); }
 
 HashService::~HashService() {
     {
@@ -78,11 +78,12 @@ HashService::Stats HashService::stats() {
 }
 
 hipError_t HashService::hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st, hipEvent_t ready,
-                             hipEvent_t done, bool announced) {
+                             hipEvent_t done, bool announced, bool urgent) {
     hipError_t e = hipEventRecord(ready, st);
     Req r;
     r.mat = mat; r.digests = digests; r.n_cols = n_cols; r.log_n = log_n; r.rate_bits = rate_bits; r.ready = ready; r.done = done;
     r.big = is_big(log_n, rate_bits);
+    r.urgent = urgent;
     r.t_arrive = now_s();
     std::unique_lock<std::mutex> lk(mu_);
     if (announced && announced_ > 0) announced_--;
@@ -105,9 +106,10 @@ void HashService::drain(std::vector<hipEvent_t>& evs) {
 }
 
 void HashService::launch_big(Req* r) {
-    hipError_t e = hipStreamWaitEvent(st_, r->ready, 0);
-    if (e == hipSuccess) e = launch_leaf_hash(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, st_);
-    if (e == hipSuccess) e = hipEventRecord(r->done, st_);
+    hipStream_t s = (r->urgent && st_high_) ? st_high_ : st_;
+    hipError_t e = hipStreamWaitEvent(s, r->ready, 0);
+    if (e == hipSuccess) e = launch_leaf_hash(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s);
+    if (e == hipSuccess) e = hipEventRecord(r->done, s);
     r->err = e;
     if (e == hipSuccess) running_big_.push_back(r->done);
 }
@@ -169,11 +171,10 @@ void HashService::launch_small(std::vector<Req*>& reqs) {
 void HashService::run() {
     (void)hipSetDevice(device_);
     int least = 0, greatest = 0;
-    if (big_priority_ && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) {
-        if (hipStreamCreateWithPriority(&st_, hipStreamNonBlocking, greatest) != hipSuccess) st_ = nullptr;
-    } else if (hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) != hipSuccess) {
-        st_ = nullptr;
-    }
+    if (hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) != hipSuccess) st_ = nullptr;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&st_high_, hipStreamNonBlocking, greatest) != hipSuccess)
+        st_high_ = nullptr;
     std::unique_lock<std::mutex> lk(mu_);
     while (true) {
         cv_.wait(lk, [&] { return stop_ || !big_.empty() || !small_.empty(); });
@@ -225,10 +226,11 @@ void HashService::run() {
         cv_.wait_for(lk, std::chrono::microseconds((long)(std::max(0.1, left_ms) * 1e3)));
     }
     lk.unlock();
-    if (st_) {
-        (void)hipStreamSynchronize(st_);
-        (void)hipStreamDestroy(st_);
-    }
+    for (hipStream_t s : {st_, st_high_})
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
     for (hipStream_t& s : small_st_)
         if (s) {
             (void)hipStreamSynchronize(s);
@@ -315,6 +317,10 @@ struct Pool {
     unsigned gen_threads = 0, trace_threads_cfg = 0, gen_running = 0, cpus = 1;
     size_t big_recordings_started = 0, big_proofs_done = 0;  // under mu
     std::map<int, int> idle_big, idle_small;                 // idle contexts by the AIR they proved last (under mu)
+    unsigned stream_priority = 0;
+    bool warm = false;        // contexts reserve the pipeline's AIRs when their threads start (pool_create waits for it)
+    unsigned warmed = 0;
+    int warm_rc = STARKHIP_OK;
     std::vector<std::thread> threads;
 
     double now() const { return now_s() - t0; }
@@ -423,6 +429,29 @@ struct Pool {
         // (growing them means hipFree + hipMalloc, and hipFree waits for every kernel on the device).  So a waiting job goes to
         // a context that proved its AIR last if one is idle; a context takes another AIR only when no idle one matches it.
         int last_air = -1;
+        bool urgent = false;
+        if (warm) {  // every context brings up what the BLS pipeline's AIRs of its class need, all contexts in parallel
+            static const struct { int air; size_t log_bytes; } BIG[] = {{STARKHIP_AIR_FINAL_EXP, (size_t)200 << 20}},
+                SMALL[] = {{STARKHIP_AIR_MILLER_LOOP, (size_t)110 << 20}, {STARKHIP_AIR_PAIRING_PRECOMP, (size_t)44 << 20}, {STARKHIP_AIR_FP12_MUL, (size_t)2 << 20}};
+            int rc = STARKHIP_OK;
+            auto one = [&](int air, size_t log_bytes) {
+                const AirInfo* a = air_get(air);
+                starkhip_config_t cfg;
+                if (!a || starkhip_config_for_air((starkhip_air_t)air, &cfg) != STARKHIP_OK) return;
+                try {
+                    const int r = ctx_reserve(c, *a, cfg, log_bytes);
+                    if (r != STARKHIP_OK) rc = r;
+                } catch (const std::exception&) {
+                    rc = STARKHIP_ERR_OOM;
+                }
+            };
+            if (big) for (const auto& w : BIG) one(w.air, w.log_bytes);
+            else for (const auto& w : SMALL) one(w.air, w.log_bytes);
+            std::lock_guard<std::mutex> g(mu);
+            if (rc != STARKHIP_OK && warm_rc == STARKHIP_OK) warm_rc = rc;
+            warmed++;
+            cv_done.notify_all();
+        }
         while (true) {
             Job* j = nullptr;
             {
@@ -455,7 +484,12 @@ struct Pool {
                 last_air = j->air;
                 j->state = 1;
                 j->t[3] = now();
+                // stream_priority 1: the LAST wave of FinalExp-class proofs -- no more of them waiting than there are contexts --
+                // is the tail every other proof has finished before; it runs on high-priority streams.  The first wave does not:
+                // strict priority starves the small proofs (a MillerLoop upload measured at 2 s behind four urgent FinalExp proofs)
+                urgent = big && stream_priority == 1 && q.size() < big_ctx.size();
             }
+            if (big && stream_priority == 1) (void)ctx_set_urgent(c, urgent);
             int rc;
             const bool announce = !big && ctx_has_hash_service(c);
             if (announce) hs->announce_small();
@@ -501,7 +535,7 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
     for (unsigned i = 0; i < n_big + n_small && rc == STARKHIP_OK; i++) {
         Ctx* c = nullptr;
         const bool is_big = i < n_big;
-        const int prio = cfg.stream_priority == 1 ? (is_big ? 1 : 0) : cfg.stream_priority == 2 ? (is_big ? 0 : 1) : 0;
+        const int prio = cfg.stream_priority == 3 ? (is_big ? 1 : 0) : cfg.stream_priority == 2 ? (is_big ? 0 : 1) : 0;
         rc = ctx_create(cfg.device, &c, prio);
         if (rc == STARKHIP_OK) (i < n_big ? p->big_ctx : p->small_ctx).push_back(c);
     }
@@ -510,7 +544,9 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
         for (Ctx* c : p->small_ctx) ctx_destroy(c);
         return rc;
     }
-    p->hs.reset(new HashService(cfg.device, cfg.stream_priority == 1 ? 1 : 0));
+    p->hs.reset(new HashService(cfg.device));
+    p->stream_priority = cfg.stream_priority;
+    p->warm = cfg.warm_up != 0;
     if (cfg.gather_ms > 0) p->hs->gather_ms = cfg.gather_ms;
     p->hs->policy = (int)cfg.commit_policy;
     if (cfg.commit_policy != 2) {  // 2: no commitment scheduling at all -- every context launches its own (A/B measurements)
@@ -521,6 +557,16 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
     for (unsigned i = 0; i < p->gen_threads; i++) p->threads.emplace_back([raw] { raw->generator_loop(); });
     for (Ctx* c : p->big_ctx) p->threads.emplace_back([raw, c] { raw->prover_loop(c, true); });
     for (Ctx* c : p->small_ctx) p->threads.emplace_back([raw, c] { raw->prover_loop(c, false); });
+    if (p->warm) {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_done.wait(lk, [&] { return p->warmed == n_big + n_small; });
+        const int wrc = p->warm_rc;
+        lk.unlock();
+        if (wrc != STARKHIP_OK) {
+            pool_destroy(p.release());
+            return wrc;
+        }
+    }
     *out = p.release();
     return STARKHIP_OK;
 }

@@ -26,7 +26,7 @@ namespace starkhip {
 
 class HashService {
   public:
-    explicit HashService(int device, int big_priority = 0);
+    explicit HashService(int device);
     ~HashService();
     HashService(const HashService&) = delete;
     HashService& operator=(const HashService&) = delete;
@@ -39,7 +39,7 @@ class HashService {
     // enqueued on `st` so far; when this returns, `st` has been made to wait for the launch (the caller goes on enqueueing).
     // `ready` / `done` are events owned by the caller's context.
     hipError_t hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st, hipEvent_t ready,
-                    hipEvent_t done, bool announced);
+                    hipEvent_t done, bool announced, bool urgent = false);
 
     static bool is_big(unsigned log_n, unsigned rate_bits) { return log_n + rate_bits >= 15; }  // >= 2048 waves: fills every SIMD twice
     double gather_ms = 25.0;  // how long a small window waits for announced proofs that have not reached their commitment
@@ -62,7 +62,7 @@ class HashService {
         size_t n_cols;
         unsigned log_n, rate_bits;
         hipEvent_t ready, done;
-        bool big;
+        bool big, urgent = false;
         int state = 0;  // 0 queued, 1 launched, 2 failed
         hipError_t err = hipSuccess;
         double t_arrive = 0;
@@ -72,8 +72,8 @@ class HashService {
     void launch_small(std::vector<Req*>& reqs);
     void drain(std::vector<hipEvent_t>& evs);
 
-    int device_, big_priority_ = 0;
-    hipStream_t st_ = nullptr;
+    int device_;
+    hipStream_t st_ = nullptr, st_high_ = nullptr;  // big commitments: ordinary / urgent (high-priority stream)
     // merged launches run side by side: each goes to a stream that is idle, so a window never queues behind an earlier one
     static const int N_SMALL_STREAMS = 12;
     hipStream_t small_st_[N_SMALL_STREAMS] = {};

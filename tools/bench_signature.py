@@ -79,7 +79,7 @@ def main():
         big = max(1, args.big_inflight if args.batch > 1 else 1)
         small = args.small_inflight if args.small_inflight > 0 else 5
         provers = S.ProofPool(local_rank, big_contexts=big, small_contexts=small, generator_threads=args.gen_threads,
-                              trace_threads=args.trace_threads, commit_policy=args.policy, gather_ms=args.gather_ms, stream_priority=args.priority)
+                              trace_threads=args.trace_threads, commit_policy=args.policy, gather_ms=args.gather_ms, stream_priority=args.priority, warm_up=1)
         all_provers = [provers]
     elif args.small_inflight > 0:
         provers = {"big": [S.Prover(local_rank) for _ in range(max(1, args.big_inflight))],

@@ -72,6 +72,7 @@ int main(int argc, char** argv) {
     starkhip_pool_config_t cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.stream_priority = 1;
+    cfg.warm_up = 1;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
@@ -87,6 +88,7 @@ int main(int argc, char** argv) {
         else if (a == "--trace-threads") cfg.trace_threads = (unsigned)strtoul(val(), nullptr, 0);
         else if (a == "--policy") cfg.commit_policy = (unsigned)strtoul(val(), nullptr, 0);
         else if (a == "--priority") cfg.stream_priority = (unsigned)strtoul(val(), nullptr, 0);
+        else if (a == "--warm") cfg.warm_up = (unsigned)strtoul(val(), nullptr, 0);
         else if (a == "--gather-ms") cfg.gather_ms = (float)atof(val());
         else if (a == "--device") cfg.device = atoi(val());
         else {
@@ -155,9 +157,11 @@ int main(int argc, char** argv) {
                 const starkhip_driver::Proof* ps[] = {&proofs[i].pp1, &proofs[i].ml1, &proofs[i].pp2, &proofs[i].ml2, &proofs[i].fp12_mul, &proofs[i].final_exp};
                 for (int k = 0; k < 6; k++) {
                     const starkhip_ticket_info_t& f = ps[k]->info;
-                    fprintf(stderr, "%zu:%-9s submit %7.1f gen %7.1f..%7.1f prove %7.1f..%7.1f | lde %5.1f merkle %6.1f quot %5.1f fri_comb %5.1f total %6.1f\n", i, names[k],
+                    fprintf(stderr, "%zu:%-9s submit %7.1f gen %7.1f..%7.1f prove %7.1f..%7.1f | up %5.1f lde %5.1f merkle %6.1f quot %5.1f qcom %5.1f open %5.1f fri_comb %5.1f "
+                            "fri_com %5.1f pow %5.1f query %5.1f total %6.1f | host fs %5.1f\n", i, names[k],
                             (f.t_submit - t0) * 1e3, (f.t_generate_start - t0) * 1e3, (f.t_generate_end - t0) * 1e3, (f.t_prove_start - t0) * 1e3,
-                            (f.t_done - t0) * 1e3, f.phase_ms[1], f.phase_ms[2], f.phase_ms[3], f.phase_ms[6], f.phase_ms[10]);
+                            (f.t_done - t0) * 1e3, f.phase_ms[0], f.phase_ms[1], f.phase_ms[2], f.phase_ms[3], f.phase_ms[4], f.phase_ms[5], f.phase_ms[6], f.phase_ms[7],
+                            f.phase_ms[8], f.phase_ms[9], f.phase_ms[10], f.host_ms[0]);
                 }
             }
         }
