@@ -230,28 +230,38 @@ __global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kern
                     const unsigned n_cosets = 1u << rate_bits;
                     char* cf_out = (char*)(coeffs + (size_t)col0 * n);
                     char* out_base = (char*)(lde + (size_t)col0 * n_cosets * n);
+                    // 16-byte stores (two adjacent words per lane: 8-byte stores reach 0.5 - 0.7 of their rate): thread t owns words
+                    // 2 t, 2 t + 1 of every block of 2 T
+                    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
                     if (is_const) {
                         const gl_t c = gl_canon(first);
 #pragma unroll
-                        for (int i = 0; i < 16; i++) *(gl_t*)(cf_out + in_off + (uint32_t)(i * T * 8)) = (t == 0 && i == 0) ? c : 0;
+                        for (int i = 0; i < 8; i++) {
+                            u64x2 w = {0, 0};
+                            if (t == 0 && i == 0) w.x = c;
+                            *(u64x2*)(cf_out + (uint32_t)((2 * t + i * 2 * T) * 8)) = w;
+                        }
+                        const u64x2 cc = {c, c};
                         for (unsigned s = 0; s < n_cosets; s++) {
-                            const uint32_t out_off = (uint32_t)(s * n + t) * 8u;
 #pragma unroll
-                            for (int i = 0; i < 16; i++) *(gl_t*)(out_base + out_off + (uint32_t)(i * T * 8)) = c;
+                            for (int i = 0; i < 8; i++) *(u64x2*)(out_base + (uint32_t)((s * n + 2 * t + i * 2 * T) * 8)) = cc;
                         }
                     } else {
                         const unsigned r = cls[2];
 #pragma unroll
-                        for (int i = 0; i < 16; i++) {
-                            const unsigned j = (unsigned)(t + i * T);
-                            *(gl_t*)(cf_out + in_off + (uint32_t)(i * T * 8)) = oh[(r * j) & (unsigned)(n - 1)];
+                        for (int i = 0; i < 8; i++) {
+                            const unsigned j = (unsigned)(2 * t + i * 2 * T);
+                            const u64x2 w = {oh[(r * j) & (unsigned)(n - 1)], oh[(r * (j + 1)) & (unsigned)(n - 1)]};
+                            *(u64x2*)(cf_out + (uint32_t)(j * 8)) = w;
                         }
                         for (unsigned s = 0; s < n_cosets; s++) {
                             const gl_t* e0 = oh + n + (size_t)s * n;
-                            const uint32_t out_off = (uint32_t)(s * n + t) * 8u;
 #pragma unroll
-                            for (int i = 0; i < 16; i++)
-                                *(gl_t*)(out_base + out_off + (uint32_t)(i * T * 8)) = e0[((unsigned)(t + i * T) - r) & (unsigned)(n - 1)];
+                            for (int i = 0; i < 8; i++) {
+                                const unsigned j = (unsigned)(2 * t + i * 2 * T);
+                                const u64x2 w = {e0[(j - r) & (unsigned)(n - 1)], e0[(j + 1 - r) & (unsigned)(n - 1)]};
+                                *(u64x2*)(out_base + (uint32_t)((s * n + j) * 8)) = w;
+                            }
                         }
                     }
                     return;

@@ -110,3 +110,58 @@ def test_by_type_schedule_starts_final_exp_after_the_small_proofs():
     order.clear()
     res, _ = G.run_jobs({"big": [object()], "small": [object(), object()]}, jobs, args, gen_threads=4, prove=prove, generate=generate)
     assert len(res) == 12 and order.index("final_exp") < 10  # both pools at once: FinalExp does not wait
+
+
+class _FakePool(S.ProofPool):
+    """Stands in for the library's proof pool on a box without a GPU: `submit_witness` unpacks the operand vector exactly as the
+    pool's generator thread does (starkhip.h's layouts), runs the REAL recording generator and returns a blob that ends in the
+    public inputs, as every proof does."""
+
+    def __init__(self):   # no starkhip_pool_create
+        self._jobs = {}
+        self._next = 1
+
+    def close(self):
+        pass
+
+    def submit_witness(self, air, *generator_args, config=None, pow_witness=S.POW_SEARCH):
+        w = S.witness_operands(air, *generator_args)
+        if air == S.AIR_FP12_MUL:
+            assert w.size == 288
+            _, pis = S.trace_fp12_mul(w[:144], w[144:], compact=True)
+        elif air == S.AIR_FINAL_EXP:
+            assert w.size == 144
+            pis = np.concatenate([w.astype(np.uint64), S.native_final_exponentiate(w).astype(np.uint64)])   # public inputs only: input, output
+        elif air == S.AIR_MILLER_LOOP:
+            assert w.size == 96
+            _, pis = S.trace_miller_loop(w[:12], w[12:24], w[24:48], w[48:72], w[72:96], compact=True)
+        elif air == S.AIR_PAIRING_PRECOMP:
+            assert w.size == 72
+            _, pis = S.trace_pairing_precomp(w[:24], w[24:48], w[48:72], compact=True)
+        else:
+            raise AssertionError(air)
+        t = self._next
+        self._next += 1
+        self._jobs[t] = np.concatenate([np.full(5, 7 + air, dtype=np.uint64), np.asarray(pis, dtype=np.uint64)])
+        return t
+
+    def wait(self, ticket, keep=True):
+        return self._jobs.pop(ticket), {"timeline_s": [0.0, 0.0, 0.01, 0.01, 0.02], "phase_ms": {}, "kernel_ms": {}, "host_ms": {}}
+
+    def stats(self):
+        return {}
+
+
+def test_pool_driver_submits_every_job_with_the_operands_its_generator_takes():
+    """signature.run_jobs_pool / one_step on a pool: the four jobs that need only the operands go first, the two that need the
+    native Miller-loop values follow; what comes back links, binds to the statement and attests to a valid signature."""
+    sigs = G.synthetic_signatures(2, _vector(), seed=11)
+    mine = G.plan_batch(2, 1)[0]
+    elapsed, results, stats, got_sigs, natives = G.one_step(None, 2, _FakePool(), mine, sigs)
+    assert sorted(results) == sorted(mine) and sorted(natives) == [0, 1]
+    verdicts = G.check_signatures(results, got_sigs, natives, 2)
+    assert verdicts == {0: True, 1: True}
+    # the FinalExp public inputs the fake pool derived from the packed operands are the natives' product and its exponentiation
+    fe = results[(1, "final_exp")][1][-288:]
+    assert np.array_equal(fe[:144], natives[1]["product"].astype(np.uint64)) and np.array_equal(fe[144:], natives[1]["final"].astype(np.uint64))
+    assert stats["generate_s"] >= 0 and elapsed > 0
