@@ -43,6 +43,11 @@ unsigned cpu_budget() {
         if (fp) fclose(fp);
     }
     if (quota > 0 && period > 0) hw = std::min(hw, std::max(1u, (unsigned)(quota / period + 0.5)));
+    // one process per GPU (torch.distributed.run exports LOCAL_WORLD_SIZE): the node's CPUs are shared by that many pools
+    if (const char* lws = getenv("LOCAL_WORLD_SIZE")) {
+        const long ranks = atol(lws);
+        if (ranks > 1) hw = std::max(1u, hw / (unsigned)ranks);
+    }
     return hw;
 }
 
