@@ -56,8 +56,15 @@ tsan-test: tests/tsan_trace_main.cpp $(ASAN_SRCS) $(HDRS)
 	@mkdir -p build/tsan
 	g++ -O1 -g -std=c++17 -fsanitize=thread -fno-omit-frame-pointer -Iinclude -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o build/tsan/tsan_trace tests/tsan_trace_main.cpp $(ASAN_SRCS) -lpthread
 	TSAN_OPTIONS=halt_on_error=1 build/tsan/tsan_trace
+	g++ -O1 -g -std=c++17 -fsanitize=thread -fno-omit-frame-pointer -Iinclude -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o build/tsan/tsan_pool tests/tsan_pool_main.cpp $(ASAN_SRCS) -lpthread
+	TSAN_OPTIONS=halt_on_error=1 build/tsan/tsan_pool
+# the same pool harness under AddressSanitizer + UndefinedBehaviorSanitizer
+asan-pool-test: tests/tsan_pool_main.cpp $(ASAN_SRCS) $(HDRS)
+	@mkdir -p build/asan
+	g++ $(filter-out -shared -fPIC,$(ASAN_FLAGS)) -o build/asan/asan_pool tests/tsan_pool_main.cpp $(ASAN_SRCS) -lpthread
+	ASAN_OPTIONS=detect_leaks=1:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 build/asan/asan_pool
 
 clean:
 	rm -rf build $(OUT)
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean demo asan asan-test tsan-test
+.PHONY: all oracle clean demo asan asan-test tsan-test asan-pool-test

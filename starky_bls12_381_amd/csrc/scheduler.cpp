@@ -228,7 +228,9 @@ void HashService::run() {
         }
         // small requests are pending but the window is still gathering: wake up when something arrives or its time is up
         const double left_ms = gather_ms - (now_s() - small_.front()->t_arrive) * 1e3;
-        cv_.wait_for(lk, std::chrono::microseconds((long)(std::max(0.1, left_ms) * 1e3)));
+        // (system_clock deadline = pthread_cond_timedwait: ThreadSanitizer of gcc 11 does not know pthread_cond_clockwait, which a
+        // steady-clock wait_for uses, and then reports the mutex as still held)
+        cv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds((long)(std::max(0.1, left_ms) * 1e3)));
     }
     lk.unlock();
     for (hipStream_t s : {st_, st_high_})
@@ -482,7 +484,7 @@ struct Pool {
                         return;
                     }
                     // shutting down: the queue may drain through other contexts without another notification
-                    if (stop) cv.wait_for(lk, std::chrono::milliseconds(20));
+                    if (stop) cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(20));
                     else cv.wait(lk);
                 }
                 idle[last_air]--;

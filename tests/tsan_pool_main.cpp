@@ -1,0 +1,115 @@
+// Sanitizer harness for the proof pool's host logic (csrc/scheduler.cpp): generator threads, context workers, the commitment
+// scheduler (gather window, merged launches, the two classes), job-to-context matching, failing jobs, shutdown with work queued.
+// Built by `make tsan-test` / `make asan-test` WITHOUT a GPU against the stand-ins of csrc/host_only_stubs.cc
+// (STARKHIP_FAKE_DEVICE=1: contexts exist, prove() sleeps and returns a blob that ends in the public inputs).  Test
+// infrastructure only: it checks threading and memory, nothing about proofs.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+#include "starkhip.h"
+
+#define CHECK(cond)                                                      \
+    do {                                                                 \
+        if (!(cond)) {                                                   \
+            fprintf(stderr, "tsan_pool: %s failed at line %d\n", #cond, __LINE__); \
+            return 1;                                                    \
+        }                                                                \
+    } while (0)
+
+static std::vector<uint32_t> limbs(size_t n, uint32_t seed) {
+    std::vector<uint32_t> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = (i % 12 == 11) ? 0x09000000u : seed * 0x9E3779B1u + 13u * (uint32_t)i;
+    return v;
+}
+
+int main() {
+    setenv("STARKHIP_FAKE_DEVICE", "1", 1);
+    for (unsigned policy = 0; policy < 3; policy++) {
+        starkhip_pool_config_t cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.big_contexts = 2;
+        cfg.small_contexts = 5;
+        cfg.generator_threads = 3;
+        cfg.trace_threads = 2;
+        cfg.commit_policy = policy;
+        cfg.stream_priority = 1;
+        cfg.warm_up = 1;
+        cfg.gather_ms = 5.0f;
+        void* pool = nullptr;
+        CHECK(starkhip_pool_create(&cfg, &pool) == STARKHIP_OK);
+        // witness jobs of three small AIRs and the toy one, submitted from several threads at once
+        struct Sub { starkhip_air_t air; std::vector<uint32_t> ops; uint64_t pow; uint64_t ticket; int rc_submit; };
+        std::vector<Sub> subs;
+        for (int k = 0; k < 4; k++) subs.push_back({STARKHIP_AIR_FP12_MUL, limbs(288, 1 + k), STARKHIP_POW_SEARCH, 0, 0});
+        for (int k = 0; k < 3; k++) subs.push_back({STARKHIP_AIR_PAIRING_PRECOMP, limbs(72, 11 + k), STARKHIP_POW_SEARCH, 0, 0});
+        for (int k = 0; k < 2; k++) subs.push_back({STARKHIP_AIR_MILLER_LOOP, limbs(96, 21 + k), STARKHIP_POW_SEARCH, 0, 0});
+        subs.push_back({STARKHIP_AIR_TEST_FIBONACCI, {3, 0, 5, 0}, STARKHIP_POW_SEARCH, 0, 0});
+        subs.push_back({STARKHIP_AIR_FP12_MUL, limbs(288, 31), 0xBAD, 0, 0});    // fails before its commitment
+        subs.push_back({STARKHIP_AIR_FP12_MUL, limbs(288, 32), 0xBAD2, 0, 0});   // fails after it
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < subs.size(); i++)
+            th.emplace_back([&, i] {
+                subs[i].rc_submit = starkhip_pool_submit_witness(pool, subs[i].air, nullptr, subs[i].ops.data(), subs[i].ops.size(), subs[i].pow, &subs[i].ticket);
+            });
+        for (auto& t : th) t.join();
+        // a FinalExp-class job from rows the caller owns (fake: only the shape is looked at) -- two of them: the second is the "last wave"
+        const size_t fe_cols = (size_t)starkhip_air_columns(STARKHIP_AIR_FINAL_EXP), fe_pis = (size_t)starkhip_air_public_inputs(STARKHIP_AIR_FINAL_EXP);
+        std::vector<uint64_t> pis(fe_pis, 7), fake_rows(16);
+        starkhip_config_t fe_cfg;
+        CHECK(starkhip_config_for_air(STARKHIP_AIR_FINAL_EXP, &fe_cfg) == STARKHIP_OK);
+        uint64_t fe_t[3];
+        for (int k = 0; k < 3; k++)
+            CHECK(starkhip_pool_submit(pool, STARKHIP_AIR_FINAL_EXP, &fe_cfg, fake_rows.data(), 8192, fe_cols, 1, 1, pis.data(), pis.size(), STARKHIP_POW_SEARCH, &fe_t[k]) == STARKHIP_OK);
+        // wrong shapes are refused at submit
+        uint64_t t_bad = 0;
+        CHECK(starkhip_pool_submit(pool, STARKHIP_AIR_FINAL_EXP, &fe_cfg, fake_rows.data(), 8192, fe_cols - 1, 1, 1, pis.data(), pis.size(), STARKHIP_POW_SEARCH, &t_bad) == STARKHIP_ERR_BAD_SHAPE);
+        CHECK(starkhip_pool_submit_witness(pool, STARKHIP_AIR_FP12_MUL, nullptr, subs[0].ops.data(), 17, STARKHIP_POW_SEARCH, &t_bad) == STARKHIP_ERR_BAD_SHAPE);
+        // waits, from two threads
+        int failures = 0;
+        auto wait_range = [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                uint64_t* proof = nullptr;
+                size_t words = 0;
+                starkhip_ticket_info_t info;
+                const int rc = subs[i].rc_submit == STARKHIP_OK ? starkhip_pool_wait(pool, subs[i].ticket, &proof, &words, &info) : subs[i].rc_submit;
+                const int want = subs[i].pow == 0xBAD ? STARKHIP_ERR_BAD_SHAPE : subs[i].pow == 0xBAD2 ? STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE : STARKHIP_OK;
+                if (rc != want) failures++;
+                if (rc == STARKHIP_OK) {
+                    const size_t n_pis = (size_t)starkhip_air_public_inputs(subs[i].air);
+                    if (words != 4 + n_pis || proof[1] != (uint64_t)subs[i].air || info.t_done < info.t_prove_start) failures++;
+                    starkhip_free(proof);
+                }
+            }
+        };
+        std::thread w1([&] { wait_range(0, subs.size() / 2); }), w2([&] { wait_range(subs.size() / 2, subs.size()); });
+        w1.join();
+        w2.join();
+        CHECK(failures == 0);
+        for (int k = 0; k < 3; k++) {
+            uint64_t* proof = nullptr;
+            size_t words = 0;
+            CHECK(starkhip_pool_wait(pool, fe_t[k], &proof, &words, nullptr) == STARKHIP_OK && words == 4 + fe_pis);
+            starkhip_free(proof);
+        }
+        uint64_t* none = nullptr;
+        size_t nw = 0;
+        CHECK(starkhip_pool_wait(pool, fe_t[0], &none, &nw, nullptr) == STARKHIP_ERR_BAD_SHAPE);  // a ticket is waited for once
+        starkhip_pool_stats_t st;
+        CHECK(starkhip_pool_stats(pool, &st) == STARKHIP_OK);
+        if (policy != 2) CHECK(st.big_commit_launches == 3 && st.small_commit_requests == 11);  // 10 good small jobs + the one that fails after its commitment
+        // shutdown with work still queued: never waited for, still run to the end and freed
+        for (int k = 0; k < 6; k++) {
+            uint64_t t = 0;
+            CHECK(starkhip_pool_submit_witness(pool, STARKHIP_AIR_FP12_MUL, nullptr, subs[0].ops.data(), 288, STARKHIP_POW_SEARCH, &t) == STARKHIP_OK);
+        }
+        starkhip_pool_destroy(pool);
+        printf("policy %u: ok (%lu small requests in %lu launches, up to %lu merged)\n", policy, st.small_commit_requests, st.small_commit_launches,
+               st.max_merged_commitments);
+    }
+    return 0;
+}

@@ -66,7 +66,7 @@ static std::vector<SignatureOperands> load_operands(const char* path, size_t wan
 static double seconds_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 
 int main(int argc, char** argv) {
-    size_t batch = 0, steps = 3, warmup = 1;
+    size_t batch = 0, steps = 3, warmup = 1, pipeline = 1;
     bool use_pool = false, timeline = false;
     const char* operands = nullptr;
     starkhip_pool_config_t cfg;
@@ -78,6 +78,7 @@ int main(int argc, char** argv) {
         auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
         if (a == "--batch") batch = strtoul(val(), nullptr, 0), use_pool = true;
         else if (a == "--steps") steps = strtoul(val(), nullptr, 0);
+        else if (a == "--pipeline") pipeline = std::max<size_t>(1, strtoul(val(), nullptr, 0));  // batches in flight: a steady stream of batches instead of one at a time
         else if (a == "--warmup") warmup = strtoul(val(), nullptr, 0);
         else if (a == "--operands") operands = val();
         else if (a == "--pool") use_pool = true;
@@ -126,17 +127,51 @@ int main(int argc, char** argv) {
         std::vector<SignatureProofs> proofs;
         double total = 0, best = 1e30;
         std::string step_ms;
-        for (size_t k = 0; k < warmup + steps; k++) {
-            const auto t0 = std::chrono::steady_clock::now();
-            proofs = starkhip_driver::prove_batch(pool, sigs, /*verify=*/false);
-            const double sec = seconds_since(t0);
-            if (k >= warmup) {
-                total += sec;
-                best = std::min(best, sec);
-                char buf[32];
-                snprintf(buf, sizeof buf, "%s%.1f", step_ms.empty() ? "" : ", ", sec * 1e3);
-                step_ms += buf;
+        if (pipeline == 1) {
+            for (size_t k = 0; k < warmup + steps; k++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                proofs = starkhip_driver::prove_batch(pool, sigs, /*verify=*/false);
+                const double sec = seconds_since(t0);
+                if (k >= warmup) {
+                    total += sec;
+                    best = std::min(best, sec);
+                    char buf[32];
+                    snprintf(buf, sizeof buf, "%s%.1f", step_ms.empty() ? "" : ", ", sec * 1e3);
+                    step_ms += buf;
+                }
             }
+        } else {
+            // a steady stream: `pipeline` batches in flight; batch k + pipeline is submitted when batch k has been waited for.  The
+            // time is that of `steps` consecutive batches in the middle of the stream (start-up and drain excluded by the warm-up
+            // batches in front and the `pipeline - 1` batches still in flight behind).
+            std::vector<std::vector<starkhip_driver::SignatureTickets>> flying;
+            auto submit_batch = [&]() {
+                std::vector<starkhip_driver::SignatureTickets> t;
+                for (const SignatureOperands& s : sigs) t.push_back(starkhip_driver::submit_signature(pool, s));
+                flying.push_back(std::move(t));
+            };
+            auto wait_batch = [&]() {
+                std::vector<SignatureProofs> out;
+                for (auto& t : flying.front()) out.push_back(starkhip_driver::wait_signature(pool, t, false));
+                flying.erase(flying.begin());
+                return out;
+            };
+            for (size_t k = 0; k < pipeline; k++) submit_batch();
+            auto t_prev = std::chrono::steady_clock::now();
+            for (size_t k = 0; k < warmup + steps; k++) {
+                proofs = wait_batch();
+                submit_batch();
+                const double sec = seconds_since(t_prev);
+                t_prev = std::chrono::steady_clock::now();
+                if (k >= warmup) {
+                    total += sec;
+                    best = std::min(best, sec);
+                    char buf[32];
+                    snprintf(buf, sizeof buf, "%s%.1f", step_ms.empty() ? "" : ", ", sec * 1e3);
+                    step_ms += buf;
+                }
+            }
+            while (!flying.empty()) proofs = wait_batch();  // drain (untimed)
         }
         const double per_step = total / (steps ? steps : 1);
         // untimed: what the reference does after each prove (verify_stark_proof) and what its recursion enforces on the public inputs
@@ -168,9 +203,9 @@ int main(int argc, char** argv) {
         const starkhip_pool_stats_t st = pool.stats();
         printf("{\"metric\": \"BLS signature checks/s, end to end from compiled host code (operands -> natives -> trace generation -> 6 STARK proofs each)\", "
                "\"value\": %.4f, \"unit\": \"signatures/s\", \"batch\": %zu, \"steps\": %zu, \"warmup\": %zu, \"ms_per_step\": %.1f, \"best_ms\": %.1f, \"step_ms\": [%s], "
-               "\"proofs_per_step\": %zu, \"proofs_verified_after_timing\": %zu, \"verify_s\": %.2f, \"signatures_valid_linked_bound\": %zu, "
+               "\"batches_in_flight\": %zu, \"proofs_per_step\": %zu, \"proofs_verified_after_timing\": %zu, \"verify_s\": %.2f, \"signatures_valid_linked_bound\": %zu, "
                "\"commit_launches\": {\"big\": %lu, \"small_merged\": %lu, \"small_requests\": %lu, \"max_merged\": %lu}, \"operands\": \"%s\"}\n",
-               batch / per_step, batch, steps, warmup, per_step * 1e3, best * 1e3, step_ms.c_str(), 6 * batch, verified, seconds_since(tv), ok, st.big_commit_launches,
+               batch / per_step, batch, steps, warmup, per_step * 1e3, best * 1e3, step_ms.c_str(), pipeline, 6 * batch, verified, seconds_since(tv), ok, st.big_commit_launches,
                st.small_commit_launches, st.small_commit_requests, st.max_merged_commitments, operands ? operands : "reference vector (src/native.rs:1480-1498)");
         return verified == 6 * batch && ok == batch ? 0 : 1;
     } catch (const std::exception& e) {
