@@ -166,8 +166,12 @@ inline Proof ec_aggregate_main(Prover& pv, const uint32_t* points, const uint8_t
 
 struct SignatureProofs {
     Proof pp1, ml1, pp2, ml2, fp12_mul, final_exp;
-    bool valid = false;  // final_exponentiate(ml1 * ml2) == 1
+    bool valid = false;  // final_exponentiate(ml1 * ml2) == 1, read from what was PROVEN (the final_exp proof's output public inputs)
     bool linked = false; // the public-input equalities the reference's recursive aggregation enforces
+    // the host natives' value of final_exponentiate(ml1 * ml2), where the driver computed it (pool drivers): the proven output
+    // must equal it -- the same cross-check aggregate.signature_is_valid makes in the Python harness
+    std::vector<uint32_t> native_final;
+    bool native_agrees = true;
 };
 
 inline void finish_links(SignatureProofs& s);  // valid / linked from the six proofs' public inputs (below)
@@ -253,7 +257,11 @@ struct SignatureOperands {
 // values (fp12_mul, final_exp: src/aggregate_proof.rs:352-363) are submitted by a helper thread as soon as those are known
 struct SignatureTickets {
     uint64_t pp1 = 0, ml1 = 0, pp2 = 0, ml2 = 0;
-    std::future<std::array<uint64_t, 2>> tail;  // fp12_mul, final_exp
+    struct Tail {
+        std::array<uint64_t, 2> tickets;      // fp12_mul, final_exp
+        std::vector<uint32_t> native_final;   // native final_exponentiate(ml1 * ml2), computed after both jobs were submitted
+    };
+    std::future<Tail> tail;
 };
 
 inline SignatureTickets submit_signature(Pool& pool, const SignatureOperands& s) {
@@ -269,9 +277,11 @@ inline SignatureTickets submit_signature(Pool& pool, const SignatureOperands& s)
         check("native_miller_loop", starkhip_native_miller_loop(s.pk_x, s.pk_y, s.hm[0], s.hm[1], s.hm[2], ml1.data()));
         check("native_miller_loop", other.get());
         check("native_fp12_mul", starkhip_native_fp12_mul(ml1.data(), ml2.data(), prod.data()));
-        std::array<uint64_t, 2> out;
-        out[1] = pool.submit(STARKHIP_AIR_FINAL_EXP, prod);  // the long pole first
-        out[0] = pool.submit(STARKHIP_AIR_FP12_MUL, detail::pack({{ml1.data(), 144}, {ml2.data(), 144}}));
+        SignatureTickets::Tail out;
+        out.tickets[1] = pool.submit(STARKHIP_AIR_FINAL_EXP, prod);  // the long pole first
+        out.tickets[0] = pool.submit(STARKHIP_AIR_FP12_MUL, detail::pack({{ml1.data(), 144}, {ml2.data(), 144}}));
+        out.native_final.resize(144);  // off the critical path: both jobs are already in the pool
+        check("native_final_exponentiate", starkhip_native_final_exponentiate(prod.data(), out.native_final.data()));
         return out;
     });
     return t;
@@ -306,7 +316,8 @@ inline bool statement_holds(const SignatureProofs& p, const SignatureOperands& s
 
 inline SignatureProofs wait_signature(Pool& pool, SignatureTickets& t, bool verify = true) {
     SignatureProofs s;
-    const std::array<uint64_t, 2> tail = t.tail.get();
+    SignatureTickets::Tail tl = t.tail.get();
+    const std::array<uint64_t, 2> tail = tl.tickets;
     s.pp1 = pool.wait(STARKHIP_AIR_PAIRING_PRECOMP, t.pp1, verify);
     s.ml1 = pool.wait(STARKHIP_AIR_MILLER_LOOP, t.ml1, verify);
     s.pp2 = pool.wait(STARKHIP_AIR_PAIRING_PRECOMP, t.pp2, verify);
@@ -314,6 +325,9 @@ inline SignatureProofs wait_signature(Pool& pool, SignatureTickets& t, bool veri
     s.fp12_mul = pool.wait(STARKHIP_AIR_FP12_MUL, tail[0], verify);
     s.final_exp = pool.wait(STARKHIP_AIR_FINAL_EXP, tail[1], verify);
     finish_links(s);
+    s.native_final = std::move(tl.native_final);
+    for (int i = 0; i < 144; i++) s.native_agrees = s.native_agrees && s.final_exp.public_inputs()[144 + i] == s.native_final[i];
+    s.valid = s.valid && s.native_agrees;
     return s;
 }
 
