@@ -11,6 +11,8 @@
 #include <chrono>
 #include <memory>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "airs.h"
@@ -480,13 +482,30 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             }
             uint32_t* h = (uint32_t*)c->host_staging;
             size_t at_r = 0, at_z = 0;
+            struct Piece { uint32_t* dst; const uint32_t* src; size_t words; };
+            std::vector<Piece> pieces;
             log->for_each_part([&](const TraceLog& part) {
-                if (!part.words.empty()) memcpy(h + part.base, part.words.data(), part.words.size() * 4);
-                if (!part.offsets.empty()) memcpy(h + nw + at_r, part.offsets.data(), part.offsets.size() * 4);
-                if (!part.late_zeros.empty()) memcpy(h + nw + nr + at_z, part.late_zeros.data(), part.late_zeros.size() * 4);
+                if (!part.words.empty()) pieces.push_back({h + part.base, part.words.data(), part.words.size()});
+                if (!part.offsets.empty()) pieces.push_back({h + nw + at_r, part.offsets.data(), part.offsets.size()});
+                if (!part.late_zeros.empty()) pieces.push_back({h + nw + nr + at_z, part.late_zeros.data(), part.late_zeros.size()});
                 at_r += part.offsets.size();
                 at_z += part.late_zeros.size();
             });
+            // 150 MB for FinalExp: gathered on a few threads (10 ms on one), pieces dealt round-robin
+            const unsigned n_thr = total * 4 > ((size_t)32 << 20) ? 4 : 1;
+            auto gather = [&](unsigned w) {
+                for (size_t i = w; i < pieces.size(); i += n_thr) memcpy(pieces[i].dst, pieces[i].src, pieces[i].words * 4);
+            };
+            std::vector<std::thread> helpers;
+            for (unsigned w = 1; w < n_thr; w++) {
+                try {
+                    helpers.emplace_back(gather, w);
+                } catch (const std::system_error&) {
+                    gather(w);  // no thread to be had: this one does that share too
+                }
+            }
+            gather(0);
+            for (std::thread& t : helpers) t.join();
             if (total) HIPCHK(hipMemcpyAsync(d_words, h, total * 4, hipMemcpyHostToDevice, st));
         }
         if (nr) HIPCHK(launch_expand_trace(d_words, d_offsets, nr, c->values.as<gl_t>(), n, st));
