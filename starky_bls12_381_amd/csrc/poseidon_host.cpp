@@ -121,6 +121,9 @@ AVX512_TARGET inline __m256i sbox_4(__m256i x) {
     return mul_4(x3, x4);
 }
 
+#define MV_A(x) _mm512_load_si512((const void*)(x))
+#define MV_B(x) _mm256_load_si256((const __m256i*)((x) + 8))
+
 // MDS layer: out[r] = sum_i CIRC[i] * s[(i + r) % 12] + (r == 0) * 8 * s[0]
 // With `partial` the vector's element 0 is zero and x0 is the value it stands for: its column of the matrix is added at
 // the end, so the scalar S-box that produces x0 runs beside the vector part instead of in front of it.
@@ -181,7 +184,60 @@ AVX512_TARGET inline void mds_t(V12& s, gl_t x0) {
     }
 }
 
+// The same layer with the INPUTS broadcast from registers and the matrix COLUMNS as constants (out = sum_j column_j * s_j), as the
+// merged triples' dense layer does: no store + unaligned reload of the state (a 64-byte load that straddles two stores is
+// not forwarded), and vpmuludq takes the low halves by itself.
+struct alignas(64) MdsColumns {
+    uint64_t col[12][16];  // column j: rows 0..7 (zmm), rows 8..11 (ymm), 4 unused
+};
+const MdsColumns& mds_columns() {
+    static const MdsColumns C = [] {
+        static const uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+        MdsColumns c = {};
+        for (int j = 0; j < 12; j++)
+            for (int r = 0; r < 12; r++) c.col[j][r] = CIRC[(j - r + 12) % 12] + ((r == 0 && j == 0) ? 8 : 0);
+        return c;
+    }();
+    return C;
+}
+AVX512_TARGET inline void mds_bcast(V12& s) {
+    const MdsColumns& C = mds_columns();
+    __m512i La = _mm512_setzero_si512(), Ha = _mm512_setzero_si512();
+    __m256i Lb = _mm256_setzero_si256(), Hb = _mm256_setzero_si256();
+    const __m512i b512 = _mm512_zextsi256_si512(s.b);
+#define MDS_TERM(SRC, LANE, J)                                                                            \
+    {                                                                                                     \
+        const __m512i x = _mm512_permutexvar_epi64(_mm512_set1_epi64(LANE), SRC);                         \
+        const __m512i xh = _mm512_srli_epi64(x, 32);                                                      \
+        const __m512i ca = MV_A(C.col[J]);                                                                \
+        const __m256i cb = MV_B(C.col[J]);                                                                \
+        La = _mm512_add_epi64(La, _mm512_mul_epu32(x, ca));                                               \
+        Ha = _mm512_add_epi64(Ha, _mm512_mul_epu32(xh, ca));                                              \
+        Lb = _mm256_add_epi64(Lb, _mm256_mul_epu32(_mm512_castsi512_si256(x), cb));                       \
+        Hb = _mm256_add_epi64(Hb, _mm256_mul_epu32(_mm512_castsi512_si256(xh), cb));                      \
+    }
+    MDS_TERM(s.a, 0, 0) MDS_TERM(s.a, 1, 1) MDS_TERM(s.a, 2, 2) MDS_TERM(s.a, 3, 3) MDS_TERM(s.a, 4, 4) MDS_TERM(s.a, 5, 5)
+    MDS_TERM(s.a, 6, 6) MDS_TERM(s.a, 7, 7) MDS_TERM(b512, 0, 8) MDS_TERM(b512, 1, 9) MDS_TERM(b512, 2, 10) MDS_TERM(b512, 3, 11)
+#undef MDS_TERM
+    {
+        const __m512i l = _mm512_add_epi64(La, _mm512_slli_epi64(Ha, 32));
+        const __m512i h = _mm512_mask_add_epi64(_mm512_srli_epi64(Ha, 32), _mm512_cmplt_epu64_mask(l, La), _mm512_srli_epi64(Ha, 32),
+                                                _mm512_set1_epi64(1));
+        s.a = reduce128_8(h, l);
+    }
+    {
+        const __m256i l = _mm256_add_epi64(Lb, _mm256_slli_epi64(Hb, 32));
+        const __m256i h = _mm256_mask_add_epi64(_mm256_srli_epi64(Hb, 32), _mm256_cmplt_epu64_mask(l, Lb), _mm256_srli_epi64(Hb, 32),
+                                                _mm256_set1_epi64x(1));
+        s.b = reduce128_4(h, l);
+    }
+}
+
+#ifdef STARKHIP_HOST_MDS_RELOAD
 AVX512_TARGET inline void mds(V12& s) { mds_t<false>(s, 0); }
+#else
+AVX512_TARGET inline void mds(V12& s) { mds_bcast(s); }
+#endif
 
 // ---- partial rounds three at a time (poseidon_merged.h).  The two intermediate element-0 values are dot products of the
 // state with one small-integer row (a multiply per half-vector and a horizontal add), the state after the third round is
@@ -218,8 +274,6 @@ const MergedVectors& merged_vectors() {
     }();
     return V;
 }
-#define MV_A(x) _mm512_load_si512((const void*)(x))
-#define MV_B(x) _mm256_load_si256((const __m256i*)((x) + 8))
 
 // (sum over the 12 lanes of lo * row) + (sum of hi * row) * 2^32 as an integer (the sums stay below 2^48, the value below 2^81)
 AVX512_TARGET inline unsigned __int128 dot_row(__m512i alo, __m512i ahi, __m256i blo, __m256i bhi, __m512i ra, __m256i rb) {
