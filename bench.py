@@ -136,7 +136,7 @@ def main():
     inflight = max(1, args.inflight)
     # the in-flight proofs go through the library's own scheduler (starkhip_pool_submit / _wait), as a caller of the C ABI would
     # drive them: `inflight` FinalExp-class contexts, one host thread each inside libstarkhip.so
-    pool = S.ProofPool(local_rank, big_contexts=inflight, small_contexts=1, generator_threads=1)
+    pool = S.ProofPool(local_rank, big_contexts=inflight, small_contexts=1, generator_threads=1, warm_up=1)
     helper = S.Prover(local_rank)  # page-locked staging for trace generation only
     work = []
     host_rows = helper.host_array((n, C))  # page-locked, reused for every generated trace

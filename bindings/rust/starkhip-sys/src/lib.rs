@@ -165,6 +165,7 @@ extern "C" {
     pub fn starkhip_verify(air: Air, cfg: *const starkhip_config_t, proof: *const u64, proof_words: usize) -> c_int;
     pub fn starkhip_proof_layout(proof: *const u64, proof_words: usize, out: *mut starkhip_proof_layout_t) -> c_int;
     pub fn starkhip_free(p: *mut c_void);
+    pub fn starkhip_proof_blob_stats(out: *mut u64);
     pub fn starkhip_error_string(code: c_int) -> *const c_char;
 }
 

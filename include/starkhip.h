@@ -212,6 +212,11 @@ int starkhip_pool_submit_witness(void* pool, starkhip_air_t air, const starkhip_
 /* returns the proof's status (what starkhip_prove would have returned); info may be NULL */
 int starkhip_pool_wait(void* pool, uint64_t ticket, uint64_t** proof, size_t* proof_words, starkhip_ticket_info_t* info);
 int starkhip_pool_stats(void* pool, starkhip_pool_stats_t* out);
+/* Proof blobs of a warmed pool are recycled page-locked buffers (the final device-to-host copy of 21 .. 69 MB runs at PCIe rate and
+ * touches no fresh pages); starkhip_free() hands them back.  Process-wide counters: [0] blobs held, [1] of them with a caller,
+ * [2] bytes held, [3] proofs served from them, [4] proofs served by malloc (no idle blob that fits).  STARKHIP_PINNED_PROOFS=0 in
+ * the environment of starkhip_pool_create turns the reservation off. */
+void starkhip_proof_blob_stats(uint64_t out[5]);
 
 /* per-phase device timings of the last prove on this ctx, milliseconds (HIP events):
  * [0] upload/transpose [1] ifft+lde [2] trace leaf hash + merkle [3] quotient [4] quotient commit

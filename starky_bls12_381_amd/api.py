@@ -7,6 +7,7 @@ There is NO CPU fallback: if the shared library is missing, importing this modul
 """
 import ctypes as C
 import os
+import time
 import weakref
 
 import numpy as np
@@ -405,7 +406,10 @@ class Prover:
             pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
             out = _u64p()
             words = C.c_size_t()
-            _chk(lib.starkhip_prove_compact(self._ctx, air, C.byref(config), trace._h, _p64(pis), pis.size, pow_witness, C.byref(out), C.byref(words)))
+            t0 = time.perf_counter()
+            rc = lib.starkhip_prove_compact(self._ctx, air, C.byref(config), trace._h, _p64(pis), pis.size, pow_witness, C.byref(out), C.byref(words))
+            self.last_call_s = time.perf_counter() - t0  # the C call alone, without the copy into a numpy array below
+            _chk(rc)
             proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy()
             lib.starkhip_free(out)
             return proof
@@ -416,8 +420,11 @@ class Prover:
         pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         out = _u64p()
         words = C.c_size_t()
-        _chk(lib.starkhip_prove(self._ctx, air, C.byref(config), trace.ctypes.data_as(C.c_void_p), n_rows, n_cols, layout, 0, _p64(pis), pis.size,
-                                pow_witness, C.byref(out), C.byref(words)))
+        t0 = time.perf_counter()
+        rc = lib.starkhip_prove(self._ctx, air, C.byref(config), trace.ctypes.data_as(C.c_void_p), n_rows, n_cols, layout, 0, _p64(pis), pis.size,
+                                pow_witness, C.byref(out), C.byref(words))
+        self.last_call_s = time.perf_counter() - t0
+        _chk(rc)
         proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy()
         lib.starkhip_free(out)
         return proof
@@ -521,6 +528,15 @@ lib.starkhip_pool_submit_compact.argtypes = [C.c_void_p, C.c_int, C.POINTER(Star
 lib.starkhip_pool_submit_witness.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), _u32p, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)]
 lib.starkhip_pool_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_u64p), C.POINTER(C.c_size_t), C.POINTER(TicketInfo)]
 lib.starkhip_pool_stats.argtypes = [C.c_void_p, C.POINTER(PoolStats)]
+lib.starkhip_proof_blob_stats.argtypes = [C.POINTER(C.c_uint64)]
+lib.starkhip_proof_blob_stats.restype = None
+
+
+def proof_blob_stats():
+    """Process-wide counters of the recycled page-locked proof blobs (starkhip_proof_blob_stats)."""
+    out = (C.c_uint64 * 5)()
+    lib.starkhip_proof_blob_stats(out)
+    return dict(zip(("blobs", "busy", "bytes", "taken", "missed"), [int(x) for x in out]))
 
 
 def witness_operands(air, *args):

@@ -6,6 +6,7 @@
 
 #include "air_eval.h"
 #include "airs.h"
+#include "blob_arena.h"
 #include "kernels.h"
 #include "trace_log.h"
 
@@ -379,7 +380,11 @@ int starkhip_verify(starkhip_air_t air, const starkhip_config_t* cfg, const uint
     return verify_proof(*a, *cfg, proof, proof_words);
 }
 
-void starkhip_free(void* p) { free(p); }
+void starkhip_proof_blob_stats(uint64_t out[5]) {
+    const starkhip::BlobArenaStats st = starkhip::blob_arena_stats();
+    out[0] = st.blobs; out[1] = st.busy; out[2] = st.bytes; out[3] = st.taken; out[4] = st.missed;
+}
+void starkhip_free(void* p) { starkhip::blob_free(p); }  // a proof blob may be a recycled page-locked one (blob_arena.h)
 
 const char* starkhip_error_string(int code) {
     switch (code) {

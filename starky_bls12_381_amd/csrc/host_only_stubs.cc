@@ -11,8 +11,10 @@
 
 #include <atomic>
 #include <chrono>
+#include <set>
 #include <thread>
 
+#include "blob_arena.h"
 #include "kernels.h"
 #include "prover.h"
 #include "scheduler.h"
@@ -29,6 +31,7 @@ struct Ctx {
     HashService* hs = nullptr;
     bool hash_requested = false, urgent = false;
     float timings[STARKHIP_N_PHASES] = {0}, ktimings[3] = {0}, htimings[2] = {0};
+    std::set<int> blob_airs;
 };
 int ctx_create(int, Ctx** out, int) {
     if (!fake_device()) {
@@ -38,7 +41,10 @@ int ctx_create(int, Ctx** out, int) {
     *out = new Ctx();
     return STARKHIP_OK;
 }
-void ctx_destroy(Ctx* c) { delete c; }
+void ctx_destroy(Ctx* c) {
+    if (c) blob_arena_drop(c);
+    delete c;
+}
 const float* ctx_timings(Ctx* c) { return c->timings; }
 const float* ctx_kernel_timings(Ctx* c) { return c->ktimings; }
 const float* ctx_host_timings(Ctx* c) { return c->htimings; }
@@ -48,7 +54,13 @@ bool ctx_has_hash_service(Ctx* c) { return c->hs != nullptr; }
 void ctx_hash_request_reset(Ctx* c) { c->hash_requested = false; }
 bool ctx_hash_requested(Ctx* c) { return c->hash_requested; }
 int ctx_set_urgent(Ctx* c, bool urgent) { c->urgent = urgent; return STARKHIP_OK; }
-int ctx_reserve(Ctx*, const AirInfo&, const starkhip_config_t&, size_t) { return STARKHIP_OK; }
+int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t&, size_t, unsigned proof_blobs) {
+    if (proof_blobs && !c->blob_airs.count(air.id)) {  // the fake proofs are tiny; what is exercised is the arena's bookkeeping
+        if (blob_arena_add(c, 64 + air.prog.n_pis * 8, proof_blobs) != 0) return STARKHIP_ERR_OOM;
+        c->blob_airs.insert(air.id);
+    }
+    return STARKHIP_OK;
+}
 
 int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64_t* trace, size_t n_rows, int layout, int, const uint64_t* pis,
           size_t n_pis, uint64_t pow_witness, uint64_t** proof_out, size_t* proof_words) {
@@ -67,7 +79,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     }
     std::this_thread::sleep_for(std::chrono::milliseconds(2));  // "the rest of the proof"
     if (pow_witness == 0xBAD2) return STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE;     // a job that fails after its commitment
-    uint64_t* out = (uint64_t*)malloc((4 + n_pis) * 8);
+    uint64_t* out = blob_alloc((4 + n_pis) * 8);
     if (!out) return STARKHIP_ERR_OOM;
     out[0] = 0xFA4EULL; out[1] = (uint64_t)air.id; out[2] = n_rows; out[3] = c->urgent;
     if (n_pis) memcpy(out + 4, pis, n_pis * 8);
@@ -107,4 +119,6 @@ hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 }

@@ -18,8 +18,9 @@ class HashService;  // scheduler.h
 void ctx_attach_hash_service(Ctx* c, HashService* hs);  // trace commitments of this context go through the pool's scheduler
 bool ctx_has_hash_service(Ctx* c);
 int ctx_set_urgent(Ctx* c, bool urgent);
-// tables, plan, work buffers and upload staging for proofs of `air`, allocated now (a pool's warm-up)
-int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t log_bytes);  // the context's next proofs on a high-priority stream
+// tables, plan, work buffers, upload staging and `proof_blobs` page-locked proof blobs (blob_arena.h) for proofs of `air`,
+// allocated now (a pool's warm-up)
+int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t log_bytes, unsigned proof_blobs = 0);
 void ctx_hash_request_reset(Ctx* c);
 bool ctx_hash_requested(Ctx* c);  // the current / last prove() reached its trace commitment
 

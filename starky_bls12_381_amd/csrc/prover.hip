@@ -10,12 +10,14 @@
 #include <algorithm>
 #include <chrono>
 #include <memory>
+#include <set>
 #include <string>
 #include <system_error>
 #include <thread>
 #include <vector>
 
 #include "airs.h"
+#include "blob_arena.h"
 #include "kernels.h"
 #include "trace_log.h"
 #include "poseidon.h"
@@ -94,6 +96,7 @@ struct Ctx {
     hipEvent_t wait_ev = nullptr;  // hipEventBlockingSync: see stream_wait()
     void* host_staging = nullptr;  // page-locked: a recording's parts gathered for one upload (prove(), layout 2)
     size_t host_staging_cap = 0;
+    std::set<int> blob_airs;  // AIRs this context has reserved page-locked proof blobs for (blob_arena.h)
     bool hash_requested = false;
     bool urgent = false;  // ctx_set_urgent
     // tuning (starkhip_set_option; defaults are the measured best)
@@ -335,6 +338,7 @@ void ctx_destroy(Ctx* c) {
     (void)hipEventDestroy(c->hash_done);
     (void)hipEventDestroy(c->wait_ev);
     if (c->host_staging) (void)hipHostFree(c->host_staging);
+    blob_arena_drop(c);
     (void)hipStreamDestroy(c->st_normal);
     if (c->st_high) (void)hipStreamDestroy(c->st_high);
     delete c;
@@ -792,7 +796,14 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     pl.C = C; pl.Q = Q; pl.log_n = log_n; pl.rate_bits = r; pl.cap_h = cap_h; pl.L = L; pl.n_queries = cfg.num_query_rounds;
     pl.final_len = geo.final_poly_len; pl.n_pis = n_pis; pl.arity_bits = cfg.arity_bits; pl.n_challenges = 2;
     pl.compute();
-    uint64_t* out = (uint64_t*)malloc(pl.total * 8);
+    if (!c->hs && !c->blob_airs.count(air.id)) {
+        // a context on its own (not a pool's: those reserve at warm-up) gets its two page-locked blobs with its first proof of an AIR,
+        // the proof that also grows the work buffers -- hipHostMalloc waits for the device like the hipMallocs before it
+        static const bool pinned = [] { const char* e = getenv("STARKHIP_PINNED_PROOFS"); return !(e && *e == '0'); }();
+        if (pinned) (void)blob_arena_add(c, pl.total * 8, 2);  // failure: malloc serves the proof
+        c->blob_airs.insert(air.id);
+    }
+    uint64_t* out = blob_alloc(pl.total * 8);  // page-locked if the context has reserved blobs (blob_arena.h)
     if (!out) return STARKHIP_ERR_OOM;
     {
         const size_t nq = cfg.num_query_rounds;
@@ -836,7 +847,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         HIPCHK_FREE(stream_wait(c));
 #undef HIPCHK_FREE
         if (err || off != stride) {
-            free(out);
+            blob_free(out);
             return STARKHIP_ERR_HIP;
         }
         memcpy(out + pl.off_final, final_poly.data(), geo.final_poly_len * 16);
@@ -844,12 +855,12 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         if (n_pis) memcpy(out + pl.off_pis, pis_host, n_pis * 8);
     }
     if (hipEventRecord(c->ev[evi++], st) != hipSuccess || stream_wait(c) != hipSuccess) {
-        free(out);
+        blob_free(out);
         return STARKHIP_ERR_HIP;
     }
     for (int i = 0; i < STARKHIP_N_PHASES - 1; i++) (void)hipEventElapsedTime(&c->timings[i], c->ev[i], c->ev[i + 1]);
     if (c->opt_quotient_debug >= 1 && c->opt_quotient_debug <= 8) {  // profiling build only: timings are valid, the proof is not
-        free(out);
+        blob_free(out);
         (void)hipEventElapsedTime(&c->timings[STARKHIP_N_PHASES - 1], c->ev[0], c->ev[STARKHIP_N_PHASES - 1]);
         (void)hipEventElapsedTime(&c->ktimings[2], c->kev[2], c->kev[3]);
         return STARKHIP_ERR_VERIFY;
@@ -870,7 +881,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
 // first job: growing a buffer later means hipFree + hipMalloc (or hipHostFree + hipHostMalloc), and those wait for EVERY stream of
 // the device -- measured in a batch of 8 signatures: a PairingPrecomp proof with 212 ms of device time held its context for 2.3 s
 // because its buffers grew while four FinalExp proofs kept the device busy.
-int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t log_bytes) {
+int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t log_bytes, unsigned proof_blobs) {
     const AirProgram& P = air.prog;
     const size_t n = air.default_rows;
     unsigned log_n = 0;
@@ -916,6 +927,10 @@ int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t
         c->host_staging_cap = 0;
         HIPCHK(hipHostMalloc(&c->host_staging, log_bytes, hipHostMallocDefault));
         c->host_staging_cap = log_bytes;
+    }
+    if (proof_blobs && !c->blob_airs.count(air.id)) {  // page-locked blobs for this AIR's proofs, once per context
+        if (blob_arena_add(c, pl.total * 8, proof_blobs) != 0) return STARKHIP_ERR_OOM;
+        c->blob_airs.insert(air.id);
     }
     return stream_wait(c) == hipSuccess ? STARKHIP_OK : STARKHIP_ERR_HIP;
 }

@@ -5,6 +5,8 @@
 // traces (trace_log.h), one host thread per prover context proves them, and a caller only submits and waits.
 #include "scheduler.h"
 
+#include "blob_arena.h"
+
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -438,22 +440,26 @@ struct Pool {
         int last_air = -1;
         bool urgent = false;
         if (warm) {  // every context brings up what the BLS pipeline's AIRs of its class need, all contexts in parallel
-            static const struct { int air; size_t log_bytes; } BIG[] = {{STARKHIP_AIR_FINAL_EXP, (size_t)200 << 20}},
-                SMALL[] = {{STARKHIP_AIR_MILLER_LOOP, (size_t)110 << 20}, {STARKHIP_AIR_PAIRING_PRECOMP, (size_t)44 << 20}, {STARKHIP_AIR_FP12_MUL, (size_t)2 << 20}};
+            // proof blobs: a context's last proof is usually still with the caller when the next one ends, hence two per big context;
+            // the small contexts' MillerLoop-sized blob (69 MB) also serves FP12Mul (42 MB) -- blob_alloc takes the smallest that fits
+            static const struct { int air; size_t log_bytes; unsigned blobs; } BIG[] = {{STARKHIP_AIR_FINAL_EXP, (size_t)200 << 20, 2}},
+                SMALL[] = {{STARKHIP_AIR_MILLER_LOOP, (size_t)110 << 20, 1}, {STARKHIP_AIR_PAIRING_PRECOMP, (size_t)44 << 20, 1}, {STARKHIP_AIR_FP12_MUL, (size_t)2 << 20, 0}};
+            const char* pe = getenv("STARKHIP_PINNED_PROOFS");
+            const bool pinned = !(pe && *pe == '0');
             int rc = STARKHIP_OK;
-            auto one = [&](int air, size_t log_bytes) {
+            auto one = [&](int air, size_t log_bytes, unsigned blobs) {
                 const AirInfo* a = air_get(air);
                 starkhip_config_t cfg;
                 if (!a || starkhip_config_for_air((starkhip_air_t)air, &cfg) != STARKHIP_OK) return;
                 try {
-                    const int r = ctx_reserve(c, *a, cfg, log_bytes);
+                    const int r = ctx_reserve(c, *a, cfg, log_bytes, pinned ? blobs : 0);
                     if (r != STARKHIP_OK) rc = r;
                 } catch (const std::exception&) {
                     rc = STARKHIP_ERR_OOM;
                 }
             };
-            if (big) for (const auto& w : BIG) one(w.air, w.log_bytes);
-            else for (const auto& w : SMALL) one(w.air, w.log_bytes);
+            if (big) for (const auto& w : BIG) one(w.air, w.log_bytes, w.blobs);
+            else for (const auto& w : SMALL) one(w.air, w.log_bytes, w.blobs);
             std::lock_guard<std::mutex> g(mu);
             if (rc != STARKHIP_OK && warm_rc == STARKHIP_OK) warm_rc = rc;
             warmed++;
@@ -592,7 +598,7 @@ void pool_destroy(Pool* p) {
     for (Ctx* c : p->small_ctx) ctx_destroy(c);
     p->hs.reset();
     for (auto& kv : p->jobs) {
-        free(kv.second->proof);
+        blob_free(kv.second->proof);
         if (kv.second->own_log) starkhip_trace_log_free(kv.second->own_log);
         delete kv.second;
     }
@@ -685,7 +691,7 @@ int pool_wait(Pool* p, uint64_t ticket, uint64_t** proof, size_t* words, starkhi
         *proof = j->proof;
         *words = j->words;
     } else {
-        free(j->proof);
+        blob_free(j->proof);
         if (proof) *proof = nullptr;
         if (words) *words = 0;
     }

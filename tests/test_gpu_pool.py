@@ -84,6 +84,35 @@ def test_witness_jobs_generate_inside_the_pool():
         pool.close()
 
 
+def test_a_warmed_pool_hands_out_recycled_page_locked_blobs():
+    """warm_up=1: every context reserves page-locked proof blobs (blob_arena.h); proofs come out of them bit-identical to the
+    ones a lone context writes, starkhip_free hands them back, and they go away with the pool."""
+    before = S.proof_blob_stats()
+    x, y = random_fp12(0x5EED3300), random_fp12(0x5EED3301)
+    args = _precomp_args(0x5EED3310)
+    pool = S.ProofPool(0, big_contexts=1, small_contexts=2, generator_threads=2, warm_up=1)
+    pv = S.Prover(0)
+    try:
+        held = S.proof_blob_stats()
+        assert held["blobs"] - before["blobs"] == 2 + 2 * 2 and held["busy"] == before["busy"]   # FinalExp x 2; (MillerLoop, Precomp) per small context
+        for rep in range(3):   # more proofs than blobs: they are recycled
+            t1 = pool.submit_witness(S.AIR_FP12_MUL, x, y)
+            t2 = pool.submit_witness(S.AIR_PAIRING_PRECOMP, *args)
+            p1, _ = pool.wait(t1)
+            p2, _ = pool.wait(t2)
+        now = S.proof_blob_stats()
+        assert now["taken"] - before["taken"] >= 6 and now["busy"] == before["busy"]
+        for air, proof, gen in ((S.AIR_FP12_MUL, p1, lambda: S.trace_fp12_mul(x, y, compact=True)),
+                                (S.AIR_PAIRING_PRECOMP, p2, lambda: S.trace_pairing_precomp(*args, compact=True))):
+            trace, pis = gen()
+            assert np.array_equal(proof, pv.prove(air, S.StarkConfig.for_air(air), trace, pis))
+    finally:
+        pv.close()
+        pool.close()
+    after = S.proof_blob_stats()
+    assert after["blobs"] == before["blobs"] and after["bytes"] == before["bytes"]
+
+
 def test_a_failing_job_reports_its_code_and_the_pool_goes_on():
     """A witness that does not satisfy the AIR (a trace cell changed) fails with the prover's own error code at wait();
     proofs submitted with it and after it are unaffected (a failed small proof must not hold the merged window open)."""

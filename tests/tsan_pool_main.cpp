@@ -90,11 +90,13 @@ int main() {
         w1.join();
         w2.join();
         CHECK(failures == 0);
+        uint64_t* kept = nullptr;  // one proof stays with the caller beyond the pool's life
         for (int k = 0; k < 3; k++) {
             uint64_t* proof = nullptr;
             size_t words = 0;
             CHECK(starkhip_pool_wait(pool, fe_t[k], &proof, &words, nullptr) == STARKHIP_OK && words == 4 + fe_pis);
-            starkhip_free(proof);
+            if (k == 0) kept = proof;
+            else starkhip_free(proof);
         }
         uint64_t* none = nullptr;
         size_t nw = 0;
@@ -108,6 +110,14 @@ int main() {
             CHECK(starkhip_pool_submit_witness(pool, STARKHIP_AIR_FP12_MUL, nullptr, subs[0].ops.data(), 288, STARKHIP_POW_SEARCH, &t) == STARKHIP_OK);
         }
         starkhip_pool_destroy(pool);
+        uint64_t bs[5];
+        starkhip_proof_blob_stats(bs);
+        CHECK(bs[3] > 0);                    // warmed contexts served proofs from the arena
+        CHECK(bs[0] == bs[1] && bs[0] <= 1);  // every idle blob went with its context; at most the kept proof's remains
+        CHECK(kept[0] == 0xFA4EULL);          // and is still readable
+        starkhip_free(kept);
+        starkhip_proof_blob_stats(bs);
+        CHECK(bs[0] == 0 && bs[2] == 0);
         printf("policy %u: ok (%lu small requests in %lu launches, up to %lu merged)\n", policy, st.small_commit_requests, st.small_commit_launches,
                st.max_merged_commitments);
     }
