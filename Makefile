@@ -11,7 +11,7 @@ EXTRA_LIBS := $(if $(ROCTX),-L$(ROCM_PATH)/lib -lrocprofiler-sdk-roctx)
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude $(EXTRA_DEFS)
 SRCS := $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.cpp)
 OBJS := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
-HDRS := $(wildcard $(CSRC)/*.h) include/starkhip.h
+HDRS := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) include/starkhip.h
 
 all: $(OUT) oracle demo
 

@@ -270,6 +270,54 @@ __global__ __launch_bounds__(256) void leaf_hash_multi_kernel(LeafHashBatch B, s
     leaf_hash_body(B.mat[blockIdx.y], n_cols, log_n, rate_bits, B.digests[blockIdx.y]);
 }
 
+// ---- the row form (poseidon_dev.h): 16 lanes per leaf, for commitments whose quad launch would leave most of the chip idle.
+// Same digests as leaf_hash_kernel.  Lane e < 8 of a row absorbs column 8 b + e of block b (the rate), lanes 8 .. 11 carry the
+// capacity, lanes 12 .. 15 idle as mirrors.  One wave = 4 leaves; adjacent rows read adjacent points of a column.
+__global__ __launch_bounds__(256) void leaf_hash_row_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                                                             gl_t* __restrict__ digests) {
+    __shared__ RcPair rcs[16][32];  // [lane of the row][round], zero beyond round 29 and on lanes 12 .. 15
+    for (unsigned idx = threadIdx.x; idx < 16 * 32; idx += blockDim.x) {
+        const unsigned e = idx / 32, r = idx % 32;
+        const gl_t c = (e < 12 && r < 30) ? POSEIDON_RC_DEV[12 * r + e] : 0;
+        rcs[e][r].lo = c & 0xFFFFFFFFull;
+        rcs[e][r].hi = c >> 32;
+    }
+    __syncthreads();
+    const unsigned log_N = log_n + rate_bits;
+    const size_t N = (size_t)1 << log_N;
+    const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const unsigned e = (unsigned)tid & 15u;
+    const size_t q = tid >> 4;
+    if (q >= N) return;  // whole rows drop out together
+    const size_t sidx = q >> log_n, k = q & (((size_t)1 << log_n) - 1);
+    const size_t i = (k << rate_bits) + sidx;
+    const size_t j = gl_bitrev((uint32_t)i, log_N);
+    const gl_t* col = mat + q;
+    if (n_cols <= 4) {  // hash_or_noop: short leaves are copied, zero padded
+        if (e < 4) digests[4 * j + e] = e < n_cols ? col[(size_t)e * N] : 0;
+        return;
+    }
+    const uint32_t c0 = e == 0 ? 17u + 8u : 17u;  // CIRC[0] + MDS_MATRIX_DIAG[0] on lane 0
+    const RcPair* rc = rcs[e];
+    const bool lane0 = e == 0;
+    const bool absorbs = e < 8;
+    gl_t s = 0;
+    const gl_t* mine = col + (size_t)(absorbs ? e : 0) * N;  // lanes 8 .. 15 never load
+    const size_t n_full = n_cols / 8, rem = n_cols % 8;
+    gl_t nx = 0;
+    if (n_full && absorbs) nx = mine[0];
+    for (size_t b = 0; b < n_full; b++) {
+        if (absorbs) s = nx;
+        if (b + 1 < n_full && absorbs) nx = mine[(8 * (b + 1)) * N];  // requested one permutation ahead
+        s = poseidon_permute_row(s, rc, c0, lane0);
+    }
+    if (rem) {  // the last, partial block overwrites elements 0 .. rem - 1 only
+        if (e < rem) s = mine[(8 * n_full) * N];
+        s = poseidon_permute_row(s, rc, c0, lane0);
+    }
+    if (e < 4) digests[4 * j + e] = gl_canon(s);
+}
+
 // Leaves stored row-major and already in tree order: leaf j = rows[j][0..width)
 __global__ __launch_bounds__(64) void leaf_hash_rows_kernel(const gl_t* __restrict__ rows, size_t width, size_t n_leaves,
                                                              gl_t* __restrict__ digests) {
@@ -323,6 +371,11 @@ hipError_t launch_leaf_hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsi
     size_t N = (size_t)1 << (log_n + rate_bits);
     if (hipError_t e = ensure_quad_merged_tables(); e != hipSuccess) return e;
     hipLaunchKernelGGL(leaf_hash_kernel, dim3(nblocks(4 * N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
+    return hipGetLastError();
+}
+hipError_t launch_leaf_hash_row(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st) {
+    size_t N = (size_t)1 << (log_n + rate_bits);
+    hipLaunchKernelGGL(leaf_hash_row_kernel, dim3(nblocks(16 * N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
     return hipGetLastError();
 }
 hipError_t launch_leaf_hash_multi(const LeafHashBatch& B, unsigned count, size_t n_cols, unsigned log_n, unsigned rate_bits, hipStream_t st) {

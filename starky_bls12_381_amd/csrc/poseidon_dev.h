@@ -382,4 +382,112 @@ __device__ __forceinline__ void poseidon_permute_quad_merged(gl_t& s0, gl_t& s1,
     poseidon_mds_quad<CAP_ONLY>(s0, s1, s2, c.cf, diag0, rc[3 * r + 3], rc[3 * r + 4], rc[3 * r + 5]);
 }
 
+// ---------------------------------------------------------------- one permutation per DPP row (16 lanes)
+// For commitments with few leaves (a 1024-row AIR has 2048 .. 4096, FP12Mul 32) the quad form is a latency chain: 128 .. 256
+// waves of up to 12 167 sequential permutations on 1024 SIMDs, and a lone wave issues one instruction per ~5 cycles
+// whether it depends on the previous one or not.  What shortens that chain is fewer instructions PER WAVE and permutation,
+// at any cost in lanes: here lane e < 12 of a row owns state element e (lanes 12 .. 15 mirror lanes 0 .. 3), so an S-box layer
+// is ONE x^7 (52 instructions instead of 3 x 52) and a linear layer is 24 multiply-adds + 28 row moves (instead of 72 + 18).
+// A wave then carries 4 leaves instead of 16: 4x the lane-instructions of the quad form, which is why the big commitments and
+// the pool's merged launches stay with the quad form (kernels_hash.hip picks).
+//
+// Rotation by k on 12 lanes with 16-lane row shifts: with x16 = x on lanes 0 .. 11 and x[0 .. 3] again on lanes 12 .. 15,
+// (row_shl:k x16)[i] = x[(i + k) mod 12] for every i < 12 as long as k <= 4; larger k go through z = rot 4 and w = rot 8,
+// mirrored again.
+template <int K>
+__device__ __forceinline__ uint32_t row_shl(uint32_t v) {  // lane i of the row reads lane i + K (lanes past the row's end: 0)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + K, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t row_mirror(uint32_t v) {  // lanes 12 .. 15 <- lanes 0 .. 3 (row_shr:12, bank 3 only)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x11C, 0xF, 0x8, false);
+}
+template <int K>
+__device__ __forceinline__ uint32_t row_ror(uint32_t v) {  // rotation over all 16 lanes of the row
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + K, 0xF, 0xF, false);
+}
+
+// out_e = seed + sum_k coef[k] * x[(e + k) mod 12]: the circulant layer with coef = CIRC (+ 8 at k = 0 on lane 0), or any
+// 12 x 12 layer with per-lane coefficients coef[k] = Mat[e][(e + k) mod 12] < 2^21.  (lo, hi): the halves of this lane's x.
+__device__ __forceinline__ gl_t row_layer(uint32_t lo, uint32_t hi, const uint32_t (&coef)[12], uint64_t A, uint64_t B) {
+#define STARKHIP_ROW_TERM(L, H, K)            \
+    A = mad32((L), coef[K], A);               \
+    B = mad32((H), coef[K], B);               \
+    asm("" : "+v"(A));                        \
+    asm("" : "+v"(B));
+    STARKHIP_ROW_TERM(lo, hi, 0)
+    const uint32_t xl = row_mirror(lo), xh = row_mirror(hi);
+    STARKHIP_ROW_TERM(row_shl<1>(xl), row_shl<1>(xh), 1)
+    STARKHIP_ROW_TERM(row_shl<2>(xl), row_shl<2>(xh), 2)
+    STARKHIP_ROW_TERM(row_shl<3>(xl), row_shl<3>(xh), 3)
+    const uint32_t z0l = row_shl<4>(xl), z0h = row_shl<4>(xh);
+    STARKHIP_ROW_TERM(z0l, z0h, 4)
+    const uint32_t zl = row_mirror(z0l), zh = row_mirror(z0h);
+    STARKHIP_ROW_TERM(row_shl<1>(zl), row_shl<1>(zh), 5)
+    STARKHIP_ROW_TERM(row_shl<2>(zl), row_shl<2>(zh), 6)
+    STARKHIP_ROW_TERM(row_shl<3>(zl), row_shl<3>(zh), 7)
+    const uint32_t w0l = row_shl<4>(zl), w0h = row_shl<4>(zh);
+    STARKHIP_ROW_TERM(w0l, w0h, 8)
+    const uint32_t wl = row_mirror(w0l), wh = row_mirror(w0h);
+    STARKHIP_ROW_TERM(row_shl<1>(wl), row_shl<1>(wh), 9)
+    STARKHIP_ROW_TERM(row_shl<2>(wl), row_shl<2>(wh), 10)
+    STARKHIP_ROW_TERM(row_shl<3>(wl), row_shl<3>(wh), 11)
+#undef STARKHIP_ROW_TERM
+    return combine_lohi_nc(A, B);  // A, B < 2^33 + 12 * 2^21 * 2^32 < 2^57
+}
+
+// The circulant layer again, as ONE scheduled asm block (tools/gen_row_layer_asm.py -> row_layer_asm.inc): a lone wave pays a
+// whole issue slot for every wait state hipcc fills with s_nop, and from the C++ above it makes 31 of them per round (one
+// temporary for every rotated operand: a write-after-read wait before each move; moves that read a register written two
+// instructions earlier).  The block rotates six temporaries and issues each group's moves under the previous group's
+// multiply-adds: 52 instructions + one s_nop.  The coefficients are inline constants; c0 = 17 (+ 8 on lane 0).
+#include "row_layer_asm.inc"
+__device__ __forceinline__ gl_t row_layer_circ(uint32_t lo, uint32_t hi, uint32_t c0, uint64_t A, uint64_t B) {
+    uint32_t t0, t1, t2, t3, t4, t5, zl, zh;
+    uint64_t carry_sink;
+    asm(STARKHIP_ROW_LAYER_CIRC_ASM
+        : "+v"(A), "+v"(B), "+v"(lo), "+v"(hi), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(zl), "=&v"(zh),
+          "=&s"(carry_sink)
+        : "v"(c0));
+    return combine_lohi_nc(A, B);  // A, B < 2^33 + 284 * 2^32
+}
+
+// x^7 of lane 0's element only (partial rounds): lane 0 forms x^3 while lane 1 forms x^4 in the same multiply.
+__device__ __forceinline__ gl_t sbox_row_lane0_nc(gl_t s, bool lane0) {
+    const gl_t sq = gl_mul_nc(s, s);
+    // lanes 0 and 1 of each quad read lane 0 (quad_perm [0,0,2,3]); only the row's first quad matters
+    const uint32_t x2l = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)sq, 0xE0, 0xF, 0xF, true);
+    const uint32_t x2h = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(sq >> 32), 0xE0, 0xF, 0xF, true);
+    const gl_t x2 = (gl_t)x2l | ((gl_t)x2h << 32);
+    const gl_t y = gl_mul_nc(x2, lane0 ? s : x2);  // lane 0: x^3, lane 1: x^4
+    // lane 0 reads lane 1 (quad_perm [1,1,2,3])
+    const uint32_t nl = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)y, 0xE5, 0xF, 0xF, true);
+    const uint32_t nh = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(y >> 32), 0xE5, 0xF, 0xF, true);
+    const gl_t x7 = gl_mul_nc(y, (gl_t)nl | ((gl_t)nh << 32));
+    return lane0 ? x7 : s;
+}
+
+// One permutation of the row form, plain rounds.  rc: this lane's round constants split in halves, rc[r] for round r < 30 and a
+// zero at rc[30]; c0 = 17 (+ 8 on lane 0): the k = 0 coefficient.  Lanes 12 .. 15 compute on mirrored copies and are never read.
+// In: canonical or not; out: any representative.
+__device__ __forceinline__ gl_t poseidon_permute_row(gl_t s, const RcPair* __restrict__ rc, uint32_t c0, bool lane0) {
+    s = gl_add_nc(s, rc[0].lo | (rc[0].hi << 32));
+    int r = 0;
+#pragma unroll 1
+    for (; r < 4; r++) {
+        s = sbox_nc(s);
+        s = row_layer_circ((uint32_t)s, (uint32_t)(s >> 32), c0, rc[r + 1].lo, rc[r + 1].hi);
+    }
+#pragma unroll 1
+    for (; r < 26; r++) {
+        s = sbox_row_lane0_nc(s, lane0);
+        s = row_layer_circ((uint32_t)s, (uint32_t)(s >> 32), c0, rc[r + 1].lo, rc[r + 1].hi);
+    }
+#pragma unroll 1
+    for (; r < 30; r++) {
+        s = sbox_nc(s);
+        s = row_layer_circ((uint32_t)s, (uint32_t)(s >> 32), c0, rc[r + 1].lo, rc[r + 1].hi);
+    }
+    return s;
+}
+
 }  // namespace starkhip

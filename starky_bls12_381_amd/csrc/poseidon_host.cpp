@@ -246,7 +246,7 @@ AVX512_TARGET inline void mds(V12& s) { mds_bcast(s); }
 // and two dense layers less per triple.
 struct alignas(64) MergedVectors {   // each vector as 16 words: rows 0..7 (zmm), rows 8..11 (ymm), 4 unused
     uint64_t n3[12][16];  // column j of N3
-    uint64_t r1[16], r2[16], b2[16], b3[16], k3[POSEIDON_MERGED_TRIPLES][16];
+    uint64_t r1[16], r2[16], r3[16], b2[16], b3[16], k3[POSEIDON_MERGED_TRIPLES][16];
     gl_t k1[POSEIDON_MERGED_TRIPLES], k2[POSEIDON_MERGED_TRIPLES];
     uint64_t m00;
 };
@@ -261,6 +261,7 @@ const MergedVectors& merged_vectors() {
         for (int i = 0; i < 12; i++) {
             v.r1[i] = P.M[0][i];
             v.r2[i] = P.N2[0][i];
+            v.r3[i] = P.N3[0][i];
             v.b2[i] = P.N2[i][0];
             v.b3[i] = P.M[i][0];
         }
@@ -289,15 +290,19 @@ AVX512_TARGET inline unsigned __int128 dot_row(__m512i alo, __m512i ahi, __m256i
 // that does not depend on them -- the dot products and the dense layer over elements 1 .. 11 -- is computed from the state
 // with element 0 zeroed, beside the chain; each link then costs one scalar multiply-add and a reduction
 // (y1 = P1 + M00 x1 + k1, y2 = P2 + N2_00 x1 + M00 x2 + k2), and x1, x2, x3 enter the dense layer as three last terms.
-AVX512_TARGET inline void partial3(V12& s, const MergedVectors& V, int t) {
+// e0: element 0 of the state as a scalar, in and out -- the next triple's S-box input is row 0 of the dense layer, formed here as
+// one more scalar link (P3 + N3_00 x1 + N2_00 x2 + M00 x3) instead of waiting for the vector layer, its fold and reduction and a
+// move back to a general register: the chain from triple to triple never leaves the scalar unit.  Lane 0 of s.a is not read.
+AVX512_TARGET inline void partial3(V12& s, const MergedVectors& V, int t, gl_t& e0) {
     const __m512i m32 = _mm512_set1_epi64((long long)EPS);
     const __m256i m32h = _mm256_set1_epi64x((long long)EPS);
-    const gl_t x1 = sbox_nc((gl_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(s.a)));  // the chain starts at once
+    const gl_t x1 = sbox_nc(e0);  // the chain starts at once
     const __m512i uz = _mm512_maskz_mov_epi64(0xFE, s.a);  // element 0 zeroed
     const __m512i alo = _mm512_and_si512(uz, m32), ahi = _mm512_srli_epi64(uz, 32);
     const __m256i blo = _mm256_and_si256(s.b, m32h), bhi = _mm256_srli_epi64(s.b, 32);
     const unsigned __int128 P1 = dot_row(alo, ahi, blo, bhi, MV_A(V.r1), MV_B(V.r1)) + V.k1[t];
     const unsigned __int128 P2 = dot_row(alo, ahi, blo, bhi, MV_A(V.r2), MV_B(V.r2)) + V.k2[t];
+    const unsigned __int128 P3 = dot_row(alo, ahi, blo, bhi, MV_A(V.r3), MV_B(V.r3)) + V.k3[t][0];
     // the dense layer over elements 1 .. 11: out = N3 ut + N2[:,0] x2 + M[:,0] x3 + k3, column 0 of N3 (times x1) added below
     alignas(64) uint64_t lo[12], hi[12];
     _mm512_store_si512((void*)lo, alo);
@@ -331,6 +336,8 @@ AVX512_TARGET inline void partial3(V12& s, const MergedVectors& V, int t) {
     ADD_TERM(x2, V.b2);
     const unsigned __int128 v2 = P2 + (unsigned __int128)V.r2[0] * x1 + (unsigned __int128)V.m00 * x2;
     const gl_t x3 = sbox_nc(reduce128_nc((uint64_t)(v2 >> 64), (uint64_t)v2));
+    const unsigned __int128 v3 = P3 + (unsigned __int128)V.r3[0] * x1 + (unsigned __int128)V.r2[0] * x2 + (unsigned __int128)V.m00 * x3;
+    e0 = reduce128_nc((uint64_t)(v3 >> 64), (uint64_t)v3);
     ADD_TERM(x3, V.b3);
 #undef ADD_TERM
     {  // value = L + H * 2^32 (L, H < 2^58), then + k3 (canonical)
@@ -362,10 +369,11 @@ AVX512_TARGET void permute_avx512(gl_t* st) {
     const MergedVectors& V = merged_vectors();
     s.a = add_8(s.a, _mm512_loadu_si512((const void*)(RC + rc)));
     s.b = add_4(s.b, _mm256_loadu_si256((const __m256i*)(RC + rc + 8)));
-    for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++) partial3(s, V, t);
+    gl_t e0 = (gl_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(s.a));
+    for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++) partial3(s, V, t, e0);
     rc += 12 * 3 * POSEIDON_MERGED_TRIPLES;  // the constants of this round are already in s
     {
-        const gl_t x0 = sbox_nc((gl_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(s.a)));  // element 0, scalar
+        const gl_t x0 = sbox_nc(e0);  // element 0, scalar
         s.a = _mm512_maskz_mov_epi64(0xFE, s.a);  // the vector part does not wait for x0
         mds_t<true>(s, x0);
         rc += 12;

@@ -120,6 +120,7 @@ struct Ctx {
     std::vector<std::unique_ptr<PlanDev>> plan_cache;
     Tables* tab = nullptr;    // the current shape's (ensure_tables)
     PlanDev* plan = nullptr;  // the current AIR's (ensure_plan)
+    long opt_leaf_hash_form = 0;     // 0: row form for a lone context's commitments of <= 4096 leaves, quad form otherwise; 1: quad always; 2: row always
     long opt_lde_closed_forms = 1;   // constant / unit-vector columns skip their transforms (kernels_lde.hip); 0: every column is transformed
     // op-stream program (quotient_impl = 1; kept as the cross-check)
     int prog_air = -1;
@@ -277,6 +278,15 @@ static int ensure_plan(Ctx* c, const AirInfo& air, size_t quotient_points) {
 static inline size_t level_off(size_t n_leaves, unsigned l) { return 2 * n_leaves - (2 * n_leaves >> l); }
 static inline size_t digest_words(size_t n_leaves) { return 8 * n_leaves; }
 
+// Which leaf-hash form a LONE context uses (a pool's commitments go through its scheduler, which merges the small ones into quad
+// launches): the quad form of a commitment with <= 4096 leaves is at most 256 waves on 1024 SIMDs, each a chain of up to 12 167
+// sequential permutations, so the form with fewer instructions per wave and permutation wins (MillerLoop 119 -> ms, kernels_hash.hip).
+static bool use_row_form(const Ctx* c, size_t n_cols, unsigned log_N) {
+    if (c->opt_leaf_hash_form == 1) return false;
+    if (c->opt_leaf_hash_form == 2) return true;
+    return log_N <= 12 && n_cols >= 64;
+}
+
 int ctx_create(int device, Ctx** out, int priority) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return STARKHIP_ERR_NO_DEVICE;
@@ -373,6 +383,7 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
     else if (k == "quotient_debug" && value >= 0 && value <= 9) c->opt_quotient_debug = value;
 #endif
     else if (k == "lde_closed_forms" && (value == 0 || value == 1)) c->opt_lde_closed_forms = value;
+    else if (k == "leaf_hash_form" && value >= 0 && value <= 2) c->opt_leaf_hash_form = value;
     else if (k == "quotient_chunks" && value >= 0 && value <= 4096) c->opt_quotient_chunks = value;  // plans are cached by (AIR, chunks)
     else return STARKHIP_ERR_BAD_SHAPE;
     return STARKHIP_OK;
@@ -547,6 +558,8 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     if (c->hs) {  // pooled: the scheduler decides when this commitment runs and which others share its launch
         c->hash_requested = true;
         HIPCHK(c->hs->hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st, c->hash_ready, c->hash_done, !HashService::is_big(log_n, r), c->urgent));
+    } else if (use_row_form(c, C, log_N)) {
+        HIPCHK(launch_leaf_hash_row(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
     } else {
         HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
     }
@@ -969,7 +982,8 @@ int merkle_cap(Ctx* c, const uint64_t* lde_natural, size_t n_cols, unsigned log_
     HIPCHK(c->lde.ensure(n_cols * N * 8));
     HIPCHK(c->digests.ensure(digest_words(N) * 8));
     HIPCHK(hipMemcpyAsync(c->lde.p, lde_natural, n_cols * N * 8, hipMemcpyHostToDevice, c->st));
-    HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
+    if (use_row_form(c, n_cols, log_N)) HIPCHK(launch_leaf_hash_row(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
+    else HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
     HIPCHK(launch_merkle_levels(c->digests.as<gl_t>(), log_N, cap_h, c->st));
     HIPCHK(hipMemcpyAsync(cap_out, c->digests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), ((size_t)4 << cap_h) * 8, hipMemcpyDeviceToHost, c->st));
     HIPCHK(stream_wait(c));

@@ -84,6 +84,26 @@ def test_merkle_cap_matches_oracle(prover, log_N, ncols, cap_h):
     assert np.array_equal(cap, O.merkle_cap(np.ascontiguousarray(mat.T), cap_h))
 
 
+@pytest.mark.parametrize("log_N,ncols,cap_h", [(5, 60285 // 16, 4), (4, 3, 4), (8, 5, 2), (12, 200, 4), (6, 8, 0), (13, 21, 4), (2, 9, 0), (3, 100, 1),
+                                               # tails of 0 .. 7 after one and after two full blocks
+                                               (10, 16, 4), (10, 24, 4), (10, 12, 4), (10, 13, 4), (10, 9, 4), (10, 17, 4), (10, 20, 4), (10, 11, 4),
+                                               (10, 10, 4), (10, 14, 4), (10, 15, 4), (10, 23, 4)])
+@pytest.mark.parametrize("form", [2, 1])
+def test_merkle_cap_in_both_leaf_hash_forms(prover, log_N, ncols, cap_h, form):
+    """The row form (16 lanes per leaf, what a lone context uses for <= 4096 leaves) and the quad form (4 lanes per leaf) give the
+    oracle's cap for every shape, whichever the automatic choice would have been."""
+    rng = np.random.default_rng(1000 + log_N + ncols)
+    mat = _rand(rng, (ncols, 1 << log_N))
+    mat[:, 0] = 0                      # an all-zero leaf
+    mat[:, -1] = np.uint64(P - 1)      # and one of p - 1
+    prover.set_option("leaf_hash_form", form)
+    try:
+        cap = prover.merkle_cap(mat, cap_h)
+    finally:
+        prover.set_option("leaf_hash_form", 0)
+    assert np.array_equal(cap, O.merkle_cap(np.ascontiguousarray(mat.T), cap_h))
+
+
 @pytest.mark.parametrize("n,rate_bits", [(16, 1), (64, 1), (64, 2), (1024, 2), (1024, 1), (8192, 2)])
 def test_toy_air_proof_is_bit_identical_to_oracle(prover, n, rate_bits):
     air = S.AIR_TEST_FIBONACCI
