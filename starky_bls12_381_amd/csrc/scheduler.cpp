@@ -327,6 +327,7 @@ struct Pool {
     size_t big_recordings_started = 0, big_proofs_done = 0;  // under mu
     std::map<int, int> idle_big, idle_small;                 // idle contexts by the AIR they proved last (under mu)
     unsigned stream_priority = 0;
+    bool fifo = false;  // STARKHIP_POOL_FIFO=1: small jobs in arrival order (A/B measurements)
     bool warm = false;        // contexts reserve the pipeline's AIRs when their threads start (pool_create waits for it)
     unsigned warmed = 0;
     int warm_rc = STARKHIP_OK;
@@ -340,6 +341,13 @@ struct Pool {
         j->state = 2;
         j->t[4] = now();
         cv_done.notify_all();
+    }
+
+    // Expected length of a small proof, for ordering only: the permutations per leaf of its commitment; trivial recordings first.
+    static unsigned long small_rank(const Job* j) {
+        const AirInfo* a = air_get(j->air);
+        if (!a) return 0;
+        return (unsigned long)a->cols + (a->default_rows <= 64 ? 1000000ul : 0ul);
     }
 
     // Threads one recording may use.  The long pole -- a FinalExp-class recording -- gets three quarters of the CPU budget (its
@@ -364,11 +372,16 @@ struct Pool {
                 // proofs fill the chip beside the first FinalExp proofs), then the FinalExp traces that will wait for a context
                 // anyway.  Few recordings run at once, each on many threads (trace_threads_for_call): the FIRST trace of each
                 // class is ready after tens of milliseconds instead of all of them after hundreds.
+                // Among the small AIRs' the LONGEST proof first (a small proof is a latency chain of cols / 8 permutations per
+                // leaf: MillerLoop 12 167, FP12Mul 7 536, PairingPrecomp 3 672), so that the batch does not end on one; recordings
+                // that cost nothing (FP12Mul: 16 rows) before all others -- their proofs are 2-wave chains that start at once.
                 auto it = q_gen.end();
                 const bool want_big = big_recordings_started < big_ctx.size() + 1;
                 for (auto k = q_gen.begin(); k != q_gen.end(); ++k)
-                    if ((*k)->big == want_big) { it = k; break; }
-                if (it == q_gen.end()) it = q_gen.begin();
+                    if ((*k)->big == want_big && (it == q_gen.end() || (!want_big && !fifo && small_rank(*k) > small_rank(*it)))) it = k;
+                if (it == q_gen.end())  // none of the wanted class: the best of the other
+                    for (auto k = q_gen.begin(); k != q_gen.end(); ++k)
+                        if (it == q_gen.end() || (want_big && !fifo && small_rank(*k) > small_rank(*it))) it = k;
                 j = *it;
                 q_gen.erase(it);
                 if (j->big) big_recordings_started++;
@@ -478,7 +491,9 @@ struct Pool {
                         if (it == q.end())
                             for (auto k = q.begin(); k != q.end(); ++k) {
                                 auto f = idle.find((*k)->air);
-                                if (f == idle.end() || f->second == 0) { it = k; break; }  // nobody idle knows this AIR better
+                                if (f != idle.end() && f->second != 0) continue;  // somebody idle knows this AIR better
+                                if (it == q.end() || (!big && !fifo && small_rank(*k) > small_rank(*it))) it = k;  // the longest proof first
+                                if (big || fifo) break;
                             }
                         if (it != q.end()) {
                             j = *it;
@@ -559,6 +574,10 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
     }
     p->hs.reset(new HashService(cfg.device));
     p->stream_priority = cfg.stream_priority;
+    {
+        const char* e = getenv("STARKHIP_POOL_FIFO");
+        p->fifo = e && *e == '1';
+    }
     p->warm = cfg.warm_up != 0;
     if (cfg.gather_ms > 0) p->hs->gather_ms = cfg.gather_ms;
     p->hs->policy = (int)cfg.commit_policy;
