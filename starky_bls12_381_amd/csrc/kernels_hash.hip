@@ -297,9 +297,15 @@ __global__ __launch_bounds__(256) void leaf_hash_row_kernel(const gl_t* __restri
         if (e < 4) digests[4 * j + e] = e < n_cols ? col[(size_t)e * N] : 0;
         return;
     }
+#ifdef STARKHIP_ROW_CPP_ROUNDS  // the C++ rounds (poseidon_permute_row): what hipcc schedules by itself, kept for comparison
     const uint32_t c0 = e == 0 ? 17u + 8u : 17u;  // CIRC[0] + MDS_MATRIX_DIAG[0] on lane 0
+#define STARKHIP_ROW_PERMUTE(s) poseidon_permute_row(s, rc, c0, e == 0)
+#else
+    RowConsts K;
+    row_consts_init(K, e);
+#define STARKHIP_ROW_PERMUTE(s) poseidon_permute_row_asm(s, rc, K)
+#endif
     const RcPair* rc = rcs[e];
-    const bool lane0 = e == 0;
     const bool absorbs = e < 8;
     gl_t s = 0;
     const gl_t* mine = col + (size_t)(absorbs ? e : 0) * N;  // lanes 8 .. 15 never load
@@ -309,13 +315,14 @@ __global__ __launch_bounds__(256) void leaf_hash_row_kernel(const gl_t* __restri
     for (size_t b = 0; b < n_full; b++) {
         if (absorbs) s = nx;
         if (b + 1 < n_full && absorbs) nx = mine[(8 * (b + 1)) * N];  // requested one permutation ahead
-        s = poseidon_permute_row(s, rc, c0, lane0);
+        s = STARKHIP_ROW_PERMUTE(s);
     }
     if (rem) {  // the last, partial block overwrites elements 0 .. rem - 1 only
         if (e < rem) s = mine[(8 * n_full) * N];
-        s = poseidon_permute_row(s, rc, c0, lane0);
+        s = STARKHIP_ROW_PERMUTE(s);
     }
     if (e < 4) digests[4 * j + e] = gl_canon(s);
+#undef STARKHIP_ROW_PERMUTE
 }
 
 // Leaves stored row-major and already in tree order: leaf j = rows[j][0..width)

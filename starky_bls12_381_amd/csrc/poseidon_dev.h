@@ -466,6 +466,65 @@ __device__ __forceinline__ gl_t sbox_row_lane0_nc(gl_t s, bool lane0) {
     return lane0 ? x7 : s;
 }
 
+// ---- whole rounds as scheduled asm blocks on fixed registers (tools/gen_row_round_asm.py -> row_round_asm.inc): the S-box's flag
+// hand-offs are filled with the other multiply of x^3 / x^4 (full rounds) or with the whole layer over the eleven elements that do
+// not pass the S-box (partial rounds: M s' = M (s with element 0 zeroed) + column 0 of M times x0^7).  120 and 113 issue slots per
+// round against 134 and 127 from the C++ above.
+#include "row_round_asm.inc"
+struct RowConsts {
+    uint32_t c0, col0;   // CIRC[0] (+ 8 on lane 0); column 0 of the MDS matrix at this lane
+    uint32_t za, zb;     // zero, opaque to the compiler: the upper halves of the multiplies' addend pairs stay in their registers
+    uint64_t mask0;      // lane 0 of every row
+};
+__device__ __forceinline__ void row_consts_init(RowConsts& K, unsigned e) {
+    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    K.c0 = e == 0 ? 25u : 17u;
+    K.col0 = e == 0 ? 25u : e < 12 ? CIRC[(12 - e) % 12] : 0u;
+    K.za = K.zb = 0;
+    K.mask0 = 0x0001000100010001ull;
+    asm volatile("" : "+v"(K.za), "+v"(K.zb), "+s"(K.mask0));
+}
+// One round; OFF = byte offset of the constant AFTER the next round's in this lane's row of the LDS table (the block reloads the seed
+// registers from there as soon as it has consumed them).  sa / sb: the next round's constant as two 64-bit addends, in and out.
+template <int OFF>
+__device__ __forceinline__ gl_t row_round_full_asm(gl_t s, uint64_t& sa, uint64_t& sb, uint32_t rc_lds, const RowConsts& K) {
+    uint64_t out;
+    asm(STARKHIP_ROW_FULL_ROUND_ASM
+        : STARKHIP_ROW_STATE_OUT(out), STARKHIP_ROW_SEED_A(sa), STARKHIP_ROW_SEED_B(sb)
+        : STARKHIP_ROW_STATE_LO((uint32_t)s), STARKHIP_ROW_STATE_HI((uint32_t)(s >> 32)), STARKHIP_ROW_ADDR(rc_lds), STARKHIP_ROW_C0(K.c0), STARKHIP_ROW_ZA(K.za),
+          STARKHIP_ROW_ZB(K.zb), [off] "n"(OFF)
+        : STARKHIP_ROW_CLOBBERS);
+    return out;
+}
+template <int OFF>
+__device__ __forceinline__ gl_t row_round_partial_asm(gl_t s, uint64_t& sa, uint64_t& sb, uint32_t rc_lds, const RowConsts& K) {
+    uint64_t out;
+    asm(STARKHIP_ROW_PARTIAL_ROUND_ASM
+        : STARKHIP_ROW_STATE_OUT(out), STARKHIP_ROW_SEED_A(sa), STARKHIP_ROW_SEED_B(sb)
+        : STARKHIP_ROW_STATE_LO((uint32_t)s), STARKHIP_ROW_STATE_HI((uint32_t)(s >> 32)), STARKHIP_ROW_ADDR(rc_lds), STARKHIP_ROW_C0(K.c0),
+          STARKHIP_ROW_COL0(K.col0), STARKHIP_ROW_ZA(K.za), STARKHIP_ROW_ZB(K.zb), STARKHIP_ROW_MASK0(K.mask0), [off] "n"(OFF)
+        : STARKHIP_ROW_CLOBBERS);
+    return out;
+}
+template <int R>
+__device__ __forceinline__ gl_t row_rounds_from(gl_t s, uint64_t& sa, uint64_t& sb, uint32_t rc_lds, const RowConsts& K) {
+    if constexpr (R < 30) {
+        constexpr int OFF = (R + 2) * (int)sizeof(RcPair);  // rc[R + 1] is in the seed registers; rc[R + 2] is fetched (rc[30], rc[31] are zero)
+        if constexpr (R < 4 || R >= 26) s = row_round_full_asm<OFF>(s, sa, sb, rc_lds, K);
+        else s = row_round_partial_asm<OFF>(s, sa, sb, rc_lds, K);
+        return row_rounds_from<R + 1>(s, sa, sb, rc_lds, K);
+    } else {
+        return s;
+    }
+}
+// rc: this lane's row of the LDS table, RcPair rc[32] (rounds 0 .. 29, then zeros)
+__device__ __forceinline__ gl_t poseidon_permute_row_asm(gl_t s, const RcPair* __restrict__ rc, const RowConsts& K) {
+    s = gl_add_nc(s, rc[0].lo | (rc[0].hi << 32));
+    uint64_t sa = rc[1].lo, sb = rc[1].hi;
+    const uint32_t rc_lds = (uint32_t)(uintptr_t)rc;  // the low half of a generic pointer into LDS is the LDS address
+    return row_rounds_from<0>(s, sa, sb, rc_lds, K);
+}
+
 // One permutation of the row form, plain rounds.  rc: this lane's round constants split in halves, rc[r] for round r < 30 and a
 // zero at rc[30]; c0 = 17 (+ 8 on lane 0): the k = 0 coefficient.  Lanes 12 .. 15 compute on mirrored copies and are never read.
 // In: canonical or not; out: any representative.
