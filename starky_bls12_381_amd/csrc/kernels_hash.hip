@@ -151,6 +151,51 @@ int quad_merged_tables_selfcheck(unsigned n) {
     return bad;
 }
 
+// ---- the row form's merged triples: per-lane coefficient rows and constants (poseidon_dev.h: RowMergedTables)
+__constant__ RowMergedTables ROW_MERGED;
+static void build_row_merged_tables(RowMergedTables& T) {
+    static PoseidonMergedTables P;
+    build_poseidon_merged_tables(P);
+    auto split = [](gl_t v) { return RcPair{v & 0xFFFFFFFFull, v >> 32}; };
+    for (int e = 0; e < 16; e++) {
+        uint32_t* c = T.coef[e];
+        for (int k = 0; k < 20; k++) c[k] = 0;
+        if (e >= 12) continue;
+        for (int k = 0; k < 12; k++) c[k] = (uint32_t)P.N3[e][(e + k) % 12];
+        c[12] = (uint32_t)P.M[0][e];
+        c[13] = (uint32_t)P.N2[0][e];
+        c[14] = (uint32_t)P.N2[e][0];
+        c[15] = (uint32_t)P.M[e][0];
+        c[16] = (uint32_t)P.N3[e][0];
+        c[17] = e == 0 ? (uint32_t)P.M[0][0] : 0;
+        c[18] = e == 0 ? (uint32_t)P.N2[0][0] : 0;
+    }
+    for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++) {
+        T.k1[t] = split(P.k1[t]);
+        T.k2[t] = split(P.k2[t]);
+        for (int e = 0; e < 12; e++) T.k3[t][e] = split(P.k3[t][e]);
+    }
+}
+static hipError_t ensure_row_merged_tables() {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu);
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (done[dev]) return hipSuccess;
+    static RowMergedTables T;
+    static bool built = false;
+    if (!built) {
+        build_row_merged_tables(T);
+        built = true;
+    }
+    e = hipMemcpyToSymbol(HIP_SYMBOL(ROW_MERGED), &T, sizeof T);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}
+
 static hipError_t ensure_quad_merged_tables() {
     static std::mutex mu;
     static bool done[64] = {false};
@@ -275,12 +320,22 @@ __global__ __launch_bounds__(256) void leaf_hash_multi_kernel(LeafHashBatch B, s
 // capacity, lanes 12 .. 15 idle as mirrors.  One wave = 4 leaves; adjacent rows read adjacent points of a column.
 __global__ __launch_bounds__(256) void leaf_hash_row_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
                                                              gl_t* __restrict__ digests) {
-    __shared__ RcPair rcs[16][32];  // [lane of the row][round], zero beyond round 29 and on lanes 12 .. 15
-    for (unsigned idx = threadIdx.x; idx < 16 * 32; idx += blockDim.x) {
-        const unsigned e = idx / 32, r = idx % 32;
-        const gl_t c = (e < 12 && r < 30) ? POSEIDON_RC_DEV[12 * r + e] : 0;
-        rcs[e][r].lo = c & 0xFFFFFFFFull;
-        rcs[e][r].hi = c >> 32;
+    // [lane of the row][entry]: entries 0 .. 31 the round constants (zero beyond round 29), 32 + 3 t + {0, 1, 2} the merged triples' k1, k2
+    // (lane 0 only) and k3; everything zero on lanes 12 .. 15
+    __shared__ RcPair rcs[16][64];
+    for (unsigned idx = threadIdx.x; idx < 16 * 64; idx += blockDim.x) {
+        const unsigned e = idx / 64, r = idx % 64;
+        RcPair c = {0, 0};
+        if (e < 12 && r < 30) {
+            const gl_t v = POSEIDON_RC_DEV[12 * r + e];
+            c.lo = v & 0xFFFFFFFFull;
+            c.hi = v >> 32;
+        } else if (e < 12 && r >= 32 && r < 32 + 3 * 7) {
+            const unsigned t = (r - 32) / 3, w = (r - 32) % 3;
+            if (w == 2) c = ROW_MERGED.k3[t][e];
+            else if (e == 0) c = w == 0 ? ROW_MERGED.k1[t] : ROW_MERGED.k2[t];
+        }
+        rcs[e][r] = c;
     }
     __syncthreads();
     const unsigned log_N = log_n + rate_bits;
@@ -302,8 +357,12 @@ __global__ __launch_bounds__(256) void leaf_hash_row_kernel(const gl_t* __restri
 #define STARKHIP_ROW_PERMUTE(s) poseidon_permute_row(s, rc, c0, e == 0)
 #else
     RowConsts K;
-    row_consts_init(K, e);
+    row_consts_init(K, e, ROW_MERGED.coef[e]);
+#ifdef STARKHIP_ROW_PLAIN_ROUNDS  // asm rounds without the merged triples
 #define STARKHIP_ROW_PERMUTE(s) poseidon_permute_row_asm(s, rc, K)
+#else
+#define STARKHIP_ROW_PERMUTE(s) poseidon_permute_row_merged_asm(s, rc, K)
+#endif
 #endif
     const RcPair* rc = rcs[e];
     const bool absorbs = e < 8;
@@ -382,6 +441,7 @@ hipError_t launch_leaf_hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsi
 }
 hipError_t launch_leaf_hash_row(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st) {
     size_t N = (size_t)1 << (log_n + rate_bits);
+    if (hipError_t e = ensure_row_merged_tables(); e != hipSuccess) return e;
     hipLaunchKernelGGL(leaf_hash_row_kernel, dim3(nblocks(16 * N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
     return hipGetLastError();
 }

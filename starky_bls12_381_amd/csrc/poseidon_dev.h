@@ -471,18 +471,34 @@ __device__ __forceinline__ gl_t sbox_row_lane0_nc(gl_t s, bool lane0) {
 // not pass the S-box (partial rounds: M s' = M (s with element 0 zeroed) + column 0 of M times x0^7).  120 and 113 issue slots per
 // round against 134 and 127 from the C++ above.
 #include "row_round_asm.inc"
+typedef uint32_t row_u32x4 __attribute__((ext_vector_type(4)));
 struct RowConsts {
     uint32_t c0, col0;   // CIRC[0] (+ 8 on lane 0); column 0 of the MDS matrix at this lane
     uint32_t za, zb;     // zero, opaque to the compiler: the upper halves of the multiplies' addend pairs stay in their registers
     uint64_t mask0;      // lane 0 of every row
+    uint64_t maske;      // even lanes
+    // merged triples (poseidon_merged.h), this lane's views: n3k[k] = N3[e][(e + k) mod 12]; misc0 = (M[0][e], N2[0][e], N2[e][0],
+    // M[e][0]); misc1 = (N3[e][0], M[0][0] on lane 0, N2[0][0] on lane 0, -).  All zero on lanes 12 .. 15.
+    row_u32x4 n3k0, n3k1, n3k2, misc0, misc1;
 };
-__device__ __forceinline__ void row_consts_init(RowConsts& K, unsigned e) {
+// Per-lane coefficient rows of the merged triples, built on the host once per device (kernels_hash.hip)
+struct RowMergedTables {
+    uint32_t coef[16][20];                       // [lane]: n3k[12], then misc0[4], misc1[4]
+    RcPair k1[7], k2[7], k3[7][12];              // POSEIDON_MERGED_TRIPLES = 7
+};
+__device__ __forceinline__ void row_consts_init(RowConsts& K, unsigned e, const uint32_t* __restrict__ coef /* RowMergedTables::coef[e] */) {
     constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     K.c0 = e == 0 ? 25u : 17u;
     K.col0 = e == 0 ? 25u : e < 12 ? CIRC[(12 - e) % 12] : 0u;
     K.za = K.zb = 0;
     K.mask0 = 0x0001000100010001ull;
-    asm volatile("" : "+v"(K.za), "+v"(K.zb), "+s"(K.mask0));
+    K.maske = 0x5555555555555555ull;
+    asm volatile("" : "+v"(K.za), "+v"(K.zb), "+s"(K.mask0), "+s"(K.maske));
+    K.n3k0 = row_u32x4{coef[0], coef[1], coef[2], coef[3]};
+    K.n3k1 = row_u32x4{coef[4], coef[5], coef[6], coef[7]};
+    K.n3k2 = row_u32x4{coef[8], coef[9], coef[10], coef[11]};
+    K.misc0 = row_u32x4{coef[12], coef[13], coef[14], coef[15]};
+    K.misc1 = row_u32x4{coef[16], coef[17], coef[18], coef[19]};
 }
 // One round; OFF = byte offset of the constant AFTER the next round's in this lane's row of the LDS table (the block reloads the seed
 // registers from there as soon as it has consumed them).  sa / sb: the next round's constant as two 64-bit addends, in and out.
@@ -506,6 +522,55 @@ __device__ __forceinline__ gl_t row_round_partial_asm(gl_t s, uint64_t& sa, uint
         : STARKHIP_ROW_CLOBBERS);
     return out;
 }
+// Three partial rounds at once.  k1 / k2 / k3: this triple's constants, each (low half, high half) as two 64-bit addends (k1 and k2
+// on lane 0 only), in; the next triple's, fetched from OFF1 / OFF2 / OFF3 of the lane's LDS row, out.
+template <int OFF1, int OFF2, int OFF3>
+__device__ __forceinline__ gl_t row_triple_asm(gl_t s, row_u32x4& k1, row_u32x4& k2, row_u32x4& k3, uint32_t rc_lds, const RowConsts& K) {
+    uint64_t out;
+    asm(STARKHIP_ROW_TRIPLE_ASM
+        : STARKHIP_ROW_STATE_OUT(out), STARKHIP_ROW_K1(k1), STARKHIP_ROW_K2(k2), STARKHIP_ROW_K3(k3)
+        : STARKHIP_ROW_STATE_LO((uint32_t)s), STARKHIP_ROW_STATE_HI((uint32_t)(s >> 32)), STARKHIP_ROW_ADDR(rc_lds), STARKHIP_ROW_N3K0(K.n3k0),
+          STARKHIP_ROW_N3K1(K.n3k1), STARKHIP_ROW_N3K2(K.n3k2), STARKHIP_ROW_MISC0(K.misc0), STARKHIP_ROW_MISC1(K.misc1), STARKHIP_ROW_ZA(K.za),
+          STARKHIP_ROW_ZB(K.zb), STARKHIP_ROW_MASK0(K.mask0), STARKHIP_ROW_MASKE(K.maske), [off1] "n"(OFF1), [off2] "n"(OFF2), [off3] "n"(OFF3)
+        : STARKHIP_ROW_CLOBBERS, STARKHIP_ROW_TRIPLE_CLOBBERS);
+    return out;
+}
+static const int ROW_TRIPLE_BASE = 32;  // LDS row: RcPair[0 .. 31] round constants (30, 31 zero), then k1, k2, k3 of triple t at 32 + 3 t
+template <int T>
+__device__ __forceinline__ gl_t row_triples_from(gl_t s, row_u32x4& k1, row_u32x4& k2, row_u32x4& k3, uint32_t rc_lds, const RowConsts& K) {
+    if constexpr (T < 7) {
+        constexpr int O = (ROW_TRIPLE_BASE + 3 * (T + 1)) * (int)sizeof(RcPair);  // the next triple's (beyond the last: unused entries of the row)
+        s = row_triple_asm<O, O + 16, O + 32>(s, k1, k2, k3, rc_lds, K);
+        return row_triples_from<T + 1>(s, k1, k2, k3, rc_lds, K);
+    } else {
+        return s;
+    }
+}
+template <int R, int END>
+__device__ __forceinline__ gl_t row_rounds_range(gl_t s, uint64_t& sa, uint64_t& sb, uint32_t rc_lds, const RowConsts& K) {
+    if constexpr (R < END) {
+        constexpr int OFF = (R + 2) * (int)sizeof(RcPair);
+        if constexpr (R < 4 || R >= 26) s = row_round_full_asm<OFF>(s, sa, sb, rc_lds, K);
+        else s = row_round_partial_asm<OFF>(s, sa, sb, rc_lds, K);
+        return row_rounds_range<R + 1, END>(s, sa, sb, rc_lds, K);
+    } else {
+        return s;
+    }
+}
+// rc: this lane's row of the LDS table, RcPair rc[64]: round constants, then the merged triples' constants
+__device__ __forceinline__ gl_t poseidon_permute_row_merged_asm(gl_t s, const RcPair* __restrict__ rc, const RowConsts& K) {
+    s = gl_add_nc(s, rc[0].lo | (rc[0].hi << 32));
+    uint64_t sa = rc[1].lo, sb = rc[1].hi;
+    const uint32_t rc_lds = (uint32_t)(uintptr_t)rc;
+    s = row_rounds_range<0, 4>(s, sa, sb, rc_lds, K);                      // leaves rc[4] added: the first partial round's constants
+    auto pair4 = [](const RcPair& c) { return row_u32x4{(uint32_t)c.lo, (uint32_t)(c.lo >> 32), (uint32_t)c.hi, (uint32_t)(c.hi >> 32)}; };
+    row_u32x4 k1 = pair4(rc[ROW_TRIPLE_BASE]), k2 = pair4(rc[ROW_TRIPLE_BASE + 1]), k3 = pair4(rc[ROW_TRIPLE_BASE + 2]);
+    s = row_triples_from<0>(s, k1, k2, k3, rc_lds, K);                     // rounds 4 .. 24; leaves rc[25] added
+    sa = rc[26].lo;
+    sb = rc[26].hi;
+    return row_rounds_range<25, 30>(s, sa, sb, rc_lds, K);                 // the 22nd partial round, then four full rounds
+}
+
 template <int R>
 __device__ __forceinline__ gl_t row_rounds_from(gl_t s, uint64_t& sa, uint64_t& sb, uint32_t rc_lds, const RowConsts& K) {
     if constexpr (R < 30) {

@@ -65,6 +65,15 @@ MASK0 = 40                     # in: lane-0 mask (bit 0 of every row)
 SINK = 42
 FLAG = [44, 52]                # per slot: CM, BR, BR2, CY pairs
 FC = 60
+MASKE = 62                     # in: even lanes (the uniform S-box of the merged triple)
+# the merged triple's operands and extra temporaries
+N3K = 140                      # in: 12 registers, coefficient of the operand rotated by k: N3[e][(e + k) mod 12]
+R1, R2, B2, B3 = 152, 153, 154, 155      # in: M[0][e], N2[0][e], N2[e][0], M[e][0]
+N3C0, L0M, L0N = 156, 157, 158           # in: N3[e][0]; M[0][0] and N2[0][0] on lane 0, 0 elsewhere
+K1, K2, K3 = 160, 164, 168     # in / out: the triple's constants, each (low half, high half) as two 64-bit addends; k1, k2 on lane 0 only
+D1A, D1B, D2A, D2B = 122, 124, 126, 128  # the two dot products' accumulators
+RT = 130                       # all-reduce: rotated copies (two pairs)
+YY, XS2, XS3 = 134, 136, 138   # y (folded), x2, x3
 
 
 class Slot:
@@ -181,6 +190,121 @@ def seeds_ready(prog):
 def prefetch(prog):
     prog.append(Ins("ds_read_b128 v[%d:%d], v%d offset:%%[off]" % (SEED_A, SEED_B + 1, ADDR), [ADDR], [SEED_A, SEED_A + 1, SEED_B, SEED_B + 1], sem=("prefetch",)))
     prog[-1].boost = True
+
+
+def fold_to(prog, dst, A, B):
+    """v[dst:dst+1] = A + B * 2^32 mod p"""
+    prog.append(Ins("v_mad_u64_u32 %s, %s, %s, -1, %s" % (vp(FT), sp(SINK), v(B + 1), vp(A)), [B + 1, A, A + 1], [FT, FT + 1], sem=("mad", FT, None, B + 1, "eps", A)))
+    prog.append(Ins("v_add_co_u32 %s, %s, %s, %s" % (v(FT + 1), sp(FC), v(FT + 1), v(B)), [FT + 1, B], [FT + 1], swrites=[FC], sem=("addco", FT + 1, FC, FT + 1, B)))
+    prog.append(Ins("v_addc_co_u32 %s, %s, 0, 0, %s" % (v(CV), sp(SINK), sp(FC)), [], [CV], sreads=[FC], sem=("addc", CV, None, None, None, FC)))
+    prog.append(Ins("v_mad_u64_u32 %s, %s, %s, -1, %s" % (vp(dst), sp(SINK), v(CV), vp(FT)), [CV, FT, FT + 1], [dst, dst + 1], sem=("mad", dst, None, CV, "eps", FT)))
+
+
+def layer_dense(prog, lo, hi):
+    """ACC_A / ACC_B = K3 + sum_k n3k[k] * (halves of element (e + k) mod 12): any 12 x 12 layer, per-lane coefficients"""
+    r = ROT
+    madc(prog, ACC_A, lo, ("v", N3K + 0), seed=K3)
+    madc(prog, ACC_B, hi, ("v", N3K + 0), seed=K3 + 2)
+    mirror(prog, lo)
+    mirror(prog, hi)
+    base = (lo, hi)
+    for group, copy in ((0, (ZC, ZC + 1)), (1, (WC, WC + 1)), (2, None)):
+        ks = (1, 2, 3, 4) if group < 2 else (1, 2, 3)
+        for k in ks:
+            kk = 4 * group + k
+            dl, dh = (copy if k == 4 else (r, r + 1))
+            if k != 4:
+                r += 2
+            shl(prog, dl, base[0], k)
+            shl(prog, dh, base[1], k)
+            madc(prog, ACC_A, dl, ("v", N3K + kk))
+            madc(prog, ACC_B, dh, ("v", N3K + kk))
+        if copy is not None:
+            mirror(prog, copy[0])
+            mirror(prog, copy[1])
+            base = copy
+
+
+def add64(prog, dst, a, b):
+    prog.append(Ins("v_lshl_add_u64 %s, %s, 0, %s" % (vp(dst), vp(a), vp(b)), [a, a + 1, b, b + 1], [dst, dst + 1], sem=("add64", dst, a, b)))
+
+
+def allreduce(prog, acc):
+    """the row's sum of a 64-bit accumulator, in every lane"""
+    for k in (8, 4, 2, 1):
+        for h in (0, 1):
+            dpp(prog, RT + h, acc + h, "row_ror:%d" % k, kind=("ror", k))
+        add64(prog, acc, acc, RT)
+
+
+def sbox_uniform(prog, dst, y, slot):
+    """dst = y^7 for a value every lane holds: even lanes form x^3, odd lanes x^4, each takes the other factor from its neighbour"""
+    yy = (y, y + 1)
+    mul(prog, X2, yy, yy, slot)
+    for h in (0, 1):
+        cndmask(prog, SEL + h, X2 + h, y + h, MASKE)            # even lanes: y, odd lanes: y^2
+    mul(prog, X4, (X2, X2 + 1), (SEL, SEL + 1), slot)            # even: y^3, odd: y^4
+    for h in (0, 1):
+        quad(prog, YN + h, X4 + h, (1, 0, 3, 2))
+    mul(prog, dst, (X4, X4 + 1), (YN, YN + 1), slot)
+
+
+def block_triple():
+    """three partial rounds (poseidon_merged.h): in: the state with the first round's constants added; out: the state three rounds
+    later with the following round's constants added"""
+    prog = []
+    prog.append(Ins("s_waitcnt lgkmcnt(0)", [], list(range(K1, K3 + 4)), sem=("nopsem",)))
+    a, b = Slot(0), Slot(1)
+    x = (S_LO, S_HI)
+    cndmask(prog, SZ, S_LO, None, MASK0)
+    cndmask(prog, SZ + 1, S_HI, None, MASK0)
+    # the parts of both dot products and of the dense layer that do not wait for x1
+    madc(prog, D1A, SZ, ("v", R1), seed=K1)
+    madc(prog, D1B, SZ + 1, ("v", R1), seed=K1 + 2)
+    madc(prog, D2A, SZ, ("v", R2), seed=K2)
+    madc(prog, D2B, SZ + 1, ("v", R2), seed=K2 + 2)
+    layer_dense(prog, SZ, SZ + 1)
+    for j, K in enumerate((K1, K2, K3)):
+        prog.append(Ins("ds_read_b128 v[%d:%d], v%d offset:%%[off%d]" % (K, K + 3, ADDR, j + 1), [ADDR], [K, K + 1, K + 2, K + 3], sem=("prefetch3", K, j)))
+        prog[-1].boost = True
+    # x1 = u0^7 on lane 0 (lane 1 forms x^4 while lane 0 forms x^3)
+    mul(prog, X2, x, x, a)
+    for h in (0, 1):
+        quad(prog, X3 + h, X2 + h, (0, 0, 2, 3))
+        cndmask(prog, SEL + h, X3 + h, x[h], MASK0)
+    mul(prog, X4, (X3, X3 + 1), (SEL, SEL + 1), a)
+    for h in (0, 1):
+        quad(prog, YN + h, X4 + h, (1, 1, 2, 3))
+    mul(prog, X7, (X4, X4 + 1), (YN, YN + 1), a)          # lane 0: x1
+    # y1 = (M ut)[0] + k1
+    madc(prog, D1A, X7, ("v", L0M))
+    madc(prog, D1B, X7 + 1, ("v", L0M))
+    allreduce(prog, D1A)
+    allreduce(prog, D1B)
+    fold_to(prog, YY, D1A, D1B)
+    # x1 to every lane for the dense layer (its values in lanes 1 .. 3 are not x1: take lane 0 explicitly)
+    for h in (0, 1):
+        quad(prog, BC + h, X7 + h, (0, 0, 0, 0))
+        dpp(prog, BC + h, BC + h, "row_shr:4", bank=0x2, bound=False, kind=("shr", 4))
+        dpp(prog, BC + h, BC + h, "row_shr:8", bank=0x4, bound=False, kind=("shr", 8))
+    madc(prog, ACC_A, BC, ("v", N3C0))
+    madc(prog, ACC_B, BC + 1, ("v", N3C0))
+    # y2 = (N2 ut)[0] + M00 x2 + k2: everything but the x2 term is summed over the row while x2 is being computed
+    madc(prog, D2A, X7, ("v", L0N))
+    madc(prog, D2B, X7 + 1, ("v", L0N))
+    allreduce(prog, D2A)
+    allreduce(prog, D2B)
+    sbox_uniform(prog, XS2, YY, b)
+    madc(prog, D2A, XS2, 25)
+    madc(prog, D2B, XS2 + 1, 25)
+    fold_to(prog, YY, D2A, D2B)
+    madc(prog, ACC_A, XS2, ("v", B2))
+    madc(prog, ACC_B, XS2 + 1, ("v", B2))
+    sbox_uniform(prog, XS3, YY, b)
+    madc(prog, ACC_A, XS3, ("v", B3))
+    madc(prog, ACC_B, XS3 + 1, ("v", B3))
+    fold_to(prog, S_LO, ACC_A, ACC_B)
+    return prog
 
 
 def block_full():
@@ -312,6 +436,19 @@ def run(order, vregs, sregs):
         k = ins.sem[0]
         if k == "nopsem":
             continue
+        if k == "prefetch3":
+            _, K, j = ins.sem
+            for q in range(4):
+                vregs[K + q] = list(vregs["next_k"][j][q])
+            continue
+        if k == "add64":
+            _, d, a, b = ins.sem
+            lo, hi = [0] * NL, [0] * NL
+            for l in range(NL):
+                x = ((V(a)[l] | (V(a + 1)[l] << 32)) + (V(b)[l] | (V(b + 1)[l] << 32))) & M64
+                lo[l], hi[l] = x & M32, x >> 32
+            vregs[d], vregs[d + 1] = lo, hi
+            continue
         if k == "prefetch":
             for j, r in enumerate((SEED_A, SEED_A + 1, SEED_B, SEED_B + 1)):
                 vregs[r] = list(vregs["next_seeds"][j])
@@ -370,6 +507,8 @@ def run(order, vregs, sregs):
                     j = l + kind[1]
                 elif kind[0] == "shr":
                     j = l - kind[1]
+                elif kind[0] == "ror":
+                    j = (l - kind[1]) % NL
                 else:
                     j = (l & ~3) + kind[1][l & 3]
                 if 0 <= j < NL:
@@ -419,6 +558,64 @@ def test(order, partial):
             assert got % P == want[e], (partial, e)
 
 
+def merged_tables(c1, c2, c3):
+    """poseidon_merged.h on Python integers: M, N2, N3 and k1, k2, k3 for the constants of the three following rounds"""
+    M = [[CIRC[(j - i) % 12] + (8 if i == 0 and j == 0 else 0) for j in range(12)] for i in range(12)]
+    Mz = [[0] * 12 if i == 0 else M[i][:] for i in range(12)]
+
+    def mm(a, b):
+        return [[sum(a[i][k] * b[k][j] for k in range(12)) for j in range(12)] for i in range(12)]
+
+    def mv(a, x):
+        return [sum(a[i][j] * x[j] for j in range(12)) % P for i in range(12)]
+    N2 = mm(M, Mz)
+    N3 = mm(N2, Mz)
+    c1z, c2z = [0] + c1[1:], [0] + c2[1:]
+    k1 = c1[0]
+    k2 = (mv(M, c1z)[0] + c2[0]) % P
+    a, b = mv(N2, c1z), mv(M, c2z)
+    k3 = [(a[i] + b[i] + c3[i]) % P for i in range(12)]
+    return M, N2, N3, k1, k2, k3
+
+
+def test_triple(order):
+    for _ in range(60):
+        state = [random.choice([0, 1, P - 1, P, M64, random.getrandbits(64), random.getrandbits(64)]) for _ in range(12)]
+        c1, c2, c3 = [[random.getrandbits(64) % P for _ in range(12)] for _ in range(3)]
+        M, N2, N3, k1, k2, k3 = merged_tables(c1, c2, c3)
+        assert max(max(r) for r in N3) < 1 << 21
+        # reference: three plain partial rounds
+        want = state
+        for c in (c1, c2, c3):
+            want = reference_round(want, c, True)
+        vregs = {r: [random.getrandbits(32) for _ in range(NL)] for r in range(120, 256)}
+        vregs[S_LO] = [x & M32 for x in state] + [random.getrandbits(32) for _ in range(4)]
+        vregs[S_HI] = [x >> 32 for x in state] + [random.getrandbits(32) for _ in range(4)]
+        for k in range(12):
+            vregs[N3K + k] = [N3[e][(e + k) % 12] for e in range(12)] + [0] * 4
+        vregs[R1] = [M[0][e] for e in range(12)] + [0] * 4
+        vregs[R2] = [N2[0][e] for e in range(12)] + [0] * 4
+        vregs[B2] = [N2[e][0] for e in range(12)] + [0] * 4
+        vregs[B3] = [M[e][0] for e in range(12)] + [0] * 4
+        vregs[N3C0] = [N3[e][0] for e in range(12)] + [0] * 4
+        vregs[L0M] = [M[0][0]] + [0] * 15
+        vregs[L0N] = [N2[0][0]] + [0] * 15
+        for K, val in ((K1, [k1] + [0] * 15), (K2, [k2] + [0] * 15), (K3, k3 + [0] * 4)):
+            vregs[K], vregs[K + 1] = [x & M32 for x in val], [0] * NL
+            vregs[K + 2], vregs[K + 3] = [x >> 32 for x in val], [0] * NL
+        vregs[ZA] = [0] * NL
+        vregs[ZB] = [0] * NL
+        sregs = {MASK0: [1] + [0] * 15, MASKE: [1, 0] * 8}
+        vregs["next_k"] = [[[random.getrandbits(32) for _ in range(NL)] for _ in range(4)] for _ in range(3)]
+        run(order, vregs, sregs)
+        for e in range(12):
+            got = vregs[S_LO][e] | (vregs[S_LO + 1][e] << 32)
+            assert got % P == want[e], ("triple", e)
+        for j, K in enumerate((K1, K2, K3)):
+            for q in range(4):
+                assert vregs[K + q] == vregs["next_k"][j][q]
+
+
 def emit(name, order, what):
     print("// %s: %d instructions (%d s_nop)" % (what, len(order), sum(1 for o in order if o.text.startswith("s_nop"))))
     print("#define %s \\" % name)
@@ -439,6 +636,16 @@ def main():
         check_hazards(order, inputs)
         test(order, partial)
         emit(name, order, what)
+    order = schedule(block_triple())
+    check_hazards(order, inputs | set(range(K1, K3 + 4)))
+    test_triple(order)
+    emit("STARKHIP_ROW_TRIPLE_ASM", order, "three partial rounds at once (poseidon_merged.h): three S-boxes, two dot products summed over the row, one dense layer")
+    for name, r in (("N3K0", N3K), ("N3K1", N3K + 4), ("N3K2", N3K + 8), ("MISC0", R1), ("MISC1", N3C0)):
+        print('#define STARKHIP_ROW_%s "{v[%d:%d]}"' % (name, r, r + 3))
+    for name, r in (("K1", K1), ("K2", K2), ("K3", K3)):
+        print('#define STARKHIP_ROW_%s "+{v[%d:%d]}"' % (name, r, r + 3))
+    print('#define STARKHIP_ROW_MASKE "{s[%d:%d]}"' % (MASKE, MASKE + 1))
+    print("#define STARKHIP_ROW_TRIPLE_CLOBBERS %s" % ", ".join(['"v%d"' % r for r in range(D1A, XS3 + 2)]))
     print('#define STARKHIP_ROW_STATE_OUT "={v[%d:%d]}"' % (S_LO, S_HI))
     print('#define STARKHIP_ROW_STATE_LO "{v%d}"' % S_LO)
     print('#define STARKHIP_ROW_STATE_HI "{v%d}"' % S_HI)
