@@ -164,7 +164,8 @@ void HashService::launch_small(std::vector<Req*>& reqs) {
                 B.digests[i] = g[at + i]->digests;
                 e = hipStreamWaitEvent(s, g[at + i]->ready, 0);
             }
-            if (e == hipSuccess && row_leaves_ && (((size_t)1 << (g[0]->log_n + g[0]->rate_bits)) <= row_leaves_)) {
+            const bool row_form = row_leaves_ && (((size_t)1 << (g[0]->log_n + g[0]->rate_bits)) <= row_leaves_);
+            if (e == hipSuccess && row_form) {
                 // the row form (16 lanes per leaf): shortest chain per leaf at 2.8 x the chip time.  Measured with every small commitment
                 // of a pool in it: one signature 0.36 -> 0.38 s, a batch of 8 3.8 -> 3.3 signatures/s; only the tiny ones take it by default
                 for (size_t i = 0; i < cnt && e == hipSuccess; i++)
@@ -179,8 +180,8 @@ void HashService::launch_small(std::vector<Req*>& reqs) {
                 if (e == hipSuccess) running_small_.push_back(r->done);
             }
             std::lock_guard<std::mutex> lock(mu_);
-            stats_.small_launches++;
-            stats_.max_merged = std::max<unsigned long>(stats_.max_merged, cnt);
+            stats_.small_launches += row_form ? cnt : 1;
+            stats_.max_merged = std::max<unsigned long>(stats_.max_merged, row_form ? 1 : cnt);
         }
     }
 }
