@@ -133,7 +133,8 @@ int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, 
  * "quotient_waves", "quotient_slots", "lde_closed_forms" (1 = constant and unit-vector trace columns take their closed-form LDE
  * instead of five transforms, 0 = every column is transformed; same bytes either way), "leaf_hash_form" (0 = a context on its own
  * hashes commitments of <= 4096 leaves in the row form -- 16 lanes per leaf, the shortest chain per leaf -- and larger ones in
- * the quad form; 1 = quad always; 2 = row always; same digests; a pool's commitments always go through its scheduler).  Unknown
+ * the quad form; 1 = quad always; 2 = row always; 3 = lane form, one lane per leaf: an experiment, slower than the quad form as it
+ * stands; same digests; a pool's commitments always go through its scheduler).  Unknown
  * name or value out of range: STARKHIP_ERR_BAD_SHAPE. */
 int starkhip_set_option(void* ctx, const char* name, long value);
 

@@ -4,6 +4,8 @@
 // reference reaches through prove() at /root/reference/src/aggregate_proof.rs:59.
 #include <hip/hip_runtime.h>
 
+#include <string.h>
+
 #include <mutex>
 
 #include "kernels.h"
@@ -384,6 +386,97 @@ __global__ __launch_bounds__(256) void leaf_hash_row_kernel(const gl_t* __restri
 #undef STARKHIP_ROW_PERMUTE
 }
 
+// ---- the lane form (poseidon_dev.h): one lane per leaf, for big commitments when several are in flight (the pool picks).
+// Same digests as leaf_hash_kernel.  64 adjacent points of a column per wave: every load is one 512-byte run.
+__constant__ LaneTables LANE_TABLES;
+__global__ __launch_bounds__(256, 2) void leaf_hash_lane_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                                                              gl_t* __restrict__ digests) {
+    __shared__ LaneTables T;
+    {
+        const uint32_t* src = (const uint32_t*)&LANE_TABLES;
+        uint32_t* dst = (uint32_t*)&T;
+        for (unsigned idx = threadIdx.x; idx < sizeof(LaneTables) / 4; idx += blockDim.x) dst[idx] = src[idx];
+    }
+    __syncthreads();
+    const unsigned log_N = log_n + rate_bits;
+    const size_t N = (size_t)1 << log_N;
+    const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    const size_t sidx = q >> log_n, k = q & (((size_t)1 << log_n) - 1);
+    const size_t i = (k << rate_bits) + sidx;
+    const size_t j = gl_bitrev((uint32_t)i, log_N);
+    const gl_t* col = mat + q;
+    if (n_cols <= 4) {
+        for (unsigned e = 0; e < 4; e++) digests[4 * j + e] = e < n_cols ? col[(size_t)e * N] : 0;
+        return;
+    }
+    gl_t s[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) s[e] = 0;
+    const size_t n_full = n_cols / 8, rem = n_cols % 8;
+    gl_t nx[8];
+    if (n_full) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) nx[e] = col[(size_t)e * N];
+    }
+    for (size_t b = 0; b < n_full; b++) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) s[e] = nx[e];
+        if (b + 1 < n_full) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) nx[e] = col[(8 * (b + 1) + e) * N];  // requested one permutation ahead
+            poseidon_permute_lane_merged<true>(s, &T);
+        } else {
+            poseidon_permute_lane_merged<false>(s, &T);
+        }
+    }
+    if (rem) {
+        for (size_t e = 0; e < rem; e++) s[e] = col[(8 * n_full + e) * N];
+        poseidon_permute_lane_merged<false>(s, &T);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) digests[4 * j + e] = gl_canon(s[e]);
+}
+static void build_lane_tables(LaneTables& T) {
+    static PoseidonMergedTables P;
+    build_poseidon_merged_tables(P);
+    auto split = [](gl_t v) { return RcPair{v & 0xFFFFFFFFull, v >> 32}; };
+    memset(&T, 0, sizeof T);
+    for (int r = 0; r < 30; r++)
+        for (int e = 0; e < 12; e++) T.rc[r][e] = split(POSEIDON_RC_HOST[12 * r + e]);
+    for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++) {
+        T.k12[t][0] = split(P.k1[t]);
+        T.k12[t][1] = split(P.k2[t]);
+        for (int e = 0; e < 12; e++) T.k3[t][e] = split(P.k3[t][e]);
+    }
+    for (int r = 0; r < 12; r++) {
+        for (int c = 0; c < 12; c++) T.row[r][c] = (uint32_t)P.N3[r][c];
+        T.row[r][12] = (uint32_t)P.N2[r][0];
+        T.row[r][13] = (uint32_t)P.M[r][0];
+        T.m0[r] = (uint32_t)P.M[0][r];
+        T.n20[r] = (uint32_t)P.N2[0][r];
+    }
+}
+static hipError_t ensure_lane_tables() {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu);
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (done[dev]) return hipSuccess;
+    static LaneTables T;
+    static bool built = false;
+    if (!built) {
+        build_lane_tables(T);
+        built = true;
+    }
+    e = hipMemcpyToSymbol(HIP_SYMBOL(LANE_TABLES), &T, sizeof T);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}
+
 // Leaves stored row-major and already in tree order: leaf j = rows[j][0..width)
 __global__ __launch_bounds__(64) void leaf_hash_rows_kernel(const gl_t* __restrict__ rows, size_t width, size_t n_leaves,
                                                              gl_t* __restrict__ digests) {
@@ -443,6 +536,12 @@ hipError_t launch_leaf_hash_row(const gl_t* mat, size_t n_cols, unsigned log_n, 
     size_t N = (size_t)1 << (log_n + rate_bits);
     if (hipError_t e = ensure_row_merged_tables(); e != hipSuccess) return e;
     hipLaunchKernelGGL(leaf_hash_row_kernel, dim3(nblocks(16 * N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
+    return hipGetLastError();
+}
+hipError_t launch_leaf_hash_lane(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st) {
+    size_t N = (size_t)1 << (log_n + rate_bits);
+    if (hipError_t e = ensure_lane_tables(); e != hipSuccess) return e;
+    hipLaunchKernelGGL(leaf_hash_lane_kernel, dim3(nblocks(N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
     return hipGetLastError();
 }
 hipError_t launch_leaf_hash_multi(const LeafHashBatch& B, unsigned count, size_t n_cols, unsigned log_n, unsigned rate_bits, hipStream_t st) {

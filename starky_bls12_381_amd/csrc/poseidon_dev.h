@@ -614,4 +614,132 @@ __device__ __forceinline__ gl_t poseidon_permute_row(gl_t s, const RcPair* __res
     return s;
 }
 
+// ---------------------------------------------------------------- one permutation per LANE, partial rounds merged
+// The quad form spends 4 lanes on a permutation because one big commitment alone has too few leaves for the chip (32 768 for
+// FinalExp: 512 waves).  With SEVERAL big commitments in flight that reason is gone, and the quad form's price shows: in the 22
+// partial rounds all four lanes execute the single S-box (three multiplies per round and quad), so a permutation costs
+// 4346 / 16 = 272 wave-instructions against ~ 195 with the whole state in one lane (full round 12 x 52 + 12 x 28, merged triple
+// 3 x 52 + 12 x 32 + 58).  Everything is uniform over the wave here -- round constants, the merged layers' coefficients -- so it comes
+// from one LDS image by broadcast reads (a scalar-register formulation would need 190 coefficients per triple in 100 SGPRs).
+struct LaneTables {
+    RcPair rc[31][12];         // round constants in halves; rc[30] = 0 (the "next round" of the last one)
+    RcPair k12[7][2];          // k1, k2 of the merged triples
+    RcPair k3[7][12];
+    uint32_t row[12][16];      // per output row of the dense layer: N3[r][0 .. 11], N2[r][0], M[r][0], -, -
+    uint32_t m0[12], n20[12];  // row 0 of M and of N2 (the two intermediate dot products)
+};
+
+// circulant layer; the accumulators start from `seed` (the next round's constants); outputs 0 .. N_OUT - 1 only
+template <int FIRST_OUT>
+__device__ __forceinline__ void mds_lane(gl_t (&s)[12], const RcPair* __restrict__ seed) {
+    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    uint32_t lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        lo[i] = (uint32_t)s[i];
+        hi[i] = (uint32_t)(s[i] >> 32);
+    }
+#pragma unroll
+    for (int r = FIRST_OUT; r < 12; r++) {
+        const RcPair c = seed[r];
+        uint64_t A = c.lo, B = c.hi;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int j = (i + r) % 12;
+            const uint32_t k = CIRC[i] + ((r == 0 && i == 0) ? 8u : 0u);
+            A = mad32(lo[j], k, A);
+            B = mad32(hi[j], k, B);
+            asm("" : "+v"(A));
+            asm("" : "+v"(B));
+        }
+        s[r] = combine_lohi_nc(A, B);
+    }
+}
+
+__device__ __forceinline__ gl_t dot_lane(const uint32_t (&lo)[12], const uint32_t (&hi)[12], const uint32_t* __restrict__ coef, const RcPair& seed, uint64_t& A,
+                                         uint64_t& B) {
+    A = seed.lo;
+    B = seed.hi;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const uint4 c = *(const uint4*)(coef + 4 * q);
+        const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            A = mad32(lo[4 * q + i], cc[i], A);
+            B = mad32(hi[4 * q + i], cc[i], B);
+            asm("" : "+v"(A));
+            asm("" : "+v"(B));
+        }
+    }
+    return 0;
+}
+
+// three partial rounds (poseidon_merged.h); s has this round's constants added on entry and the round's after the third on exit
+__device__ __forceinline__ void partial3_lane(gl_t (&s)[12], const LaneTables* __restrict__ T, int t) {
+    s[0] = sbox_nc(s[0]);  // x1
+    uint32_t lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        lo[i] = (uint32_t)s[i];
+        hi[i] = (uint32_t)(s[i] >> 32);
+    }
+    uint64_t A, B;
+    uint32_t zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    dot_lane(lo, hi, (const uint32_t*)((const char*)T->m0 + zoff), T->k12[t][0], A, B);
+    const gl_t x2 = sbox_nc(combine_lohi_nc(A, B));
+    const uint32_t x2l = (uint32_t)x2, x2h = (uint32_t)(x2 >> 32);
+    dot_lane(lo, hi, (const uint32_t*)((const char*)T->n20 + zoff), T->k12[t][1], A, B);
+    A = mad32(x2l, 25u, A);  // M[0][0] x2
+    B = mad32(x2h, 25u, B);
+    const gl_t x3 = sbox_nc(combine_lohi_nc(A, B));
+    const uint32_t x3l = (uint32_t)x3, x3h = (uint32_t)(x3 >> 32);
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        // The rows are the same for every triple: left alone, hipcc keeps all 190 coefficients in registers (474 of them, one wave per
+        // SIMD).  The OFFSET is made opaque, not the pointer: the loads stay LDS loads.
+        uint32_t off = (uint32_t)r * (uint32_t)sizeof(T->row[0]);
+        asm volatile("" : "+v"(off));
+        const uint32_t* rowp = (const uint32_t*)((const char*)&T->row[0][0] + off);
+        dot_lane(lo, hi, rowp, T->k3[t][r], A, B);
+        const uint32_t b2 = rowp[12], b3 = rowp[13];
+        A = mad32(x2l, b2, A);
+        B = mad32(x2h, b2, B);
+        A = mad32(x3l, b3, A);
+        B = mad32(x3h, b3, B);
+        s[r] = combine_lohi_nc(A, B);  // A, B < 2^57
+    }
+}
+
+// One permutation, the whole state in this lane.  CAP_ONLY: only elements 8 .. 11 of the result are computed (the caller overwrites
+// the rate).  In: any representatives; out: any representatives.
+template <bool CAP_ONLY>
+__device__ __forceinline__ void poseidon_permute_lane_merged(gl_t (&s)[12], const LaneTables* __restrict__ T) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add_nc(s[i], T->rc[0][i].lo | (T->rc[0][i].hi << 32));
+    int r = 0;
+#pragma unroll 1
+    for (; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox_nc(s[i]);
+        mds_lane<0>(s, T->rc[r + 1]);
+    }
+#pragma unroll 1
+    for (int t = 0; t < QUAD_MERGED_TRIPLES; t++) partial3_lane(s, T, t);
+    r = 4 + 3 * QUAD_MERGED_TRIPLES;  // 25
+    s[0] = sbox_nc(s[0]);
+    mds_lane<0>(s, T->rc[r + 1]);
+    r++;
+#pragma unroll 1
+    for (; r < 29; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox_nc(s[i]);
+        mds_lane<0>(s, T->rc[r + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = sbox_nc(s[i]);
+    mds_lane<CAP_ONLY ? 8 : 0>(s, T->rc[30]);
+}
+
 }  // namespace starkhip

@@ -284,6 +284,7 @@ static inline size_t digest_words(size_t n_leaves) { return 8 * n_leaves; }
 static bool use_row_form(const Ctx* c, size_t n_cols, unsigned log_N) {
     if (c->opt_leaf_hash_form == 1) return false;
     if (c->opt_leaf_hash_form == 2) return true;
+    if (c->opt_leaf_hash_form == 3) return false;
     return log_N <= 12 && n_cols >= 64;
 }
 
@@ -383,7 +384,7 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
     else if (k == "quotient_debug" && value >= 0 && value <= 9) c->opt_quotient_debug = value;
 #endif
     else if (k == "lde_closed_forms" && (value == 0 || value == 1)) c->opt_lde_closed_forms = value;
-    else if (k == "leaf_hash_form" && value >= 0 && value <= 2) c->opt_leaf_hash_form = value;
+    else if (k == "leaf_hash_form" && value >= 0 && value <= 3) c->opt_leaf_hash_form = value;
     else if (k == "quotient_chunks" && value >= 0 && value <= 4096) c->opt_quotient_chunks = value;  // plans are cached by (AIR, chunks)
     else return STARKHIP_ERR_BAD_SHAPE;
     return STARKHIP_OK;
@@ -558,6 +559,8 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     if (c->hs) {  // pooled: the scheduler decides when this commitment runs and which others share its launch
         c->hash_requested = true;
         HIPCHK(c->hs->hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st, c->hash_ready, c->hash_done, !HashService::is_big(log_n, r), c->urgent));
+    } else if (c->opt_leaf_hash_form == 3) {
+        HIPCHK(launch_leaf_hash_lane(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
     } else if (use_row_form(c, C, log_N)) {
         HIPCHK(launch_leaf_hash_row(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
     } else {
@@ -982,7 +985,8 @@ int merkle_cap(Ctx* c, const uint64_t* lde_natural, size_t n_cols, unsigned log_
     HIPCHK(c->lde.ensure(n_cols * N * 8));
     HIPCHK(c->digests.ensure(digest_words(N) * 8));
     HIPCHK(hipMemcpyAsync(c->lde.p, lde_natural, n_cols * N * 8, hipMemcpyHostToDevice, c->st));
-    if (use_row_form(c, n_cols, log_N)) HIPCHK(launch_leaf_hash_row(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
+    if (c->opt_leaf_hash_form == 3) HIPCHK(launch_leaf_hash_lane(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
+    else if (use_row_form(c, n_cols, log_N)) HIPCHK(launch_leaf_hash_row(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
     else HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
     HIPCHK(launch_merkle_levels(c->digests.as<gl_t>(), log_N, cap_h, c->st));
     HIPCHK(hipMemcpyAsync(cap_out, c->digests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), ((size_t)4 << cap_h) * 8, hipMemcpyDeviceToHost, c->st));

@@ -117,8 +117,11 @@ void HashService::drain(std::vector<hipEvent_t>& evs) {
 
 void HashService::launch_big(Req* r) {
     hipStream_t s = (r->urgent && st_high_) ? st_high_ : st_;
-    hipError_t e = hipStreamWaitEvent(s, r->ready, 0);
-    if (e == hipSuccess) e = launch_leaf_hash(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s);
+    hipError_t e = hipSuccess;
+    if (big_lane_) s = pick_small_stream(&e);  // lane-form grids are a quarter of the chip each: they must overlap, not queue in one stream
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, r->ready, 0);
+    if (e == hipSuccess) e = big_lane_ ? launch_leaf_hash_lane(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s)
+                                       : launch_leaf_hash(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s);
     if (e == hipSuccess) e = hipEventRecord(r->done, s);
     r->err = e;
     if (e == hipSuccess) running_big_.push_back(r->done);
@@ -592,12 +595,15 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
     }
     p->hs.reset(new HashService(cfg.device));
     p->stream_priority = cfg.stream_priority;
+    bool big_lane = false;
     size_t row_leaves = 64;  // a commitment this small is a handful of waves in either form: the shorter chain costs nothing (FP12Mul: 32 leaves)
     {
         const char* e = getenv("STARKHIP_POOL_FIFO");
         p->fifo = e && *e == '1';
         const char* n = getenv("STARKHIP_GEN_NICE");
         if (n && *n) p->gen_nice = atoi(n);
+        const char* bl = getenv("STARKHIP_POOL_BIG_LANE");
+        big_lane = bl && *bl == '1';
         const char* rl = getenv("STARKHIP_POOL_ROW_LEAVES");
         if (rl && *rl) row_leaves = (size_t)atol(rl);
     }
@@ -605,6 +611,7 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
     if (cfg.gather_ms > 0) p->hs->gather_ms = cfg.gather_ms;
     p->hs->policy = (int)cfg.commit_policy;
     p->hs->row_leaves_ = row_leaves;
+    p->hs->big_lane_ = big_lane;
     if (cfg.commit_policy != 2) {  // 2: no commitment scheduling at all -- every context launches its own (A/B measurements)
         for (Ctx* c : p->big_ctx) ctx_attach_hash_service(c, p->hs.get());
         for (Ctx* c : p->small_ctx) ctx_attach_hash_service(c, p->hs.get());

@@ -49,6 +49,7 @@ class HashService {
     // against 0.47 s -- a lone wave on a SIMD runs about twice as fast as one of two, so a FinalExp commitment that starts
     // beside a MillerLoop latency chain loses less than it would by waiting for it.
     int policy = 0;
+    bool big_lane_ = false;  // STARKHIP_POOL_BIG_LANE=1: big commitments in the lane form (one lane per leaf)
     size_t row_leaves_ = 64;  // STARKHIP_POOL_ROW_LEAVES: small commitments of at most this many leaves go out in the row form, one launch each (0: never)
 
     struct Stats {

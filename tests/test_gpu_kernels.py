@@ -88,7 +88,7 @@ def test_merkle_cap_matches_oracle(prover, log_N, ncols, cap_h):
                                                # tails of 0 .. 7 after one and after two full blocks
                                                (10, 16, 4), (10, 24, 4), (10, 12, 4), (10, 13, 4), (10, 9, 4), (10, 17, 4), (10, 20, 4), (10, 11, 4),
                                                (10, 10, 4), (10, 14, 4), (10, 15, 4), (10, 23, 4)])
-@pytest.mark.parametrize("form", [2, 1])
+@pytest.mark.parametrize("form", [2, 1, 3])
 def test_merkle_cap_in_both_leaf_hash_forms(prover, log_N, ncols, cap_h, form):
     """The row form (16 lanes per leaf, what a lone context uses for <= 4096 leaves) and the quad form (4 lanes per leaf) give the
     oracle's cap for every shape, whichever the automatic choice would have been."""
