@@ -410,15 +410,16 @@ __global__ __launch_bounds__(256, 2) void leaf_hash_lane_kernel(const gl_t* __re
         for (unsigned e = 0; e < 4; e++) digests[4 * j + e] = e < n_cols ? col[(size_t)e * N] : 0;
         return;
     }
-    gl_t s[12];
-#pragma unroll
-    for (int e = 0; e < 12; e++) s[e] = 0;
     const size_t n_full = n_cols / 8, rem = n_cols % 8;
     gl_t nx[8];
     if (n_full) {
 #pragma unroll
         for (int e = 0; e < 8; e++) nx[e] = col[(size_t)e * N];
     }
+#ifdef STARKHIP_LANE_CPP_ROUNDS  // what hipcc makes of the C++ rounds (poseidon_permute_lane_merged), kept for comparison
+    gl_t s[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) s[e] = 0;
     for (size_t b = 0; b < n_full; b++) {
 #pragma unroll
         for (int e = 0; e < 8; e++) s[e] = nx[e];
@@ -436,6 +437,37 @@ __global__ __launch_bounds__(256, 2) void leaf_hash_lane_kernel(const gl_t* __re
     }
 #pragma unroll
     for (int e = 0; e < 4; e++) digests[4 * j + e] = gl_canon(s[e]);
+#else
+    LaneZeros Z;
+    lane_zeros_init(Z);
+    LaneState st;
+#pragma unroll
+    for (int w = 0; w < 8; w++) st.t0[w] = st.t1[w] = st.t2[w] = 0;
+    for (size_t b = 0; b < n_full; b++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            lane_set(st.t0, e, nx[e]);
+            lane_set(st.t1, e, nx[4 + e]);
+        }
+        if (b + 1 < n_full) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) nx[e] = col[(8 * (b + 1) + e) * N];  // requested one permutation ahead
+            poseidon_permute_lane_asm<true>(st, &T, Z);
+        } else {
+            poseidon_permute_lane_asm<false>(st, &T, Z);
+        }
+    }
+    if (rem) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if ((size_t)e < rem) lane_set(st.t0, e, col[(8 * n_full + e) * N]);
+            if ((size_t)(4 + e) < rem) lane_set(st.t1, e, col[(8 * n_full + 4 + e) * N]);
+        }
+        poseidon_permute_lane_asm<false>(st, &T, Z);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) digests[4 * j + e] = gl_canon(lane_get(st.t0, e));
+#endif
 }
 static void build_lane_tables(LaneTables& T) {
     static PoseidonMergedTables P;

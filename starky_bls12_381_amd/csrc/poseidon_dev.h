@@ -742,4 +742,64 @@ __device__ __forceinline__ void poseidon_permute_lane_merged(gl_t (&s)[12], cons
     mds_lane<CAP_ONLY ? 8 : 0>(s, T->rc[30]);
 }
 
+// ---- the lane form's rounds as scheduled asm blocks (tools/gen_lane_round_asm.py -> lane_round_asm.inc): 989 slots per full round,
+// 732 per merged triple, LDS loads a row ahead with counted waits -- against 1337 and 1464 (a third of them wait states) from the C++
+// above.  The state lives in three 8-register tuples bound to v[80:103]: the rate is the first two, the capacity the third.
+#include "lane_round_asm.inc"
+typedef uint32_t lane_u32x8 __attribute__((ext_vector_type(8)));
+struct LaneState {
+    lane_u32x8 t0, t1, t2;
+};
+struct LaneZeros {
+    uint32_t za, zb;
+};
+__device__ __forceinline__ void lane_zeros_init(LaneZeros& Z) {
+    Z.za = Z.zb = 0;
+    asm volatile("" : "+v"(Z.za), "+v"(Z.zb));
+}
+#define STARKHIP_LANE_ROUND_BLOCK(NAME, TEXT)                                                                                              \
+    __device__ __forceinline__ void NAME(LaneState& st, uint32_t seed_lds, const LaneZeros& Z) {                                           \
+        asm(TEXT                                                                                                                           \
+            : STARKHIP_LANE_STATE0(st.t0), STARKHIP_LANE_STATE1(st.t1), STARKHIP_LANE_STATE2(st.t2)                                        \
+            : STARKHIP_LANE_A_SEED(seed_lds), STARKHIP_LANE_ZA(Z.za), STARKHIP_LANE_ZB(Z.zb)                                               \
+            : STARKHIP_LANE_CLOBBERS);                                                                                                     \
+    }
+STARKHIP_LANE_ROUND_BLOCK(lane_full_round_asm, STARKHIP_LANE_FULL_ROUND_ASM)
+STARKHIP_LANE_ROUND_BLOCK(lane_last_round_asm, STARKHIP_LANE_LAST_ROUND_ASM)
+STARKHIP_LANE_ROUND_BLOCK(lane_partial_round_asm, STARKHIP_LANE_PARTIAL_ROUND_ASM)
+#undef STARKHIP_LANE_ROUND_BLOCK
+__device__ __forceinline__ void lane_triple_asm(LaneState& st, uint32_t k3_lds, uint32_t k12_lds, uint32_t coef_lds, const LaneZeros& Z) {
+    asm(STARKHIP_LANE_TRIPLE_ASM
+        : STARKHIP_LANE_STATE0(st.t0), STARKHIP_LANE_STATE1(st.t1), STARKHIP_LANE_STATE2(st.t2)
+        : STARKHIP_LANE_A_K3(k3_lds), STARKHIP_LANE_A_K12(k12_lds), STARKHIP_LANE_A_COEF(coef_lds), STARKHIP_LANE_ZA(Z.za), STARKHIP_LANE_ZB(Z.zb)
+        : STARKHIP_LANE_CLOBBERS);
+}
+__device__ __forceinline__ gl_t lane_get(const lane_u32x8& t, int i) { return (gl_t)t[2 * i] | ((gl_t)t[2 * i + 1] << 32); }
+__device__ __forceinline__ void lane_set(lane_u32x8& t, int i, gl_t x) {
+    t[2 * i] = (uint32_t)x;
+    t[2 * i + 1] = (uint32_t)(x >> 32);
+}
+// One permutation.  CAP_ONLY: only the capacity (st.t2) of the result is computed -- the caller overwrites the rate.
+template <bool CAP_ONLY>
+__device__ __forceinline__ void poseidon_permute_lane_asm(LaneState& st, const LaneTables* __restrict__ T, const LaneZeros& Z) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        lane_set(st.t0, i, gl_add_nc(lane_get(st.t0, i), T->rc[0][i].lo | (T->rc[0][i].hi << 32)));
+        lane_set(st.t1, i, gl_add_nc(lane_get(st.t1, i), T->rc[0][4 + i].lo | (T->rc[0][4 + i].hi << 32)));
+        lane_set(st.t2, i, gl_add_nc(lane_get(st.t2, i), T->rc[0][8 + i].lo | (T->rc[0][8 + i].hi << 32)));
+    }
+    const uint32_t rc_lds = (uint32_t)(uintptr_t)&T->rc[0][0], k3_lds = (uint32_t)(uintptr_t)&T->k3[0][0], k12_lds = (uint32_t)(uintptr_t)&T->k12[0][0],
+                   coef_lds = (uint32_t)(uintptr_t)&T->row[0][0];
+    constexpr uint32_t RC_ROW = 12 * sizeof(RcPair);
+#pragma unroll 1
+    for (uint32_t r = 0; r < 4; r++) lane_full_round_asm(st, rc_lds + (r + 1) * RC_ROW, Z);
+#pragma unroll 1
+    for (uint32_t t = 0; t < 7; t++) lane_triple_asm(st, k3_lds + t * RC_ROW, k12_lds + t * 2 * (uint32_t)sizeof(RcPair), coef_lds, Z);
+    lane_partial_round_asm(st, rc_lds + 26 * RC_ROW, Z);
+#pragma unroll 1
+    for (uint32_t r = 26; r < 29; r++) lane_full_round_asm(st, rc_lds + (r + 1) * RC_ROW, Z);
+    if (CAP_ONLY) lane_last_round_asm(st, rc_lds + 30 * RC_ROW, Z);
+    else lane_full_round_asm(st, rc_lds + 30 * RC_ROW, Z);
+}
+
 }  // namespace starkhip

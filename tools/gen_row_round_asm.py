@@ -352,13 +352,19 @@ def block_partial():
 
 # ---------------------------------------------------------------- scheduler
 def schedule(prog):
+    return schedule_with(prog, None)
+
+
+def schedule_with(prog, adjust):
+    """adjust(producer, consumer, distance) -> distance: a hook for read-after-write distances (load latencies of other generators)"""
     n = len(prog)
     preds = [[] for _ in range(n)]
     last_w, last_sw, readers, sreaders = {}, {}, {}, {}
     for i, ins in enumerate(prog):
         for r in ins.reads:
             if r in last_w:
-                preds[i].append((last_w[r], 3 if ins.dpp else 1))      # W2
+                d = 3 if ins.dpp else 1                                  # W2
+                preds[i].append((last_w[r], adjust(prog[last_w[r]], ins, d) if adjust else d))
         for r in ins.sreads:
             if r in last_sw:
                 preds[i].append((last_sw[r], 3))                        # W1
@@ -436,6 +442,11 @@ def run(order, vregs, sregs):
         k = ins.sem[0]
         if k == "nopsem":
             continue
+        if k == "ldsload":  # ("ldsload", first register, count, key): registers <- vregs["mem"][key] (a list of per-lane lists)
+            _, first, count, key = ins.sem
+            for q in range(count):
+                vregs[first + q] = list(vregs["mem"][key][q])
+            continue
         if k == "prefetch3":
             _, K, j = ins.sem
             for q in range(4):
@@ -467,6 +478,8 @@ def run(order, vregs, sregs):
                 sregs[cout] = co
         elif k == "mov":
             vregs[ins.sem[1]] = V(ins.sem[2])[:]
+        elif k == "mov64":
+            vregs[ins.sem[1]], vregs[ins.sem[1] + 1] = V(ins.sem[2])[:], V(ins.sem[2] + 1)[:]
         elif k == "subb":
             _, d, bout, a, b, bin_ = ins.sem
             out, bo = [0] * NL, [0] * NL
