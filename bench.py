@@ -100,10 +100,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary", action="store_true", help="skip the untimed host-boundary / compact-trace legs")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=6,
                     help="proofs in flight per GPU (independent contexts on separate host threads and HIP streams); "
-                         "1 = one proof at a time (latency); the default hides the host-side Fiat-Shamir hashing and the launch gaps of "
-                         "each proof behind the kernels of the others")
+                         "1 = one proof at a time (latency); several hide the host-side Fiat-Shamir hashing and the launch gaps of "
+                         "each proof behind the kernels of the others, and from five on the pool sends the trace commitments out in groups "
+                         "of four in the lane form of the leaf hash (6.3 proofs/s at six, 184 GB of HBM; 5.65 at four in the quad form)")
     args = ap.parse_args()
 
     import numpy as np
@@ -225,6 +226,26 @@ def main():
                "leaf_hash": 8.0 * C * N,              # read the LDE once
                "quotient_eval": 8.0 * C * N}          # read the LDE on the quotient coset once
         # HBM-side bytes per launch from the committed PMC passes (bench.py cannot collect counters itself)
+        # How the trace commitments ran INSIDE the timed region: with five or more proofs in flight the pool sends them out in groups of
+        # four in the lane form (leaf_hash_lane_kernel), not as the quad-form launches the one-in-flight figures below describe.  The
+        # group durations come from the committed kernel trace of this very command (bench.py cannot trace itself).
+        timed_region_commitments = {"form": ("lane form (one lane per leaf), groups of up to four commitments side by side" if inflight >= 5
+                                             else "quad form (four lanes per leaf), one launch per commitment"),
+                                    "kernel": "leaf_hash_lane_kernel" if inflight >= 5 else "leaf_hash_kernel"}
+        try:
+            from tools.kernel_fingerprint import kernel_fingerprint as _kf
+            lg = json.load(open(os.path.join(ROOT, "profiles", "lane_group_latest.json")))
+            if lg.get("source_sha256") == _kf("leaf_hash_kernel") and timed_region_commitments["kernel"] in lg:
+                g = lg[timed_region_commitments["kernel"]]
+                timed_region_commitments.update(profile=g, profile_source=lg.get("_source"))
+                ms4 = g.get("average_ms_in_groups_of_four")
+                if ms4:
+                    timed_region_commitments["algorithmic_GBps_four_side_by_side"] = 4 * 8.0 * C * N / (ms4 * 1e-3) / 1e9
+                    timed_region_commitments["ms_per_commitment_four_side_by_side"] = ms4 / 4
+            else:
+                timed_region_commitments["profile"] = None
+        except (OSError, ValueError, ImportError):
+            timed_region_commitments["profile"] = None
         pmc, pmc_src, pmc_stale = {}, None, []
         try:
             from tools.kernel_fingerprint import kernel_fingerprint
@@ -278,6 +299,7 @@ def main():
                          "traffic_source": pmc_src, "traffic_stale_for": pmc_stale or None, "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": solo_ms[dominant],
                          "durations": "one proof in flight (uncontended), HIP events on the library's stream, mean of 3 launches",
                          "limiter": "integer VALU issue" if dominant == "leaf_hash" else "see kernels", "valu": valu if dominant == "leaf_hash" else None},
+            "timed_region_commitments": timed_region_commitments,
             "kernels": kernels,
             # the two rates the proof is governed by, from the same uncontended launches
             "poseidon_perms_per_s": perms / (lh_ms * 1e-3) if lh_ms > 0 else None,

@@ -133,8 +133,8 @@ int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, 
  * "quotient_waves", "quotient_slots", "lde_closed_forms" (1 = constant and unit-vector trace columns take their closed-form LDE
  * instead of five transforms, 0 = every column is transformed; same bytes either way), "leaf_hash_form" (0 = a context on its own
  * hashes commitments of <= 4096 leaves in the row form -- 16 lanes per leaf, the shortest chain per leaf -- and larger ones in
- * the quad form; 1 = quad always; 2 = row always; 3 = lane form, one lane per leaf: an experiment, slower than the quad form as it
- * stands (5.1 against 5.6 proofs/s with eight proofs in flight); same digests; a pool's commitments always go through its scheduler).  Unknown
+ * the quad form; 1 = quad always; 2 = row always; 3 = lane form, one lane per leaf: what a pool with five or more big contexts uses for groups of big
+ * commitments, slower than the quad form for one commitment alone; same digests; a pool's commitments always go through its scheduler).  Unknown
  * name or value out of range: STARKHIP_ERR_BAD_SHAPE. */
 int starkhip_set_option(void* ctx, const char* name, long value);
 
@@ -172,7 +172,8 @@ int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_
  * stay the caller's and must stay valid until the ticket has been waited for; submit_witness copies its operands. */
 typedef struct {
     int device;
-    unsigned big_contexts;      /* 0 = default (3) */
+    unsigned big_contexts;      /* 0 = default (3).  Five or more: the trace commitments of these proofs go out in groups of up to four in the
+                                   lane form of the leaf hash (6.3 against 5.65 proofs/s on one MI355X; ~ 30 GB of HBM per context) */
     unsigned small_contexts;    /* 0 = default (16) */
     unsigned generator_threads; /* recordings under way at once; 0 = default (a quarter of the CPUs the process may use -- its
                                    cgroup quota or affinity mask --, 3 .. 12) */

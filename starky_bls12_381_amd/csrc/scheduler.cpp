@@ -82,6 +82,23 @@ void HashService::abandon_small() {
     cv_.notify_all();
 }
 
+void HashService::announce_big() {
+    std::lock_guard<std::mutex> g(mu_);
+    big_expected_++;
+    big_active_++;
+}
+void HashService::finish_big() {
+    std::lock_guard<std::mutex> g(mu_);
+    if (big_active_ > 0) big_active_--;
+}
+void HashService::abandon_big() {
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        if (big_expected_ > 0) big_expected_--;
+    }
+    cv_.notify_all();
+}
+
 HashService::Stats HashService::stats() {
     std::lock_guard<std::mutex> g(mu_);
     return stats_;
@@ -97,6 +114,7 @@ hipError_t HashService::hash(const gl_t* mat, size_t n_cols, unsigned log_n, uns
     r.t_arrive = now_s();
     std::unique_lock<std::mutex> lk(mu_);
     if (announced && announced_ > 0) announced_--;
+    if (r.big && big_expected_ > 0) big_expected_--;
     if (e != hipSuccess) {
         lk.unlock();
         cv_.notify_all();
@@ -115,13 +133,13 @@ void HashService::drain(std::vector<hipEvent_t>& evs) {
     evs.clear();
 }
 
-void HashService::launch_big(Req* r) {
+void HashService::launch_big(Req* r, bool lane) {
     hipStream_t s = (r->urgent && st_high_) ? st_high_ : st_;
     hipError_t e = hipSuccess;
-    if (big_lane_) s = pick_small_stream(&e);  // lane-form grids are a quarter of the chip each: they must overlap, not queue in one stream
+    if (lane) s = pick_small_stream(&e);  // lane-form grids are a quarter of the chip each: they must overlap, not queue in one stream
     if (e == hipSuccess) e = hipStreamWaitEvent(s, r->ready, 0);
-    if (e == hipSuccess) e = big_lane_ ? launch_leaf_hash_lane(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s)
-                                       : launch_leaf_hash(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s);
+    if (e == hipSuccess) e = lane ? launch_leaf_hash_lane(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s)
+                                  : launch_leaf_hash(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s);
     if (e == hipSuccess) e = hipEventRecord(r->done, s);
     r->err = e;
     if (e == hipSuccess) running_big_.push_back(r->done);
@@ -206,18 +224,34 @@ void HashService::run() {
             const double waited = (now_s() - small_.front()->t_arrive) * 1e3;
             small_ready = announced_ <= 0 || waited >= gather_ms || stop_;
         }
-        const bool take_big = !big_.empty() && (!small_ready || !last_was_big_);
+        // Lane form (one lane per leaf: 208 instead of 272 wave-instructions per permutation, but 512 waves of 256 registers per
+        // commitment -- a quarter of the chip): FOUR side by side run at the issue limit, 394 ms for four against 141 ms each in the quad
+        // form.  Launched one by one as they arrive they leave the chip half empty and fall into step behind each other, so they go out in
+        // GROUPS: a group waits (bounded) while big proofs that have started have not reached their commitment; a commitment that ends
+        // up alone goes out in the quad form.
+        bool big_ready = !big_.empty();
+        if (big_lane_ && !big_.empty()) {
+            const double waited = (now_s() - big_.front()->t_arrive) * 1e3;
+            // a busy pool (five or more big proofs under way) always waits for a full group, bounded; a quiet one only for the proofs that
+            // are on their way to their commitment -- a lone proof is not held up
+            const bool busy = big_active_ >= (int)BIG_LANE_GROUP + 1;
+            big_ready = big_.size() >= BIG_LANE_GROUP || (!busy && big_expected_ <= 0) || waited >= big_gather_ms_ || stop_;
+        }
+        const bool take_big = big_ready && (!small_ready || !last_was_big_);
         if (take_big) {
-            Req* r = big_.front();
-            big_.pop_front();
+            std::vector<Req*> group;
+            while (!big_.empty() && group.size() < (big_lane_ ? BIG_LANE_GROUP : 1u)) {
+                group.push_back(big_.front());
+                big_.pop_front();
+            }
             std::vector<hipEvent_t> wait_for;
             wait_for.swap(running_small_);
             lk.unlock();
             if (policy == 1) drain(wait_for);  // exclusive classes: the small window has left the chip
-            launch_big(r);
+            for (Req* r : group) launch_big(r, big_lane_ && group.size() >= 2);
             lk.lock();
-            r->state = r->err == hipSuccess ? 1 : 2;
-            stats_.big_launches++;
+            for (Req* r : group) r->state = r->err == hipSuccess ? 1 : 2;
+            stats_.big_launches += group.size();
             last_was_big_ = true;
             cv_done_.notify_all();
             continue;
@@ -242,8 +276,10 @@ void HashService::run() {
             cv_done_.notify_all();
             continue;
         }
-        // small requests are pending but the window is still gathering: wake up when something arrives or its time is up
-        const double left_ms = gather_ms - (now_s() - small_.front()->t_arrive) * 1e3;
+        // requests are pending but their window is still gathering: wake up when something arrives or its time is up
+        double left_ms = 1e9;
+        if (!small_.empty()) left_ms = std::min(left_ms, gather_ms - (now_s() - small_.front()->t_arrive) * 1e3);
+        if (big_lane_ && !big_.empty()) left_ms = std::min(left_ms, big_gather_ms_ - (now_s() - big_.front()->t_arrive) * 1e3);
         // (system_clock deadline = pthread_cond_timedwait: ThreadSanitizer of gcc 11 does not know pthread_cond_clockwait, which a
         // steady-clock wait_for uses, and then reports the mutex as still held)
         cv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds((long)(std::max(0.1, left_ms) * 1e3)));
@@ -542,6 +578,8 @@ struct Pool {
             int rc;
             const bool announce = !big && ctx_has_hash_service(c);
             if (announce) hs->announce_small();
+            const bool announce_big = big && ctx_has_hash_service(c);
+            if (announce_big) hs->announce_big();
             ctx_hash_request_reset(c);
             try {
                 const AirInfo* a = air_get(j->air);
@@ -553,6 +591,8 @@ struct Pool {
                 rc = STARKHIP_ERR_BAD_SHAPE;
             }
             if (announce && !ctx_hash_requested(c)) hs->abandon_small();  // failed before its commitment: do not hold the window open
+            if (announce_big && !ctx_hash_requested(c)) hs->abandon_big();
+            if (announce_big) hs->finish_big();
             if (big) {
                 std::lock_guard<std::mutex> g(mu);
                 if (big_recordings_started > 0) big_recordings_started--;  // a context is free again: the next FinalExp-class recording moves up
@@ -603,7 +643,7 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
         const char* n = getenv("STARKHIP_GEN_NICE");
         if (n && *n) p->gen_nice = atoi(n);
         const char* bl = getenv("STARKHIP_POOL_BIG_LANE");
-        big_lane = bl && *bl == '1';
+        big_lane = (bl && *bl) ? *bl == '1' : p->big_ctx.size() >= 5;  // with four or fewer in flight the quad form is faster (5.65 against 4.05 proofs/s)
         const char* rl = getenv("STARKHIP_POOL_ROW_LEAVES");
         if (rl && *rl) row_leaves = (size_t)atol(rl);
     }

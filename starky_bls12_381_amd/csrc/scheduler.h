@@ -34,6 +34,9 @@ class HashService {
     // A pooled proof of the small class announces itself when it starts and calls hash() (or abandon()) exactly once: the
     // service holds a small window open while announced proofs have not arrived yet (bounded by `gather_ms`).
     void announce_small();
+    void announce_big();   // a FinalExp-class proof has started: its commitment will come (lane-form groups wait for it)
+    void abandon_big();
+    void finish_big();     // that proof has ended
     void abandon_small();
     // Leaf digests of the coset-major LDE `mat` (kernels_hash.hip: launch_leaf_hash) into `digests`, ordered after everything
     // enqueued on `st` so far; when this returns, `st` has been made to wait for the launch (the caller goes on enqueueing).
@@ -49,7 +52,12 @@ class HashService {
     // against 0.47 s -- a lone wave on a SIMD runs about twice as fast as one of two, so a FinalExp commitment that starts
     // beside a MillerLoop latency chain loses less than it would by waiting for it.
     int policy = 0;
-    bool big_lane_ = false;  // STARKHIP_POOL_BIG_LANE=1: big commitments in the lane form (one lane per leaf)
+    static const unsigned BIG_LANE_GROUP = 4;
+    double big_gather_ms_ = 150.0;  // lane form: how long a group of big commitments waits for announced ones to join
+    bool big_lane_ = false;  // big commitments in groups, a group of two or more in the lane form (pools with five or more big contexts;
+                             // STARKHIP_POOL_BIG_LANE=0 / 1 overrides)
+    int big_expected_ = 0;   // big proofs that have started and not yet reached their commitment
+    int big_active_ = 0;     // big proofs being proved (before, in or after their commitment)  // STARKHIP_POOL_BIG_LANE=1: big commitments in the lane form (one lane per leaf)
     size_t row_leaves_ = 64;  // STARKHIP_POOL_ROW_LEAVES: small commitments of at most this many leaves go out in the row form, one launch each (0: never)
 
     struct Stats {
@@ -70,7 +78,7 @@ class HashService {
         double t_arrive = 0;
     };
     void run();
-    void launch_big(Req* r);
+    void launch_big(Req* r, bool lane);
     void launch_small(std::vector<Req*>& reqs);
     void drain(std::vector<hipEvent_t>& evs);
 

@@ -167,6 +167,28 @@ def test_final_exp_four_in_flight_match_the_oracle_digest():
     assert stats["big_commit_launches"] == 4
 
 
+def test_final_exp_in_lane_form_groups_match_the_oracle_digest(monkeypatch):
+    """Pools with five or more FinalExp-class contexts send their big commitments out in GROUPS in the lane form (one lane per leaf,
+    scheduled asm rounds; scheduler.cpp).  Forced here on four contexts: eight proofs of the benchmark's first seeded input, two groups
+    of four commitments -- every proof's SHA-256 is the CPU oracle's."""
+    air = S.AIR_FINAL_EXP
+    cfg = S.StarkConfig.for_air(air)
+    want = open(os.path.join(GOLDEN, "final_exp_seed_5eed0001_proof.sha256")).read().split()[0]
+    trace, pis = S.trace_final_exp(random_fp12(0x5EED0001))
+    cols = S.trace_rows_to_poly_values(trace)
+    del trace
+    monkeypatch.setenv("STARKHIP_POOL_BIG_LANE", "1")   # read by starkhip_pool_create
+    pool = S.ProofPool(0, big_contexts=4, small_contexts=1, generator_threads=1)
+    try:
+        tickets = [pool.submit(air, cfg, cols, pis, layout=1) for _ in range(8)]
+        digests = [hashlib.sha256(pool.wait(t)[0].tobytes()).hexdigest() for t in tickets]
+        stats = pool.stats()
+    finally:
+        pool.close()
+    assert digests == [want] * 8
+    assert stats["big_commit_launches"] == 8
+
+
 def test_cpp_demo_proves_a_batch_on_the_pool():
     """tools/signature_demo.cpp --batch 2: compiled host code above the C ABI only; 12 proofs in flight, all verified, linked and
     bound to their statements (exit code 0)."""

@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--inflight", type=int, default=6, help="prover contexts per GPU when --small-inflight is 0 (one pool)")
-    ap.add_argument("--big-inflight", type=int, default=4, help="contexts for FinalExp proofs (two pools)")
+    ap.add_argument("--big-inflight", type=int, default=6, help="contexts for FinalExp proofs (two pools); five or more: lane-form commitment groups")
     ap.add_argument("--priority", type=int, default=1, help="pool: 1 = FinalExp-class contexts on high-priority streams, 0 = all alike")
     ap.add_argument("--small-inflight", type=int, default=0, help="contexts for the 1024-row AIRs; 0 = one pool of --inflight contexts; "
                                                                    "default for --batch > 1: 16")
@@ -74,7 +74,7 @@ def main():
     dev = "cpu" if rehearse else f"cuda:{local_rank}"
 
     if args.small_inflight == 0 and args.batch > 1:
-        args.small_inflight = 16
+        args.small_inflight = 12
     if args.driver == "pool":
         big = max(1, args.big_inflight if args.batch > 1 else 1)
         small = args.small_inflight if args.small_inflight > 0 else 5

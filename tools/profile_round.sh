@@ -19,7 +19,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -o kt -- python3 $R/bench.py --
 rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_fetch -o fetch -- $ONE > $OUT/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/prof_write -o write -- $ONE > $OUT/prof_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_BUSY_CYCLES -d $OUT/prof_sq -o sq -- $ONE > $OUT/prof_sq.log 2>&1
-rocprofv3 --kernel-trace -d $OUT/prof_ov -o ov -- python3 $R/bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-boundary > $OUT/prof_ov.log 2>&1
+rocprofv3 --kernel-trace -d $OUT/prof_ov -o ov -- python3 $R/bench.py --steps 24 --warmup 2 --no-cpu-baseline --no-boundary > $OUT/prof_ov.log 2>&1
 cd $R
 db() { find $OUT/$1 -name "*results.db" | head -1; }
 python3 tools/rocprof_export.py stats $(db prof_kt) $OUT/${TAG}_kernel_stats.csv
@@ -29,6 +29,8 @@ python3 tools/rocprof_export.py pmc $(db prof_write) $OUT/${TAG}_pmc_write_size.
 python3 tools/rocprof_export.py pmc $(db prof_sq) $OUT/${TAG}_pmc_sq_counters.csv
 python3 tools/pmc_traffic.py $(db prof_fetch) $(db prof_write) $OUT/${TAG}_pmc_traffic.json
 python3 tools/kernel_overlap.py $(db prof_ov) > $OUT/${TAG}_kernel_overlap.txt
+python3 tools/rocprof_export.py bygrid $(db prof_ov) $OUT/${TAG}_kernel_stats_by_grid_in_flight.csv
+python3 tools/lane_group_stats.py $(db prof_ov) $OUT/${TAG}_lane_groups.json > /dev/null
 tail -1 $OUT/prof_kt.log > $OUT/${TAG}_bench_under_rocprof.json
 rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq $OUT/prof_ov
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rate_bench tools/valu_rate_bench.hip && /tmp/valu_rate_bench > $OUT/${TAG}_valu_rates.txt 2>&1 || true
