@@ -29,7 +29,10 @@ static std::vector<uint32_t> limbs(size_t n, uint32_t seed) {
 
 int main() {
     setenv("STARKHIP_FAKE_DEVICE", "1", 1);
-    for (unsigned policy = 0; policy < 3; policy++) {
+    for (unsigned pass = 0; pass < 4; pass++) {
+        const unsigned policy = pass < 3 ? pass : 0;
+        // the fourth pass: big commitments gathered into lane-form groups (what pools with five or more big contexts do)
+        if (pass == 3) setenv("STARKHIP_POOL_BIG_LANE", "1", 1);
         starkhip_pool_config_t cfg;
         memset(&cfg, 0, sizeof cfg);
         cfg.big_contexts = 2;
