@@ -100,11 +100,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary", action="store_true", help="skip the untimed host-boundary / compact-trace legs")
-    ap.add_argument("--inflight", type=int, default=6,
+    ap.add_argument("--inflight", type=int, default=8,
                     help="proofs in flight per GPU (independent contexts on separate host threads and HIP streams); "
                          "1 = one proof at a time (latency); several hide the host-side Fiat-Shamir hashing and the launch gaps of "
                          "each proof behind the kernels of the others, and from five on the pool sends the trace commitments out in groups "
-                         "of four in the lane form of the leaf hash (6.3 proofs/s at six, 184 GB of HBM; 5.65 at four in the quad form)")
+                         "of four in the lane form of the leaf hash (6.5 proofs/s at eight, 250 of the card's 309 GB at the peak; 6.3 at six, 184 GB; "
+                         "5.65 at four in the quad form)")
     args = ap.parse_args()
 
     import numpy as np
@@ -137,7 +138,19 @@ def main():
     inflight = max(1, args.inflight)
     # the in-flight proofs go through the library's own scheduler (starkhip_pool_submit / _wait), as a caller of the C ABI would
     # drive them: `inflight` FinalExp-class contexts, one host thread each inside libstarkhip.so
-    pool = S.ProofPool(local_rank, big_contexts=inflight, small_contexts=1, generator_threads=1, warm_up=1)
+    # (a pool reserves every buffer of its contexts when it is created -- ~ 24 GB per FinalExp-class context, ~ 235 GB of the card's 309 GB
+    # with eight and their traces; should that ever not fit, fewer proofs in flight are still a valid measurement of the same metric)
+    pool = None
+    for k in sorted({inflight, min(inflight, 6), min(inflight, 4)}, reverse=True):
+        try:
+            pool = S.ProofPool(local_rank, big_contexts=k, small_contexts=1, generator_threads=1, warm_up=2)  # 2: the traces are device-resident
+            inflight = k
+            break
+        except S.StarkhipError as e:
+            print(f"bench.py: a pool of {k} FinalExp-class contexts could not be created ({e}); trying fewer", file=sys.stderr)
+            torch.cuda.empty_cache()
+    if pool is None:
+        raise SystemExit("bench.py: no proof pool could be created")
     helper = S.Prover(local_rank)  # page-locked staging for trace generation only
     work = []
     host_rows = helper.host_array((n, C))  # page-locked, reused for every generated trace
@@ -148,6 +161,7 @@ def main():
         d_rows = torch.from_numpy(host_rows.view(np.int64)).to(f"cuda:{local_rank}")
         work.append((d_rows.t().contiguous(), pis, x, seed))  # trace_rows_to_poly_values
         del d_rows
+        torch.cuda.empty_cache()  # the row-major copy goes back to the device, not into torch's cache: the library allocates beside torch
     torch.cuda.synchronize()
 
     def submit(i):
@@ -321,9 +335,13 @@ def main():
         if not args.no_boundary and world == 1:  # per-GPU figures, taken at N = 1 (other ranks would wait in the teardown meanwhile)
             # ---- untimed: the reference's own boundary (host rows in, proof out) and the compact-trace hand-over
             try:
-                nb = inflight  # as many in flight as the timed region keeps (staging buffers: 4.8 GB more per context)
-                x0 = work[0][2]
+                nb = min(inflight, 4)  # four in flight, on a pool of their own: these legs need a trace buffer and an upload staging
+                x0 = work[0][2]        # buffer per context (9.6 GB) that the timed region's pool does not hold
                 _, pis0 = S.trace_final_exp(x0, out=host_rows)
+                pool.close()
+                del work[:]
+                torch.cuda.empty_cache()
+                pool = S.ProofPool(local_rank, big_contexts=nb, small_contexts=1, generator_threads=1, warm_up=1)
 
                 def leg(trace, pis, reps):
                     for t in [pool.submit(air, cfg, trace, pis) for _ in range(nb)]:  # warm-up: staging buffers

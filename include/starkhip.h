@@ -186,7 +186,9 @@ typedef struct {
                                    contexts) on high-priority streams; 2 = the small contexts, 3 = all FinalExp-class proofs (measurements) */
     unsigned warm_up;           /* != 0: starkhip_pool_create returns when every context has allocated what the BLS pipeline's AIRs of its class
                                    need (FinalExp on the big contexts; MillerLoop, PairingPrecomp, FP12Mul on the small ones: tables, constraint
-                                   plans, buffers, upload staging), so that no proof pays for -- or stalls the device with -- allocations */
+                                   plans, buffers, upload staging), so that no proof pays for -- or stalls the device with -- allocations;
+                                   2: the same without the trace buffer and the upload staging (4.8 GB each per FinalExp-class context): for a
+                                   caller whose traces are already column-major device memory (starkhip_pool_submit with trace_on_device) */
     float gather_ms;            /* how long a merged launch waits for small proofs that have started but not reached their commitment; 0 = default (25) */
 } starkhip_pool_config_t;
 typedef struct {

@@ -54,7 +54,7 @@ bool ctx_has_hash_service(Ctx* c) { return c->hs != nullptr; }
 void ctx_hash_request_reset(Ctx* c) { c->hash_requested = false; }
 bool ctx_hash_requested(Ctx* c) { return c->hash_requested; }
 int ctx_set_urgent(Ctx* c, bool urgent) { c->urgent = urgent; return STARKHIP_OK; }
-int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t&, size_t, unsigned proof_blobs) {
+int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t&, size_t, unsigned proof_blobs, bool) {
     if (proof_blobs && !c->blob_airs.count(air.id)) {  // the fake proofs are tiny; what is exercised is the arena's bookkeeping
         if (blob_arena_add(c, 64 + air.prog.n_pis * 8, proof_blobs) != 0) return STARKHIP_ERR_OOM;
         c->blob_airs.insert(air.id);

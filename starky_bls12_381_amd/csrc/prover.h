@@ -20,7 +20,7 @@ bool ctx_has_hash_service(Ctx* c);
 int ctx_set_urgent(Ctx* c, bool urgent);
 // tables, plan, work buffers, upload staging and `proof_blobs` page-locked proof blobs (blob_arena.h) for proofs of `air`,
 // allocated now (a pool's warm-up)
-int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t log_bytes, unsigned proof_blobs = 0);
+int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t log_bytes, unsigned proof_blobs = 0, bool device_traces = false);
 void ctx_hash_request_reset(Ctx* c);
 bool ctx_hash_requested(Ctx* c);  // the current / last prove() reached its trace commitment
 

@@ -897,7 +897,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
 // first job: growing a buffer later means hipFree + hipMalloc (or hipHostFree + hipHostMalloc), and those wait for EVERY stream of
 // the device -- measured in a batch of 8 signatures: a PairingPrecomp proof with 212 ms of device time held its context for 2.3 s
 // because its buffers grew while four FinalExp proofs kept the device busy.
-int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t log_bytes, unsigned proof_blobs) {
+int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t log_bytes, unsigned proof_blobs, bool device_traces) {
     const AirProgram& P = air.prog;
     const size_t n = air.default_rows;
     unsigned log_n = 0;
@@ -929,7 +929,11 @@ int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t
                           {&c->fri_coef, 2 * N * 8}, {&c->fri_vals, 2 * N * 8}, {&c->scale_tab, N * 8}, {&c->pow_state, 12 * 8}, {&c->pow_best, 8},
                           {&c->qidx, cfg.num_query_rounds * 4}, {&c->gather_t, cfg.num_query_rounds * pl.query_words * 8},
                           {&c->staging, log_bytes + 64}};
-    for (const Want& w : wants) HIPCHK(w.b->ensure(w.bytes));
+    for (const Want& w : wants) {
+        // traces that arrive as column-major device memory are proven where they lie: no trace buffer, no upload staging (4.8 GB each for FinalExp)
+        if (device_traces && (w.b == &c->values || w.b == &c->staging)) continue;
+        HIPCHK(w.b->ensure(w.bytes));
+    }
     size_t len = N;
     for (size_t l = 0; l < L; l++) {
         const unsigned ab = geo.arities[l];
@@ -937,7 +941,7 @@ int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t
         HIPCHK(c->fri_digests[l].ensure(digest_words(len >> ab) * 8));
         len >>= ab;
     }
-    if (log_bytes && c->host_staging_cap < log_bytes) {
+    if (log_bytes && !device_traces && c->host_staging_cap < log_bytes) {
         if (c->host_staging) (void)hipHostFree(c->host_staging);
         c->host_staging = nullptr;
         c->host_staging_cap = 0;

@@ -377,6 +377,7 @@ struct Pool {
     size_t big_recordings_started = 0, big_proofs_done = 0;  // under mu
     std::map<int, int> idle_big, idle_small;                 // idle contexts by the AIR they proved last (under mu)
     unsigned stream_priority = 0;
+    bool warm_device_traces = false;  // warm_up == 2: the caller's traces are column-major device memory: no trace buffers are reserved
     bool fifo = false;  // STARKHIP_POOL_FIFO=1: small jobs in arrival order (A/B measurements)
     int gen_nice = 10;  // STARKHIP_GEN_NICE: nice value of the generator threads (0: as the rest of the process)
     bool warm = false;        // contexts reserve the pipeline's AIRs when their threads start (pool_create waits for it)
@@ -522,7 +523,7 @@ struct Pool {
                 starkhip_config_t cfg;
                 if (!a || starkhip_config_for_air((starkhip_air_t)air, &cfg) != STARKHIP_OK) return;
                 try {
-                    const int r = ctx_reserve(c, *a, cfg, log_bytes, pinned ? blobs : 0);
+                    const int r = ctx_reserve(c, *a, cfg, log_bytes, pinned ? blobs : 0, warm_device_traces);
                     if (r != STARKHIP_OK) rc = r;
                 } catch (const std::exception&) {
                     rc = STARKHIP_ERR_OOM;
@@ -648,6 +649,7 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
         if (rl && *rl) row_leaves = (size_t)atol(rl);
     }
     p->warm = cfg.warm_up != 0;
+    p->warm_device_traces = cfg.warm_up == 2;
     if (cfg.gather_ms > 0) p->hs->gather_ms = cfg.gather_ms;
     p->hs->policy = (int)cfg.commit_policy;
     p->hs->row_leaves_ = row_leaves;
