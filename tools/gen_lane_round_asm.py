@@ -170,19 +170,22 @@ def schedule(prog):
     for ins in prog:
         ins.min_after_load = LOAD_LATENCY
     order = G.schedule_with(prog, lambda producer, consumer, d: max(d, LOAD_LATENCY) if getattr(producer, "is_load", False) else d)
-    out, pending = [], []          # pending: loads in issue order, each the set of its registers
+    out, pending = [], []          # pending: loads in issue order: (registers, position of issue)
     for ins in order:
         if getattr(ins, "is_load", False):
-            pending.append(set(ins.writes))
+            pending.append((set(ins.writes), len(out)))
             assert len(pending) <= 15
             out.append(ins)
             continue
         need = -1
         touched = ins.reads | ins.writes
-        for i, regs in enumerate(pending):
+        for i, (regs, _) in enumerate(pending):
             if regs & touched:
                 need = i
         if need >= 0:
+            # the wait also covers the later loads that were issued long enough ago to be back: one wait per row instead of one per load
+            while need + 1 < len(pending) and pending[need + 1][1] <= len(out) - LOAD_LATENCY:
+                need += 1
             left = len(pending) - 1 - need
             out.append(Ins("s_waitcnt lgkmcnt(%d)" % left, [], []))
             pending = pending[need + 1:]
