@@ -654,6 +654,10 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
     p->hs->policy = (int)cfg.commit_policy;
     p->hs->row_leaves_ = row_leaves;
     p->hs->big_lane_ = big_lane;
+    {
+        const char* lg = getenv("STARKHIP_POOL_LANE_GROUP");
+        if (lg && *lg && atoi(lg) >= 2 && atoi(lg) <= 8) p->hs->BIG_LANE_GROUP = (unsigned)atoi(lg);
+    }
     if (cfg.commit_policy != 2) {  // 2: no commitment scheduling at all -- every context launches its own (A/B measurements)
         for (Ctx* c : p->big_ctx) ctx_attach_hash_service(c, p->hs.get());
         for (Ctx* c : p->small_ctx) ctx_attach_hash_service(c, p->hs.get());

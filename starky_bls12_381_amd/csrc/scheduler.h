@@ -52,7 +52,7 @@ class HashService {
     // against 0.47 s -- a lone wave on a SIMD runs about twice as fast as one of two, so a FinalExp commitment that starts
     // beside a MillerLoop latency chain loses less than it would by waiting for it.
     int policy = 0;
-    static const unsigned BIG_LANE_GROUP = 4;
+    unsigned BIG_LANE_GROUP = 4;  // STARKHIP_POOL_LANE_GROUP: commitments per lane-form group (four fill the chip: two waves of 256 registers per SIMD)
     double big_gather_ms_ = 150.0;  // lane form: how long a group of big commitments waits for announced ones to join
     bool big_lane_ = false;  // big commitments in groups, a group of two or more in the lane form (pools with five or more big contexts;
                              // STARKHIP_POOL_BIG_LANE=0 / 1 overrides)
