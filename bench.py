@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
 """Benchmark: starky proofs/s for FinalExponentiateStark (73527 columns x 8192 rows) on N MI355X.
 
-A "step" is one full prove() of one FinalExp trace whose column-major u64[C][n] values are already
-resident in HBM (BASELINE.json configs[2]).  Each rank proves its own independent proofs (the six proofs
-of a signature verification shard at proof granularity): weak scaling, no data-path
-collective; torch.distributed is used only for the barrier and the max-over-ranks time.
+A "step" is one full proof of one FinalExp statement AT THE REFERENCE'S OWN BOUNDARY: the timed region starts from the
+driver's operand (one Fp12, 144 u32 limbs on the host) and ends with the proof blob in host memory -- generate_trace, the
+upload, trace_rows_to_poly_values, prove() and the read-back are all inside, exactly what
+/root/reference/src/aggregate_proof.rs:158-176 brackets with `Instant::now()` (proofs/s including H2D and
+D2H).  The proofs go through the library's own scheduler (`starkhip_pool_submit_witness` / `starkhip_pool_wait`): `--inflight`
+FinalExp-class contexts per GPU, generator threads that record the traces, lane-form commitment groups.  Each rank proves its
+own independent proofs (the six proofs of a signature verification shard at proof granularity): weak
+scaling, no data-path collective; torch.distributed is used only for the barrier and the max-over-ranks time.
 
-Prints ONE JSON line on rank 0.  What is measured where (DESIGN.md §6 has every field):
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts itself under torch.distributed.run as a CHILD
+process (before torch or the GPU is touched) and relays its output; launched by torchrun it just runs as a rank.
 
-  value / ms_per_step     the timed region: `--inflight` contexts per GPU, each with its OWN trace resident in HBM
-  roofline, kernels       an untimed pass with ONE proof in flight on rank 0 (uncontended HIP-event durations of the three
-                          heavy kernels, the figures the committed rocprof summaries under profiles/ must agree with);
-                          HBM-side traffic per launch from profiles/pmc_traffic_latest.json
-  value_host_boundary     rank 0, untimed: host rows in page-locked memory -> H2D -> transpose -> proof (the boundary the
-                          reference has), as many in flight as the timed region;  value_compact: the same from recorded (compact) traces
-  cpu_baseline            rank 0 at N = 1: the CPU oracle on a bounded sample of the same workload
+Prints ONE JSON line on rank 0.  What is measured where (DESIGN.md section 6 has every field):
+
+  value / ms_per_step     the timed region: operands -> proof bytes, `--inflight` contexts per GPU
+  roofline                the kernel with the most device time INSIDE the timed region (with five or more in flight:
+                          leaf_hash_lane_kernel in groups), HIP events on the stream it is launched on, taken in the timed region
+  kernels                 rank 0, untimed, ONE proof in flight: uncontended HIP-event durations of the three heavy kernels (the
+                          figures the committed rocprof summaries under profiles/ must agree with); PMC traffic per launch from
+                          profiles/pmc_traffic_latest.json
+  value_host_rows         rank 0, untimed leg on the SAME pool: page-locked host ROWS -> H2D -> transpose -> proof -> D2H
+                          (BASELINE.md section 4's literal hand-over); value_compact: a recorded trace; value_device_resident: the
+                          column-major trace already in HBM (rounds 1-3's headline)
+  cpu_baseline            rank 0 at N = 1: the CPU oracle on a bounded sample of the same workload, measured in this run
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,24 +44,70 @@ VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
 # VALU instructions of one permutation in the 4-lane form (ISA of poseidon_dev.h: 8 full rounds, 7 merged triples of
 # partial rounds, 1 single partial round)
 POSEIDON_QUAD_INSTRS = 7 * 261 + 204 + 7 * 309 + 152
+# issue slots of one permutation in the lane form, one permutation per lane (tools/gen_lane_round_asm.py --count)
+POSEIDON_LANE_SLOTS = 12900
 KERNELS = ("lde_columns", "leaf_hash", "quotient_eval")
-PMC_NAMES = {"lde_columns": ("lde_columns_v2_kernel",), "leaf_hash": ("leaf_hash_kernel",),
+PMC_NAMES = {"lde_columns": ("lde_columns_v2_kernel",), "leaf_hash": ("leaf_hash_kernel",), "leaf_hash_lane": ("leaf_hash_lane_kernel",),
              "quotient_eval": ("quotient_tiles_kernel", "quotient_eval_kernel")}
+FORM_KERNEL = {"quad": "leaf_hash_kernel", "lane": "leaf_hash_lane_kernel", "row": "leaf_hash_row_kernel", "merged": "leaf_hash_multi_kernel"}
+
+
+def self_launch(argv, n_gpus, script=None):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start `python -m torch.distributed.run ... bench.py <args>` as a child,
+    relay its stdout line by line, return its exit code.  Nothing in THIS process has imported torch or touched the GPU.
+    (tools/bench_signature.py starts itself the same way, with `script` = its own path.)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(script or __file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    try:
+        for line in child.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    finally:
+        rc = child.wait()
+    return rc
+
+
+def cpu_quota():
+    """CPUs the process may use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, round(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, round(q / p)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def synthetic_final_exp_input(seed):
-    """12 Fp coordinates below p from splitmix64(seed) (SURVEY.md §8d); any invertible Fp12 is provable."""
+    """12 Fp coordinates below p from splitmix64(seed) (SURVEY.md section 8d); any invertible Fp12 is provable."""
     from bls_util import random_fp12
     return random_fp12(seed)
 
 
 def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=4096, budget_points=1024):
-    """Time the CPU oracle on a bounded slice of the same workload and scale to one whole proof.
+    """Time the CPU oracle on a bounded slice of the same workload IN THIS RUN and scale to one whole proof.
 
     LDE + Merkle leaf hashing run on `budget_cols` of the C columns (cost linear in C); the constraint
     evaluation runs on `budget_points` of the N coset points with all C columns (cost linear in points).
     Openings / FRI are < 5 % of the CPU time and are left out, which flatters the CPU."""
     import numpy as np
+    # the oracle's OpenMP team = the CPUs this process may really use (a GPU box shows 256 hardware threads, its cgroup grants 16:
+    # more threads than the quota are throttled, not faster -- profiles/r03_cpu_share.txt), so that `cores` is what was used
+    if "OMP_NUM_THREADS" not in os.environ:
+        os.environ["OMP_NUM_THREADS"] = str(cpu_quota())
     import oracle_lib as O
     rng = np.random.default_rng(1)
     n = 1 << log_n
@@ -70,43 +127,45 @@ def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=4096, bud
     t_q = time.time() - t0
     scale_c = n_cols / budget_cols
     total = t_lde * scale_c + t_hash * scale_c + t_q * (N / budget_points)
-    # The oracle has also proven a WHOLE FinalExp trace on a GPU box's host (tests/make_final_exp_golden.py: 254.2 s in round 1,
-    # 256.2 s in round 3 for the input 0x5EED0001, 256 threads; the first line of the committed log).  That measured time is
-    # `value`; the bounded sample taken in THIS run (which leaves out openings / FRI and scales linearly) is reported beside it.
-    full_s, full_src, full_threads = None, None, 0
+    out = {"value": 1.0 / total, "unit": "proofs/s", "cores": int(O.lib.oracle_num_threads()), "kind": "port",
+           "sample": (f"measured in this run: CPU oracle (OpenMP C restatement, not the reference's Rust), {t_lde + t_hash + t_q:.1f} s of work: LDE + leaf hash on "
+                      f"{budget_cols}/{n_cols} columns x {n} rows, constraint evaluation on {budget_points}/{N} coset points; scaled linearly "
+                      f"to one proof (lde {t_lde * scale_c:.1f} s + hash {t_hash * scale_c:.1f} s + quotient {t_q * N / budget_points:.1f} s = {total:.1f} s; "
+                      f"openings / FRI omitted); `cores` = the OpenMP threads used = the CPUs the box's cgroup grants")}
+    # The oracle has also proven a WHOLE FinalExp trace once on a GPU box's host (tests/make_final_exp_golden.py): a constant from
+    # another run, reported apart from this run's measurement.
     for name in ("r03_oracle_full_final_exp.txt", "r01_oracle_full_final_exp.txt"):
         try:
             line = open(os.path.join(ROOT, "profiles", name)).readline()
-            full_s, full_src = float(line.split("prove:")[1].split("s")[0]), "profiles/" + name + ": " + line.strip()
-            full_threads = int(line.split(" on ")[1].split()[0])
+            full_s = float(line.split("prove:")[1].split("s")[0])
+            out["recorded_full_proof"] = {"value": 1.0 / full_s, "unit": "proofs/s", "seconds": full_s, "threads": int(line.split(" on ")[1].split()[0]),
+                                          "source": "profiles/" + name + " (an earlier run on another box; not measured now): " + line.strip()}
             break
         except (OSError, IndexError, ValueError):
             continue
-    sample = (f"this run: CPU oracle (OpenMP C restatement, not the reference's Rust), {t_lde + t_hash + t_q:.1f} s of work: LDE + leaf hash on "
-              f"{budget_cols}/{n_cols} columns x {n} rows, constraint evaluation on {budget_points}/{N} coset points; scaled linearly "
-              f"to one proof (lde {t_lde * scale_c:.1f} s + hash {t_hash * scale_c:.1f} s + quotient {t_q * N / budget_points:.1f} s = {total:.1f} s; "
-              f"openings / FRI omitted)")
-    if full_s:
-        return {"value": 1.0 / full_s, "unit": "proofs/s", "cores": full_threads, "kind": "port",
-                "sample": f"one WHOLE FinalExp proof by the CPU oracle on a GPU box's host, measured once and committed ({full_src}); " + sample,
-                "sample_scaled_value": 1.0 / total, "sample_cores": int(O.lib.oracle_num_threads())}
-    return {"value": 1.0 / total, "unit": "proofs/s", "cores": int(O.lib.oracle_num_threads()), "kind": "port", "sample": sample}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-boundary", action="store_true", help="skip the untimed host-boundary / compact-trace legs")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the untimed legs (host rows, recorded trace, device-resident trace)")
+    ap.add_argument("--no-solo", action="store_true", help="skip the untimed one-proof-in-flight pass (`kernels`, latency); for profiling runs")
+    ap.add_argument("--input", choices=("witness", "device"), default="witness",
+                    help="what the TIMED region starts from: witness = the driver's operand on the host (generate_trace, upload and read-back inside; "
+                         "the reference's boundary, the default); device = a column-major trace already in HBM (rounds 1-3's headline, for A/B runs)")
     ap.add_argument("--inflight", type=int, default=8,
                     help="proofs in flight per GPU (independent contexts on separate host threads and HIP streams); "
                          "1 = one proof at a time (latency); several hide the host-side Fiat-Shamir hashing and the launch gaps of "
                          "each proof behind the kernels of the others, and from five on the pool sends the trace commitments out in groups "
-                         "of four in the lane form of the leaf hash (6.5 proofs/s at eight, 250 of the card's 309 GB at the peak; 6.3 at six, 184 GB; "
-                         "5.65 at four in the quad form)")
+                         "of four in the lane form of the leaf hash (~ 25 GB of HBM per context)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
 
     import numpy as np
     import torch
@@ -133,17 +192,17 @@ def main():
     log_n = n.bit_length() - 1
     N = n << cfg.rate_bits
 
-    # synthetic inputs, a different one per rank AND per context; traces generated on the host (the reference's generate_trace
-    # side), moved to HBM as column-major u64 (as int64 bit patterns) before the timed region
     inflight = max(1, args.inflight)
-    # the in-flight proofs go through the library's own scheduler (starkhip_pool_submit / _wait), as a caller of the C ABI would
-    # drive them: `inflight` FinalExp-class contexts, one host thread each inside libstarkhip.so
-    # (a pool reserves every buffer of its contexts when it is created -- ~ 24 GB per FinalExp-class context, ~ 235 GB of the card's 309 GB
-    # with eight and their traces; should that ever not fit, fewer proofs in flight are still a valid measurement of the same metric)
+    if rehearse and world > 1:
+        inflight = max(1, min(inflight, 8 // world))  # the rehearsing ranks share ONE card's memory
+    # the in-flight proofs go through the library's own scheduler, as a caller of the C ABI would drive them: `inflight` FinalExp-class
+    # contexts, one host thread each inside libstarkhip.so, generator threads that record the traces (a pool reserves every buffer of
+    # its contexts when it is created -- ~ 25 GB per FinalExp-class context; should eight ever not fit, fewer proofs in flight are
+    # still a valid measurement of the same metric)
     pool = None
     for k in sorted({inflight, min(inflight, 6), min(inflight, 4)}, reverse=True):
         try:
-            pool = S.ProofPool(local_rank, big_contexts=k, small_contexts=1, generator_threads=1, warm_up=2)  # 2: the traces are device-resident
+            pool = S.ProofPool(local_rank, big_contexts=k, small_contexts=1, warm_up=1)
             inflight = k
             break
         except S.StarkhipError as e:
@@ -151,32 +210,47 @@ def main():
             torch.cuda.empty_cache()
     if pool is None:
         raise SystemExit("bench.py: no proof pool could be created")
-    helper = S.Prover(local_rank)  # page-locked staging for trace generation only
-    work = []
-    host_rows = helper.host_array((n, C))  # page-locked, reused for every generated trace
-    for i in range(inflight):
-        seed = 0x5EED0000 + 1 + rank * inflight + i
-        x = synthetic_final_exp_input(seed)
-        _, pis = S.trace_final_exp(x, out=host_rows)
-        d_rows = torch.from_numpy(host_rows.view(np.int64)).to(f"cuda:{local_rank}")
-        work.append((d_rows.t().contiguous(), pis, x, seed))  # trace_rows_to_poly_values
-        del d_rows
-        torch.cuda.empty_cache()  # the row-major copy goes back to the device, not into torch's cache: the library allocates beside torch
-    torch.cuda.synchronize()
+    reservation = pool.reservation()
+
+    # synthetic statements, a different one per rank AND per context
+    seeds = [0x5EED0000 + 1 + rank * inflight + i for i in range(inflight)]
+    inputs = [synthetic_final_exp_input(s) for s in seeds]
+    helper = S.Prover(local_rank)  # page-locked staging for the host-rows leg / device traces
+    host_rows = None
+    device_work = []
+
+    def make_device_traces():
+        # traces generated on the host, moved to HBM as column-major u64 (as int64 bit patterns)
+        nonlocal host_rows
+        if device_work:
+            return
+        if host_rows is None:
+            host_rows = helper.host_array((n, C))  # page-locked, reused for every generated trace
+        for i in range(inflight):
+            _, pis = S.trace_final_exp(inputs[i], out=host_rows)
+            d_rows = torch.from_numpy(host_rows.view(np.int64)).to(f"cuda:{local_rank}")
+            device_work.append((d_rows.t().contiguous(), pis))  # trace_rows_to_poly_values
+            del d_rows
+            torch.cuda.empty_cache()  # the row-major copy goes back to the device, not into torch's cache: the library allocates beside torch
+        torch.cuda.synchronize()
+
+    if args.input == "device":
+        make_device_traces()
 
     def submit(i):
-        d_cols, pis, _, _ = work[i % inflight]
-        return pool.submit_device(air, cfg, d_cols.data_ptr(), n, pis, layout=1)
+        if args.input == "device":
+            d_cols, pis = device_work[i % inflight]
+            return pool.submit_device(air, cfg, d_cols.data_ptr(), n, pis, layout=1)
+        return pool.submit_witness(air, inputs[i % inflight])
 
     # warm-up: every context proves once (buffers, tables, plans); one proof in flight at a time gives the reference bytes of
     # each input, which the proofs of the timed region are compared with below
     solo_proofs = {}
+    for i in range(inflight):
+        pr, _ = pool.wait(submit(i))
+        solo_proofs[i] = pr
     for w in range(max(1, args.warmup)):
-        for i in range(inflight):
-            pr, _ = pool.wait(submit(i))
-            solo_proofs[i] = pr
-        tickets = [submit(i) for i in range(inflight)]  # ... and all contexts at once
-        for t in tickets:
+        for t in [submit(i) for i in range(inflight)]:  # ... and all contexts at once
             pool.wait(t, keep=False)
     phase_ms = {k: 0.0 for k in S.PHASE_NAMES}
 
@@ -186,6 +260,9 @@ def main():
     t0 = time.perf_counter()
     tickets = [submit(k) for k in range(args.steps)]
     timed_last = {}
+    timed_kernel_ms = {}  # kernel name -> launch durations of the trace-commitment / LDE / quotient kernels inside the timed region
+    timed_groups = []
+    gen_ms = []
     for k, t in enumerate(tickets):
         keep = k >= args.steps - inflight  # the LAST proof of every input made inside the timed region is kept and checked below
         pr, info = pool.wait(t, keep=keep)
@@ -193,6 +270,14 @@ def main():
             timed_last[k % inflight] = pr
         for name, v in info["phase_ms"].items():
             phase_ms[name] += v
+        hk = FORM_KERNEL[info["leaf_hash_form"]]
+        timed_kernel_ms.setdefault(hk, []).append(info["kernel_ms"]["leaf_hash"])
+        timed_kernel_ms.setdefault("lde_columns_v2_kernel", []).append(info["kernel_ms"]["lde_columns"])
+        timed_kernel_ms.setdefault("quotient_tiles_kernel", []).append(info["kernel_ms"]["quotient_eval"])
+        if info["leaf_hash_form"] == "lane":
+            timed_groups.append(info["leaf_hash_group"])
+        tl = info["timeline_s"]
+        gen_ms.append((tl[2] - tl[1]) * 1e3)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -205,13 +290,13 @@ def main():
     for i, pr in sorted(timed_last.items()):
         S.verify_stark_proof(air, cfg, pr)
         if not np.array_equal(pr, solo_proofs[i]):
-            raise SystemExit(f"proof of input {work[i][3]:#x} made with {inflight} in flight differs from the one made alone")
+            raise SystemExit(f"proof of input {seeds[i]:#x} made with {inflight} in flight differs from the one made alone")
         timed_verified += 1
     oracle_match = None
     if rank == 0 and 0 in timed_last:
         try:
             import hashlib
-            want = open(os.path.join(ROOT, "tests", "golden", "final_exp_seed_%x_proof.sha256" % work[0][3])).read().split()[0]
+            want = open(os.path.join(ROOT, "tests", "golden", "final_exp_seed_%x_proof.sha256" % seeds[0])).read().split()[0]
             oracle_match = hashlib.sha256(timed_last[0].tobytes()).hexdigest() == want
         except OSError:
             pass
@@ -220,46 +305,15 @@ def main():
 
     if rank == 0:
         steps = max(1, args.steps)
-        # ---- untimed: the same proof with the GPU to itself (one in flight): uncontended kernel and phase durations
-        solo_ms = {k: 0.0 for k in KERNELS}
-        solo_phase = {k: 0.0 for k in S.PHASE_NAMES}
-        solo_host = {"fiat_shamir": 0.0, "other": 0.0}
-        n_solo = 3
-        t_solo = time.perf_counter()
-        for _ in range(n_solo):
-            _, info = pool.wait(submit(0), keep=False)
-            for k, v in info["kernel_ms"].items():
-                solo_ms[k] += v / n_solo
-            for k, v in info["phase_ms"].items():
-                solo_phase[k] += v / n_solo
-            for k, v in info["host_ms"].items():
-                solo_host[k] += v / n_solo
-        t_solo = (time.perf_counter() - t_solo) / n_solo
-        # algorithmic bytes per launch: u64 cells, dense, minimum traffic of the decomposition
         alg = {"lde_columns": 8.0 * C * (n + n + N),  # read values, write coeffs + LDE (IFFT and LDE fused in one kernel)
                "leaf_hash": 8.0 * C * N,              # read the LDE once
                "quotient_eval": 8.0 * C * N}          # read the LDE on the quotient coset once
-        # HBM-side bytes per launch from the committed PMC passes (bench.py cannot collect counters itself)
-        # How the trace commitments ran INSIDE the timed region: with five or more proofs in flight the pool sends them out in groups of
-        # four in the lane form (leaf_hash_lane_kernel), not as the quad-form launches the one-in-flight figures below describe.  The
-        # group durations come from the committed kernel trace of this very command (bench.py cannot trace itself).
-        timed_region_commitments = {"form": ("lane form (one lane per leaf), groups of up to four commitments side by side" if inflight >= 5
-                                             else "quad form (four lanes per leaf), one launch per commitment"),
-                                    "kernel": "leaf_hash_lane_kernel" if inflight >= 5 else "leaf_hash_kernel"}
-        try:
-            from tools.kernel_fingerprint import kernel_fingerprint as _kf
-            lg = json.load(open(os.path.join(ROOT, "profiles", "lane_group_latest.json")))
-            if lg.get("source_sha256") == _kf("leaf_hash_kernel") and timed_region_commitments["kernel"] in lg:
-                g = lg[timed_region_commitments["kernel"]]
-                timed_region_commitments.update(profile=g, profile_source=lg.get("_source"))
-                ms4 = g.get("average_ms_in_groups_of_four")
-                if ms4:
-                    timed_region_commitments["algorithmic_GBps_four_side_by_side"] = 4 * 8.0 * C * N / (ms4 * 1e-3) / 1e9
-                    timed_region_commitments["ms_per_commitment_four_side_by_side"] = ms4 / 4
-            else:
-                timed_region_commitments["profile"] = None
-        except (OSError, ValueError, ImportError):
-            timed_region_commitments["profile"] = None
+        alg_by_kernel = {"lde_columns_v2_kernel": alg["lde_columns"], "quotient_tiles_kernel": alg["quotient_eval"]}
+        for kname in FORM_KERNEL.values():
+            alg_by_kernel[kname] = alg["leaf_hash"]
+        perms = (C + 7) // 8 * N
+        # HBM-side bytes per launch from the committed PMC passes (bench.py cannot collect counters itself); a figure taken on another
+        # version of the kernel's sources is stale: not reported as this run's traffic
         pmc, pmc_src, pmc_stale = {}, None, []
         try:
             from tools.kernel_fingerprint import kernel_fingerprint
@@ -268,7 +322,6 @@ def main():
             for k, names in PMC_NAMES.items():
                 for nm in names:
                     if nm in raw:
-                        # a figure taken on another version of the kernel's sources is stale: not reported as this run's traffic
                         if raw[nm].get("source_sha256") == kernel_fingerprint(nm):
                             pmc[k] = raw[nm]["traffic_bytes"]
                         else:
@@ -276,25 +329,74 @@ def main():
                         break
         except Exception:
             pass
+
+        # ---- the roofline block: the kernel with the most device time INSIDE the timed region, durations from HIP events recorded on
+        # the stream the kernel was launched on (the pool's scheduler records them around each commitment launch)
+        dom = max(timed_kernel_ms, key=lambda k: sum(timed_kernel_ms[k]))
+        dom_ms = sum(timed_kernel_ms[dom]) / len(timed_kernel_ms[dom])
+        side = (sum(timed_groups) / len(timed_groups)) if (dom == "leaf_hash_lane_kernel" and timed_groups) else 1.0
+        per_launch_gbs = alg_by_kernel[dom] / (dom_ms * 1e-3) / 1e9
+        pmc_key = {"leaf_hash_lane_kernel": "leaf_hash_lane", "leaf_hash_kernel": "leaf_hash", "lde_columns_v2_kernel": "lde_columns",
+                   "quotient_tiles_kernel": "quotient_eval"}.get(dom)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": per_launch_gbs * side, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": per_launch_gbs * side / HBM_PEAK_GBS, "traffic": pmc.get(pmc_key),
+                    "traffic_source": pmc_src, "traffic_stale_for": pmc_stale or None,
+                    "algorithmic_bytes_per_launch": alg_by_kernel[dom], "avg_launch_ms": dom_ms, "launches_timed": len(timed_kernel_ms[dom]),
+                    "launches_side_by_side": side, "achieved_per_launch": per_launch_gbs,
+                    "achieved_is": ("algorithmic bytes per launch / average launch duration x the launches of a group that run side by side (a lane-form "
+                                    "launch holds a quarter of the chip's registers; `achieved_per_launch` is the plain quotient)"
+                                    if side > 1 else "algorithmic bytes per launch / average launch duration"),
+                    "durations": f"HIP events on the launch stream, the {len(timed_kernel_ms[dom])} launches of the timed region ({inflight} proofs in flight)",
+                    "share_of_timed_kernel_time": {k: sum(v) for k, v in timed_kernel_ms.items()},
+                    "limiter": "integer VALU issue" if dom.startswith("leaf_hash") else "see kernels"}
+        if dom == "leaf_hash_lane_kernel":
+            slots = perms / 64.0 * POSEIDON_LANE_SLOTS
+            roofline["valu"] = {"issue_slots_per_launch": slots, "achieved_Gslots_per_s": slots * side / (dom_ms * 1e-3) / 1e9, "peak_Ginstr_per_s": VALU_PEAK_GINSTR,
+                                "frac": slots * side / (dom_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR,
+                                "basis": f"{POSEIDON_LANE_SLOTS} issue slots per permutation and lane (tools/gen_lane_round_asm.py), {perms} permutations / 64 lanes; peak = 256 CUs x 4 "
+                                         "SIMDs x 2.4 GHz / 4 cycles per integer VALU instruction (tools/valu_rate_bench.hip); some slots are 2-cycle instructions"}
+
+        # ---- untimed: the same proof with the GPU to itself (one in flight): uncontended kernel and phase durations
+        solo_ms = {k: 0.0 for k in KERNELS}
+        solo_phase = {k: 0.0 for k in S.PHASE_NAMES}
+        solo_host = {"fiat_shamir": 0.0, "other": 0.0}
+        t_solo, solo_gen = None, None
         kernels = {}
-        for k in KERNELS:
-            ms = solo_ms[k]
-            gbs = alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            kernels[k] = {"avg_ms": ms, "algorithmic_bytes": alg[k], "algorithmic_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
-                          "traffic_bytes": pmc.get(k), "traffic_over_algorithmic": (pmc[k] / alg[k]) if k in pmc else None}
-        dominant = max(KERNELS, key=lambda k: solo_ms[k])
-        # the leaf hash is bound by integer-VALU instruction issue, not by HBM: static instruction count of one quad
-        # permutation x permutations / 16 quads per wave, against one instruction per SIMD per 4 cycles
-        perms = (C + 7) // 8 * N
-        wave_instr = perms * POSEIDON_QUAD_INSTRS / 16.0
+        if not args.no_solo:
+            n_solo = 3
+            t_solo = time.perf_counter()
+            solo_gen = 0.0
+            for _ in range(n_solo):
+                _, info = pool.wait(submit(0), keep=False)
+                for k, v in info["kernel_ms"].items():
+                    solo_ms[k] += v / n_solo
+                for k, v in info["phase_ms"].items():
+                    solo_phase[k] += v / n_solo
+                for k, v in info["host_ms"].items():
+                    solo_host[k] += v / n_solo
+                solo_gen += (info["timeline_s"][2] - info["timeline_s"][1]) * 1e3 / n_solo
+            t_solo = (time.perf_counter() - t_solo) / n_solo
+            for k in KERNELS:
+                ms = solo_ms[k]
+                gbs = alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                kernels[k] = {"avg_ms": ms, "algorithmic_bytes": alg[k], "algorithmic_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                              "traffic_bytes": pmc.get(k), "traffic_over_algorithmic": (pmc[k] / alg[k]) if k in pmc else None}
+            # the quad-form leaf hash alone: static instruction count of one quad permutation x permutations / 16 quads per wave
+            wave_instr = perms * POSEIDON_QUAD_INSTRS / 16.0
+            lh_ms = solo_ms["leaf_hash"]
+            kernels["leaf_hash"]["valu"] = {"kernel": "leaf_hash_kernel", "wave_instructions": wave_instr,
+                                            "achieved_Ginstr_per_s": wave_instr / (lh_ms * 1e-3) / 1e9 if lh_ms > 0 else 0.0, "peak_Ginstr_per_s": VALU_PEAK_GINSTR,
+                                            "frac": (wave_instr / (lh_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR) if lh_ms > 0 else 0.0}
+        if "leaf_hash_lane_kernel" in timed_kernel_ms:
+            v = timed_kernel_ms["leaf_hash_lane_kernel"]
+            ms = sum(v) / len(v)
+            g = sum(timed_groups) / len(timed_groups)
+            kernels["leaf_hash_lane_in_groups"] = {"avg_ms": ms, "launches": len(v), "launches_side_by_side": g, "ms_per_commitment": ms / g,
+                                                   "algorithmic_bytes": alg["leaf_hash"], "algorithmic_GBps": alg["leaf_hash"] * g / (ms * 1e-3) / 1e9,
+                                                   "hbm_frac": alg["leaf_hash"] * g / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic_bytes": pmc.get("leaf_hash_lane"),
+                                                   "traffic_over_algorithmic": (pmc["leaf_hash_lane"] / alg["leaf_hash"]) if "leaf_hash_lane" in pmc else None,
+                                                   "measured": "inside the timed region"}
         lh_ms = solo_ms["leaf_hash"]
-        valu = {"kernel": "leaf_hash_kernel", "wave_instructions": wave_instr,
-                "achieved_Ginstr_per_s": wave_instr / (lh_ms * 1e-3) / 1e9 if lh_ms > 0 else 0.0, "peak_Ginstr_per_s": VALU_PEAK_GINSTR,
-                "basis": "7 full rounds x 261 + the last one x 204 (capacity only: the rate outputs are overwritten by the next absorb) + 7 merged "
-                         "triples of partial rounds x 309 + 1 partial round x 152 VALU instructions per 4-lane permutation (ISA count, "
-                         "profiles/r02_isa_histograms.txt); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per integer VALU instruction "
-                         "(tools/valu_rate_bench.hip, profiles/r02_valu_rates.txt)"}
-        valu["frac"] = valu["achieved_Ginstr_per_s"] / VALU_PEAK_GINSTR
         out = {
             "metric": "starky proofs/sec (FinalExponentiateStark 73527x8192)",
             "value": world * args.steps / elapsed,
@@ -307,15 +409,16 @@ def main():
             "config": {"workload": "FinalExponentiateStark 73527 cols x 8192 rows, rate_bits 2, 360800 constraints, "
                                    "standard_fast_config (84 queries, 16 pow bits); independent proofs, a different input per context and rank",
                        "parallelism": f"proof-parallel x{world}", "proofs_in_flight_per_gpu": inflight,
-                       "driver": "starkhip_pool_submit / starkhip_pool_wait (in-flight scheduling inside libstarkhip.so)"},
-            "roofline": {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": kernels[dominant]["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": kernels[dominant]["hbm_frac"], "traffic": kernels[dominant]["traffic_bytes"],
-                         "traffic_source": pmc_src, "traffic_stale_for": pmc_stale or None, "algorithmic_bytes_per_launch": alg[dominant], "avg_launch_ms": solo_ms[dominant],
-                         "durations": "one proof in flight (uncontended), HIP events on the library's stream, mean of 3 launches",
-                         "limiter": "integer VALU issue" if dominant == "leaf_hash" else "see kernels", "valu": valu if dominant == "leaf_hash" else None},
-            "timed_region_commitments": timed_region_commitments,
+                       "timed_region": ("operand (one Fp12 on the host) -> generate_trace (recorded, 153 MB) -> upload -> expansion on the device -> prove -> proof bytes "
+                                        "on the host: the reference's own boundary (src/aggregate_proof.rs:158-176)" if args.input == "witness"
+                                        else "column-major trace resident in HBM -> prove -> proof bytes on the host (--input device)"),
+                       "driver": ("starkhip_pool_submit_witness" if args.input == "witness" else "starkhip_pool_submit (device pointer)")
+                                 + " / starkhip_pool_wait (in-flight scheduling inside libstarkhip.so)",
+                       "pool_reservation_GB": {"device": reservation["device_bytes"] / 1e9, "per_final_exp_context": reservation["big_context_device_bytes"] / 1e9,
+                                               "page_locked_host": reservation["pinned_host_bytes"] / 1e9}},
+            "roofline": roofline,
             "kernels": kernels,
-            # the two rates the proof is governed by, from the same uncontended launches
+            # the two rates the proof is governed by, from the uncontended launches
             "poseidon_perms_per_s": perms / (lh_ms * 1e-3) if lh_ms > 0 else None,
             "constraint_evals_per_s": (S.air_num_constraints(air) * float(N) / (solo_ms["quotient_eval"] * 1e-3)) if solo_ms["quotient_eval"] > 0 else None,
             "timed_proofs_verified": timed_verified,
@@ -323,43 +426,48 @@ def main():
                                    "the proof of the same input made with one in flight"
                                    + ("; input 0x5eed0001 also matches the CPU oracle's digest (tests/golden/final_exp_seed_5eed0001_proof.sha256)" if oracle_match else "")),
             "oracle_digest_match": oracle_match,
-            "latency_ms_one_in_flight": t_solo * 1e3,
-            "phase_ms_one_in_flight": solo_phase,
+            "generate_trace_ms_timed_region": (sum(gen_ms) / len(gen_ms)) if (gen_ms and args.input == "witness") else None,
+            "latency_ms_one_in_flight": t_solo * 1e3 if t_solo else None,
+            "generate_trace_ms_one_in_flight": solo_gen if args.input == "witness" else None,
+            "phase_ms_one_in_flight": solo_phase if t_solo else None,
             "host_ms_one_in_flight": dict(solo_host, note="wall time of host work inside prove(): the challenger's sequential Poseidon sponge (inside the "
-                                                            "device phases fri_combine / fri_commit), and the FRI batches' divisions by X - z"),
+                                                            "device phases fri_combine / fri_commit), and the FRI batches' divisions by X - z") if t_solo else None,
             "phase_ms_timed_region": {k: v / steps for k, v in phase_ms.items()},
-            "note": ("roofline / kernels: durations with ONE proof in flight; phase_ms_timed_region: HIP-event phase durations inside the timed "
+            "note": ("roofline: the timed region's dominant kernel, durations taken inside the timed region; kernels: durations with ONE proof in flight "
+                     "(+ the lane-form groups of the timed region); phase_ms_timed_region: HIP-event phase durations inside the timed "
                      "region, which include the time a kernel shares the CUs with the other contexts' kernels"),
             "reference_published": {"value": 1 / 92.0, "unit": "proofs/s", "hardware": "AWS r6a.8xlarge, 32-core EPYC 7R13 (reference README.md:39)"},
         }
         if not args.no_boundary and world == 1:  # per-GPU figures, taken at N = 1 (other ranks would wait in the teardown meanwhile)
-            # ---- untimed: the reference's own boundary (host rows in, proof out) and the compact-trace hand-over
+            # ---- untimed legs on the SAME pool, `inflight` in flight: the other hand-over forms of the same boundary
             try:
-                nb = min(inflight, 4)  # four in flight, on a pool of their own: these legs need a trace buffer and an upload staging
-                x0 = work[0][2]        # buffer per context (9.6 GB) that the timed region's pool does not hold
-                _, pis0 = S.trace_final_exp(x0, out=host_rows)
-                pool.close()
-                del work[:]
-                torch.cuda.empty_cache()
-                pool = S.ProofPool(local_rank, big_contexts=nb, small_contexts=1, generator_threads=1, warm_up=1)
-
-                def leg(trace, pis, reps):
-                    for t in [pool.submit(air, cfg, trace, pis) for _ in range(nb)]:  # warm-up: staging buffers
+                def leg(submit_one, reps):
+                    for t in [submit_one(i) for i in range(inflight)]:  # warm-up
                         pool.wait(t, keep=False)
                     t0 = time.perf_counter()
-                    for t in [pool.submit(air, cfg, trace, pis) for _ in range(reps)]:
+                    for t in [submit_one(i) for i in range(reps)]:
                         pool.wait(t, keep=False)
-                    return time.perf_counter() - t0
-                reps = 2 * nb + 2
-                t_host = leg(host_rows, pis0, reps)
-                compact, cpis = S.trace_final_exp(x0, compact=True)
-                t_comp = leg(compact, cpis, reps)
-                out["value_host_boundary"] = {"value": reps / t_host, "unit": "proofs/s per GPU", "in_flight": nb,
-                                              "what": "page-locked host rows (4.8 GB) -> H2D -> transpose -> proof -> D2H, end to end"}
-                out["value_compact"] = {"value": reps / t_comp, "unit": "proofs/s per GPU", "in_flight": nb,
-                                        "what": "recorded trace (153 MB of runs) -> upload -> expansion on the device -> proof -> D2H"}
+                    return reps / (time.perf_counter() - t0)
+                reps = 2 * inflight + 2
+                if host_rows is None:
+                    host_rows = helper.host_array((n, C))
+                _, pis0 = S.trace_final_exp(inputs[0], out=host_rows)
+                out["value_host_rows"] = {"value": leg(lambda i: pool.submit(air, cfg, host_rows, pis0), reps), "unit": "proofs/s per GPU", "in_flight": inflight,
+                                          "what": "page-locked host ROWS (4.8 GB, what generate_trace returns) -> H2D -> transpose -> proof -> D2H; generation not included"}
+                compact, cpis = S.trace_final_exp(inputs[0], compact=True)
+                out["value_compact"] = {"value": leg(lambda i: pool.submit(air, cfg, compact, cpis), reps), "unit": "proofs/s per GPU", "in_flight": inflight,
+                                        "what": "recorded trace (153 MB of runs) -> upload -> expansion on the device -> proof -> D2H; generation not included"}
+                if args.input == "witness":
+                    make_device_traces()
+                    out["value_device_resident"] = {"value": leg(lambda i: pool.submit_device(air, cfg, device_work[i % inflight][0].data_ptr(), n,
+                                                                                              device_work[i % inflight][1], layout=1), reps),
+                                                    "unit": "proofs/s per GPU", "in_flight": inflight,
+                                                    "what": "column-major trace already in HBM -> proof -> D2H (rounds 1-3's headline; no generation, no upload)"}
+                else:
+                    out["value_witness"] = {"value": leg(lambda i: pool.submit_witness(air, inputs[i % inflight]), reps), "unit": "proofs/s per GPU",
+                                            "in_flight": inflight, "what": "operand -> generate_trace -> upload -> proof -> D2H"}
             except Exception as e:  # never lose the main line to an auxiliary leg
-                out["value_host_boundary"] = {"value": None, "error": str(e)}
+                out["value_host_rows"] = {"value": None, "error": str(e)}
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: other ranks would sit in the teardown barrier meanwhile
             try:
                 out["cpu_baseline"] = cpu_baseline_sample(S, S.air_program(air), C, log_n, cfg.rate_bits)

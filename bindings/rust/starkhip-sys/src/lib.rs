@@ -113,6 +113,9 @@ pub struct starkhip_ticket_info_t {
     pub t_generate_end: f64,
     pub t_prove_start: f64,
     pub t_done: f64,
+    /// 0 quad form, 1 row form, 2 merged with other proofs' commitments, 3 lane form (`kernel_ms[1]` is that kernel's own duration)
+    pub leaf_hash_form: c_int,
+    pub leaf_hash_group: c_uint,
 }
 
 extern "C" {
@@ -152,6 +155,10 @@ extern "C" {
     pub fn starkhip_pool_submit(pool: *mut c_void, air: Air, cfg: *const starkhip_config_t, trace: *const u64, n_rows: usize, n_cols: usize,
                                 trace_layout: c_int, trace_on_device: c_int, public_inputs: *const u64, n_pis: usize, pow_witness: u64,
                                 ticket: *mut u64) -> c_int;
+    pub fn starkhip_prove_columns(ctx: *mut c_void, air: Air, cfg: *const starkhip_config_t, columns: *const *const u64, n_rows: usize, n_cols: usize,
+                                  public_inputs: *const u64, n_pis: usize, pow_witness: u64, proof: *mut *mut u64, proof_words: *mut usize) -> c_int;
+    pub fn starkhip_pool_submit_columns(pool: *mut c_void, air: Air, cfg: *const starkhip_config_t, columns: *const *const u64, n_rows: usize,
+                                        n_cols: usize, public_inputs: *const u64, n_pis: usize, pow_witness: u64, ticket: *mut u64) -> c_int;
     pub fn starkhip_pool_submit_compact(pool: *mut c_void, air: Air, cfg: *const starkhip_config_t, log: *const c_void, public_inputs: *const u64,
                                         n_pis: usize, pow_witness: u64, ticket: *mut u64) -> c_int;
     pub fn starkhip_pool_submit_witness(pool: *mut c_void, air: Air, cfg: *const starkhip_config_t, operands: *const u32, n_limbs: usize,
@@ -295,6 +302,23 @@ impl Prover {
         Ok(unsafe { Prover::take(p, w) })
     }
 
+    /// `prove(stark, &config, trace_poly_values, &public_inputs, &mut timing)` with the reference's literal argument
+    /// (src/aggregate_proof.rs:168-175): `trace_poly_values: Vec<PolynomialValues<F>>` is one heap allocation per column.  Pass
+    /// each `PolynomialValues::values` as a `&[u64]` (canonical cells); the library gathers the scattered columns itself.
+    pub fn prove_columns(&mut self, air: Air, cfg: &Config, columns: &[&[u64]], public_inputs: &[u64]) -> Result<Proof, Error> {
+        let n_rows = columns.first().map_or(0, |c| c.len());
+        if columns.iter().any(|c| c.len() != n_rows) {
+            return Err(Error(STARKHIP_ERR_BAD_SHAPE));
+        }
+        let ptrs: Vec<*const u64> = columns.iter().map(|c| c.as_ptr()).collect();
+        let (mut p, mut w) = (std::ptr::null_mut::<u64>(), 0usize);
+        check(unsafe {
+            starkhip_prove_columns(self.ctx, air, cfg, ptrs.as_ptr(), n_rows, ptrs.len(), public_inputs.as_ptr(), public_inputs.len(),
+                                   STARKHIP_POW_SEARCH, &mut p, &mut w)
+        })?;
+        Ok(unsafe { Prover::take(p, w) })
+    }
+
     /// The same proof, byte for byte, from a recorded trace (expanded on the device).
     pub fn prove_recorded(&mut self, air: Air, cfg: &Config, trace: &RecordedTrace) -> Result<Proof, Error> {
         let (mut p, mut w) = (std::ptr::null_mut::<u64>(), 0usize);
@@ -328,7 +352,26 @@ impl Drop for Pool {
         unsafe { starkhip_pool_destroy(self.pool) }
     }
 }
-pub struct Ticket(pub Air, pub u64);
+/// A proof in flight.  The lifetime ties the ticket to the pool AND to everything the pool still reads for it: `submit_rows`
+/// hands the library borrowed rows, which a prover thread uploads some time after `submit_rows` has returned (starkhip.h:
+/// "must stay valid until the ticket has been waited for").  The borrow therefore lasts until `wait` consumes the ticket, and a
+/// ticket that is dropped un-waited waits in its `Drop` (the proof is discarded), so safe code cannot free or mutate the rows
+/// under the copy.  (`std::mem::forget` of a ticket leaks the job, and with it the library's right to read the rows: do not.)
+pub struct Ticket<'a> {
+    pub air: Air,
+    pub id: u64,
+    pool: &'a Pool,
+    waited: bool,
+    _inputs: std::marker::PhantomData<&'a [u64]>,
+}
+impl<'a> Drop for Ticket<'a> {
+    fn drop(&mut self) {
+        if !self.waited {
+            // the library may still be reading the borrowed inputs: block until it is done with them, drop the proof
+            unsafe { starkhip_pool_wait(self.pool.pool, self.id, std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut()) };
+        }
+    }
+}
 
 impl Pool {
     pub fn new(cfg: &starkhip_pool_config_t) -> Result<Pool, Error> {
@@ -336,27 +379,48 @@ impl Pool {
         check(unsafe { starkhip_pool_create(cfg, &mut pool) })?;
         Ok(Pool { pool })
     }
+    fn ticket<'a>(&'a self, air: Air, id: u64) -> Ticket<'a> {
+        Ticket { air, id, pool: self, waited: false, _inputs: std::marker::PhantomData }
+    }
     /// generate_trace + prove of one of the reference's drivers (src/aggregate_proof.rs:23-179) from its operands as u32 limbs,
-    /// packed as `starkhip.h` says (e.g. MillerLoop: px, py, qx, qy, qz).
-    pub fn submit(&self, air: Air, operands: &[u32]) -> Result<Ticket, Error> {
+    /// packed as `starkhip.h` says (e.g. MillerLoop: px, py, qx, qy, qz).  The operands are copied: nothing stays borrowed but the pool.
+    pub fn submit<'a>(&'a self, air: Air, operands: &[u32]) -> Result<Ticket<'a>, Error> {
         let mut t = 0u64;
         check(unsafe { starkhip_pool_submit_witness(self.pool, air, std::ptr::null(), operands.as_ptr(), operands.len(), STARKHIP_POW_SEARCH, &mut t) })?;
-        Ok(Ticket(air, t))
+        Ok(self.ticket(air, t))
     }
-    /// The reference's own generator stays: hand over the rows `generate_trace` returned.  `trace` and `public_inputs` must
-    /// outlive the ticket (they are borrowed until `wait` returns).
-    pub fn submit_rows<'a, const COLUMNS: usize>(&'a self, air: Air, cfg: &Config, trace: &'a [[u64; COLUMNS]], public_inputs: &'a [u64]) -> Result<Ticket, Error> {
+    /// The reference's own generator stays: hand over the rows `generate_trace` returned.  `trace` and `public_inputs` stay
+    /// borrowed for as long as the ticket lives, i.e. until `wait` has returned (or the ticket has been dropped, which waits).
+    pub fn submit_rows<'a, const COLUMNS: usize>(&'a self, air: Air, cfg: &Config, trace: &'a [[u64; COLUMNS]], public_inputs: &'a [u64]) -> Result<Ticket<'a>, Error> {
         let mut t = 0u64;
         check(unsafe {
             starkhip_pool_submit(self.pool, air, cfg, trace.as_ptr() as *const u64, trace.len(), COLUMNS, 0, 0, public_inputs.as_ptr(),
                                  public_inputs.len(), STARKHIP_POW_SEARCH, &mut t)
         })?;
-        Ok(Ticket(air, t))
+        Ok(self.ticket(air, t))
+    }
+    /// `prove(stark, &config, trace_poly_values, ..)` with the literal argument of src/aggregate_proof.rs:168-175: one heap
+    /// allocation per column (`Vec<PolynomialValues<F>>`, F = GoldilocksField is `repr(transparent)` over u64).  The library
+    /// gathers the scattered columns through its page-locked staging; the column vectors stay borrowed until `wait`.
+    pub fn submit_columns<'a>(&'a self, air: Air, cfg: &Config, columns: &'a [Vec<u64>], public_inputs: &'a [u64]) -> Result<Ticket<'a>, Error> {
+        let n_rows = columns.first().map_or(0, |c| c.len());
+        if columns.iter().any(|c| c.len() != n_rows) {
+            return Err(Error(STARKHIP_ERR_BAD_SHAPE));
+        }
+        // the pointer table is copied by the library before submit_columns returns
+        let ptrs: Vec<*const u64> = columns.iter().map(|c| c.as_ptr()).collect();
+        let mut t = 0u64;
+        check(unsafe {
+            starkhip_pool_submit_columns(self.pool, air, cfg, ptrs.as_ptr(), n_rows, ptrs.len(), public_inputs.as_ptr(), public_inputs.len(),
+                                         STARKHIP_POW_SEARCH, &mut t)
+        })?;
+        Ok(self.ticket(air, t))
     }
     /// Blocks until the proof is done; the `Err` is what `prove` would have returned.
-    pub fn wait(&self, ticket: Ticket) -> Result<Proof, Error> {
+    pub fn wait(&self, mut ticket: Ticket<'_>) -> Result<Proof, Error> {
         let (mut p, mut w) = (std::ptr::null_mut::<u64>(), 0usize);
-        check(unsafe { starkhip_pool_wait(self.pool, ticket.1, &mut p, &mut w, std::ptr::null_mut()) })?;
+        ticket.waited = true; // starkhip_pool_wait consumes the ticket whatever it returns
+        check(unsafe { starkhip_pool_wait(self.pool, ticket.id, &mut p, &mut w, std::ptr::null_mut()) })?;
         Ok(unsafe { Prover::take(p, w) })
     }
 }

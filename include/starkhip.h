@@ -128,6 +128,15 @@ int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, 
                    int trace_layout, int trace_on_device, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness,
                    uint64_t** proof, size_t* proof_words);
 
+/* The same proof from the LITERAL argument of starky's prove(): `trace_poly_values: Vec<PolynomialValues<F>>`
+ * (src/aggregate_proof.rs:57-65, :104-111, :137-144, :168-175) is one heap allocation per column -- 73 527 of them for FinalExp.
+ * `columns` is a table of n_cols host pointers, each to n_rows canonical words (PolynomialValues<GoldilocksField>::values; the field
+ * type is repr(transparent) over u64).  The library gathers the scattered columns through the context's page-locked staging, half
+ * by half under the copies, so a binding at prove() itself needs no 4.8 GB host-side repack.  Byte-identical to starkhip_prove on
+ * the same matrix; shapes and errors as starkhip_prove (a NULL column pointer: STARKHIP_ERR_BAD_SHAPE). */
+int starkhip_prove_columns(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* const* columns, size_t n_rows, size_t n_cols,
+                           const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness, uint64_t** proof, size_t* proof_words);
+
 /* Tuning knobs of a context (defaults are the measured best; tests and profiling tools use them to reach the other code
  * paths): "quotient_impl" 0 = tiled evaluator / 1 = op-stream interpreter, "quotient_chunks" (0 = automatic),
  * "quotient_waves", "quotient_slots", "lde_closed_forms" (1 = constant and unit-vector trace columns take their closed-form LDE
@@ -173,7 +182,8 @@ int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_
 typedef struct {
     int device;
     unsigned big_contexts;      /* 0 = default (3).  Five or more: the trace commitments of these proofs go out in groups of up to four in the
-                                   lane form of the leaf hash (6.3 against 5.65 proofs/s on one MI355X; ~ 30 GB of HBM per context) */
+                                   lane form of the leaf hash (6.3 against 5.65 proofs/s on one MI355X; ~ 25 GB of HBM per context,
+                                   starkhip_pool_reservation) */
     unsigned small_contexts;    /* 0 = default (16) */
     unsigned generator_threads; /* recordings under way at once; 0 = default (a quarter of the CPUs the process may use -- its
                                    cgroup quota or affinity mask --, 3 .. 12) */
@@ -187,8 +197,8 @@ typedef struct {
     unsigned warm_up;           /* != 0: starkhip_pool_create returns when every context has allocated what the BLS pipeline's AIRs of its class
                                    need (FinalExp on the big contexts; MillerLoop, PairingPrecomp, FP12Mul on the small ones: tables, constraint
                                    plans, buffers, upload staging), so that no proof pays for -- or stalls the device with -- allocations;
-                                   2: the same without the trace buffer and the upload staging (4.8 GB each per FinalExp-class context): for a
-                                   caller whose traces are already column-major device memory (starkhip_pool_submit with trace_on_device) */
+                                   2: the same without the page-locked upload staging: for a caller whose traces are already column-major
+                                   device memory (starkhip_pool_submit with trace_on_device) */
     float gather_ms;            /* how long a merged launch waits for small proofs that have started but not reached their commitment; 0 = default (25) */
 } starkhip_pool_config_t;
 typedef struct {
@@ -196,6 +206,9 @@ typedef struct {
     float kernel_ms[3];   /* as starkhip_last_kernel_timings */
     float host_ms[2];     /* as starkhip_last_host_timings */
     double t_submit, t_generate_start, t_generate_end, t_prove_start, t_done; /* seconds since the pool was created */
+    int leaf_hash_form;       /* how the trace commitment went out: 0 quad form, 1 row form, 2 one grid merged with other proofs' commitments
+                                 (quad form), 3 lane form; kernel_ms[1] is that kernel's own duration on its launch stream */
+    unsigned leaf_hash_group; /* commitments that were launched side by side with it (itself included) */
 } starkhip_ticket_info_t;
 typedef struct {
     unsigned long big_commit_launches, small_commit_launches, small_commit_requests, max_merged_commitments;
@@ -206,6 +219,10 @@ void starkhip_pool_destroy(void* pool); /* runs what is queued to the end first 
 int starkhip_pool_submit(void* pool, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows, size_t n_cols,
                          int trace_layout, int trace_on_device, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness,
                          uint64_t* ticket);
+/* as starkhip_prove_columns; the pointer TABLE is copied before this returns, the columns themselves (and the public inputs) stay the
+ * caller's until the ticket has been waited for */
+int starkhip_pool_submit_columns(void* pool, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* const* columns, size_t n_rows,
+                                 size_t n_cols, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness, uint64_t* ticket);
 int starkhip_pool_submit_compact(void* pool, starkhip_air_t air, const starkhip_config_t* cfg, const void* log, const uint64_t* public_inputs,
                                  size_t n_pis, uint64_t pow_witness, uint64_t* ticket);
 /* generate_trace + prove (src/aggregate_proof.rs:23-179, one driver each) from the driver's operands as u32 limbs, packed:
@@ -218,6 +235,15 @@ int starkhip_pool_submit_witness(void* pool, starkhip_air_t air, const starkhip_
 /* returns the proof's status (what starkhip_prove would have returned); info may be NULL */
 int starkhip_pool_wait(void* pool, uint64_t ticket, uint64_t** proof, size_t* proof_words, starkhip_ticket_info_t* info);
 int starkhip_pool_stats(void* pool, starkhip_pool_stats_t* out);
+/* What the pool has reserved (a warmed pool: everything its proofs will ever need; read it between proofs): device memory of all
+ * contexts, page-locked upload staging, and the largest context of each class.  A FinalExp-class context holds the trace columns
+ * (4.8 GB; the coefficients replace them in place), the LDE (19.3 GB; row-major uploads and recordings are staged in it before the
+ * LDE kernel writes it) and ~ 0.5 GB of small buffers. */
+typedef struct {
+    uint64_t device_bytes, pinned_host_bytes, big_context_device_bytes, small_context_device_bytes;
+    unsigned big_contexts, small_contexts;
+} starkhip_pool_reservation_t;
+int starkhip_pool_reservation(void* pool, starkhip_pool_reservation_t* out);
 /* Proof blobs of a warmed pool are recycled page-locked buffers (the final device-to-host copy of 21 .. 69 MB runs at PCIe rate and
  * touches no fresh pages); starkhip_free() hands them back.  Process-wide counters: [0] blobs held, [1] of them with a caller,
  * [2] bytes held, [3] proofs served from them, [4] proofs served by malloc (no idle blob that fits).  STARKHIP_PINNED_PROOFS=0 in

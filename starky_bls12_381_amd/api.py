@@ -81,6 +81,8 @@ lib.starkhip_shutdown.argtypes = [C.c_void_p]
 lib.starkhip_shutdown.restype = None
 lib.starkhip_prove.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _u64p, C.c_size_t,
                                C.c_uint64, C.POINTER(_u64p), C.POINTER(C.c_size_t)]
+lib.starkhip_prove_columns.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t, _u64p, C.c_size_t,
+                                       C.c_uint64, C.POINTER(_u64p), C.POINTER(C.c_size_t)]
 lib.starkhip_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
 lib.starkhip_last_kernel_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
 lib.starkhip_last_host_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -381,6 +383,16 @@ def poseidon_permute_host(state):
     return s
 
 
+def _column_table(columns):
+    """(pointer table, the arrays it points into, n_rows) for starkhip_prove_columns / starkhip_pool_submit_columns."""
+    keep = [np.ascontiguousarray(c, dtype=np.uint64) for c in columns]
+    if not keep or any(c.ndim != 1 or c.size != keep[0].size for c in keep):
+        raise StarkhipError(ERR_BAD_SHAPE)
+    addrs = np.fromiter((c.ctypes.data for c in keep), dtype=np.uint64, count=len(keep))
+    table = (C.c_void_p * len(keep)).from_buffer_copy(addrs.tobytes())
+    return table, keep, keep[0].size
+
+
 # ----------------------------------------------------------------------------- prover / verifier
 class Prover:
     """One context per GPU (starkhip_init).  `prove` mirrors starky::prover::prove."""
@@ -425,6 +437,19 @@ class Prover:
                                 pow_witness, C.byref(out), C.byref(words))
         self.last_call_s = time.perf_counter() - t0
         _chk(rc)
+        proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy()
+        lib.starkhip_free(out)
+        return proof
+
+    def prove_columns(self, air, config, columns, public_inputs, pow_witness=POW_SEARCH):
+        """starky's literal `prove(stark, &config, trace_poly_values, ..)`: `columns` is a sequence of separately allocated 1-D uint64
+        arrays, one per trace column (`Vec<PolynomialValues<F>>`, src/aggregate_proof.rs:168-175)."""
+        table, keep, n_rows = _column_table(columns)
+        pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        out = _u64p()
+        words = C.c_size_t()
+        _chk(lib.starkhip_prove_columns(self._ctx, air, C.byref(config), table, n_rows, len(keep), _p64(pis), pis.size, pow_witness, C.byref(out),
+                                        C.byref(words)))
         proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy()
         lib.starkhip_free(out)
         return proof
@@ -511,7 +536,8 @@ class PoolConfig(C.Structure):
 
 class TicketInfo(C.Structure):
     _fields_ = [("phase_ms", C.c_float * N_PHASES), ("kernel_ms", C.c_float * 3), ("host_ms", C.c_float * 2), ("t_submit", C.c_double), ("t_generate_start", C.c_double),
-                ("t_generate_end", C.c_double), ("t_prove_start", C.c_double), ("t_done", C.c_double)]
+                ("t_generate_end", C.c_double), ("t_prove_start", C.c_double), ("t_done", C.c_double), ("leaf_hash_form", C.c_int),
+                ("leaf_hash_group", C.c_uint)]
 
 
 class PoolStats(C.Structure):
@@ -528,6 +554,16 @@ lib.starkhip_pool_submit_compact.argtypes = [C.c_void_p, C.c_int, C.POINTER(Star
 lib.starkhip_pool_submit_witness.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), _u32p, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)]
 lib.starkhip_pool_wait.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_u64p), C.POINTER(C.c_size_t), C.POINTER(TicketInfo)]
 lib.starkhip_pool_stats.argtypes = [C.c_void_p, C.POINTER(PoolStats)]
+lib.starkhip_pool_submit_columns.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t, _u64p, C.c_size_t,
+                                             C.c_uint64, C.POINTER(C.c_uint64)]
+
+
+class PoolReservation(C.Structure):
+    _fields_ = [("device_bytes", C.c_uint64), ("pinned_host_bytes", C.c_uint64), ("big_context_device_bytes", C.c_uint64),
+                ("small_context_device_bytes", C.c_uint64), ("big_contexts", C.c_uint), ("small_contexts", C.c_uint)]
+
+
+lib.starkhip_pool_reservation.argtypes = [C.c_void_p, C.POINTER(PoolReservation)]
 lib.starkhip_proof_blob_stats.argtypes = [C.POINTER(C.c_uint64)]
 lib.starkhip_proof_blob_stats.restype = None
 
@@ -616,6 +652,16 @@ class ProofPool:
         self._keep[t.value] = (pis, cfg)
         return t.value
 
+    def submit_columns(self, air, config, columns, public_inputs, pow_witness=POW_SEARCH):
+        """As Prover.prove_columns, asynchronously: one separately allocated array per trace column."""
+        table, keep, n_rows = _column_table(columns)
+        pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        cfg = StarkConfig.from_buffer_copy(config)
+        t = C.c_uint64()
+        _chk(lib.starkhip_pool_submit_columns(self._h, air, C.byref(cfg), table, n_rows, len(keep), _p64(pis), pis.size, pow_witness, C.byref(t)))
+        self._keep[t.value] = (keep, pis, cfg)  # the table itself was copied by the library
+        return t.value
+
     def submit_witness(self, air, *generator_args, config=None, pow_witness=POW_SEARCH):
         """generate_trace + prove inside the pool, from the arguments of `trace_<air>`."""
         ops = witness_operands(air, *generator_args)
@@ -638,7 +684,14 @@ class ProofPool:
         return proof, {"phase_ms": dict(zip(PHASE_NAMES, [float(x) for x in info.phase_ms])),
                        "kernel_ms": {"lde_columns": float(info.kernel_ms[0]), "leaf_hash": float(info.kernel_ms[1]), "quotient_eval": float(info.kernel_ms[2])},
                        "host_ms": {"fiat_shamir": float(info.host_ms[0]), "other": float(info.host_ms[1])},
-                       "timeline_s": [info.t_submit, info.t_generate_start, info.t_generate_end, info.t_prove_start, info.t_done]}
+                       "timeline_s": [info.t_submit, info.t_generate_start, info.t_generate_end, info.t_prove_start, info.t_done],
+                       "leaf_hash_form": ("quad", "row", "merged", "lane")[info.leaf_hash_form & 3], "leaf_hash_group": int(info.leaf_hash_group)}
+
+    def reservation(self):
+        """starkhip_pool_reservation: what the pool's contexts hold (bytes)."""
+        r = PoolReservation()
+        _chk(lib.starkhip_pool_reservation(self._h, C.byref(r)))
+        return {n: int(getattr(r, n)) for n, _ in PoolReservation._fields_}
 
     def stats(self):
         s = PoolStats()

@@ -161,6 +161,24 @@ int starkhip_prove(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, 
     }
 }
 
+int starkhip_prove_columns(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* const* columns, size_t n_rows, size_t n_cols,
+                           const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness, uint64_t** proof, size_t* proof_words) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    const AirInfo* a = air_get(air);
+    if (!a) return STARKHIP_ERR_BAD_AIR;
+    if (!cfg || !columns || !proof || !proof_words || (n_pis && !public_inputs)) return STARKHIP_ERR_BAD_SHAPE;
+    if (n_cols != a->cols) return STARKHIP_ERR_BAD_SHAPE;  // the table is read as `columns` pointers of n_rows words each
+    for (size_t i = 0; i < n_cols; i++)
+        if (!columns[i]) return STARKHIP_ERR_BAD_SHAPE;
+    try {
+        return prove((Ctx*)ctx, *a, *cfg, (const uint64_t*)columns, n_rows, 3, 0, public_inputs, n_pis, pow_witness, proof, proof_words);
+    } catch (const std::bad_alloc&) {
+        return STARKHIP_ERR_OOM;
+    } catch (const std::exception&) {
+        return STARKHIP_ERR_BAD_SHAPE;
+    }
+}
+
 int starkhip_set_option(void* ctx, const char* name, long value) {
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;
     return ctx_set_option((Ctx*)ctx, name, value);
@@ -296,6 +314,11 @@ int starkhip_pool_submit(void* pool, starkhip_air_t air, const starkhip_config_t
     if (!pool) return STARKHIP_ERR_NO_DEVICE;
     return pool_submit((Pool*)pool, air, cfg, trace, n_rows, n_cols, trace_layout, trace_on_device, public_inputs, n_pis, pow_witness, ticket);
 }
+int starkhip_pool_submit_columns(void* pool, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* const* columns, size_t n_rows,
+                                 size_t n_cols, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness, uint64_t* ticket) {
+    if (!pool) return STARKHIP_ERR_NO_DEVICE;
+    return pool_submit_columns((Pool*)pool, air, cfg, columns, n_rows, n_cols, public_inputs, n_pis, pow_witness, ticket);
+}
 int starkhip_pool_submit_compact(void* pool, starkhip_air_t air, const starkhip_config_t* cfg, const void* log, const uint64_t* public_inputs,
                                  size_t n_pis, uint64_t pow_witness, uint64_t* ticket) {
     if (!pool) return STARKHIP_ERR_NO_DEVICE;
@@ -314,6 +337,10 @@ int starkhip_pool_submit_witness(void* pool, starkhip_air_t air, const starkhip_
 int starkhip_pool_wait(void* pool, uint64_t ticket, uint64_t** proof, size_t* proof_words, starkhip_ticket_info_t* info) {
     if (!pool) return STARKHIP_ERR_NO_DEVICE;
     return pool_wait((Pool*)pool, ticket, proof, proof_words, info);
+}
+int starkhip_pool_reservation(void* pool, starkhip_pool_reservation_t* out) {
+    if (!pool || !out) return STARKHIP_ERR_BAD_SHAPE;
+    return pool_reservation((Pool*)pool, out);
 }
 int starkhip_pool_stats(void* pool, starkhip_pool_stats_t* out) {
     if (!pool || !out) return STARKHIP_ERR_BAD_SHAPE;

@@ -45,9 +45,12 @@ void ctx_destroy(Ctx* c) {
     if (c) blob_arena_drop(c);
     delete c;
 }
+size_t ctx_device_bytes(Ctx*) { return 0; }
+size_t ctx_pinned_bytes(Ctx*) { return 0; }
 const float* ctx_timings(Ctx* c) { return c->timings; }
 const float* ctx_kernel_timings(Ctx* c) { return c->ktimings; }
 const float* ctx_host_timings(Ctx* c) { return c->htimings; }
+void ctx_commit_info(Ctx*, int* form, unsigned* group) { *form = 0; *group = 1; }
 int ctx_set_option(Ctx*, const char*, long) { return STARKHIP_ERR_NO_DEVICE; }
 void ctx_attach_hash_service(Ctx* c, HashService* hs) { c->hs = hs; }
 bool ctx_has_hash_service(Ctx* c) { return c->hs != nullptr; }
@@ -121,6 +124,7 @@ hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 }

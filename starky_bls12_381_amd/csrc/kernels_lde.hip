@@ -168,8 +168,11 @@ struct LdePasses {
 };
 
 // values [C][n] (or coefficients when from_coeffs) -> coeffs [C][n] (nullable) and lde [C][2^rate][n], coset-major.
+// `coeffs` MAY BE `values` (the prover transforms a trace in place: values and coefficients are never both needed, 4.8 GB per
+// FinalExp context): a thread reads its 16 words of a column before it writes exactly those 16 back, and the closed-form branch
+// writes other words only after the workgroup's barriers -- so neither pointer is `__restrict__`.
 template <int LOGN>
-__global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kernel(const gl_t* __restrict__ values, gl_t* __restrict__ coeffs,
+__global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kernel(const gl_t* values, gl_t* coeffs,
                                                                                     gl_t* __restrict__ lde, unsigned n_cols, unsigned rate_bits,
                                                                                     const gl_t* __restrict__ tw_fwd,
                                                                                     const gl_t* __restrict__ tw_inv, const gl_t* __restrict__ cs,

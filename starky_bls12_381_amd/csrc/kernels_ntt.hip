@@ -81,7 +81,7 @@ __device__ __forceinline__ void lds_ntt_dit(gl_t* a, const gl_t* __restrict__ tw
 //   lde     [C][R][n]   output, coset-major
 // LDS: COLS_PER_BLOCK * n * 8 bytes (64 KiB at n = 8192).
 template <int LOGN, int COLS_PER_BLOCK, int THREADS>
-__global__ __launch_bounds__(THREADS) void lde_columns_kernel(const gl_t* __restrict__ values, gl_t* __restrict__ coeffs,
+__global__ __launch_bounds__(THREADS) void lde_columns_kernel(const gl_t* values, gl_t* coeffs,  // coeffs may be values (in place): every word of a column is in LDS, behind a barrier, before any is written
                                                                gl_t* __restrict__ lde, size_t n_cols, unsigned rate_bits,
                                                                const gl_t* __restrict__ tw_fwd, const gl_t* __restrict__ tw_inv,
                                                                unsigned tw_log, const gl_t* __restrict__ coset_scale, int from_coeffs) {

@@ -13,6 +13,7 @@ void ctx_destroy(Ctx* c);
 const float* ctx_timings(Ctx* c);
 const float* ctx_kernel_timings(Ctx* c);
 const float* ctx_host_timings(Ctx* c);
+void ctx_commit_info(Ctx* c, int* form, unsigned* group);  // how the last proof's trace commitment went out (HashService::Timing)
 int ctx_set_option(Ctx* c, const char* name, long value);
 class HashService;  // scheduler.h
 void ctx_attach_hash_service(Ctx* c, HashService* hs);  // trace commitments of this context go through the pool's scheduler
@@ -29,11 +30,16 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out);
 void pool_destroy(Pool* p);
 int pool_submit(Pool* p, int air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows, size_t n_cols, int layout, int on_device,
                 const uint64_t* pis, size_t n_pis, uint64_t pow, uint64_t* ticket);
+int pool_submit_columns(Pool* p, int air, const starkhip_config_t* cfg, const uint64_t* const* columns, size_t n_rows, size_t n_cols,
+                        const uint64_t* pis, size_t n_pis, uint64_t pow, uint64_t* ticket);
 int pool_submit_compact(Pool* p, int air, const starkhip_config_t* cfg, const void* log, const uint64_t* pis, size_t n_pis, uint64_t pow,
                         uint64_t* ticket);
 int pool_submit_witness(Pool* p, int air, const starkhip_config_t* cfg, const uint32_t* operands, size_t n_limbs, uint64_t pow, uint64_t* ticket);
 int pool_wait(Pool* p, uint64_t ticket, uint64_t** proof, size_t* words, starkhip_ticket_info_t* info);
 int pool_stats(Pool* p, starkhip_pool_stats_t* out);
+int pool_reservation(Pool* p, starkhip_pool_reservation_t* out);
+size_t ctx_device_bytes(Ctx* c);  // device memory this context holds (work buffers, tables, plans)
+size_t ctx_pinned_bytes(Ctx* c);  // page-locked host memory it holds (upload staging; proof blobs are counted by starkhip_proof_blob_stats)
 
 int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64_t* trace, size_t n_rows, int layout, int on_device,
           const uint64_t* pis, size_t n_pis, uint64_t pow_witness, uint64_t** proof_out, size_t* proof_words);

@@ -93,9 +93,11 @@ struct Ctx {
     float htimings[2] = {0};      // host time inside the last prove: Fiat-Shamir hashing (the challenger's sequential sponge), other host arithmetic
     HashService* hs = nullptr;    // a pooled context's trace commitments are launched by the pool's scheduler (scheduler.h)
     hipEvent_t hash_ready = nullptr, hash_done = nullptr;
+    HashService::Timing hash_timing;  // pooled: the commitment kernel's own start / stop on ITS launch stream, its form and group
     hipEvent_t wait_ev = nullptr;  // hipEventBlockingSync: see stream_wait()
-    void* host_staging = nullptr;  // page-locked: a recording's parts gathered for one upload (prove(), layout 2)
+    void* host_staging = nullptr;  // page-locked: a recording's parts gathered for one upload (prove(), layout 2); scattered columns (layout 3)
     size_t host_staging_cap = 0;
+    hipEvent_t col_ev[2] = {nullptr, nullptr};  // layout 3: the two halves of host_staging, each free again when its copy has run
     std::set<int> blob_airs;  // AIRs this context has reserved page-locked proof blobs for (blob_arena.h)
     bool hash_requested = false;
     bool urgent = false;  // ctx_set_urgent
@@ -129,7 +131,12 @@ struct Ctx {
     unsigned prog_slots = 0;
     std::vector<uint32_t> chunk_k_after;
     // work buffers
-    DevBuf staging, values, coeffs, lde, digests, pis, apow, chunk_scale, partial, qvals, qcoef, qlde, qdigests, zpow, gzpow, open_local,
+    // `values` holds the trace columns and, after the inverse transforms, their coefficients IN PLACE (a column's values are dead once
+    // its coefficients exist; lde_columns_v2_kernel reads a column completely before it writes it).  Only a trace that already lies in
+    // the caller's device memory (layout 1, on_device) is left untouched: its coefficients go to `values` as a separate output.
+    // Upload staging (row-major rows before the transpose, a recording's words before the expansion) lives in `lde`, which nothing
+    // needs before the LDE kernel writes it.  Together: 4.8 + 19.3 GB per FinalExp context instead of 4.8 + 4.8 + 4.8 + 19.3.
+    DevBuf staging, values, lde, digests, pis, apow, chunk_scale, partial, qvals, qcoef, qlde, qdigests, zpow, gzpow, open_local,
         open_next, open_q, ext_apow, comb_partial, comb_out, fri_coef, fri_vals, fri_rows[16], fri_digests[16], scale_tab, pow_state,
         pow_best, qidx, gather_t, gather_q;
 };
@@ -311,10 +318,13 @@ int ctx_create(int device, Ctx** out, int priority) {
     ok = ok && hipEventCreateWithFlags(&c->hash_ready, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->hash_done, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
+    ok = ok && hipEventCreate(&c->hash_timing.t0) == hipSuccess && hipEventCreate(&c->hash_timing.t1) == hipSuccess;
     if (!ok) {  // release whatever was created
         if (c->hash_ready) (void)hipEventDestroy(c->hash_ready);
         if (c->hash_done) (void)hipEventDestroy(c->hash_done);
         if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
+        if (c->hash_timing.t0) (void)hipEventDestroy(c->hash_timing.t0);
+        if (c->hash_timing.t1) (void)hipEventDestroy(c->hash_timing.t1);
         for (auto& e : c->ev)
             if (e) (void)hipEventDestroy(e);
         for (auto& e : c->kev)
@@ -336,7 +346,7 @@ void ctx_destroy(Ctx* c) {
     for (auto& d : c->plan_cache)
         for (DevBuf* b : {&d->q_recs, &d->q_pieces, &d->q_streams, &d->q_chunk_tile_off, &d->q_tile_list, &d->q_contrib_off, &d->q_contribs, &d->q_consts, &d->q_apow}) b->release();
     DevBuf* bufs[] = {&c->d_ops, &c->d_loads, &c->d_chunk_off, &c->staging,
-                      &c->values, &c->coeffs, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial, &c->qvals, &c->qcoef,
+                      &c->values, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial, &c->qvals, &c->qcoef,
                       &c->qlde, &c->qdigests, &c->zpow, &c->gzpow, &c->open_local, &c->open_next, &c->open_q, &c->ext_apow, &c->comb_partial,
                       &c->comb_out, &c->fri_coef, &c->fri_vals, &c->scale_tab, &c->pow_state, &c->pow_best, &c->qidx, &c->gather_t,
                       &c->gather_q};
@@ -348,6 +358,10 @@ void ctx_destroy(Ctx* c) {
     (void)hipEventDestroy(c->hash_ready);
     (void)hipEventDestroy(c->hash_done);
     (void)hipEventDestroy(c->wait_ev);
+    (void)hipEventDestroy(c->hash_timing.t0);
+    (void)hipEventDestroy(c->hash_timing.t1);
+    for (auto& e : c->col_ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->host_staging) (void)hipHostFree(c->host_staging);
     blob_arena_drop(c);
     (void)hipStreamDestroy(c->st_normal);
@@ -389,9 +403,29 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
     else return STARKHIP_ERR_BAD_SHAPE;
     return STARKHIP_OK;
 }
+size_t ctx_device_bytes(Ctx* c) {
+    size_t total = 0;
+    for (auto& t : c->table_cache)
+        for (DevBuf* b : {&t->tw_fwd, &t->tw_inv, &t->coset_scale, &t->qtab, &t->qshift_inv, &t->lde2_fwd, &t->lde2_inv, &t->lde2_cs, &t->lde2_oh}) total += b->cap;
+    for (auto& d : c->plan_cache)
+        for (DevBuf* b : {&d->q_recs, &d->q_pieces, &d->q_streams, &d->q_chunk_tile_off, &d->q_tile_list, &d->q_contrib_off, &d->q_contribs, &d->q_consts, &d->q_apow}) total += b->cap;
+    DevBuf* bufs[] = {&c->d_ops, &c->d_loads, &c->d_chunk_off, &c->staging, &c->values, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial,
+                      &c->qvals, &c->qcoef, &c->qlde, &c->qdigests, &c->zpow, &c->gzpow, &c->open_local, &c->open_next, &c->open_q, &c->ext_apow,
+                      &c->comb_partial, &c->comb_out, &c->fri_coef, &c->fri_vals, &c->scale_tab, &c->pow_state, &c->pow_best, &c->qidx, &c->gather_t,
+                      &c->gather_q};
+    for (auto b : bufs) total += b->cap;
+    for (auto& b : c->fri_rows) total += b.cap;
+    for (auto& b : c->fri_digests) total += b.cap;
+    return total;
+}
+size_t ctx_pinned_bytes(Ctx* c) { return c->host_staging_cap; }
 const float* ctx_timings(Ctx* c) { return c->timings; }
 const float* ctx_kernel_timings(Ctx* c) { return c->ktimings; }
 const float* ctx_host_timings(Ctx* c) { return c->htimings; }
+void ctx_commit_info(Ctx* c, int* form, unsigned* group) {
+    *form = c->hash_timing.form;
+    *group = c->hash_timing.group;
+}
 
 // (F(X) - F(z)) / (X - z), padded with one zero coefficient back to length n (plonky2 divide_by_linear + push(0))
 static void divide_by_linear(const gl2_t* F, size_t n, gl2_t z, gl2_t* q) {
@@ -438,7 +472,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     const unsigned n_chunks = tiled ? c->plan->chunks : c->prog_chunks;
 
     // ---- buffers
-    HIPCHK(c->coeffs.ensure(C * n * 8));
+    HIPCHK(c->values.ensure(C * n * 8));
     HIPCHK(c->lde.ensure(C * N * 8));
     HIPCHK(c->digests.ensure(digest_words(N) * 8));
     HIPCHK(c->pis.ensure(std::max<size_t>(1, n_pis) * 8));
@@ -476,9 +510,8 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         const TraceLog* log = (const TraceLog*)trace;
         const size_t nw = log->total_words(), nr = log->total_records(), nz = log->total_late_zeros();
         if (log->rows != n || log->cols != C) return STARKHIP_ERR_BAD_SHAPE;
-        HIPCHK(c->values.ensure(C * n * 8));
-        HIPCHK(c->staging.ensure((nw + nr + nz + 2) * 4));
-        uint32_t* d_words = c->staging.as<uint32_t>();
+        HIPCHK(c->lde.ensure(std::max(C * N * 8, (nw + nr + nz + 2) * 4)));  // the recording's words wait in the (still unused) LDE buffer
+        uint32_t* d_words = c->lde.as<uint32_t>();
         uint32_t* d_offsets = d_words + nw;
         uint32_t* d_zeros = d_offsets + nr;
         HIPCHK(hipMemsetAsync(c->values.p, 0, C * n * 8, st));
@@ -527,21 +560,64 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         if (nr) HIPCHK(launch_expand_trace(d_words, d_offsets, nr, c->values.as<gl_t>(), n, st));
         if (nz) HIPCHK(launch_zero_cells(d_zeros, nz / 2, c->values.as<gl_t>(), n, st));
         d_values = c->values.as<gl_t>();
+    } else if (layout == 3) {
+        // The literal argument of starky's prove(): `Vec<PolynomialValues<F>>`, one heap allocation per column
+        // (/root/reference/src/aggregate_proof.rs:168-175) -- `trace` is a table of C column pointers.  C separate pageable copies of
+        // 64 KB would each be staged by the runtime (73 527 of them for FinalExp); instead host threads gather runs of columns into
+        // the two halves of the context's page-locked staging and every half goes up as one copy, the gather of the next half under
+        // the copy of this one.  Column-major device memory is just the columns back to back.
+        const uint64_t* const* cols = (const uint64_t* const*)trace;
+        const size_t col_bytes = n * 8;
+        if (c->host_staging_cap < 2 * col_bytes || c->host_staging_cap < ((size_t)32 << 20)) {
+            const size_t want = std::max<size_t>(2 * col_bytes, (size_t)128 << 20);
+            if (c->host_staging_cap < want) {
+                if (c->host_staging) (void)hipHostFree(c->host_staging);
+                c->host_staging = nullptr;
+                c->host_staging_cap = 0;
+                HIPCHK(hipHostMalloc(&c->host_staging, want, hipHostMallocDefault));
+                c->host_staging_cap = want;
+            }
+        }
+        for (auto& e : c->col_ev)
+            if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
+        const size_t half_bytes = c->host_staging_cap / 2, per_half = std::max<size_t>(1, half_bytes / col_bytes);
+        bool used[2] = {false, false};
+        unsigned h = 0;
+        for (size_t c0 = 0; c0 < C; c0 += per_half, h ^= 1) {
+            const size_t cnt = std::min(per_half, C - c0);
+            char* dst = (char*)c->host_staging + (size_t)h * half_bytes;
+            if (used[h]) HIPCHK(hipEventSynchronize(c->col_ev[h]));  // the copy that last read this half has run
+            const unsigned n_thr = cnt * col_bytes > ((size_t)8 << 20) ? 4 : 1;
+            auto gather = [&](unsigned w) {
+                for (size_t i = w; i < cnt; i += n_thr) memcpy(dst + i * col_bytes, cols[c0 + i], col_bytes);
+            };
+            std::vector<std::thread> helpers;
+            for (unsigned w = 1; w < n_thr; w++) {
+                try {
+                    helpers.emplace_back(gather, w);
+                } catch (const std::system_error&) {
+                    gather(w);
+                }
+            }
+            gather(0);
+            for (std::thread& t : helpers) t.join();
+            HIPCHK(hipMemcpyAsync(c->values.as<gl_t>() + c0 * n, dst, cnt * col_bytes, hipMemcpyHostToDevice, st));
+            HIPCHK(hipEventRecord(c->col_ev[h], st));
+            used[h] = true;
+        }
+        d_values = c->values.as<gl_t>();
     } else if (on_device && layout == 1) {
-        d_values = trace;
+        d_values = trace;  // the caller's memory: read only (the coefficients go to c->values)
     } else if (on_device) {
-        HIPCHK(c->values.ensure(C * n * 8));
         HIPCHK(launch_transpose(trace, c->values.as<gl_t>(), n, C, st));
         d_values = c->values.as<gl_t>();
     } else if (layout == 1) {
-        HIPCHK(c->values.ensure(C * n * 8));
         HIPCHK(hipMemcpyAsync(c->values.p, trace, C * n * 8, hipMemcpyHostToDevice, st));
         d_values = c->values.as<gl_t>();
     } else {
-        HIPCHK(c->values.ensure(C * n * 8));
-        HIPCHK(c->staging.ensure(C * n * 8));
-        HIPCHK(hipMemcpyAsync(c->staging.p, trace, C * n * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(launch_transpose(c->staging.as<gl_t>(), c->values.as<gl_t>(), n, C, st));
+        // row-major host rows: up into the LDE buffer (idle until the LDE kernel writes it), transposed from there
+        HIPCHK(hipMemcpyAsync(c->lde.p, trace, C * n * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(launch_transpose(c->lde.as<gl_t>(), c->values.as<gl_t>(), n, C, st));
         d_values = c->values.as<gl_t>();
     }
     HIPCHK(hipEventRecord(c->ev[evi++], st));
@@ -549,7 +625,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
 
     // ---- phase 1: IFFT + LDE (PolynomialBatch::from_values, App. A.3)
     HIPCHK(hipEventRecord(c->kev[4], st));
-    HIPCHK(run_lde(c, d_values, c->coeffs.as<gl_t>(), c->lde.as<gl_t>(), C, log_n, r, 0));
+    HIPCHK(run_lde(c, d_values, c->values.as<gl_t>(), c->lde.as<gl_t>(), C, log_n, r, 0));
     HIPCHK(hipEventRecord(c->kev[5], st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
     ranges.next("starkhip:trace_merkle");
@@ -558,12 +634,16 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(hipEventRecord(c->kev[0], st));
     if (c->hs) {  // pooled: the scheduler decides when this commitment runs and which others share its launch
         c->hash_requested = true;
-        HIPCHK(c->hs->hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st, c->hash_ready, c->hash_done, !HashService::is_big(log_n, r), c->urgent));
+        HIPCHK(c->hs->hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st, c->hash_ready, c->hash_done, !HashService::is_big(log_n, r), c->urgent,
+                           &c->hash_timing));
     } else if (c->opt_leaf_hash_form == 3) {
+        c->hash_timing.form = 3; c->hash_timing.group = 1;
         HIPCHK(launch_leaf_hash_lane(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
     } else if (use_row_form(c, C, log_N)) {
+        c->hash_timing.form = 1; c->hash_timing.group = 1;
         HIPCHK(launch_leaf_hash_row(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
     } else {
+        c->hash_timing.form = 0; c->hash_timing.group = 1;
         HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
     }
     HIPCHK(hipEventRecord(c->kev[1], st));
@@ -678,7 +758,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     std::vector<gl2_t> op_local(C), op_next(C), op_q(Q);
     HIPCHK(launch_ext_powers(c->zpow.as<gl2_t>(), zeta, n, st));
     HIPCHK(launch_ext_powers(c->gzpow.as<gl2_t>(), gzeta, n, st));
-    HIPCHK(launch_openings(c->coeffs.as<gl_t>(), C, n, c->zpow.as<gl2_t>(), c->gzpow.as<gl2_t>(), c->open_local.as<gl2_t>(),
+    HIPCHK(launch_openings(c->values.as<gl_t>(), C, n, c->zpow.as<gl2_t>(), c->gzpow.as<gl2_t>(), c->open_local.as<gl2_t>(),
                            c->open_next.as<gl2_t>(), st));
     HIPCHK(launch_openings(c->qcoef.as<gl_t>(), Q, n, c->zpow.as<gl2_t>(), nullptr, c->open_q.as<gl2_t>(), nullptr, st));
     HIPCHK(hipMemcpyAsync(op_local.data(), c->open_local.p, C * 16, hipMemcpyDeviceToHost, st));
@@ -699,7 +779,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     {
         HIPCHK(launch_ext_powers(c->ext_apow.as<gl2_t>(), fri_alpha, C + Q, st));
         gl2_t* comb = c->comb_out.as<gl2_t>();
-        HIPCHK(launch_fri_combine(c->coeffs.as<gl_t>(), C, n, c->ext_apow.as<gl2_t>(), comb_ppc, comb_chunks, c->comb_partial.as<gl2_t>(), st));
+        HIPCHK(launch_fri_combine(c->values.as<gl_t>(), C, n, c->ext_apow.as<gl2_t>(), comb_ppc, comb_chunks, c->comb_partial.as<gl2_t>(), st));
         HIPCHK(launch_ext_reduce(c->comb_partial.as<gl2_t>(), comb_chunks, n, comb, st));  // sum_j alpha^j trace_j
         HIPCHK(launch_fri_combine(c->qcoef.as<gl_t>(), Q, n, c->ext_apow.as<gl2_t>() + C, Q, 1, comb + n, st));  // alpha^(C+q) quotient_q
         std::vector<gl2_t> F1(n), tailq(n), F0(n), q0(n), q1(n);
@@ -885,7 +965,10 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     c->htimings[0] = (float)fs.ms;
     c->htimings[1] = (float)host_other.ms;
     (void)hipEventElapsedTime(&c->ktimings[0], c->kev[4], c->kev[5]);
-    (void)hipEventElapsedTime(&c->ktimings[1], c->kev[0], c->kev[1]);
+    // pooled: the commitment kernel's own duration on the scheduler's launch stream (kev[0] .. kev[1] on this context's stream would
+    // include the wait for its group to form)
+    if (c->hs) (void)hipEventElapsedTime(&c->ktimings[1], c->hash_timing.t0, c->hash_timing.t1);
+    else (void)hipEventElapsedTime(&c->ktimings[1], c->kev[0], c->kev[1]);
     (void)hipEventElapsedTime(&c->ktimings[2], c->kev[2], c->kev[3]);
     *proof_out = out;
     *proof_words = pl.total;
@@ -921,19 +1004,14 @@ int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t
     pl.final_len = geo.final_poly_len; pl.n_pis = P.n_pis; pl.arity_bits = cfg.arity_bits; pl.n_challenges = 2;
     pl.compute();
     struct Want { DevBuf* b; size_t bytes; };
-    const Want wants[] = {{&c->values, C * n * 8}, {&c->coeffs, C * n * 8}, {&c->lde, C * N * 8}, {&c->digests, digest_words(N) * 8},
+    const Want wants[] = {{&c->values, C * n * 8}, {&c->lde, std::max(C * N * 8, log_bytes + 64)}, {&c->digests, digest_words(N) * 8},
                           {&c->pis, std::max<size_t>(1, P.n_pis) * 8}, {&c->apow, 2 * (AIR_MAX_GROUP + 1) * 8}, {&c->chunk_scale, 2 * (size_t)n_chunks * 8},
                           {&c->partial, (size_t)n_chunks * 2 * size * 8}, {&c->qvals, 2 * size * 8}, {&c->qcoef, Q * n * 8}, {&c->qlde, Q * N * 8},
                           {&c->qdigests, digest_words(N) * 8}, {&c->zpow, n * 16}, {&c->gzpow, n * 16}, {&c->open_local, C * 16}, {&c->open_next, C * 16},
                           {&c->open_q, Q * 16}, {&c->ext_apow, (C + Q) * 16}, {&c->comb_partial, comb_chunks * n * 16}, {&c->comb_out, 2 * n * 16},
                           {&c->fri_coef, 2 * N * 8}, {&c->fri_vals, 2 * N * 8}, {&c->scale_tab, N * 8}, {&c->pow_state, 12 * 8}, {&c->pow_best, 8},
-                          {&c->qidx, cfg.num_query_rounds * 4}, {&c->gather_t, cfg.num_query_rounds * pl.query_words * 8},
-                          {&c->staging, log_bytes + 64}};
-    for (const Want& w : wants) {
-        // traces that arrive as column-major device memory are proven where they lie: no trace buffer, no upload staging (4.8 GB each for FinalExp)
-        if (device_traces && (w.b == &c->values || w.b == &c->staging)) continue;
-        HIPCHK(w.b->ensure(w.bytes));
-    }
+                          {&c->qidx, cfg.num_query_rounds * 4}, {&c->gather_t, cfg.num_query_rounds * pl.query_words * 8}};
+    for (const Want& w : wants) HIPCHK(w.b->ensure(w.bytes));
     size_t len = N;
     for (size_t l = 0; l < L; l++) {
         const unsigned ab = geo.arities[l];
@@ -963,11 +1041,10 @@ int lde_batch(Ctx* c, const uint64_t* values, size_t n_cols, unsigned log_n, uns
     if ((rc = ensure_tables(c, log_n, rate_bits, 0))) return rc;
     const size_t n = (size_t)1 << log_n, N = n << rate_bits;
     HIPCHK(c->values.ensure(n_cols * n * 8));
-    HIPCHK(c->coeffs.ensure(n_cols * n * 8));
     HIPCHK(c->lde.ensure(n_cols * N * 8));
     HIPCHK(hipMemcpyAsync(c->values.p, values, n_cols * n * 8, hipMemcpyHostToDevice, c->st));
-    HIPCHK(run_lde(c, c->values.as<gl_t>(), c->coeffs.as<gl_t>(), c->lde.as<gl_t>(), n_cols, log_n, rate_bits, 0));
-    if (coeffs_out) HIPCHK(hipMemcpyAsync(coeffs_out, c->coeffs.p, n_cols * n * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(run_lde(c, c->values.as<gl_t>(), c->values.as<gl_t>(), c->lde.as<gl_t>(), n_cols, log_n, rate_bits, 0));
+    if (coeffs_out) HIPCHK(hipMemcpyAsync(coeffs_out, c->values.p, n_cols * n * 8, hipMemcpyDeviceToHost, c->st));  // in place
     HIPCHK(stream_wait(c));
     if (lde_out) {
         // device layout is coset-major; hand back NATURAL point order i = k * R + s

@@ -105,9 +105,10 @@ HashService::Stats HashService::stats() {
 }
 
 hipError_t HashService::hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st, hipEvent_t ready,
-                             hipEvent_t done, bool announced, bool urgent) {
+                             hipEvent_t done, bool announced, bool urgent, Timing* timing) {
     hipError_t e = hipEventRecord(ready, st);
     Req r;
+    r.timing = timing;
     r.mat = mat; r.digests = digests; r.n_cols = n_cols; r.log_n = log_n; r.rate_bits = rate_bits; r.ready = ready; r.done = done;
     r.big = is_big(log_n, rate_bits);
     r.urgent = urgent;
@@ -133,16 +134,38 @@ void HashService::drain(std::vector<hipEvent_t>& evs) {
     evs.clear();
 }
 
-void HashService::launch_big(Req* r, bool lane) {
+void HashService::launch_big(Req* r, bool lane, unsigned group) {
     hipStream_t s = (r->urgent && st_high_) ? st_high_ : st_;
     hipError_t e = hipSuccess;
     if (lane) s = pick_small_stream(&e);  // lane-form grids are a quarter of the chip each: they must overlap, not queue in one stream
     if (e == hipSuccess) e = hipStreamWaitEvent(s, r->ready, 0);
+    if (r->timing) {
+        r->timing->form = lane ? 3 : 0;
+        r->timing->group = group;
+        if (e == hipSuccess && r->timing->t0) e = hipEventRecord(r->timing->t0, s);
+    }
     if (e == hipSuccess) e = lane ? launch_leaf_hash_lane(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s)
                                   : launch_leaf_hash(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s);
+    if (e == hipSuccess && r->timing && r->timing->t1) e = hipEventRecord(r->timing->t1, s);
     if (e == hipSuccess) e = hipEventRecord(r->done, s);
     r->err = e;
-    if (e == hipSuccess) running_big_.push_back(r->done);
+    if (e == hipSuccess) track(running_big_, r->done);
+}
+
+// Done events of launches that may still be executing.  Only policy 1 (exclusive classes) ever waits for them, so only policy 1
+// keeps them; events whose launch has completed are dropped first (a context re-records its event with its next proof: a stale
+// entry would make drain() wait for that later proof, and a pool that proves one class only would grow the list for ever).
+void HashService::track(std::vector<hipEvent_t>& evs, hipEvent_t done) {
+    if (policy != 1) return;
+    size_t keep = 0;
+    for (hipEvent_t ev : evs) {
+        if (ev == done) continue;
+        const bool finished = hipEventQuery(ev) == hipSuccess;
+        (void)hipGetLastError();  // hipErrorNotReady is not an error
+        if (!finished) evs[keep++] = ev;
+    }
+    evs.resize(keep);
+    evs.push_back(done);
 }
 
 // A stream with nothing pending (a merged launch must not wait in stream order behind an earlier window's latency chain); all
@@ -186,6 +209,12 @@ void HashService::launch_small(std::vector<Req*>& reqs) {
                 e = hipStreamWaitEvent(s, g[at + i]->ready, 0);
             }
             const bool row_form = row_leaves_ && (((size_t)1 << (g[0]->log_n + g[0]->rate_bits)) <= row_leaves_);
+            for (size_t i = 0; i < cnt; i++)
+                if (Timing* t = g[at + i]->timing) {
+                    t->form = row_form ? 1 : 2;
+                    t->group = (unsigned)cnt;
+                    if (e == hipSuccess && t->t0) e = hipEventRecord(t->t0, s);
+                }
             if (e == hipSuccess && row_form) {
                 // the row form (16 lanes per leaf): shortest chain per leaf at 2.8 x the chip time.  Measured with every small commitment
                 // of a pool in it: one signature 0.36 -> 0.38 s, a batch of 8 3.8 -> 3.3 signatures/s; only the tiny ones take it by default
@@ -196,9 +225,10 @@ void HashService::launch_small(std::vector<Req*>& reqs) {
             }
             for (size_t i = 0; i < cnt; i++) {
                 Req* r = g[at + i];
+                if (e == hipSuccess && r->timing && r->timing->t1) e = hipEventRecord(r->timing->t1, s);
                 if (e == hipSuccess) e = hipEventRecord(r->done, s);
                 r->err = e;
-                if (e == hipSuccess) running_small_.push_back(r->done);
+                if (e == hipSuccess) track(running_small_, r->done);
             }
             std::lock_guard<std::mutex> lock(mu_);
             stats_.small_launches += row_form ? cnt : 1;
@@ -248,7 +278,7 @@ void HashService::run() {
             wait_for.swap(running_small_);
             lk.unlock();
             if (policy == 1) drain(wait_for);  // exclusive classes: the small window has left the chip
-            for (Req* r : group) launch_big(r, big_lane_ && group.size() >= 2);
+            for (Req* r : group) launch_big(r, big_lane_ && group.size() >= 2, (unsigned)group.size());
             lk.lock();
             for (Req* r : group) r->state = r->err == hipSuccess ? 1 : 2;
             stats_.big_launches += group.size();
@@ -302,7 +332,7 @@ extern void set_thread_trace_threads(int n);  // capi.cpp: trace_threads() of th
 
 namespace {
 
-enum JobKind { JOB_DENSE, JOB_COMPACT, JOB_WITNESS };
+enum JobKind { JOB_DENSE, JOB_COMPACT, JOB_WITNESS, JOB_COLUMNS };
 
 struct Job {
     uint64_t id = 0;
@@ -315,6 +345,7 @@ struct Job {
     const uint64_t* pis = nullptr;
     size_t n_pis = 0;
     uint64_t pow = 0;
+    std::vector<const uint64_t*> columns;  // JOB_COLUMNS: the caller's column pointers (the table is copied at submit, the columns are not)
     std::vector<uint32_t> operands;   // witness jobs
     void* own_log = nullptr;          // witness jobs: the recording, freed when proven
     std::vector<uint64_t> own_pis, own_rows;  // own_rows: the toy AIR's generator writes plain rows (it does not record)
@@ -327,6 +358,8 @@ struct Job {
     float phase_ms[STARKHIP_N_PHASES] = {0};
     float kernel_ms[3] = {0};
     float host_ms[2] = {0};
+    int leaf_hash_form = 0;
+    unsigned leaf_hash_group = 1;
     double t[5] = {0, 0, 0, 0, 0};  // submit, generation start / end, proof start / end (seconds since the pool was created)
 };
 
@@ -375,6 +408,8 @@ struct Pool {
     bool stop = false;
     unsigned gen_threads = 0, trace_threads_cfg = 0, gen_running = 0, cpus = 1;
     size_t big_recordings_started = 0, big_proofs_done = 0;  // under mu
+    size_t big_in_gen = 0;  // FinalExp-class witness jobs queued for, or in, their recording (under mu)
+    unsigned waiters = 0;   // callers inside pool_wait (under mu): pool_destroy lets them leave before it frees anything
     std::map<int, int> idle_big, idle_small;                 // idle contexts by the AIR they proved last (under mu)
     unsigned stream_priority = 0;
     bool warm_device_traces = false;  // warm_up == 2: the caller's traces are column-major device memory: no trace buffers are reserved
@@ -475,9 +510,12 @@ struct Pool {
                 {
                     std::lock_guard<std::mutex> g(mu);
                     gen_running--;
+                    if (j->big && big_in_gen > 0) big_in_gen--;
                     j->t[2] = now();
                 }
                 finish(j, rc);
+                cv_big.notify_all();  // contexts that are shutting down re-check whether a generator may still feed them
+                cv_small.notify_all();
                 continue;
             }
             std::lock_guard<std::mutex> g(mu);
@@ -496,8 +534,10 @@ struct Pool {
             }
             j->pis = j->own_pis.data();
             j->n_pis = j->own_pis.size();
+            if (j->big && big_in_gen > 0) big_in_gen--;
             (j->big ? q_big : q_small).push_back(j);
-            (j->big ? cv_big : cv_small).notify_all();
+            cv_big.notify_all();
+            cv_small.notify_all();
         }
     }
 
@@ -558,7 +598,9 @@ struct Pool {
                             q.erase(it);
                             break;
                         }
-                    } else if (stop) {
+                    } else if (stop && q_gen.empty() && gen_running == 0) {
+                        // (a witness job still queued for, or in, its recording lands in q_big / q_small later: "runs what is queued
+                        // to the end first" holds for those too, so a context leaves only when no generator can hand it anything)
                         idle[last_air]--;
                         return;
                     }
@@ -573,7 +615,9 @@ struct Pool {
                 // stream_priority 1: the LAST wave of FinalExp-class proofs -- no more of them waiting than there are contexts --
                 // is the tail every other proof has finished before; it runs on high-priority streams.  The first wave does not:
                 // strict priority starves the small proofs (a MillerLoop upload measured at 2 s behind four urgent FinalExp proofs)
-                urgent = big && stream_priority == 1 && q.size() < big_ctx.size();
+                // (big jobs still queued for, or in, their recording count as waiting: with submit_witness they trickle into q_big
+                // one at a time, and q_big alone would make the FIRST wave look like the last)
+                urgent = big && stream_priority == 1 && q.size() + big_in_gen < big_ctx.size();
             }
             if (big && stream_priority == 1) (void)ctx_set_urgent(c, urgent);
             int rc;
@@ -584,8 +628,8 @@ struct Pool {
             ctx_hash_request_reset(c);
             try {
                 const AirInfo* a = air_get(j->air);
-                rc = prove(c, *a, j->cfg, j->trace, j->n_rows, j->kind == JOB_COMPACT ? 2 : j->layout, j->on_device, j->pis, j->n_pis, j->pow, &j->proof,
-                           &j->words);
+                rc = prove(c, *a, j->cfg, j->trace, j->n_rows, j->kind == JOB_COMPACT ? 2 : j->kind == JOB_COLUMNS ? 3 : j->layout, j->on_device, j->pis,
+                           j->n_pis, j->pow, &j->proof, &j->words);
             } catch (const std::bad_alloc&) {
                 rc = STARKHIP_ERR_OOM;
             } catch (const std::exception&) {
@@ -601,6 +645,7 @@ struct Pool {
             memcpy(j->phase_ms, ctx_timings(c), sizeof j->phase_ms);
             memcpy(j->kernel_ms, ctx_kernel_timings(c), sizeof j->kernel_ms);
             memcpy(j->host_ms, ctx_host_timings(c), sizeof j->host_ms);
+            ctx_commit_info(c, &j->leaf_hash_form, &j->leaf_hash_group);
             if (j->own_log) {
                 starkhip_trace_log_free(j->own_log);
                 j->own_log = nullptr;
@@ -690,6 +735,10 @@ void pool_destroy(Pool* p) {
     p->cv_big.notify_all();
     p->cv_small.notify_all();
     for (std::thread& t : p->threads) t.join();  // queued jobs are still run to completion: their callers may be waiting
+    {   // every job is done now, so every caller blocked in pool_wait is on its way out: let them go before anything is freed
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_done.wait(lk, [&] { return p->waiters == 0; });
+    }
     for (Ctx* c : p->big_ctx) ctx_destroy(c);
     for (Ctx* c : p->small_ctx) ctx_destroy(c);
     p->hs.reset();
@@ -717,6 +766,7 @@ static int pool_enqueue(Pool* p, Job* j, uint64_t* ticket) {
     p->jobs[j->id] = j;
     *ticket = j->id;
     if (j->kind == JOB_WITNESS) {
+        if (j->big) p->big_in_gen++;
         p->q_gen.push_back(j);
         p->cv_gen.notify_one();
     } else {
@@ -735,6 +785,26 @@ int pool_submit(Pool* p, int air, const starkhip_config_t* cfg, const uint64_t* 
     if (!j) return STARKHIP_ERR_OOM;
     j->air = air; j->cfg = *cfg; j->kind = JOB_DENSE; j->trace = trace; j->n_rows = n_rows; j->n_cols = n_cols; j->layout = layout;
     j->on_device = on_device; j->pis = pis; j->n_pis = n_pis; j->pow = pow;
+    return pool_enqueue(p, j, ticket);
+}
+
+int pool_submit_columns(Pool* p, int air, const starkhip_config_t* cfg, const uint64_t* const* columns, size_t n_rows, size_t n_cols,
+                        const uint64_t* pis, size_t n_pis, uint64_t pow, uint64_t* ticket) {
+    const AirInfo* a = air_get(air);
+    if (!a) return STARKHIP_ERR_BAD_AIR;
+    if (!cfg || !columns || !ticket || (n_pis && !pis) || n_cols != a->cols) return STARKHIP_ERR_BAD_SHAPE;
+    for (size_t i = 0; i < n_cols; i++)
+        if (!columns[i]) return STARKHIP_ERR_BAD_SHAPE;
+    Job* j = new (std::nothrow) Job();
+    if (!j) return STARKHIP_ERR_OOM;
+    try {
+        j->columns.assign(columns, columns + n_cols);
+    } catch (const std::bad_alloc&) {
+        delete j;
+        return STARKHIP_ERR_OOM;
+    }
+    j->air = air; j->cfg = *cfg; j->kind = JOB_COLUMNS; j->trace = (const uint64_t*)j->columns.data(); j->n_rows = n_rows; j->n_cols = n_cols;
+    j->pis = pis; j->n_pis = n_pis; j->pow = pow;
     return pool_enqueue(p, j, ticket);
 }
 
@@ -772,8 +842,11 @@ int pool_wait(Pool* p, uint64_t ticket, uint64_t** proof, size_t* words, starkhi
         auto it = p->jobs.find(ticket);
         if (it == p->jobs.end()) return STARKHIP_ERR_BAD_SHAPE;
         j = it->second;
+        p->waiters++;
         p->cv_done.wait(lk, [&] { return j->state == 2; });
-        p->jobs.erase(it);
+        p->jobs.erase(ticket);
+        p->waiters--;
+        if (p->stop) p->cv_done.notify_all();
     }
     const int rc = j->rc;
     if (info) {
@@ -782,6 +855,8 @@ int pool_wait(Pool* p, uint64_t ticket, uint64_t** proof, size_t* words, starkhi
         memcpy(info->host_ms, j->host_ms, sizeof info->host_ms);
         info->t_submit = j->t[0]; info->t_generate_start = j->t[1]; info->t_generate_end = j->t[2]; info->t_prove_start = j->t[3];
         info->t_done = j->t[4];
+        info->leaf_hash_form = j->leaf_hash_form;
+        info->leaf_hash_group = j->leaf_hash_group;
     }
     if (rc == STARKHIP_OK && proof && words) {
         *proof = j->proof;
@@ -793,6 +868,25 @@ int pool_wait(Pool* p, uint64_t ticket, uint64_t** proof, size_t* words, starkhi
     }
     delete j;
     return rc;
+}
+
+// What the pool holds: device memory of all its contexts, their page-locked staging; per FinalExp-class context for sizing.
+// Read between proofs (the contexts grow their buffers only inside prove()).
+int pool_reservation(Pool* p, starkhip_pool_reservation_t* out) {
+    memset(out, 0, sizeof *out);
+    for (Ctx* c : p->big_ctx) {
+        out->device_bytes += ctx_device_bytes(c);
+        out->pinned_host_bytes += ctx_pinned_bytes(c);
+        out->big_context_device_bytes = std::max<uint64_t>(out->big_context_device_bytes, ctx_device_bytes(c));
+    }
+    for (Ctx* c : p->small_ctx) {
+        out->device_bytes += ctx_device_bytes(c);
+        out->pinned_host_bytes += ctx_pinned_bytes(c);
+        out->small_context_device_bytes = std::max<uint64_t>(out->small_context_device_bytes, ctx_device_bytes(c));
+    }
+    out->big_contexts = (unsigned)p->big_ctx.size();
+    out->small_contexts = (unsigned)p->small_ctx.size();
+    return STARKHIP_OK;
 }
 
 int pool_stats(Pool* p, starkhip_pool_stats_t* out) {

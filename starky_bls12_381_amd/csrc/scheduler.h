@@ -41,8 +41,16 @@ class HashService {
     // Leaf digests of the coset-major LDE `mat` (kernels_hash.hip: launch_leaf_hash) into `digests`, ordered after everything
     // enqueued on `st` so far; when this returns, `st` has been made to wait for the launch (the caller goes on enqueueing).
     // `ready` / `done` are events owned by the caller's context.
+    // `timing` (optional): two timing-enabled events of the caller's, recorded on the LAUNCH stream right before and after the kernel
+    // that hashes this commitment (its own duration, not the wait for its group), and how it went out: form 0 = quad, 1 = row,
+    // 2 = one grid merged with other proofs' commitments (quad form), 3 = lane; group = commitments launched side by side with it.
+    struct Timing {
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        int form = 0;
+        unsigned group = 1;
+    };
     hipError_t hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st, hipEvent_t ready,
-                    hipEvent_t done, bool announced, bool urgent = false);
+                    hipEvent_t done, bool announced, bool urgent = false, Timing* timing = nullptr);
 
     static bool is_big(unsigned log_n, unsigned rate_bits) { return log_n + rate_bits >= 15; }  // >= 2048 waves: fills every SIMD twice
     double gather_ms = 25.0;  // how long a small window waits for announced proofs that have not reached their commitment
@@ -76,11 +84,13 @@ class HashService {
         int state = 0;  // 0 queued, 1 launched, 2 failed
         hipError_t err = hipSuccess;
         double t_arrive = 0;
+        Timing* timing = nullptr;
     };
     void run();
-    void launch_big(Req* r, bool lane);
+    void launch_big(Req* r, bool lane, unsigned group);
     void launch_small(std::vector<Req*>& reqs);
     void drain(std::vector<hipEvent_t>& evs);
+    void track(std::vector<hipEvent_t>& evs, hipEvent_t done);
 
     int device_;
     hipStream_t st_ = nullptr, st_high_ = nullptr;  // big commitments: ordinary / urgent (high-priority stream)

@@ -189,6 +189,100 @@ def test_final_exp_in_lane_form_groups_match_the_oracle_digest(monkeypatch):
     assert stats["big_commit_launches"] == 8
 
 
+def _signature_points(count, seed):
+    """`count` different valid (pk, H(m), signature) triples on the curve (signature.synthetic_signatures over the reference's vector)."""
+    from bls_util import native_vectors
+    from starky_bls12_381_amd import signature as G
+    return G.synthetic_signatures(count, native_vectors()["bls_signature"], seed=seed)
+
+
+def test_batch_regime_miller_and_precomp_beside_a_lane_group_match_the_oracle(monkeypatch):
+    """The regime the batch-of-signatures figure is measured in (tools/bench_signature.py, build/signature_demo --batch): MillerLoop and
+    PairingPrecomp commitments merged in leaf_hash_multi_kernel windows WHILE a FinalExp lane-form group is on the chip.  Two
+    MillerLoop + two PairingPrecomp witness jobs and four FinalExp jobs (the benchmark's first seeded input) go in together;
+    every small proof equals the CPU oracle's proof of the same trace byte for byte, every FinalExp proof the oracle's digest."""
+    monkeypatch.setenv("STARKHIP_POOL_BIG_LANE", "1")   # lane-form groups on four big contexts (pools of five or more do it by themselves)
+    want_fe = open(os.path.join(GOLDEN, "final_exp_seed_5eed0001_proof.sha256")).read().split()[0]
+    x_fe = random_fp12(0x5EED0001)
+    sigs = _signature_points(2, 0x5EED3400)
+    ml = [(pk[0], pk[1], hm[0], hm[1], hm[2]) for pk, hm, _ in sigs]     # miller_loop_main(pk, H(m)), src/aggregate_proof.rs:117-148
+    pp = [(sig[0], sig[1], sig[2]) for _, _, sig in sigs]                  # calc_pairing_precomp(signature), :23-69
+    pool = S.ProofPool(0, big_contexts=4, small_contexts=4, generator_threads=4, warm_up=1)
+    try:
+        t_fe = [pool.submit_witness(S.AIR_FINAL_EXP, x_fe) for _ in range(4)]
+        t_ml = [pool.submit_witness(S.AIR_MILLER_LOOP, *a) for a in ml]
+        t_pp = [pool.submit_witness(S.AIR_PAIRING_PRECOMP, *a) for a in pp]
+        got_ml = [pool.wait(t) for t in t_ml]
+        got_pp = [pool.wait(t) for t in t_pp]
+        got_fe = [pool.wait(t) for t in t_fe]
+        stats = pool.stats()
+    finally:
+        pool.close()
+    assert [hashlib.sha256(p.tobytes()).hexdigest() for p, _ in got_fe] == [want_fe] * 4
+    assert {info["leaf_hash_form"] for _, info in got_fe} == {"lane"} and max(info["leaf_hash_group"] for _, info in got_fe) >= 2
+    assert stats["small_commit_requests"] == 4 and stats["big_commit_launches"] == 4
+    # the small commitments went through the scheduler's merged windows (quad form, grid.y = proofs), beside the big ones
+    assert {info["leaf_hash_form"] for _, info in got_ml + got_pp} == {"merged"}
+    fe_span = (min(info["timeline_s"][3] for _, info in got_fe), max(info["timeline_s"][4] for _, info in got_fe))
+    assert all(fe_span[0] < info["timeline_s"][4] and info["timeline_s"][3] < fe_span[1] for _, info in got_ml + got_pp)   # they overlapped in time
+    for air, gen, args, got in ((S.AIR_MILLER_LOOP, S.trace_miller_loop, ml, got_ml), (S.AIR_PAIRING_PRECOMP, S.trace_pairing_precomp, pp, got_pp)):
+        cfg = S.StarkConfig.for_air(air)
+        for a, (proof, _) in zip(args, got):
+            trace, pis = gen(*a)
+            assert np.array_equal(proof, O.prove(S.air_program(air), cfg, S.trace_rows_to_poly_values(trace), pis))
+
+
+def test_prove_from_separately_allocated_columns_matches_the_oracle(prover):
+    """starky's literal `prove(stark, &config, trace_poly_values, ..)`: `Vec<PolynomialValues<F>>` is one heap allocation per column
+    (src/aggregate_proof.rs:57-65 for FP12MulStark).  60 285 separately allocated numpy columns through starkhip_prove_columns and
+    through starkhip_pool_submit_columns: the oracle's bytes both times; a NULL column or a wrong count is refused."""
+    import ctypes as C
+    air = S.AIR_FP12_MUL
+    cfg = S.StarkConfig.for_air(air)
+    trace, pis = S.trace_fp12_mul(random_fp12(0x5EED3500), random_fp12(0x5EED3501))
+    columns = [trace[:, c].copy() for c in range(trace.shape[1])]   # 60 285 separate allocations
+    assert len({c.ctypes.data for c in columns}) == len(columns)
+    want = O.prove(S.air_program(air), cfg, S.trace_rows_to_poly_values(trace), pis)
+    assert np.array_equal(prover.prove_columns(air, cfg, columns, pis), want)
+    pool = S.ProofPool(0, big_contexts=1, small_contexts=2, generator_threads=1)
+    try:
+        t1 = pool.submit_columns(air, cfg, columns, pis)
+        t2 = pool.submit_columns(air, cfg, columns, pis)
+        assert np.array_equal(pool.wait(t1)[0], want) and np.array_equal(pool.wait(t2)[0], want)
+        with pytest.raises(S.StarkhipError) as e:
+            pool.submit_columns(air, cfg, columns[:-1], pis)
+        assert e.value.code == S.ERR_BAD_SHAPE
+    finally:
+        pool.close()
+    # a bigger shape, many halves of the staging: PairingPrecomp (29 376 columns x 1024 rows = 240 MB)
+    air = S.AIR_PAIRING_PRECOMP
+    cfg = S.StarkConfig.for_air(air)
+    trace, pis = S.trace_pairing_precomp(*_precomp_args(0x5EED3510))
+    columns = [trace[:, c].copy() for c in range(trace.shape[1])]
+    assert np.array_equal(prover.prove_columns(air, cfg, columns, pis), prover.prove(air, cfg, trace, pis))
+    table = (C.c_void_p * len(columns))(*[c.ctypes.data for c in columns])
+    table[17] = None
+    out, words = C.POINTER(C.c_uint64)(), C.c_size_t()
+    rc = S.lib.starkhip_prove_columns(prover._ctx, air, C.byref(cfg), table, trace.shape[0], len(columns), pis.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      pis.size, S.POW_SEARCH, C.byref(out), C.byref(words))
+    assert rc == S.ERR_BAD_SHAPE
+
+
+def test_pool_reports_its_reservation():
+    """starkhip_pool_reservation: a warmed FinalExp-class context holds the trace columns (the coefficients replace them in place), the
+    LDE (uploads are staged in it) and small buffers -- under 26 GB, where rounds 1-3 held 30 (values + coefficients + staging + LDE)."""
+    pool = S.ProofPool(0, big_contexts=1, small_contexts=1, generator_threads=1, warm_up=1)
+    try:
+        r = pool.reservation()
+    finally:
+        pool.close()
+    C_, n = S.air_columns(S.AIR_FINAL_EXP), 8192
+    assert r["big_contexts"] == 1 and r["small_contexts"] == 1
+    assert 8 * C_ * n * 5 <= r["big_context_device_bytes"] <= 26e9
+    assert r["device_bytes"] >= r["big_context_device_bytes"] + r["small_context_device_bytes"] > r["big_context_device_bytes"]
+    assert r["pinned_host_bytes"] >= 200 << 20
+
+
 def test_cpp_demo_proves_a_batch_on_the_pool():
     """tools/signature_demo.cpp --batch 2: compiled host code above the C ABI only; 12 proofs in flight, all verified, linked and
     bound to their statements (exit code 0)."""

@@ -64,14 +64,18 @@ def test_batch_of_eight_different_signatures_end_to_end():
     sigs = G.synthetic_signatures(batch, native_vectors()["bls_signature"], seed=0x8516)
     mine = G.plan_batch(batch, 1)[0]
     assert len(mine) == 48
-    args, natives = G.job_arguments(sigs, mine)
-    provers = [S.Prover(0) for _ in range(6)]
+    # the product path, exactly what tools/bench_signature.py times: signature.one_step on the library's proof pool
+    # (run_jobs_pool: submit_witness per job, natives on host threads, merged commitments, lane-form groups for the FinalExp proofs)
+    pool = S.ProofPool(0, big_contexts=6, small_contexts=12, stream_priority=1, warm_up=1)
     try:
-        results, stats = G.run_jobs(provers, mine, args, gen_threads=6)
+        elapsed, results, stats, sigs_seen, natives = G.one_step(None, batch, pool, mine, sigs)
+        pstats = pool.stats()
     finally:
-        for pv in provers:
-            pv.close()
-    assert sorted(results) == sorted(mine)
+        pool.close()
+    assert sorted(results) == sorted(mine) and elapsed > 0
+    assert all(np.array_equal(a, b) for s0, s1 in zip(sigs, sigs_seen) for a, b in zip(s0, s1))
+    assert pstats["big_commit_launches"] == 8 and pstats["small_commit_requests"] == 40
+    assert pstats["max_merged_commitments"] >= 2   # small commitments shared launches
     for (_, name), (air, proof, cfg) in results.items():
         assert air == A.JOB_AIR[name]
         S.verify_stark_proof(air, cfg, proof)

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -112,7 +113,23 @@ int main() {
             uint64_t t = 0;
             CHECK(starkhip_pool_submit_witness(pool, STARKHIP_AIR_FP12_MUL, nullptr, subs[0].ops.data(), 288, STARKHIP_POW_SEARCH, &t) == STARKHIP_OK);
         }
+        // ... and witness jobs that are still queued for (or in) their RECORDING when the pool is destroyed: the contexts must not
+        // leave before the generators have handed them over, and a caller blocked in wait on one of them must get its proof
+        uint64_t t_late[3];
+        for (int k = 0; k < 3; k++)
+            CHECK(starkhip_pool_submit_witness(pool, k == 1 ? STARKHIP_AIR_PAIRING_PRECOMP : STARKHIP_AIR_MILLER_LOOP, nullptr,
+                                               subs[k == 1 ? 4 : 7].ops.data(), k == 1 ? 72 : 96, STARKHIP_POW_SEARCH, &t_late[k]) == STARKHIP_OK);
+        int late_rc = -100;
+        size_t late_words = 0;
+        std::thread late([&] {
+            uint64_t* proof = nullptr;
+            late_rc = starkhip_pool_wait(pool, t_late[2], &proof, &late_words, nullptr);
+            if (late_rc == STARKHIP_OK) starkhip_free(proof);
+        });
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));  // the waiter is inside pool_wait (its job's recording takes longer)
         starkhip_pool_destroy(pool);
+        late.join();
+        CHECK(late_rc == STARKHIP_OK && late_words == 4 + (size_t)starkhip_air_public_inputs(STARKHIP_AIR_MILLER_LOOP));
         uint64_t bs[5];
         starkhip_proof_blob_stats(bs);
         CHECK(bs[3] > 0);                    // warmed contexts served proofs from the arena

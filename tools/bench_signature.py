@@ -4,6 +4,7 @@
 BASELINE.json configs[3] (six proofs of one signature sharded over GPUs) and configs[4] (a batch of 8 signatures = 48 proofs):
 
     python tools/bench_signature.py --batch 8                                   # one GPU
+    python tools/bench_signature.py --gpus N --batch 8                          # starts itself under torch.distributed.run (a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         tools/bench_signature.py --gpus N --batch 8                             # one process per GPU, RCCL
 
@@ -54,6 +55,12 @@ def main():
     ap.add_argument("--collect", action="store_true", help="N > 1: gather every proof on every rank afterwards (raw buffers) and check all signatures")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python tools/bench_signature.py --gpus N` by itself: one child `python -m torch.distributed.run ...` (never an exec, and
+        # before torch or the GPU is touched in this process); its output is relayed, its exit code returned
+        from bench import self_launch
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus, script=__file__))
 
     import torch
     import starky_bls12_381_amd as S

@@ -19,7 +19,12 @@ rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -o kt -- python3 $R/bench.py --
 rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_fetch -o fetch -- $ONE > $OUT/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/prof_write -o write -- $ONE > $OUT/prof_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_BUSY_CYCLES -d $OUT/prof_sq -o sq -- $ONE > $OUT/prof_sq.log 2>&1
-rocprofv3 --kernel-trace -d $OUT/prof_ov -o ov -- python3 $R/bench.py --steps 24 --warmup 2 --no-cpu-baseline --no-boundary > $OUT/prof_ov.log 2>&1
+# the default run (eight in flight, lane-form commitment groups): kernel trace, then the counters of leaf_hash_lane_kernel in passes of their own
+rocprofv3 --kernel-trace --stats -d $OUT/prof_ov -o ov -- python3 $R/bench.py --steps 24 --warmup 2 --no-cpu-baseline --no-boundary --no-solo > $OUT/prof_ov.log 2>&1
+LANE="python3 $R/bench.py --steps 8 --warmup 1 --no-cpu-baseline --no-boundary --no-solo"
+rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_lfetch -o fetch -- $LANE > $OUT/prof_lfetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/prof_lwrite -o write -- $LANE > $OUT/prof_lwrite.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_BUSY_CYCLES -d $OUT/prof_lsq -o sq -- $LANE > $OUT/prof_lsq.log 2>&1
 cd $R
 db() { find $OUT/$1 -name "*results.db" | head -1; }
 python3 tools/rocprof_export.py stats $(db prof_kt) $OUT/${TAG}_kernel_stats.csv
@@ -27,12 +32,17 @@ python3 tools/rocprof_export.py bygrid $(db prof_kt) $OUT/${TAG}_kernel_stats_by
 python3 tools/rocprof_export.py pmc $(db prof_fetch) $OUT/${TAG}_pmc_fetch_size.csv
 python3 tools/rocprof_export.py pmc $(db prof_write) $OUT/${TAG}_pmc_write_size.csv
 python3 tools/rocprof_export.py pmc $(db prof_sq) $OUT/${TAG}_pmc_sq_counters.csv
-python3 tools/pmc_traffic.py $(db prof_fetch) $(db prof_write) $OUT/${TAG}_pmc_traffic.json
+python3 tools/rocprof_export.py pmc $(db prof_lfetch) $OUT/${TAG}_pmc_fetch_size_in_flight.csv
+python3 tools/rocprof_export.py pmc $(db prof_lwrite) $OUT/${TAG}_pmc_write_size_in_flight.csv
+python3 tools/rocprof_export.py pmc $(db prof_lsq) $OUT/${TAG}_pmc_sq_counters_in_flight.csv
+python3 tools/pmc_traffic.py $OUT/${TAG}_pmc_traffic.json $(db prof_fetch) $(db prof_write) $(db prof_lfetch) $(db prof_lwrite)
 python3 tools/kernel_overlap.py $(db prof_ov) > $OUT/${TAG}_kernel_overlap.txt
 python3 tools/rocprof_export.py bygrid $(db prof_ov) $OUT/${TAG}_kernel_stats_by_grid_in_flight.csv
+python3 tools/rocprof_export.py stats $(db prof_ov) $OUT/${TAG}_kernel_stats_in_flight.csv
+tail -1 $OUT/prof_ov.log > $OUT/${TAG}_bench_in_flight_under_rocprof.json
 python3 tools/lane_group_stats.py $(db prof_ov) $OUT/${TAG}_lane_groups.json > /dev/null
 tail -1 $OUT/prof_kt.log > $OUT/${TAG}_bench_under_rocprof.json
-rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq $OUT/prof_ov
+rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq $OUT/prof_ov $OUT/prof_lfetch $OUT/prof_lwrite $OUT/prof_lsq
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rate_bench tools/valu_rate_bench.hip && /tmp/valu_rate_bench > $OUT/${TAG}_valu_rates.txt 2>&1 || true
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 head -8 $OUT/${TAG}_kernel_stats.csv; cat $OUT/${TAG}_kernel_overlap.txt; cat $OUT/${TAG}_pmc_traffic.json | head -40; tail -c 3000 $OUT/${TAG}_bench.json
