@@ -64,7 +64,19 @@ asan-pool-test: tests/tsan_pool_main.cpp $(ASAN_SRCS) $(HDRS)
 	g++ $(filter-out -shared -fPIC,$(ASAN_FLAGS)) -o build/asan/asan_pool tests/tsan_pool_main.cpp $(ASAN_SRCS) -lpthread
 	ASAN_OPTIONS=detect_leaks=1:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 build/asan/asan_pool
 
+# Experiment builds of the device code for A/B runs on one box: `make variant NAME=x DEFS="-D..."` -> build/x/libstarkhip_x.so, selected
+# at run time with STARKHIP_LIBRARY=build/x/libstarkhip_x.so (e.g. NAME=nomfma DEFS=-DSTARKHIP_LANE_NO_MFMA: the lane-form leaf hash with every
+# round as multiply-add chains; NAME=prio DEFS=-DSTARKHIP_ALL_PRIO: every kernel but the lane-form hash at a raised issue priority)
+NAME ?= variant
+VAR_OBJS := $(patsubst $(CSRC)/%.hip,build/$(NAME)/%.hip.o,$(wildcard $(CSRC)/*.hip))
+build/$(NAME)/%.hip.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/$(NAME)
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $< -o $@
+variant: build/$(NAME)/libstarkhip_$(NAME).so
+build/$(NAME)/libstarkhip_$(NAME).so: $(VAR_OBJS) $(filter %.cpp.o,$(OBJS))
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread $(EXTRA_LIBS)
+
 clean:
 	rm -rf build $(OUT)
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean demo asan asan-test tsan-test asan-pool-test
+.PHONY: all oracle clean demo asan asan-test tsan-test asan-pool-test variant

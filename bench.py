@@ -106,9 +106,9 @@ def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=4096, bud
     import numpy as np
     # the oracle's OpenMP team = the CPUs this process may really use (a GPU box shows 256 hardware threads, its cgroup grants 16:
     # more threads than the quota are throttled, not faster -- profiles/r03_cpu_share.txt), so that `cores` is what was used
-    if "OMP_NUM_THREADS" not in os.environ:
-        os.environ["OMP_NUM_THREADS"] = str(cpu_quota())
     import oracle_lib as O
+    if "OMP_NUM_THREADS" not in os.environ:
+        O.lib.oracle_set_threads(cpu_quota())  # (the OpenMP runtime is already loaded -- by torch -- so the environment is not read again)
     rng = np.random.default_rng(1)
     n = 1 << log_n
     N = n << rate_bits

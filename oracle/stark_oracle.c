@@ -644,6 +644,15 @@ EXPORT fe oracle_bench_quotient(const uint64_t* air_blob, size_t air_words, cons
 EXPORT void oracle_free(void* p) { free(p); }
 EXPORT fe oracle_mul(fe a, fe b) { return f_mul(a, b); }
 EXPORT fe oracle_mul_slow(fe a, fe b) { return f_mul_slow(a, b); }
+/* size of the OpenMP team of the calls that follow (a caller that knows its CPU quota: a container may show 256 hardware threads and
+ * be entitled to 16 of them) */
+EXPORT void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 EXPORT int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

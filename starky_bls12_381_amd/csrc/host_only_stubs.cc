@@ -103,7 +103,7 @@ int quad_merged_tables_selfcheck(unsigned) { return 0; }  // the real one is com
 static std::atomic<unsigned long> g_fake_launches(0), g_fake_merged(0);
 hipError_t launch_leaf_hash(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t) { g_fake_launches++; return hipSuccess; }
 hipError_t launch_leaf_hash_row(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t) { g_fake_launches++; return hipSuccess; }
-hipError_t launch_leaf_hash_lane(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t) { g_fake_launches++; return hipSuccess; }
+hipError_t launch_leaf_hash_lane(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t, bool) { g_fake_launches++; return hipSuccess; }
 hipError_t launch_leaf_hash_multi(const LeafHashBatch&, unsigned count, size_t, unsigned, unsigned, hipStream_t) {
     g_fake_launches++;
     g_fake_merged += count;

@@ -9,7 +9,7 @@
 namespace starkhip {
 
 // out[i] = base^i in the extension, i < count (SoA-free: array of gl2_t)
-__global__ void ext_powers_kernel(gl2_t* out, gl2_t base, size_t count) {
+__global__ void ext_powers_kernel(gl2_t* out, gl2_t base, size_t count) { STARKHIP_PRIO_ENTRY
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < count) out[i] = gl2_pow(base, i);
 }
@@ -19,7 +19,7 @@ __global__ void ext_powers_kernel(gl2_t* out, gl2_t base, size_t count) {
 // coeffs is read exactly once; zpow / gzpow (n extension elements each) stay in L2.
 __global__ __launch_bounds__(256) void openings_kernel(const gl_t* __restrict__ coeffs, size_t n, const gl2_t* __restrict__ zpow,
                                                        const gl2_t* __restrict__ gzpow, gl2_t* __restrict__ out_z,
-                                                       gl2_t* __restrict__ out_gz) {
+                                                       gl2_t* __restrict__ out_gz) { STARKHIP_PRIO_ENTRY
     const size_t c = blockIdx.x;
     const gl_t* col = coeffs + c * n;
     gl2_t a = gl2_zero(), b = gl2_zero();
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void openings_kernel(const gl_t* __restrict__ 
 // partial[jc][k] = sum_{j in chunk jc} apow[j0 + j] * coeffs[j][k]
 __global__ __launch_bounds__(256) void fri_combine_kernel(const gl_t* __restrict__ coeffs, size_t n_polys, size_t n,
                                                           const gl2_t* __restrict__ apow, size_t polys_per_chunk,
-                                                          gl2_t* __restrict__ partial) {
+                                                          gl2_t* __restrict__ partial) { STARKHIP_PRIO_ENTRY
     size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (k >= n) return;
     size_t j0 = (size_t)blockIdx.y * polys_per_chunk;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void fri_combine_kernel(const gl_t* __restrict
     partial[(size_t)blockIdx.y * n + k] = acc;
 }
 // out[k] = sum_jc partial[jc][k]
-__global__ void ext_reduce_kernel(const gl2_t* __restrict__ partial, size_t n_chunks, size_t n, gl2_t* __restrict__ out) {
+__global__ void ext_reduce_kernel(const gl2_t* __restrict__ partial, size_t n_chunks, size_t n, gl2_t* __restrict__ out) { STARKHIP_PRIO_ENTRY
     size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (k >= n) return;
     gl2_t acc = gl2_zero();
@@ -69,7 +69,7 @@ __global__ void ext_reduce_kernel(const gl2_t* __restrict__ partial, size_t n_ch
 
 // ---------------------------------------------------------------- FRI commit phase
 // values SoA [2][len] natural order  ->  leaf rows [len / arity][2 * arity]: row r, slot e = value at bitrev(r * arity + e)
-__global__ void fri_leaves_kernel(const gl_t* __restrict__ vals, unsigned log_len, unsigned arity_bits, gl_t* __restrict__ rows) {
+__global__ void fri_leaves_kernel(const gl_t* __restrict__ vals, unsigned log_len, unsigned arity_bits, gl_t* __restrict__ rows) { STARKHIP_PRIO_ENTRY
     size_t len = (size_t)1 << log_len;
     size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (j >= len) return;
@@ -78,7 +78,7 @@ __global__ void fri_leaves_kernel(const gl_t* __restrict__ vals, unsigned log_le
     rows[2 * j + 1] = vals[len + src];
 }
 // coefficient fold: out[k] = sum_{i < arity} beta^i * in[k * arity + i]; in SoA [2][len], out SoA [2][len / arity]
-__global__ void fri_fold_kernel(const gl_t* __restrict__ in, size_t len, unsigned arity_bits, gl2_t beta, gl_t* __restrict__ out) {
+__global__ void fri_fold_kernel(const gl_t* __restrict__ in, size_t len, unsigned arity_bits, gl2_t beta, gl_t* __restrict__ out) { STARKHIP_PRIO_ENTRY
     size_t arity = (size_t)1 << arity_bits, olen = len >> arity_bits;
     size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (k >= olen) return;

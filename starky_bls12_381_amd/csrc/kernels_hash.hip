@@ -306,14 +306,14 @@ __device__ __forceinline__ void leaf_hash_body(const gl_t* __restrict__ mat, siz
 }
 
 __global__ __launch_bounds__(256) void leaf_hash_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
-                                                         gl_t* __restrict__ digests) {
+                                                         gl_t* __restrict__ digests) { STARKHIP_PRIO_ENTRY
     leaf_hash_body(mat, n_cols, log_n, rate_bits, digests);
 }
 
 // The same over K matrices of ONE shape in one launch (grid.y = matrix): the commitments of K proofs of the same AIR.  A
 // 1024-row AIR has 2048 .. 4096 leaves, i.e. 128 .. 256 waves of up to 12 167 sequential permutations each -- a latency chain
 // that leaves 7/8 of the chip idle; K of them side by side fill it (scheduler.hip gathers them).
-__global__ __launch_bounds__(256) void leaf_hash_multi_kernel(LeafHashBatch B, size_t n_cols, unsigned log_n, unsigned rate_bits) {
+__global__ __launch_bounds__(256) void leaf_hash_multi_kernel(LeafHashBatch B, size_t n_cols, unsigned log_n, unsigned rate_bits) { STARKHIP_PRIO_ENTRY
     leaf_hash_body(B.mat[blockIdx.y], n_cols, log_n, rate_bits, B.digests[blockIdx.y]);
 }
 
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void leaf_hash_multi_kernel(LeafHashBatch B, s
 // Same digests as leaf_hash_kernel.  Lane e < 8 of a row absorbs column 8 b + e of block b (the rate), lanes 8 .. 11 carry the
 // capacity, lanes 12 .. 15 idle as mirrors.  One wave = 4 leaves; adjacent rows read adjacent points of a column.
 __global__ __launch_bounds__(256) void leaf_hash_row_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
-                                                             gl_t* __restrict__ digests) {
+                                                             gl_t* __restrict__ digests) { STARKHIP_PRIO_ENTRY
     // [lane of the row][entry]: entries 0 .. 31 the round constants (zero beyond round 29), 32 + 3 t + {0, 1, 2} the merged triples' k1, k2
     // (lane 0 only) and k3; everything zero on lanes 12 .. 15
     __shared__ RcPair rcs[16][64];
@@ -400,14 +400,18 @@ __global__ __launch_bounds__(256, 2) void leaf_hash_lane_kernel(const gl_t* __re
     __syncthreads();
     const unsigned log_N = log_n + rate_bits;
     const size_t N = (size_t)1 << log_N;
-    const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (q >= N) return;
+    // Every lane of a wave stays active to the end: the matrix-pipe rounds read the operand registers of all 64 lanes whatever EXEC
+    // says (a lane that left early would feed garbage weights into its partner half's sums).  Lanes beyond the last leaf shadow it.
+    const size_t q_raw = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const bool live = q_raw < N;
+    const size_t q = live ? q_raw : N - 1;
     const size_t sidx = q >> log_n, k = q & (((size_t)1 << log_n) - 1);
     const size_t i = (k << rate_bits) + sidx;
     const size_t j = gl_bitrev((uint32_t)i, log_N);
     const gl_t* col = mat + q;
     if (n_cols <= 4) {
-        for (unsigned e = 0; e < 4; e++) digests[4 * j + e] = e < n_cols ? col[(size_t)e * N] : 0;
+        if (live)
+            for (unsigned e = 0; e < 4; e++) digests[4 * j + e] = e < n_cols ? col[(size_t)e * N] : 0;
         return;
     }
     const size_t n_full = n_cols / 8, rem = n_cols % 8;
@@ -435,11 +439,16 @@ __global__ __launch_bounds__(256, 2) void leaf_hash_lane_kernel(const gl_t* __re
         for (size_t e = 0; e < rem; e++) s[e] = col[(8 * n_full + e) * N];
         poseidon_permute_lane_merged<false>(s, &T);
     }
+    if (live) {
 #pragma unroll
-    for (int e = 0; e < 4; e++) digests[4 * j + e] = gl_canon(s[e]);
+        for (int e = 0; e < 4; e++) digests[4 * j + e] = gl_canon(s[e]);
+    }
 #else
     LaneZeros Z;
     lane_zeros_init(Z);
+    LaneMfma M;
+    const unsigned lane = threadIdx.x & 63u;
+    lane_mfma_init(M, lane);
     LaneState st;
 #pragma unroll
     for (int w = 0; w < 8; w++) st.t0[w] = st.t1[w] = st.t2[w] = 0;
@@ -452,9 +461,9 @@ __global__ __launch_bounds__(256, 2) void leaf_hash_lane_kernel(const gl_t* __re
         if (b + 1 < n_full) {
 #pragma unroll
             for (int e = 0; e < 8; e++) nx[e] = col[(8 * (b + 1) + e) * N];  // requested one permutation ahead
-            poseidon_permute_lane_asm<true>(st, &T, Z);
+            poseidon_permute_lane_asm<true>(st, &T, Z, M, lane);
         } else {
-            poseidon_permute_lane_asm<false>(st, &T, Z);
+            poseidon_permute_lane_asm<false>(st, &T, Z, M, lane);
         }
     }
     if (rem) {
@@ -463,10 +472,12 @@ __global__ __launch_bounds__(256, 2) void leaf_hash_lane_kernel(const gl_t* __re
             if ((size_t)e < rem) lane_set(st.t0, e, col[(8 * n_full + e) * N]);
             if ((size_t)(4 + e) < rem) lane_set(st.t1, e, col[(8 * n_full + 4 + e) * N]);
         }
-        poseidon_permute_lane_asm<false>(st, &T, Z);
+        poseidon_permute_lane_asm<false>(st, &T, Z, M, lane);
     }
+    if (live) {
 #pragma unroll
-    for (int e = 0; e < 4; e++) digests[4 * j + e] = gl_canon(lane_get(st.t0, e));
+        for (int e = 0; e < 4; e++) digests[4 * j + e] = gl_canon(lane_get(st.t0, e));
+    }
 #endif
 }
 static void build_lane_tables(LaneTables& T) {
@@ -476,6 +487,7 @@ static void build_lane_tables(LaneTables& T) {
     memset(&T, 0, sizeof T);
     for (int r = 0; r < 30; r++)
         for (int e = 0; e < 12; e++) T.rc[r][e] = split(POSEIDON_RC_HOST[12 * r + e]);
+    for (int e = 0; e < 12; e++) T.rc0[e] = POSEIDON_RC_HOST[e];
     for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++) {
         T.k12[t][0] = split(P.k1[t]);
         T.k12[t][1] = split(P.k2[t]);
@@ -488,6 +500,27 @@ static void build_lane_tables(LaneTables& T) {
         T.m0[r] = (uint32_t)P.M[0][r];
         T.n20[r] = (uint32_t)P.N2[0][r];
     }
+    // The matrix-pipe rounds (poseidon_dev.h: poseidon_permute_lane_asm): table m serves the round whose layer is seeded with rc[next[m]].
+    // The products see signed bytes (byte - 128) and the spare K-values add 34 818 = STARKHIP_LANE_K_OFFSET to every plane, so the 64-bit
+    // constant whose bytes ride in the weight tile is  RC[g] = rc[g] - (34 818 - 128 rowsum[g]) * 0x0101010101010101  mod p.
+    static const int CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    static const int NEXT_ROUND[8] = {1, 2, 3, 4, 26, 27, 28, 29};
+    for (int m = 0; m < 8; m++)
+        for (unsigned lane = 0; lane < 64; lane++) {
+            const unsigned row = lane & 31u, half = lane >> 5, g = (row & 3u) + 4u * (row >> 3);
+            const bool live = ((row >> 2) & 1u) == half && g < 12u;
+            gl_t RC = 0;
+            if (live) {
+                uint64_t rowsum = 0;
+                for (int j = 0; j < 12; j++) rowsum += (uint64_t)CIRC[(j + 12 - (int)g) % 12] + ((g == 0 && j == 0) ? 8u : 0u);
+                const gl_t off = gl_mul((gl_t)(STARKHIP_LANE_K_OFFSET - 128 * rowsum), 0x0101010101010101ull % GL_P);
+                RC = gl_sub(POSEIDON_RC_HOST[12 * NEXT_ROUND[m] + g], off);
+            }
+            for (int b = 0; b < 8; b++) {
+                const uint32_t byte = (uint32_t)(RC >> (8 * b)) & 0xFFu;
+                T.rcb[m][b][lane] = live ? ((byte & 0x7Fu) | ((2u * (byte >> 7) + 40u) << 8) | (127u << 16) | (127u << 24)) : 0u;
+            }
+        }
 }
 static hipError_t ensure_lane_tables() {
     static std::mutex mu;
@@ -511,7 +544,7 @@ static hipError_t ensure_lane_tables() {
 
 // Leaves stored row-major and already in tree order: leaf j = rows[j][0..width)
 __global__ __launch_bounds__(64) void leaf_hash_rows_kernel(const gl_t* __restrict__ rows, size_t width, size_t n_leaves,
-                                                             gl_t* __restrict__ digests) {
+                                                             gl_t* __restrict__ digests) { STARKHIP_PRIO_ENTRY
     size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (j >= n_leaves) return;
     gl_t out[4];
@@ -520,7 +553,7 @@ __global__ __launch_bounds__(64) void leaf_hash_rows_kernel(const gl_t* __restri
     for (int e = 0; e < 4; e++) digests[4 * j + e] = out[e];
 }
 
-__global__ __launch_bounds__(64) void merkle_level_kernel(const gl_t* __restrict__ child, gl_t* __restrict__ parent, size_t n_parent) {
+__global__ __launch_bounds__(64) void merkle_level_kernel(const gl_t* __restrict__ child, gl_t* __restrict__ parent, size_t n_parent) { STARKHIP_PRIO_ENTRY
     size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (j >= n_parent) return;
     gl_t out[4];
@@ -529,7 +562,7 @@ __global__ __launch_bounds__(64) void merkle_level_kernel(const gl_t* __restrict
     for (int e = 0; e < 4; e++) parent[4 * j + e] = out[e];
 }
 
-__global__ void permute_batch_kernel(gl_t* states, size_t n) {
+__global__ void permute_batch_kernel(gl_t* states, size_t n) { STARKHIP_PRIO_ENTRY
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     gl_t s[12];
@@ -544,7 +577,7 @@ __global__ void permute_batch_kernel(gl_t* states, size_t n) {
 // pending inputs already written in; candidate nonce goes to lane `pos`; the response is state[7]
 // after one permutation.  Keeps the MINIMUM valid nonce in *best (initialised to UINT64_MAX).
 __global__ void pow_grind_kernel(const gl_t* __restrict__ base_state, int pos, unsigned pow_bits, uint64_t start, uint64_t count,
-                                 unsigned long long* best) {
+                                 unsigned long long* best) { STARKHIP_PRIO_ENTRY
     uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= count) return;
     uint64_t w = start + t;
@@ -570,10 +603,22 @@ hipError_t launch_leaf_hash_row(const gl_t* mat, size_t n_cols, unsigned log_n, 
     hipLaunchKernelGGL(leaf_hash_row_kernel, dim3(nblocks(16 * N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
     return hipGetLastError();
 }
-hipError_t launch_leaf_hash_lane(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st) {
+// share_cu: a lane-form workgroup is four waves of 256 registers, one per SIMD; two of them own a CU's register file, and a group of four
+// commitments owns the chip's -- the 512-thread LDE / quotient workgroups of the other proofs in flight then wait for the group to end
+// (17 -> 50 ms and 27 -> 73 ms on average in the kernel trace) and the two kinds of work alternate, each leaving issue slots empty that the
+// other could fill (the LDE issues vector instructions 71 % of the time, the quotient about 80 %).  With an LDS reservation of just over
+// half a CU's 160 KB per workgroup a CU takes ONE lane workgroup: 256 registers per SIMD and 78 KB of LDS stay free -- exactly one LDE
+// workgroup (8 waves x <= 128 registers, 69.6 KB) or one quotient workgroup (78.3 KB) fits beside it.
+static constexpr unsigned LANE_SHARE_LDS = 82944;  // > 163 840 / 2; + the quotient's 78 336 bytes <= 163 840
+hipError_t launch_leaf_hash_lane(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st, bool share_cu) {
     size_t N = (size_t)1 << (log_n + rate_bits);
     if (hipError_t e = ensure_lane_tables(); e != hipSuccess) return e;
-    hipLaunchKernelGGL(leaf_hash_lane_kernel, dim3(nblocks(N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
+    unsigned dyn = 0;
+    if (share_cu) {
+        dyn = LANE_SHARE_LDS - (unsigned)sizeof(LaneTables);
+        if (hipError_t e = hipFuncSetAttribute((const void*)leaf_hash_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(leaf_hash_lane_kernel, dim3(nblocks(N, 256)), dim3(256), dyn, st, mat, n_cols, log_n, rate_bits, digests);
     return hipGetLastError();
 }
 hipError_t launch_leaf_hash_multi(const LeafHashBatch& B, unsigned count, size_t n_cols, unsigned log_n, unsigned rate_bits, hipStream_t st) {

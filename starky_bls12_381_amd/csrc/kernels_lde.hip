@@ -17,6 +17,8 @@
 // Arithmetic is the lazy-reduction form of gl_dev.h; values are canonicalised when stored to HBM.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <vector>
 
 #include "gl_dev.h"
@@ -176,9 +178,10 @@ __global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kern
                                                                                     gl_t* __restrict__ lde, unsigned n_cols, unsigned rate_bits,
                                                                                     const gl_t* __restrict__ tw_fwd,
                                                                                     const gl_t* __restrict__ tw_inv, const gl_t* __restrict__ cs,
-                                                                                    const gl_t* __restrict__ oh, int from_coeffs) {
+                                                                                    const gl_t* __restrict__ oh, int from_coeffs, int prio) { STARKHIP_PRIO_ENTRY
     using PL = LdePlan<LOGN>;
     constexpr int T = PL::T, n = PL::N;
+    if (prio) __builtin_amdgcn_s_setprio(2);
     extern __shared__ gl_t lds_all[];
     __shared__ unsigned cls[3];  // closed-form classes (below): [0] flags, [1] number of ones, [2] row of a one
     if constexpr (PL::CPB == 1) {
@@ -333,8 +336,16 @@ static hipError_t launch_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, size_t 
     }
     const unsigned blocks = (unsigned)((n_cols + PL::CPB - 1) / PL::CPB);
     hipLaunchKernelGGL(lde_columns_v2_kernel<LOGN>, dim3(blocks), dim3(PL::THREADS), lds_bytes, st, values, coeffs, lde, (unsigned)n_cols,
-                       rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs);
+                       rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs, (int)kernel_issue_priority());
     return hipGetLastError();
+}
+
+unsigned kernel_issue_priority() {
+    static const unsigned prio = [] {
+        const char* e = getenv("STARKHIP_KERNEL_PRIO");
+        return (e && *e) ? (unsigned)atoi(e) : 0u;
+    }();
+    return prio;
 }
 
 bool lde_v2_supported(unsigned log_n) { return log_n >= 8 && log_n <= 13; }

@@ -21,13 +21,13 @@ namespace starkhip {
 
 // ---------------------------------------------------------------- twiddle tables
 // tw[j] = root^j for j < n/2
-__global__ void fill_powers_kernel(gl_t* out, gl_t base, gl_t mult, size_t count) {
+__global__ void fill_powers_kernel(gl_t* out, gl_t base, gl_t mult, size_t count) { STARKHIP_PRIO_ENTRY
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < count) out[i] = gl_mul(base, gl_pow(mult, i));
 }
 
 // coset scale table: sc[s][k] = n^-1 * (7 * w_N^s)^k
-__global__ void fill_coset_scale_kernel(gl_t* out, unsigned log_n, unsigned rate_bits) {
+__global__ void fill_coset_scale_kernel(gl_t* out, unsigned log_n, unsigned rate_bits) { STARKHIP_PRIO_ENTRY
     size_t n = (size_t)1 << log_n;
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= (n << rate_bits)) return;
@@ -38,7 +38,7 @@ __global__ void fill_coset_scale_kernel(gl_t* out, unsigned log_n, unsigned rate
 
 // ---------------------------------------------------------------- row-major -> column-major
 // in [rows][cols] -> out [cols][rows]; 32x32 tiles through LDS
-__global__ void transpose_kernel(const gl_t* __restrict__ in, gl_t* __restrict__ out, size_t rows, size_t cols) {
+__global__ void transpose_kernel(const gl_t* __restrict__ in, gl_t* __restrict__ out, size_t rows, size_t cols) { STARKHIP_PRIO_ENTRY
     __shared__ gl_t tile[32][33];
     size_t c0 = (size_t)blockIdx.x * 32, r0 = (size_t)blockIdx.y * 32;
     for (int j = threadIdx.y; j < 32; j += blockDim.y) {
@@ -84,7 +84,7 @@ template <int LOGN, int COLS_PER_BLOCK, int THREADS>
 __global__ __launch_bounds__(THREADS) void lde_columns_kernel(const gl_t* values, gl_t* coeffs,  // coeffs may be values (in place): every word of a column is in LDS, behind a barrier, before any is written
                                                                gl_t* __restrict__ lde, size_t n_cols, unsigned rate_bits,
                                                                const gl_t* __restrict__ tw_fwd, const gl_t* __restrict__ tw_inv,
-                                                               unsigned tw_log, const gl_t* __restrict__ coset_scale, int from_coeffs) {
+                                                               unsigned tw_log, const gl_t* __restrict__ coset_scale, int from_coeffs) { STARKHIP_PRIO_ENTRY
     constexpr int n = 1 << LOGN;
     constexpr int TPC = THREADS / COLS_PER_BLOCK;  // threads cooperating on one column
     constexpr int EPT = (n + TPC - 1) / TPC;       // coefficients kept in registers per thread
@@ -169,7 +169,7 @@ hipError_t launch_lde_columns(const gl_t* values, gl_t* coeffs, gl_t* lde, size_
 // pre_scale / post_scale (nullable): element-wise multipliers (coset shift powers) applied before / after.
 __global__ __launch_bounds__(1024) void ntt_global_kernel(gl_t* data, size_t vec_stride, unsigned log_n, const gl_t* __restrict__ tw,
                                                            unsigned tw_log, const gl_t* __restrict__ pre_scale,
-                                                           const gl_t* __restrict__ post_scale, gl_t final_mul) {
+                                                           const gl_t* __restrict__ post_scale, gl_t final_mul) { STARKHIP_PRIO_ENTRY
     gl_t* a = data + (size_t)blockIdx.x * vec_stride;
     const size_t n = (size_t)1 << log_n;
     const int tid = threadIdx.x, nt = blockDim.x;

@@ -12,7 +12,7 @@ __device__ __forceinline__ size_t level_off_dev(size_t n_leaves, unsigned l) { r
 
 // out[q * stride + off + c] = mat[c * N + phys(bitrev(x_q))]  for the coset-major matrix `mat`; x_q = tree leaf index
 __global__ void query_leaf_colmajor_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
-                                           const uint32_t* __restrict__ xs, gl_t* __restrict__ out, size_t stride, size_t off) {
+                                           const uint32_t* __restrict__ xs, gl_t* __restrict__ out, size_t stride, size_t off) { STARKHIP_PRIO_ENTRY
     const size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (c >= n_cols) return;
     const size_t q = blockIdx.y;
@@ -25,7 +25,7 @@ __global__ void query_leaf_colmajor_kernel(const gl_t* __restrict__ mat, size_t 
 
 // out[q * stride + off + e] = rows[(x_q >> shift) * width + e]
 __global__ void query_leaf_rows_kernel(const gl_t* __restrict__ rows, size_t width, const uint32_t* __restrict__ xs, unsigned shift,
-                                       gl_t* __restrict__ out, size_t stride, size_t off) {
+                                       gl_t* __restrict__ out, size_t stride, size_t off) { STARKHIP_PRIO_ENTRY
     const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (e >= width) return;
     const size_t q = blockIdx.y;
@@ -34,7 +34,7 @@ __global__ void query_leaf_rows_kernel(const gl_t* __restrict__ rows, size_t wid
 
 // siblings bottom-up: out[q * stride + off + 4 l + e] = digest(level l, ((x_q >> shift) >> l) ^ 1)[e], l < depth
 __global__ void query_path_kernel(const gl_t* __restrict__ digests, size_t n_leaves, unsigned depth, const uint32_t* __restrict__ xs,
-                                  unsigned shift, gl_t* __restrict__ out, size_t stride, size_t off) {
+                                  unsigned shift, gl_t* __restrict__ out, size_t stride, size_t off) { STARKHIP_PRIO_ENTRY
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 4 * depth) return;
     const size_t q = blockIdx.y;

@@ -51,7 +51,7 @@ struct alignas(16) QLoads {
 // Per-point tables in the quotient domain's physical order t = s' * n + k  <->  i = k * 2^qdb + s',
 // x = 7 * w_size^i:  tab[0][t] = x - g^-1 (z_last), tab[1][t] = L_first(x), tab[2][t] = L_last(x),
 // tab[3][t] = 1 / Z_H(x).
-__global__ void quotient_tables_kernel(gl_t* tab, unsigned log_n, unsigned qdb) {
+__global__ void quotient_tables_kernel(gl_t* tab, unsigned log_n, unsigned qdb) { STARKHIP_PRIO_ENTRY
     const size_t n = (size_t)1 << log_n, size = n << qdb;
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= size) return;
@@ -188,7 +188,7 @@ __device__ __forceinline__ void quotient_eval_batch(const QBatch& cur, const gl_
 }
 
 template <bool CACHE>
-__global__ __launch_bounds__(64) void quotient_eval_kernel(QuotientParams P) {
+__global__ __launch_bounds__(64) void quotient_eval_kernel(QuotientParams P) { STARKHIP_PRIO_ENTRY
     extern __shared__ gl_t cell_cache[];  // [n_slots][64]
     const size_t n = (size_t)1 << P.log_n, size = n << P.qdb;
     const unsigned t_raw = blockIdx.x * blockDim.x + threadIdx.x;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64) void quotient_eval_kernel(QuotientParams P) {
 
 // out[j][i] (natural quotient index i) = (sum_p partial[p][j][t] * chunk_scale[p][j]) / Z_H(x_i)
 __global__ void quotient_combine_kernel(const gl_t* __restrict__ partial, const gl_t* __restrict__ chunk_scale, unsigned n_chunks,
-                                        const gl_t* __restrict__ tab, unsigned log_n, unsigned qdb, gl_t* __restrict__ out) {
+                                        const gl_t* __restrict__ tab, unsigned log_n, unsigned qdb, gl_t* __restrict__ out) { STARKHIP_PRIO_ENTRY
     const size_t n = (size_t)1 << log_n, size = n << qdb;
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= size) return;
@@ -290,6 +290,7 @@ struct QTParams {
     gl_t* partial;                    // [n_chunks][2][size]
     unsigned log_n, rate_bits, qdb, n_cols;
     unsigned dbg;  // profiling only: 1 = the producer loads nothing, 2 = the evaluators skip the arithmetic (results are garbage)
+    unsigned prio; // != 0: the waves raise their issue priority (s_setprio): beside a co-resident leaf-hash wave they issue first
 };
 
 // (hi:lo) += (xh:xl) as one carry chain (the sums involved stay far below 2^128)
@@ -354,9 +355,10 @@ __device__ __forceinline__ gl_t qt_fold_sums(const uint64_t (&S)[6]) {
 }
 
 template <bool SMALL_N, unsigned DBG>
-__global__ __launch_bounds__(64 * (QT_WAVES + 1)) void quotient_tiles_kernel(QTParams P) {
+__global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(QTParams P) { STARKHIP_PRIO_ENTRY
     __shared__ gl_t tile[2][QT_TILE_COLS * QT_TILE_ROWS];
     __shared__ uint32_t rec_ring[QT_WAVES][3][32][4];  // per evaluating wave: three blocks of 16 records (32 x 16 bytes each)
+    if (P.prio) __builtin_amdgcn_s_setprio(2);
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 .. QT_WAVES - 1 evaluate, QT_WAVES stages the tiles
     const unsigned lane = threadIdx.x & 63u;
     const size_t n = (size_t)1 << P.log_n, size = n << P.qdb;
@@ -496,43 +498,50 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1)) void quotient_tiles_kernel(QTP
     ring_fill(1, 1);
     gates_request();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // Record pipeline.  While record g is evaluated (slot U = g % 4 of the unrolled loop):
-    //   the control word of record g + 4 is requested from the ring                        (used two steps later)
-    //   the control word of record g + 2, requested two steps ago, goes to a scalar register; with it the cell of record
-    //   g + 2 and the whole record g + 2 (weights) are requested                           (used two steps later)
-    // so nothing a step needs was requested less than two steps (~100+ instructions) before: no LDS round trip is exposed.
-    Rec W0, W1, W2, W3;            // records g .. g + 2 (weights)
-    uint32_t cv0, cv1, cv2, cv3;   // control words as read from the ring (vector registers), records g + 2 .. g + 4
-    uint32_t sc0, sc1, sc2, sc3;   // control words in scalar registers, records g .. g + 2
-    gl_t x0, x1, x2 = 0, x3 = 0;   // cells of records g .. g + 2
-    unsigned g = 0;                // index of the record being evaluated, a multiple of four at the top of the loop
-    uint32_t b0 = 0, b1 = 128;     // ring offsets of the groups of four that hold records g and g + 4
+    // Record pipeline (round 4).  A record is read WHOLE from the ring (two broadcast ds_read_b128: control word, weights) four steps
+    // before it is evaluated, into the register set the step that has just finished frees; its cell is requested two steps ahead, the
+    // address coming from the control word in that vector register.  So nothing a step needs was requested less than two steps before.
+    // 77 % of the records are PLAIN (x = a cell of the tile, accumulate; no flag set) and sit in runs -- the planner sorts nothing for
+    // it, monomials of one cell simply dominate.  The length of the run that follows it rides in bits 31:24 of every special record
+    // (build_quotient_plan), and a run is evaluated four records at a time by a straight-line block without a single test:
+    // per record one cell read, one record read, twelve multiply-adds (the round-3 loop spent ~ 34 issue slots per record -- a
+    // control-word read of its own, a v_readfirstlane, two scalar tests and the copies hipcc's flow blocks add at every merge --
+    // and scalar instructions cost issue slots like vector ones here).  Everything else takes the generic step.
+    Rec W0, W1, W2, W3;                   // records g .. g + 3 (slot U = g % 4 holds record g)
+    gl_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;  // their cells
+    unsigned g = 0;                       // index of the record being evaluated
+    uint32_t b1 = 128;                    // ring offset of the group of four that holds record g + 4 (entry g % 4)
     unsigned next_block = 2, next_slot = 2;
-    ring_read(b0, 0, W0);
-    ring_read(b0, 1, W1);
-    cv2 = ring_read_ctl(b0, 2);
-    cv3 = ring_read_ctl(b0, 3);
-    sc0 = __builtin_amdgcn_readfirstlane(W0.a.x);
-    sc1 = __builtin_amdgcn_readfirstlane(W1.a.x);
-    sc2 = sc3 = 0;
-    cv0 = cv1 = 0;
-    W2 = W0;
-    W3 = W0;
+    uint32_t n_plain = 0;                 // plain records known to follow (wave-uniform)
+    ring_read(0, 0, W0);
+    ring_read(0, 1, W1);
+    ring_read(0, 2, W2);
+    ring_read(0, 3, W3);
     asm volatile("s_barrier" ::: "memory");  // tile 0 is staged
 
     uint32_t lds_cur = lds_local;  // this lane's row in the tile buffer in use (byte offset from tile[0])
-    // `c` may be the control word as it came from the ring (a vector register): offset = low half, one add
+    // `c`: the control word as it came from the ring (a vector register): offset = low half, one add
     auto lds_read = [&](uint32_t c, gl_t& x) {
         uint32_t a = (c & QT_OFF_MASK) + lds_cur;
         if (SMALL_N) a = (c & QT_OFF_MASK) + ((c & QT_NEXT) ? lds_cur - lds_local + lds_next : lds_cur);
         x = *(const gl_t*)((const char*)tile[0] + a);
     };
-    lds_read(sc0, x0);
-    lds_read(sc1, x1);
+    lds_read(W0.a.x, x0);
+    lds_read(W1.a.x, x1);
     unsigned ti = 0;
-    // U: slot; (CV4, B4, I4): where the control word of record g + 4 goes / comes from; CV2: control word of g + 2 (vector);
-    // (SC, W, X): scalar control word, weights, cell of record g; (SC1, X1): of record g + 1; (SC2, W2, X2, BW2, IW2): of record g + 2
-#define QT_STEP(U, CV4, I4, CV2, SC, W, X, SC1, X1, SC2, WW2, X2, BW2, IW2)                                           \
+#define QT_MADS(W, XV)                                                                                                \
+    if (!(DBG & 2u)) {                                                                                                \
+        const uint32_t xl_ = (uint32_t)(XV), xh_ = (uint32_t)((XV) >> 32);                                            \
+        const uint32_t w0_[3] = {W.a.z, W.a.w, W.b.x}, w1_[3] = {W.b.y, W.b.z, W.b.w};                                \
+        _Pragma("unroll") for (int l = 0; l < 3; l++) {                                                               \
+            S0[l] += (uint64_t)xl_ * w0_[l];                                                                          \
+            S0[3 + l] += (uint64_t)xh_ * w0_[l];                                                                      \
+            S1[l] += (uint64_t)xl_ * w1_[l];                                                                          \
+            S1[3 + l] += (uint64_t)xh_ * w1_[l];                                                                      \
+        }                                                                                                             \
+    }
+    // the end of every step: record g + 4 replaces record g in its register set
+#define QT_ADVANCE(U, W)                                                                                              \
     {                                                                                                                 \
         if ((U) == 0) {                                                                                               \
             if (__builtin_expect(((g + 4u) & 15u) == 0, 0)) {                                                         \
@@ -545,41 +554,49 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1)) void quotient_tiles_kernel(QTP
                 next_slot = next_slot == 2 ? 0 : next_slot + 1;                                                       \
             }                                                                                                         \
         }                                                                                                             \
-        CV4 = ring_read_ctl(b1, I4);                                                                                  \
-        SC2 = __builtin_amdgcn_readfirstlane(CV2);                                                                    \
-        lds_read(CV2, X2);                                                                                            \
-        ring_read(BW2, IW2, WW2);                                                                                     \
-        const uint32_t ctl = SC;                                                                                      \
-        gl_t x = X;                                                                                                   \
-        if (__builtin_expect((ctl & QT_ODD_SOURCE) != 0, 0)) {                                                        \
-            if (ctl & (QT_TILE | QT_STOP)) {                                                                          \
-                /* every LDS read of this tile has returned; the gate loads of the next piece stay in flight */       \
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \
-                ti++;                                                                                                 \
-                if ((ctl & QT_STOP) != 0 || ti >= n_tiles) goto stream_done;                                          \
-                lds_cur = lds_local + (ti & 1u) * (uint32_t)(QT_TILE_COLS * QT_TILE_ROWS * sizeof(gl_t));             \
-                lds_read(SC1, X1); /* the cells of the next two records live in the new tile */                       \
-                lds_read(SC2, X2);                                                                                    \
-                goto next_##U;                                                                                        \
+        ring_read(b1, (U), W);                                                                                        \
+        if ((U) == 3) b1 = b1 == 1408 ? 0 : b1 + 128;                                                                 \
+        g++;                                                                                                          \
+    }
+    // one record of a plain run: (W, X) record g and its cell, (WC2, X2) of record g + 2
+#define QT_PLAIN(U, W, X, WC2, X2)                                                                                    \
+    {                                                                                                                 \
+        lds_read(WC2.a.x, X2);                                                                                        \
+        QT_MADS(W, X)                                                                                                 \
+        QT_ADVANCE(U, W)                                                                                              \
+    }
+    // any record: (W1c, X1) of record g + 1 as well (re-read when the tile changes)
+#define QT_GENERIC(U, W, X, WC1, X1, WC2, X2)                                                                         \
+    {                                                                                                                 \
+        lds_read(WC2.a.x, X2);                                                                                        \
+        if (n_plain != 0) { /* the tail of a run (fewer than four left) */                                            \
+            n_plain--;                                                                                                \
+            QT_MADS(W, X)                                                                                             \
+        } else {                                                                                                      \
+            const uint32_t ctl = __builtin_amdgcn_readfirstlane(W.a.x);                                               \
+            n_plain = ctl >> QT_RUN_SHIFT;                                                                            \
+            gl_t x = X;                                                                                               \
+            if ((ctl & QT_ODD_SOURCE) != 0) {                                                                         \
+                if (ctl & (QT_TILE | QT_STOP)) {                                                                      \
+                    /* every LDS read of this tile has returned; the gate loads of the next piece stay in flight */   \
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                 \
+                    ti++;                                                                                             \
+                    if ((ctl & QT_STOP) != 0 || ti >= n_tiles) goto stream_done;                                      \
+                    lds_cur = lds_local + (ti & 1u) * (uint32_t)(QT_TILE_COLS * QT_TILE_ROWS * sizeof(gl_t));         \
+                    lds_read(WC1.a.x, X1); /* the cells of the next two records live in the new tile */               \
+                    lds_read(WC2.a.x, X2);                                                                            \
+                    goto advance_##U;                                                                                 \
+                }                                                                                                     \
+                if (ctl & QT_SRC_ONE) x = 1;                                                                          \
+                if ((ctl & QT_SRC_GLOBAL) && !(DBG & 8u)) x = direct(__builtin_amdgcn_readfirstlane(W.a.y), ctl & QT_NEXT); \
+                if (ctl & QT_MULV) x = gl_mul_nc(v, x);                                                               \
+                if (ctl & QT_SETV) {                                                                                  \
+                    v = x;                                                                                            \
+                    goto advance_##U;                                                                                 \
+                }                                                                                                     \
             }                                                                                                         \
-            if (ctl & QT_SRC_ONE) x = 1;                                                                              \
-            if ((ctl & QT_SRC_GLOBAL) && !(DBG & 8u)) x = direct(__builtin_amdgcn_readfirstlane(W.a.y), ctl & QT_NEXT); \
-            if (ctl & QT_MULV) x = gl_mul_nc(v, x);                                                                   \
-            if (ctl & QT_SETV) {                                                                                      \
-                v = x;                                                                                                \
-                goto next_##U;                                                                                        \
-            }                                                                                                         \
-        }                                                                                                             \
-        if (!(DBG & 2u)) {                                                                                            \
-            const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);                                                \
-            const uint32_t w0[3] = {W.a.z, W.a.w, W.b.x}, w1[3] = {W.b.y, W.b.z, W.b.w};                              \
-            _Pragma("unroll") for (int l = 0; l < 3; l++) {                                                           \
-                S0[l] += (uint64_t)xl * w0[l];                                                                        \
-                S0[3 + l] += (uint64_t)xh * w0[l];                                                                    \
-                S1[l] += (uint64_t)xl * w1[l];                                                                        \
-                S1[3 + l] += (uint64_t)xh * w1[l];                                                                    \
-            }                                                                                                         \
-            if (__builtin_expect((ctl & QT_END) != 0, 0) && !(DBG & 4u)) {                                            \
+            QT_MADS(W, x)                                                                                             \
+            if ((ctl & QT_END) != 0 && !(DBG & 4u) && !(DBG & 2u)) {                                                  \
                 const uint32_t kind = piece_ctl & 3u, ng = (piece_ctl >> 2) & 7u, cm = piece_ctl >> 5;                \
                 gl_t G = kind == KIND_PLAIN ? (gl_t)1 : kind == KIND_TRANSITION ? mask_tr : kind == KIND_FIRST ? mask_first : mask_last; \
                 _Pragma("unroll") for (unsigned q = 0; q < 4; q++) if (q < ng) {                                      \
@@ -594,21 +611,49 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1)) void quotient_tiles_kernel(QTP
                 gates_request();                                                                                      \
             }                                                                                                         \
         }                                                                                                             \
-    next_##U:                                                                                                         \
-        g++;                                                                                                          \
+    advance_##U:                                                                                                      \
+        QT_ADVANCE(U, W)                                                                                              \
     }
     if (n_tiles)
         for (;;) {
-            //       U  CV4  I4 CV2  SC   W   X   SC1  X1  SC2  WW2 X2  BW2 IW2
-            QT_STEP(0, cv0, 0, cv2, sc0, W0, x0, sc1, x1, sc2, W2, x2, b0, 2)
-            QT_STEP(1, cv1, 1, cv3, sc1, W1, x1, sc2, x2, sc3, W3, x3, b0, 3)
-            QT_STEP(2, cv2, 2, cv0, sc2, W2, x2, sc3, x3, sc0, W0, x0, b1, 0)
-            QT_STEP(3, cv3, 3, cv1, sc3, W3, x3, sc0, x0, sc1, W1, x1, b1, 1)
-            b0 = b1;
-            b1 = b1 == 1408 ? 0 : b1 + 128;
+            while (n_plain >= 4u) {
+                QT_PLAIN(0, W0, x0, W2, x2)
+                QT_PLAIN(1, W1, x1, W3, x3)
+                QT_PLAIN(2, W2, x2, W0, x0)
+                QT_PLAIN(3, W3, x3, W1, x1)
+                n_plain -= 4u;
+            }
+            QT_GENERIC(0, W0, x0, W1, x1, W2, x2)
+            while (n_plain >= 4u) {
+                QT_PLAIN(1, W1, x1, W3, x3)
+                QT_PLAIN(2, W2, x2, W0, x0)
+                QT_PLAIN(3, W3, x3, W1, x1)
+                QT_PLAIN(0, W0, x0, W2, x2)
+                n_plain -= 4u;
+            }
+            QT_GENERIC(1, W1, x1, W2, x2, W3, x3)
+            while (n_plain >= 4u) {
+                QT_PLAIN(2, W2, x2, W0, x0)
+                QT_PLAIN(3, W3, x3, W1, x1)
+                QT_PLAIN(0, W0, x0, W2, x2)
+                QT_PLAIN(1, W1, x1, W3, x3)
+                n_plain -= 4u;
+            }
+            QT_GENERIC(2, W2, x2, W3, x3, W0, x0)
+            while (n_plain >= 4u) {
+                QT_PLAIN(3, W3, x3, W1, x1)
+                QT_PLAIN(0, W0, x0, W2, x2)
+                QT_PLAIN(1, W1, x1, W3, x3)
+                QT_PLAIN(2, W2, x2, W0, x0)
+                n_plain -= 4u;
+            }
+            QT_GENERIC(3, W3, x3, W0, x0, W1, x1)
         }
 stream_done:
-#undef QT_STEP
+#undef QT_MADS
+#undef QT_ADVANCE
+#undef QT_PLAIN
+#undef QT_GENERIC
     // waves whose stream ended before the chunk's last tile (never by construction) would desynchronise the barrier count
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
@@ -625,7 +670,7 @@ stream_done:
 }
 
 // apow[j][e] = alpha_j^e, e < K
-__global__ void quotient_alpha_powers_kernel(gl_t* apow, gl_t alpha0, gl_t alpha1, uint32_t K) {
+__global__ void quotient_alpha_powers_kernel(gl_t* apow, gl_t alpha0, gl_t alpha1, uint32_t K) { STARKHIP_PRIO_ENTRY
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * K) return;
     const uint32_t j = i >= K, e = j ? i - K : i;
@@ -634,7 +679,7 @@ __global__ void quotient_alpha_powers_kernel(gl_t* apow, gl_t alpha0, gl_t alpha
 
 // per-proof weights of every record: w_j = sum over its terms of coefficient * alpha_j^e, split into three 22-bit limbs
 __global__ void quotient_weights_kernel(QTRec* recs, const uint32_t* contrib_off, const QTContrib* contribs, uint32_t n_recs,
-                                        const gl_t* apow, uint32_t K, const gl_t* consts, const gl_t* pis) {
+                                        const gl_t* apow, uint32_t K, const gl_t* consts, const gl_t* pis) { STARKHIP_PRIO_ENTRY
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_recs) return;
     const uint32_t c0 = contrib_off[r], c1 = contrib_off[r + 1];
@@ -663,7 +708,7 @@ __global__ void quotient_weights_kernel(QTRec* recs, const uint32_t* contrib_off
 
 // out[j][i] (natural quotient index i) = (sum_c partial[c][j][t]) / Z_H(x_i)
 __global__ void quotient_tiles_combine_kernel(const gl_t* __restrict__ partial, unsigned n_chunks, const gl_t* __restrict__ tab, unsigned log_n,
-                                              unsigned qdb, gl_t* __restrict__ out) {
+                                              unsigned qdb, gl_t* __restrict__ out) { STARKHIP_PRIO_ENTRY
     const size_t n = (size_t)1 << log_n, size = n << qdb;
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= size) return;
@@ -689,6 +734,7 @@ hipError_t launch_quotient_tiles(const QTRec* recs, const QTPiece* pieces, const
                                  unsigned rate_bits, unsigned qdb, unsigned n_cols, unsigned dbg, hipStream_t st) {
     QTParams P;
     P.dbg = dbg;
+    P.prio = kernel_issue_priority();
     P.recs = recs; P.pieces = pieces; P.streams = streams; P.chunk_tile_off = chunk_tile_off; P.tile_list = tile_list;
     P.lde = lde; P.tab = tab; P.partial = partial; P.log_n = log_n; P.rate_bits = rate_bits; P.qdb = qdb; P.n_cols = n_cols;
     const size_t size = (size_t)1 << (log_n + qdb);

@@ -19,7 +19,7 @@ __device__ __forceinline__ gl_t pow2_case(gl_t x, int e) {
     return 0;
 }
 
-__global__ void field_ops_kernel(int op, const gl_t* __restrict__ a, const gl_t* __restrict__ b, gl_t* __restrict__ out, size_t n) {
+__global__ void field_ops_kernel(int op, const gl_t* __restrict__ a, const gl_t* __restrict__ b, gl_t* __restrict__ out, size_t n) { STARKHIP_PRIO_ENTRY
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const gl_t x = a[i], y = b[i];

@@ -16,7 +16,7 @@ namespace starkhip {
 static constexpr unsigned TRACE_RECORDS_PER_WAVE = 8;
 
 __global__ __launch_bounds__(64) void expand_trace_kernel(const uint32_t* __restrict__ words, const uint32_t* __restrict__ offsets,
-                                                          size_t n_records, gl_t* __restrict__ values, size_t n_rows) {
+                                                          size_t n_records, gl_t* __restrict__ values, size_t n_rows) { STARKHIP_PRIO_ENTRY
     const size_t first = (size_t)blockIdx.x * TRACE_RECORDS_PER_WAVE;
     const unsigned lane = threadIdx.x;
     for (unsigned k = 0; k < TRACE_RECORDS_PER_WAVE; k++) {
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64) void expand_trace_kernel(const uint32_t* __rest
 }
 
 // cells the generator cleared after writing them (trace_log.h, TraceLog::set): applied after the expansion, in stream order
-__global__ void zero_cells_kernel(const uint32_t* __restrict__ col_row, size_t n_cells, gl_t* __restrict__ values, size_t n_rows) {
+__global__ void zero_cells_kernel(const uint32_t* __restrict__ col_row, size_t n_cells, gl_t* __restrict__ values, size_t n_rows) { STARKHIP_PRIO_ENTRY
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n_cells) values[(size_t)col_row[2 * i] * n_rows + col_row[2 * i + 1]] = 0;
 }

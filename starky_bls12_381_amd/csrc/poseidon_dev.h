@@ -627,6 +627,11 @@ struct LaneTables {
     RcPair k3[7][12];
     uint32_t row[12][16];      // per output row of the dense layer: N3[r][0 .. 11], N2[r][0], M[r][0], -, -
     uint32_t m0[12], n20[12];  // row 0 of M and of N2 (the two intermediate dot products)
+    // The rounds whose circulant layer runs on the matrix pipe (full rounds 0 .. 3 and 26 .. 28, the lone partial round 25; lane_round_asm.inc,
+    // tools/gen_lane_round_asm.py): per round, byte plane and LANE the fourth dword of the weight tile -- the constant bytes that ride in
+    // the spare K-values (kernels_hash.hip: build_lane_tables)
+    uint32_t rcb[8][8][64];
+    gl_t rc0[12];              // the first round's constants as whole words (added to the state at the start of every permutation)
 };
 
 // circulant layer; the accumulators start from `seed` (the next round's constants); outputs 0 .. N_OUT - 1 only
@@ -774,23 +779,89 @@ __device__ __forceinline__ void lane_triple_asm(LaneState& st, uint32_t k3_lds, 
         : STARKHIP_LANE_A_K3(k3_lds), STARKHIP_LANE_A_K12(k12_lds), STARKHIP_LANE_A_COEF(coef_lds), STARKHIP_LANE_ZA(Z.za), STARKHIP_LANE_ZB(Z.zb)
         : STARKHIP_LANE_CLOBBERS);
 }
+// The operands of the matrix-pipe rounds that live across the whole kernel: the weight tile of v_mfma_i32_32x32x32_i8 for THIS lane
+// (two copies of its dwords 0 .. 2; dword 3 is loaded per plane inside the blocks) and the constant fourth dword of the state-side tuples.
+struct LaneMfma {
+    uint32_t aw[2][4];
+    uint32_t bc[4];
+};
+// Weight tile: lane (row = lane & 31, half = lane >> 5) holds the 16 K-values of that row that meet the K-values of the lane half `half`
+// of the other operand.  Output g = (row & 3) + 4 (row >> 3) of a permutation lands in result register g of its own lane when the row's
+// bit 2 equals the lane half: those rows carry M[g][0 .. 11] (circulant, + 8 at [0][0]); every other (row, half) is zero -- a block
+// diagonal tile that multiplies the two lane halves' states separately (tools/experiments/mfma_mds_probe.hip).
+__device__ __forceinline__ void lane_mfma_init(LaneMfma& M, unsigned lane) {
+    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const unsigned row = lane & 31u, half = lane >> 5, g = (row & 3u) + 4u * (row >> 3);
+    const bool live = ((row >> 2) & 1u) == half && g < 12u;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const unsigned j = 4 * d + i;
+            uint32_t c = 0;
+#pragma unroll
+            for (unsigned gg = 0; gg < 12; gg++)  // (a table walk the compiler folds; g is per lane)
+                if (gg == g) c = CIRC[(j + 12u - gg) % 12u] + ((gg == 0 && j == 0) ? 8u : 0u);
+            w |= c << (8 * i);
+        }
+        M.aw[0][d] = M.aw[1][d] = live ? w : 0u;
+    }
+    M.aw[0][3] = M.aw[1][3] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) M.bc[k] = STARKHIP_LANE_B_CONST;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int d = 0; d < 4; d++) asm volatile("" : "+v"(M.aw[k][d]));
+#pragma unroll
+    for (int k = 0; k < 4; k++) asm volatile("" : "+v"(M.bc[k]));
+}
+#define STARKHIP_LANE_MFMA_BLOCK(NAME, TEXT)                                                                                               \
+    __device__ __forceinline__ void NAME(LaneState& st, uint32_t rcb_lds, const LaneZeros& Z, LaneMfma& M) {                               \
+        asm(TEXT                                                                                                                           \
+            : STARKHIP_LANE_STATE0(st.t0), STARKHIP_LANE_STATE1(st.t1), STARKHIP_LANE_STATE2(st.t2), STARKHIP_LANE_AW03(M.aw[0][3]),       \
+              STARKHIP_LANE_AW13(M.aw[1][3])                                                                                               \
+            : STARKHIP_LANE_A_RCB(rcb_lds), STARKHIP_LANE_ZA(Z.za), STARKHIP_LANE_ZB(Z.zb), STARKHIP_LANE_AW00(M.aw[0][0]),                \
+              STARKHIP_LANE_AW01(M.aw[0][1]), STARKHIP_LANE_AW02(M.aw[0][2]), STARKHIP_LANE_AW10(M.aw[1][0]), STARKHIP_LANE_AW11(M.aw[1][1]), \
+              STARKHIP_LANE_AW12(M.aw[1][2]), STARKHIP_LANE_BC0(M.bc[0]), STARKHIP_LANE_BC1(M.bc[1]), STARKHIP_LANE_BC2(M.bc[2]),          \
+              STARKHIP_LANE_BC3(M.bc[3]), STARKHIP_LANE_S_SEL_A(STARKHIP_LANE_SEL_A_VALUE), STARKHIP_LANE_S_SEL_B(STARKHIP_LANE_SEL_B_VALUE), \
+              STARKHIP_LANE_S_SEL_C(STARKHIP_LANE_SEL_C_VALUE), STARKHIP_LANE_S_SEL_D(STARKHIP_LANE_SEL_D_VALUE),                          \
+              STARKHIP_LANE_S_X80(0x80808080u), STARKHIP_LANE_S_K64K(65536u)                                                               \
+            : STARKHIP_LANE_CLOBBERS, STARKHIP_LANE_MFMA_CLOBBERS);                                                                        \
+    }
+STARKHIP_LANE_MFMA_BLOCK(lane_full_round_mfma_asm, STARKHIP_LANE_FULL_ROUND_MFMA_ASM)
+STARKHIP_LANE_MFMA_BLOCK(lane_partial_round_mfma_asm, STARKHIP_LANE_PARTIAL_ROUND_MFMA_ASM)
+#undef STARKHIP_LANE_MFMA_BLOCK
 __device__ __forceinline__ gl_t lane_get(const lane_u32x8& t, int i) { return (gl_t)t[2 * i] | ((gl_t)t[2 * i + 1] << 32); }
 __device__ __forceinline__ void lane_set(lane_u32x8& t, int i, gl_t x) {
     t[2 * i] = (uint32_t)x;
     t[2 * i + 1] = (uint32_t)(x >> 32);
 }
 // One permutation.  CAP_ONLY: only the capacity (st.t2) of the result is computed -- the caller overwrites the rate.
+// Rounds 0 .. 3, 25 (the lone partial round) and 26 .. 28 run their circulant layer on the matrix pipe (866 and 292 slots against 980 and
+// 418); the merged triples (21-bit coefficients: three weight planes, no gain) and the capacity-only last round stay multiply-add chains.
+// -DSTARKHIP_LANE_NO_MFMA: the round-3 form throughout (A/B measurements).
 template <bool CAP_ONLY>
-__device__ __forceinline__ void poseidon_permute_lane_asm(LaneState& st, const LaneTables* __restrict__ T, const LaneZeros& Z) {
+__device__ __forceinline__ void poseidon_permute_lane_asm(LaneState& st, const LaneTables* __restrict__ T, const LaneZeros& Z, LaneMfma& M, unsigned lane) {
+    {
+        // the first round's constants are read HERE, every permutation: hoisted out of the caller's loop they are 48 registers hipcc
+        // spills to scratch and reloads one after the other (the pointer goes through an empty asm so that it cannot)
+        const gl_t* rc0 = T->rc0;
+        asm volatile("" : "+v"(rc0));
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        lane_set(st.t0, i, gl_add_nc(lane_get(st.t0, i), T->rc[0][i].lo | (T->rc[0][i].hi << 32)));
-        lane_set(st.t1, i, gl_add_nc(lane_get(st.t1, i), T->rc[0][4 + i].lo | (T->rc[0][4 + i].hi << 32)));
-        lane_set(st.t2, i, gl_add_nc(lane_get(st.t2, i), T->rc[0][8 + i].lo | (T->rc[0][8 + i].hi << 32)));
+        for (int i = 0; i < 4; i++) {
+            lane_set(st.t0, i, gl_add_nc(lane_get(st.t0, i), rc0[i]));
+            lane_set(st.t1, i, gl_add_nc(lane_get(st.t1, i), rc0[4 + i]));
+            lane_set(st.t2, i, gl_add_nc(lane_get(st.t2, i), rc0[8 + i]));
+        }
     }
     const uint32_t rc_lds = (uint32_t)(uintptr_t)&T->rc[0][0], k3_lds = (uint32_t)(uintptr_t)&T->k3[0][0], k12_lds = (uint32_t)(uintptr_t)&T->k12[0][0],
                    coef_lds = (uint32_t)(uintptr_t)&T->row[0][0];
     constexpr uint32_t RC_ROW = 12 * sizeof(RcPair);
+#ifdef STARKHIP_LANE_NO_MFMA
+    (void)M;
+    (void)lane;
 #pragma unroll 1
     for (uint32_t r = 0; r < 4; r++) lane_full_round_asm(st, rc_lds + (r + 1) * RC_ROW, Z);
 #pragma unroll 1
@@ -798,6 +869,17 @@ __device__ __forceinline__ void poseidon_permute_lane_asm(LaneState& st, const L
     lane_partial_round_asm(st, rc_lds + 26 * RC_ROW, Z);
 #pragma unroll 1
     for (uint32_t r = 26; r < 29; r++) lane_full_round_asm(st, rc_lds + (r + 1) * RC_ROW, Z);
+#else
+    const uint32_t rcb_lds = (uint32_t)(uintptr_t)&T->rcb[0][0][0] + lane * 4u;
+    constexpr uint32_t RCB_ROUND = 8 * 64 * 4;
+#pragma unroll 1
+    for (uint32_t m = 0; m < 4; m++) lane_full_round_mfma_asm(st, rcb_lds + m * RCB_ROUND, Z, M);
+#pragma unroll 1
+    for (uint32_t t = 0; t < 7; t++) lane_triple_asm(st, k3_lds + t * RC_ROW, k12_lds + t * 2 * (uint32_t)sizeof(RcPair), coef_lds, Z);
+    lane_partial_round_mfma_asm(st, rcb_lds + 4 * RCB_ROUND, Z, M);
+#pragma unroll 1
+    for (uint32_t m = 5; m < 8; m++) lane_full_round_mfma_asm(st, rcb_lds + m * RCB_ROUND, Z, M);
+#endif
     if (CAP_ONLY) lane_last_round_asm(st, rc_lds + 30 * RC_ROW, Z);
     else lane_full_round_asm(st, rc_lds + 30 * RC_ROW, Z);
 }

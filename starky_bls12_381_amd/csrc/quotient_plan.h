@@ -45,6 +45,7 @@ static const unsigned QT_MAX_PIECE = 192;   // records per piece after splitting
 // Y = S3 + hi(S1) 2^22 + lo(S2) 2^12 + lo(S4) 2^22 + hi(X)), i.e. < (0.9375 + 2^-9) * 2^64: no wrap.  At 1024 records the sums
 // themselves still fit but X and Y can wrap -- planner, host replay and kernel all use THIS bound.
 static const unsigned QT_MAX_CHAIN = 960;
+static const unsigned QT_MAX_RUN = 252;     // longest plain run one special record announces (a multiple of four that fits eight bits)
 static const unsigned QT_LIMB_BITS = 22;    // weights are split into three limbs of 22 bits
 
 // record control word
@@ -59,6 +60,9 @@ enum : uint32_t {
     QT_END = 1u << 21,         // last record of its piece: acc_j += mask * G * T_j, next piece descriptor
     QT_TILE = 1u << 22,        // no cell: the wave is done with this tile (barrier, next tile)
     QT_STOP = 1u << 23,        // end of stream
+    QT_RUN_SHIFT = 24,         // [31:24] of a SPECIAL record (any flag below set): the number of plain records (no flag at all) that
+                               // follow it before the next special one, at most QT_MAX_RUN -- the kernel evaluates such a run four
+                               // records at a time without looking at their control words' flags; plain records carry 0 here
     QT_SPECIAL = QT_SRC_ONE | QT_SRC_GLOBAL | QT_SETV | QT_MULV | QT_END | QT_TILE | QT_STOP,
     QT_ODD_SOURCE = QT_SRC_ONE | QT_SRC_GLOBAL | QT_SETV | QT_MULV | QT_TILE | QT_STOP
 };
@@ -379,6 +383,10 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         }
         for (unsigned w = 0; w < QT_WAVES; w++) {
             Q.streams.push_back({(uint32_t)Q.recs.size(), (uint32_t)Q.pieces.size()});
+            const size_t stream_first = Q.recs.size();
+            // a run of plain records needs a special record in front of it that announces its length; nothing precedes the first record
+            // of a stream, so every stream opens with a no-op (v = 1, no accumulation)
+            push_rec(QT_SRC_ONE | QT_SETV, 0, 0, 0);
             for (uint32_t t = t_lo; t < t_hi; t++) {
                 const uint32_t tile = tiles[t];
                 const std::vector<uint32_t>& mine = assign[t - t_lo][w];
@@ -441,6 +449,55 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                 push_rec(QT_TILE, 0, 0, 0);
             }
             push_rec(QT_STOP, 0, 0, 0);
+            // run lengths: walk the stream backwards; a run longer than QT_MAX_RUN is cut by more no-ops
+            {
+                std::vector<QTRec> out;
+                std::vector<uint32_t> ocb, oce;
+                out.reserve(Q.recs.size() - stream_first + 8);
+                std::vector<uint32_t> run_after(Q.recs.size() - stream_first, 0);
+                uint32_t run = 0;
+                for (size_t r = Q.recs.size(); r-- > stream_first;) {
+                    if ((Q.recs[r].ctl & QT_SPECIAL) == 0) run++;
+                    else {
+                        run_after[r - stream_first] = run;
+                        run = 0;
+                    }
+                }
+                for (size_t r = stream_first; r < Q.recs.size(); r++) {
+                    QTRec rec = Q.recs[r];
+                    uint32_t left = (rec.ctl & QT_SPECIAL) ? run_after[r - stream_first] : 0;
+                    if (rec.ctl & QT_SPECIAL) {
+                        rec.ctl |= std::min<uint32_t>(left, QT_MAX_RUN) << QT_RUN_SHIFT;
+                        left -= std::min<uint32_t>(left, QT_MAX_RUN);
+                    }
+                    out.push_back(rec);
+                    ocb.push_back(rec_c_begin[r]);
+                    oce.push_back(rec_c_end[r]);
+                    // the plain records this special one announces follow; if the run is longer, a no-op goes in after QT_MAX_RUN of them
+                    size_t q = r + 1;
+                    for (uint32_t done = 0; (rec.ctl & QT_SPECIAL) && q < Q.recs.size() && (Q.recs[q].ctl & QT_SPECIAL) == 0; q++) {
+                        if (done == QT_MAX_RUN) {
+                            const uint32_t more = std::min<uint32_t>(left, QT_MAX_RUN);
+                            out.push_back({QT_SRC_ONE | QT_SETV | (more << QT_RUN_SHIFT), 0, {0, 0, 0, 0, 0, 0}});
+                            ocb.push_back(0);
+                            oce.push_back(0);
+                            left -= more;
+                            done = 0;
+                        }
+                        out.push_back(Q.recs[q]);
+                        ocb.push_back(rec_c_begin[q]);
+                        oce.push_back(rec_c_end[q]);
+                        done++;
+                    }
+                    r = q - 1;
+                }
+                Q.recs.resize(stream_first);
+                rec_c_begin.resize(stream_first);
+                rec_c_end.resize(stream_first);
+                Q.recs.insert(Q.recs.end(), out.begin(), out.end());
+                rec_c_begin.insert(rec_c_begin.end(), ocb.begin(), ocb.end());
+                rec_c_end.insert(rec_c_end.end(), oce.begin(), oce.end());
+            }
             // the kernel fetches a few records / one descriptor beyond the end of a stream
             for (int z = 0; z < 4; z++) push_rec(QT_STOP, 0, 0, 0);
             Q.pieces.push_back({0, {0, 0, 0, 0}, {0, 0, 0}});
@@ -508,8 +565,18 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
             unsigned n_in_piece = 0;
             bool in_product = false;
             gl_t v = 1;
+            uint32_t announced = 0;  // plain records the last special record said would follow
+            if ((rec->ctl & QT_SPECIAL) == 0) return false;  // a stream opens with a special record (the kernel knows no run length before it)
             for (;; rec++) {
                 const uint32_t ctl = rec->ctl;
+                if ((ctl & QT_SPECIAL) == 0) {  // plain: must have been announced, and carries no run length itself
+                    if (announced == 0 || (ctl >> QT_RUN_SHIFT) != 0) return false;
+                    announced--;
+                } else {
+                    if (announced != 0) return false;  // a special record inside an announced run: the kernel would not look at its flags
+                    announced = ctl >> QT_RUN_SHIFT;
+                    if (announced > QT_MAX_RUN) return false;
+                }
                 if (ctl & QT_STOP) break;
                 if (ctl & QT_TILE) {
                     if (in_product) return false;  // a piece may go on in the next tile (same supergroup), a monomial may not
@@ -531,8 +598,10 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
                 if (ctl & QT_MULV) x = gl_mul(v, x);
                 if (ctl & QT_SETV) {
                     v = x;
-                    in_product = true;
                     if (ctl & QT_END) return false;
+                    // (x = 1 with SETV alone is the planner's no-op -- a stream's opening record, or the record that cuts a run longer
+                    // than QT_MAX_RUN --, not the first factor of a product)
+                    if ((ctl & (QT_SRC_ONE | QT_MULV)) != QT_SRC_ONE) in_product = true;
                     continue;
                 }
                 in_product = false;

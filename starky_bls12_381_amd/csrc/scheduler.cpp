@@ -144,7 +144,7 @@ void HashService::launch_big(Req* r, bool lane, unsigned group) {
         r->timing->group = group;
         if (e == hipSuccess && r->timing->t0) e = hipEventRecord(r->timing->t0, s);
     }
-    if (e == hipSuccess) e = lane ? launch_leaf_hash_lane(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s)
+    if (e == hipSuccess) e = lane ? launch_leaf_hash_lane(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s, lane_share_)
                                   : launch_leaf_hash(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s);
     if (e == hipSuccess && r->timing && r->timing->t1) e = hipEventRecord(r->timing->t1, s);
     if (e == hipSuccess) e = hipEventRecord(r->done, s);
@@ -260,7 +260,7 @@ void HashService::run() {
         // GROUPS: a group waits (bounded) while big proofs that have started have not reached their commitment; a commitment that ends
         // up alone goes out in the quad form.
         bool big_ready = !big_.empty();
-        if (big_lane_ && !big_.empty()) {
+        if (big_lane_ && !lane_share_ && !big_.empty()) {
             const double waited = (now_s() - big_.front()->t_arrive) * 1e3;
             // a busy pool (five or more big proofs under way) always waits for a full group, bounded; a quiet one only for the proofs that
             // are on their way to their commitment -- a lone proof is not held up
@@ -270,7 +270,7 @@ void HashService::run() {
         const bool take_big = big_ready && (!small_ready || !last_was_big_);
         if (take_big) {
             std::vector<Req*> group;
-            while (!big_.empty() && group.size() < (big_lane_ ? BIG_LANE_GROUP : 1u)) {
+            while (!big_.empty() && group.size() < ((big_lane_ && !lane_share_) ? BIG_LANE_GROUP : 1u)) {
                 group.push_back(big_.front());
                 big_.pop_front();
             }
@@ -278,7 +278,7 @@ void HashService::run() {
             wait_for.swap(running_small_);
             lk.unlock();
             if (policy == 1) drain(wait_for);  // exclusive classes: the small window has left the chip
-            for (Req* r : group) launch_big(r, big_lane_ && group.size() >= 2, (unsigned)group.size());
+            for (Req* r : group) launch_big(r, big_lane_ && (lane_share_ || group.size() >= 2), (unsigned)group.size());
             lk.lock();
             for (Req* r : group) r->state = r->err == hipSuccess ? 1 : 2;
             stats_.big_launches += group.size();
@@ -309,7 +309,7 @@ void HashService::run() {
         // requests are pending but their window is still gathering: wake up when something arrives or its time is up
         double left_ms = 1e9;
         if (!small_.empty()) left_ms = std::min(left_ms, gather_ms - (now_s() - small_.front()->t_arrive) * 1e3);
-        if (big_lane_ && !big_.empty()) left_ms = std::min(left_ms, big_gather_ms_ - (now_s() - big_.front()->t_arrive) * 1e3);
+        if (big_lane_ && !lane_share_ && !big_.empty()) left_ms = std::min(left_ms, big_gather_ms_ - (now_s() - big_.front()->t_arrive) * 1e3);
         // (system_clock deadline = pthread_cond_timedwait: ThreadSanitizer of gcc 11 does not know pthread_cond_clockwait, which a
         // steady-clock wait_for uses, and then reports the mutex as still held)
         cv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds((long)(std::max(0.1, left_ms) * 1e3)));
@@ -699,6 +699,10 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
     p->hs->policy = (int)cfg.commit_policy;
     p->hs->row_leaves_ = row_leaves;
     p->hs->big_lane_ = big_lane;
+    {
+        const char* ls = getenv("STARKHIP_POOL_LANE_SHARE");
+        p->hs->lane_share_ = big_lane && ls && *ls == '1';
+    }
     {
         const char* lg = getenv("STARKHIP_POOL_LANE_GROUP");
         if (lg && *lg && atoi(lg) >= 2 && atoi(lg) <= 8) p->hs->BIG_LANE_GROUP = (unsigned)atoi(lg);

@@ -64,6 +64,8 @@ class HashService {
     double big_gather_ms_ = 150.0;  // lane form: how long a group of big commitments waits for announced ones to join
     bool big_lane_ = false;  // big commitments in groups, a group of two or more in the lane form (pools with five or more big contexts;
                              // STARKHIP_POOL_BIG_LANE=0 / 1 overrides)
+    bool lane_share_ = false;  // STARKHIP_POOL_LANE_SHARE=1: big commitments go out one by one in the lane form, each launch taking half of every
+                               // CU (launch_leaf_hash_lane share_cu): the LDE / quotient workgroups of the other proofs run beside them
     int big_expected_ = 0;   // big proofs that have started and not yet reached their commitment
     int big_active_ = 0;     // big proofs being proved (before, in or after their commitment)  // STARKHIP_POOL_BIG_LANE=1: big commitments in the lane form (one lane per leaf)
     size_t row_leaves_ = 64;  // STARKHIP_POOL_ROW_LEAVES: small commitments of at most this many leaves go out in the row form, one launch each (0: never)

@@ -49,8 +49,8 @@ class Slot:
 
 
 def load(prog, first, count, addr, off, key):
-    op = {4: "ds_read_b128", 2: "ds_read_b64"}[count]
-    rng = "v[%d:%d]" % (first, first + count - 1)
+    op = {4: "ds_read_b128", 2: "ds_read_b64", 1: "ds_read_b32"}[count]
+    rng = "v[%d:%d]" % (first, first + count - 1) if count > 1 else v(first)
     prog.append(Ins("%s %s, %s offset:%d" % (op, rng, v(addr), off), [addr], list(range(first, first + count)), sem=("ldsload", first, count, key)))
     prog[-1].is_load = True
     prog[-1].boost = True
@@ -161,15 +161,203 @@ def block_triple():
     return prog
 
 
+# ---------------------------------------------------------------- the circulant layer on the matrix pipe
+# One permutation per lane: the layer  out[i] = rc[i] + sum_j M[i][j] s[j]  over all 64 lanes IS a (12 x 12) x (12 x 64) product of a
+# matrix of 6-bit weights with 64-bit words, i.e. eight products with the words' BYTE PLANES (bytes are exact in the i8 pipe, the
+# 12-term sums stay below 2^17): v_mfma_i32_32x32x32_i8 with the weights as the A tile and byte plane b of the state as the B tile.
+# Lane l of the B operand holds 16 K-values of column l & 31; lanes l and l + 32 are two different permutations here, so the weight
+# tile is block diagonal: rows whose results land in the lower lane half (rows 0-3, 8-11, 16-19 = output g = (row & 3) + 4 (row >> 3))
+# carry M[g][.] against the lower half's K-values and zeros against the upper half's, rows 4-7, 12-15, 20-23 the other way round
+# (tools/experiments/mfma_mds_probe.hip checks this map with exact integer data on all 64 lanes).  Result register g of a lane is then
+#   S_b[g] = sum_j M[g][j] sbyte_b(s[j]) + (what the four spare K-values add),
+# sbyte = byte XOR 0x80 read as signed = byte - 128 (the pipe's operands are signed).  The spare K-values 12 .. 15 carry the constants:
+# the B side holds (1, 64, 127, 127) in every lane, the A side -- per row, round and plane, one dword per lane from LDS -- holds
+# (c7, 2 m + 40, 127, 127) with c7 + 128 m = byte b of a 64-bit constant RC[g]: together + RC byte + 34 818, which makes every S_b[g]
+# non-negative (34 818 >= 128 * 272, the largest row sum) and lets the host fold the offsets into RC (kernels_hash.hip).
+# Recombination: lo = S0 + S1 2^8 + S2 2^16 + S3 2^24 (two v_lshl_add_u32 and one multiply-add by 2^16), hi likewise from planes 4 .. 7,
+# then the fold lo + hi 2^32 the multiply-add form already uses.  Per round 24 XORs + 48 byte permutes + 8 LDS dwords + 8 MFMA (which
+# cost the vector issue < 1 slot each, measured by the probe) + 72 + 48 instead of 288 multiply-adds + 48 + 12 LDS rows.
+AW = [52, 56]            # in: the weight tile's dwords 0 .. 2, twice (v52-54, v56-58); dword 3 (v55, v59) is loaded per plane
+BP = [60, 64, 68, 72]    # the B tuples of planes b mod 4; dwords 0 .. 2 are written here, dword 3 (v63, v67, v71, v75) in: 0x7F7F4001
+A_RCB = 79               # in: LDS address of this lane's dword in the round's constant table (plane b at byte offset 256 b)
+DT = [128 + 12 * b for b in range(8)]   # result tiles, one per plane: sixteen registers are written, the first twelve are results; the four
+                         # junk registers are the next tile's first four, which the next MFMA (issued later, one pipe: it completes later)
+                         # overwrites with its results.  v128 .. v227
+HIP = S                  # hi halves (12 pairs): the S-box outputs' registers in a full round (every permute has read them by then)
+ST = 248                 # byte-transpose temporaries (8)
+UT = [228, 229, 230, 231]     # 32-bit partial sums
+MFOLD = 232              # the folds' temporaries here (the usual ones lie under the tiles): 232 .. 238
+S_SEL = {"A": 64, "B": 65, "C": 66, "D": 67}   # SGPRs in: v_perm_b32 selectors
+S_X80, S_64K = 68, 69    # SGPRs in: 0x80808080, 65536
+MFMA_PIPE = 9999         # a pseudo register that chains the MFMAs (they share one pipe: issued closer than its occupancy they would stall the wave)
+MFMA_RESULT, MFMA_SPACING, MFMA_OPERAND, MFMA_WAR = 20, 9, 3, 6   # slots: result -> first VALU read; MFMA -> next MFMA; VALU write -> MFMA operand; MFMA operand read -> overwrite
+SEL_VALUE = {"A": 0x05010400, "B": 0x07030602, "C": 0x05040100, "D": 0x07060302}
+B_CONST = 0x7F7F4001
+K_OFFSET = 2 * 127 * 127 + 64 * 40
+
+
+def mds_coef(r, j):
+    return CIRC[(j - r) % 12] + (8 if r == 0 and j == 0 else 0)
+
+
+def perm(prog, dst, s0, s1, sel):
+    prog.append(Ins("v_perm_b32 %s, %s, %s, s%d" % (v(dst), v(s0), v(s1), S_SEL[sel]), [s0, s1], [dst], sem=("perm", dst, s0, s1, sel)))
+
+
+def xor80(prog, reg):
+    prog.append(Ins("v_xor_b32 %s, s%d, %s" % (v(reg), S_X80, v(reg)), [reg], [reg], sem=("xor80", reg)))
+
+
+def lshl_add(prog, dst, a, sh, b):
+    prog.append(Ins("v_lshl_add_u32 %s, %s, %d, %s" % (v(dst), v(a), sh, v(b)), [a, b], [dst], sem=("lshladd", dst, a, sh, b)))
+
+
+def mfma(prog, k, plane):
+    a, b, d = AW[k % 2], BP[k], DT[plane]
+    load(prog, a + 3, 1, A_RCB, 256 * plane, ("rcb", plane))
+    # (the junk registers d + 12 .. d + 15 are not listed as written: nothing reads them, and the MFMA that owns them is ordered behind
+    # this one through the pipe's pseudo register)
+    ins = Ins("v_mfma_i32_32x32x32_i8 v[%d:%d], v[%d:%d], v[%d:%d], 0" % (d, d + 15, a, a + 3, b, b + 3),
+              [a, a + 1, a + 2, a + 3, b, b + 1, b + 2, b + 3, MFMA_PIPE], list(range(d, d + 12)) + [MFMA_PIPE], sem=("mfma", d, a, b, plane))
+    ins.is_mfma = True
+    ins.junk = set(range(d + 12, d + 16))
+    prog.append(ins)
+
+
+def fold_hi_lo(prog, dst, A, B, k):
+    """fold_to with its temporaries at MFOLD"""
+    FT, CV, FC = MFOLD + 4 * k, MFOLD + 4 * k + 2, FCS[k]
+    prog.append(Ins("v_mad_u64_u32 %s, %s, %s, -1, %s" % (vp(FT), sp(SINK), v(B + 1), vp(A)), [B + 1, A, A + 1], [FT, FT + 1], sem=("mad", FT, None, B + 1, "eps", A)))
+    prog.append(Ins("v_add_co_u32 %s, %s, %s, %s" % (v(FT + 1), sp(FC), v(FT + 1), v(B)), [FT + 1, B], [FT + 1], swrites=[FC], sem=("addco", FT + 1, FC, FT + 1, B)))
+    prog.append(Ins("v_addc_co_u32 %s, %s, 0, 0, %s" % (v(CV), sp(SINK), sp(FC)), [], [CV], sreads=[FC], sem=("addc", CV, None, None, None, FC)))
+    prog.append(Ins("v_mad_u64_u32 %s, %s, %s, -1, %s" % (vp(dst), sp(SINK), v(CV), vp(FT)), [CV, FT, FT + 1], [dst, dst + 1], sem=("mad", dst, None, CV, "eps", FT)))
+
+
+def circulant_mfma(prog, in_base, out_base):
+    """out[i] = RC[i] + sum_j M[i][j] in[j] for all twelve outputs; RC comes in through the table at A_RCB.  The low dwords of the inputs
+    make planes 0 .. 3, the high dwords planes 4 .. 7.  All eight products are issued before anything is recombined (a tile per plane),
+    so the wait for the last one is filled with the recombination of the first ones; the low halves of the results go to `out_base`,
+    the high halves to HIP, both only after every input has been read (in_base may be out_base or HIP)."""
+    for half in range(2):
+        for q in range(3):
+            w = [in_base + 2 * (4 * q + k) + half for k in range(4)]
+            t = ST + 4 * (q % 2)
+            perm(prog, t + 0, w[1], w[0], "A")   # (w0.b0, w1.b0, w0.b1, w1.b1)
+            perm(prog, t + 1, w[1], w[0], "B")   # (w0.b2, w1.b2, w0.b3, w1.b3)
+            perm(prog, t + 2, w[3], w[2], "A")
+            perm(prog, t + 3, w[3], w[2], "B")
+            perm(prog, BP[0] + q, t + 2, t + 0, "C")   # byte 0 of w0 .. w3
+            perm(prog, BP[1] + q, t + 2, t + 0, "D")   # byte 1
+            perm(prog, BP[2] + q, t + 3, t + 1, "C")   # byte 2
+            perm(prog, BP[3] + q, t + 3, t + 1, "D")   # byte 3
+            for k in range(4):
+                xor80(prog, BP[k] + q)
+        for k in range(4):
+            mfma(prog, k, 4 * half + k)
+    for half in range(2):
+        for i in range(12):
+            ad = AD[i % 2]
+            u = UT[(2 * half + i) % 4]
+            d0, d1, d2, d3 = (DT[4 * half + k] + i for k in range(4))
+            lshl_add(prog, ad, d1, 8, d0)
+            lshl_add(prog, u, d3, 8, d2)
+            dst = (out_base if half == 0 else HIP) + 2 * i
+            prog.append(Ins("v_mad_u64_u32 %s, %s, %s, s%d, %s" % (vp(dst), sp(SINK), v(u), S_64K, vp(ad)), [u, ad, ad + 1], [dst, dst + 1],
+                            sem=("mad", dst, None, u, ("const", 65536), ad)))
+    for i in range(12):
+        fold_hi_lo(prog, out_base + 2 * i, out_base + 2 * i, HIP + 2 * i, i % 2)
+
+
+def block_full_mfma():
+    prog = []
+    for e in range(12):
+        sbox(prog, S + 2 * e, T + 2 * e, e % 2)
+    circulant_mfma(prog, S, T)
+    return prog
+
+
+def block_partial_mfma():
+    prog = []
+    sbox(prog, T, T, 0)       # element 0 in place; the layer reads T and writes T (every input is in the B tuples before any output exists)
+    circulant_mfma(prog, T, T)
+    return prog
+
+
 # ---------------------------------------------------------------- scheduling with load latency, counted waits
 LOAD_LATENCY = 16
 
 
+def schedule_lane(prog):
+    """gen_row_round_asm.schedule_with plus the matrix pipe's distances (MFMA_*)."""
+    n = len(prog)
+    preds = [[] for _ in range(n)]
+    last_w, last_sw, readers, sreaders = {}, {}, {}, {}
+    is_mfma = [getattr(x, "is_mfma", False) for x in prog]
+    is_load = [getattr(x, "is_load", False) for x in prog]
+    for i, ins in enumerate(prog):
+        for r in ins.reads:
+            if r in last_w:
+                j = last_w[r]
+                d = 1
+                if is_load[j]:
+                    d = LOAD_LATENCY
+                elif is_mfma[j]:
+                    d = MFMA_SPACING if r == MFMA_PIPE else MFMA_RESULT
+                elif is_mfma[i]:
+                    d = MFMA_OPERAND
+                preds[i].append((j, d))
+        for r in ins.sreads:
+            if r in last_sw:
+                preds[i].append((last_sw[r], 3))                        # W1
+        for w in ins.writes:
+            if w in last_w:
+                j = last_w[w]
+                preds[i].append((j, MFMA_RESULT if is_mfma[j] and w != MFMA_PIPE else 1))
+            for j in readers.get(w, []):
+                if j != i:
+                    preds[i].append((j, MFMA_WAR if is_mfma[j] else 1 if is_load[i] else 2))   # W3
+        for w in ins.swrites:
+            if w in last_sw:
+                preds[i].append((last_sw[w], 1))
+            for j in sreaders.get(w, []):
+                if j != i:
+                    preds[i].append((j, 1))
+        for r in ins.reads:
+            readers.setdefault(r, []).append(i)
+        for r in ins.sreads:
+            sreaders.setdefault(r, []).append(i)
+        for w in ins.writes:
+            last_w[w] = i
+            readers[w] = [i] if w in ins.reads else []
+        for w in ins.swrites:
+            last_sw[w] = i
+            sreaders[w] = []
+    succs = [[] for _ in range(n)]
+    for i in range(n):
+        for j, d in preds[i]:
+            succs[j].append((i, d))
+    prio = [0] * n
+    for i in reversed(range(n)):
+        prio[i] = 1 + max([prio[k] + d - 1 for k, d in succs[i]] + [0])
+        if getattr(prog[i], "boost", False):
+            prio[i] += 1000
+    pos, order, slot, remaining = {}, [], 0, set(range(n))
+    while remaining:
+        ready = [i for i in remaining if all(j in pos and pos[j] + d <= slot for j, d in preds[i])]
+        if ready:
+            i = max(ready, key=lambda k: (prio[k], -k))
+            pos[i] = slot
+            order.append(prog[i])
+            remaining.discard(i)
+        else:
+            order.append(Ins("s_nop 0", [], []))
+        slot += 1
+    return order
+
+
 def schedule(prog):
     # a consumer of a loaded register is kept LOAD_LATENCY slots behind the load (there is other work); the waits are counted below
-    for ins in prog:
-        ins.min_after_load = LOAD_LATENCY
-    order = G.schedule_with(prog, lambda producer, consumer, d: max(d, LOAD_LATENCY) if getattr(producer, "is_load", False) else d)
+    order = schedule_lane(prog)
     out, pending = [], []          # pending: loads in issue order: (registers, position of issue)
     for ins in order:
         if getattr(ins, "is_load", False):
@@ -193,7 +381,47 @@ def schedule(prog):
     return out
 
 
+def check_mfma_distances(order):
+    """the final order (waits included, they only add slots) keeps every matrix-pipe distance"""
+    last_mfma_write, last_mfma_read, last_valu_write, last_mfma = {}, {}, {}, None
+    junk_since = {}   # registers an MFMA fills with junk rows: dead until something writes them again
+    for i, ins in enumerate(order):
+        m = getattr(ins, "is_mfma", False)
+        for r in ins.reads:
+            assert r not in junk_since, ("reads an MFMA's junk row", i, ins.text)
+        for w in ins.writes:
+            if w in junk_since:
+                assert m or i - junk_since[w] >= MFMA_RESULT, ("writes where an MFMA's junk row is still to land", i, ins.text)
+                del junk_since[w]
+        for r in ins.reads:
+            if r in last_mfma_write and r != MFMA_PIPE:
+                assert i - last_mfma_write[r] >= MFMA_RESULT, ("MFMA result read too early", i, ins.text)
+            if m and r in last_valu_write and r != MFMA_PIPE:
+                assert i - last_valu_write[r] >= MFMA_OPERAND, ("MFMA operand written too late", i, ins.text)
+        for w in ins.writes:
+            if w == MFMA_PIPE:
+                continue
+            if w in last_mfma_read and not getattr(ins, "is_load", False):
+                assert i - last_mfma_read[w] >= MFMA_WAR, ("MFMA operand overwritten too early", i, ins.text)
+            if w in last_mfma_write:
+                assert i - last_mfma_write[w] >= MFMA_RESULT, ("MFMA result overwritten too early", i, ins.text)
+        if m:
+            assert last_mfma is None or i - last_mfma >= MFMA_SPACING, ("MFMAs too close", i)
+            last_mfma = i
+            for w in getattr(ins, "junk", ()):
+                junk_since[w] = i
+            for r in ins.reads:
+                last_mfma_read[r] = i
+            for w in ins.writes:
+                last_mfma_write[w] = i
+        else:
+            for w in ins.writes:
+                last_valu_write[w] = i
+                last_mfma_write.pop(w, None)
+
+
 def check_hazards(order):
+    check_mfma_distances(order)
     real = [o for o in order]
     for i, ins in enumerate(real):
         for back in (1, 2):
@@ -204,7 +432,70 @@ def check_hazards(order):
             assert not (ins.writes & (real[i - 1].reads - real[i - 1].writes)), ("W3", i, ins.text)
 
 
+# ---------------------------------------------------------------- interpreter of the matrix-pipe blocks' extra instructions
+def run_lane(order, vregs, sregs):
+    """gen_row_round_asm.run plus v_perm_b32, v_xor_b32, v_lshl_add_u32, and the MFMA as ONE LANE sees it (its own twelve K-values
+    against the weight rows that land in it; the cross-lane map itself is checked on the device, tools/experiments/mfma_mds_probe.hip)."""
+    for ins in order:
+        k = ins.sem[0] if ins.sem else None
+        if k == "perm":
+            _, d, s0, s1, sel = ins.sem
+            src = (vregs[s1][0] & M32) | ((vregs[s0][0] & M32) << 32)
+            out = 0
+            for i in range(4):
+                out |= ((src >> (8 * ((SEL_VALUE[sel] >> (8 * i)) & 0xFF))) & 0xFF) << (8 * i)
+            vregs[d] = [out]
+        elif k == "xor80":
+            vregs[ins.sem[1]] = [vregs[ins.sem[1]][0] ^ 0x80808080]
+        elif k == "lshladd":
+            _, d, a, sh, b = ins.sem
+            vregs[d] = [((vregs[a][0] << sh) + vregs[b][0]) & M32]
+        elif k == "mfma":
+            _, d, a, b, plane = ins.sem
+            assert vregs[b + 3][0] == B_CONST, "B tuple's constant dword"
+            assert vregs[a + 3][0] == 0xC0DE00 + plane, ("A tuple holds another plane's constants", plane, vregs[a + 3][0])
+            by = []
+            for q in range(3):
+                for i in range(4):
+                    x = (vregs[b + q][0] >> (8 * i)) & 0xFF
+                    by.append(x - 256 if x >= 128 else x)
+            rc = vregs["rcbytes"][plane]
+            for g in range(12):
+                val = sum(mds_coef(g, j) * by[j] for j in range(12)) + (rc[g] & 0x7F) + 64 * (2 * (rc[g] >> 7) + 40) + 2 * 127 * 127
+                assert 0 <= val < (1 << 17)
+                vregs[d + g] = [val]
+            for g in range(12, 16):  # the junk rows: anything
+                vregs[d + g] = [0xDEAD0000 + g]
+        else:
+            G.run([ins], vregs, sregs)
+
+
 # ---------------------------------------------------------------- tests
+def mfma_round_constants(rc):
+    """the 64-bit constants whose bytes ride in the weight tile: RC[g] = rc[g] - (K - 128 rowsum[g]) * 0x0101010101010101 mod p"""
+    ones = 0x0101010101010101
+    return [(rc[g] - (K_OFFSET - 128 * sum(mds_coef(g, j) for j in range(12))) * ones) % P for g in range(12)]
+
+
+def test_round_mfma(order, partial):
+    for _ in range(40):
+        state = [rnd() for _ in range(12)]
+        rc = [random.getrandbits(64) % P for _ in range(12)]
+        vregs = fresh()
+        for r in range(52, 76):
+            vregs[r] = [random.getrandbits(32)]
+        for k in range(4):
+            vregs[BP[k] + 3] = [B_CONST]
+        set_state(vregs, state)
+        RC = mfma_round_constants(rc)
+        vregs["rcbytes"] = [[(RC[g] >> (8 * b)) & 0xFF for g in range(12)] for b in range(8)]
+        for b in range(8):
+            vregs["mem"][("rcb", b)] = [[0xC0DE00 + b]]
+        run_lane(order, vregs, {})
+        want = G.reference_round(state, rc, partial)
+        assert get_state(vregs) == want, partial
+
+
 def rnd():
     return random.choice([0, 1, P - 1, P, M64, random.getrandbits(64), random.getrandbits(64)])
 
@@ -290,7 +581,9 @@ def main():
             ("STARKHIP_LANE_FULL_ROUND_ASM", block_full(), lambda o: test_round(o, False), "full round: twelve S-boxes, circulant layer"),
             ("STARKHIP_LANE_LAST_ROUND_ASM", block_full(8), lambda o: test_round(o, False, 8), "last full round before an absorb: the capacity outputs only"),
             ("STARKHIP_LANE_PARTIAL_ROUND_ASM", block_partial(), lambda o: test_round(o, True), "partial round"),
-            ("STARKHIP_LANE_TRIPLE_ASM", block_triple(), test_triple, "three partial rounds at once (poseidon_merged.h)")):
+            ("STARKHIP_LANE_TRIPLE_ASM", block_triple(), test_triple, "three partial rounds at once (poseidon_merged.h)"),
+            ("STARKHIP_LANE_FULL_ROUND_MFMA_ASM", block_full_mfma(), lambda o: test_round_mfma(o, False), "full round, circulant layer on the matrix pipe"),
+            ("STARKHIP_LANE_PARTIAL_ROUND_MFMA_ASM", block_partial_mfma(), lambda o: test_round_mfma(o, True), "partial round, circulant layer on the matrix pipe")):
         order = schedule(prog)
         check_hazards(order)
         tester(order)
@@ -307,6 +600,22 @@ def main():
     vs = [r for r in range(S, 256) if r not in bound]
     ss = list(range(SINK, FCS[1] + 2))
     print("#define STARKHIP_LANE_CLOBBERS %s" % ", ".join(['"v%d"' % r for r in vs] + ['"s%d"' % r for r in ss]))
+    # the matrix-pipe blocks: weight tiles (dword 3 of each is loaded inside: in / out), the B tuples' constant dwords, the constant
+    # table's address, the selectors and constants in scalar registers; the B tuples' other dwords are clobbered on top of the rest
+    for k in range(2):
+        for d in range(3):
+            print('#define STARKHIP_LANE_AW%d%d "{v%d}"' % (k, d, AW[k] + d))
+        print('#define STARKHIP_LANE_AW%d3 "+{v%d}"' % (k, AW[k] + 3))
+    for k in range(4):
+        print('#define STARKHIP_LANE_BC%d "{v%d}"' % (k, BP[k] + 3))
+    print('#define STARKHIP_LANE_A_RCB "{v%d}"' % A_RCB)
+    for name, reg in (("SEL_A", S_SEL["A"]), ("SEL_B", S_SEL["B"]), ("SEL_C", S_SEL["C"]), ("SEL_D", S_SEL["D"]), ("X80", S_X80), ("K64K", S_64K)):
+        print('#define STARKHIP_LANE_S_%s "{s%d}"' % (name, reg))
+    for name, val in sorted(SEL_VALUE.items()):
+        print("#define STARKHIP_LANE_SEL_%s_VALUE 0x%08xu" % (name, val))
+    print("#define STARKHIP_LANE_B_CONST 0x%08xu" % B_CONST)
+    print("#define STARKHIP_LANE_K_OFFSET %du" % K_OFFSET)
+    print("#define STARKHIP_LANE_MFMA_CLOBBERS %s" % ", ".join(['"v%d"' % (BP[k] + d) for k in range(4) for d in range(3)]))
 
 
 if __name__ == "__main__":
