@@ -124,6 +124,8 @@ struct Ctx {
     PlanDev* plan = nullptr;  // the current AIR's (ensure_plan)
     long opt_leaf_hash_form = 0;     // 0: row form for a lone context's commitments of <= 4096 leaves, quad form otherwise; 1: quad always; 2: row always
     long opt_lde_closed_forms = 1;   // constant / unit-vector columns skip their transforms (kernels_lde.hip); 0: every column is transformed
+    long opt_host_commit_leaves = 64; // trace commitments of at most this many leaves (and >= 64 columns) are hashed by host threads (0: never)
+    std::vector<gl_t> host_lde;      // their LDE on the host
     // op-stream program (quotient_impl = 1; kept as the cross-check)
     int prog_air = -1;
     unsigned prog_chunks = 0;
@@ -398,6 +400,7 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
     else if (k == "quotient_debug" && value >= 0 && value <= 9) c->opt_quotient_debug = value;
 #endif
     else if (k == "lde_closed_forms" && (value == 0 || value == 1)) c->opt_lde_closed_forms = value;
+    else if (k == "host_commit_leaves" && value >= 0 && value <= 4096) c->opt_host_commit_leaves = value;
     else if (k == "leaf_hash_form" && value >= 0 && value <= 3) c->opt_leaf_hash_form = value;
     else if (k == "quotient_chunks" && value >= 0 && value <= 4096) c->opt_quotient_chunks = value;  // plans are cached by (AIR, chunks)
     else return STARKHIP_ERR_BAD_SHAPE;
@@ -632,7 +635,52 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
 
     // ---- phase 2: Merkle tree over bit-reversed LDE rows
     HIPCHK(hipEventRecord(c->kev[0], st));
-    if (c->hs) {  // pooled: the scheduler decides when this commitment runs and which others share its launch
+    if (N <= (size_t)c->opt_host_commit_leaves && C >= 64 && c->opt_leaf_hash_form == 0) {
+        // A commitment of a few leaves is a latency chain on the GPU whatever the form: FP12Mul (16 rows at blow-up 2) has 32 leaves of
+        // 7 536 sequential permutations -- 42 ms in the row form at 5.6 us per permutation on eight waves of a chip that holds 4 096.
+        // The host permutation the challenger uses runs at 0.8 us, and 32 independent leaves spread over the process's CPUs: the LDE
+        // (15 MB) comes down, host threads hash the leaves, the digests go back up and the tree is built on the device as usual.
+        // Same function, same bytes (tests/test_gpu_airs.py: FP12Mul against the oracle).
+        if (c->hs && !HashService::is_big(log_n, r)) {  // a pooled proof was announced to the scheduler's window: it is not coming
+            c->hs->abandon_small();
+            c->hash_requested = true;
+        }
+        c->hash_timing.form = 4;
+        c->hash_timing.group = 1;
+        c->host_lde.resize(C * N);
+        HIPCHK(hipMemcpyAsync(c->host_lde.data(), c->lde.p, C * N * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(stream_wait(c));
+        std::vector<gl_t> leaf_digests(4 * N);
+        const gl_t* lde_h = c->host_lde.data();
+        const unsigned n_thr = (unsigned)std::min<size_t>(N, std::max(1u, cpu_budget()));
+        auto work = [&](unsigned w) {
+            for (size_t j = w; j < N; j += n_thr) {
+                size_t i = 0;  // leaf j holds the LDE row of natural point index bitrev(j) = k * R + s, stored coset-major at [s][k]
+                for (unsigned b = 0; b < log_N; b++) i |= ((j >> b) & 1) << (log_N - 1 - b);
+                const size_t s_ = i & (((size_t)1 << r) - 1), k_ = i >> r;
+                gl_t state[12] = {0};
+                const gl_t* col = lde_h + s_ * n + k_;
+                for (size_t off = 0; off < C; off += 8) {
+                    const size_t cnt = std::min<size_t>(8, C - off);
+                    for (size_t e = 0; e < cnt; e++) state[e] = col[(off + e) * N];
+                    poseidon_permute_host(state);
+                }
+                for (int e = 0; e < 4; e++) leaf_digests[4 * j + e] = state[e];
+            }
+        };
+        std::vector<std::thread> helpers;
+        for (unsigned w = 1; w < n_thr; w++) {
+            try {
+                helpers.emplace_back(work, w);
+            } catch (const std::system_error&) {
+                work(w);
+            }
+        }
+        work(0);
+        for (std::thread& t : helpers) t.join();
+        HIPCHK(hipMemcpyAsync(c->digests.p, leaf_digests.data(), 4 * N * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(stream_wait(c));  // leaf_digests goes out of scope
+    } else if (c->hs) {  // pooled: the scheduler decides when this commitment runs and which others share its launch
         c->hash_requested = true;
         HIPCHK(c->hs->hash(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st, c->hash_ready, c->hash_done, !HashService::is_big(log_n, r), c->urgent,
                            &c->hash_timing));
@@ -967,7 +1015,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     (void)hipEventElapsedTime(&c->ktimings[0], c->kev[4], c->kev[5]);
     // pooled: the commitment kernel's own duration on the scheduler's launch stream (kev[0] .. kev[1] on this context's stream would
     // include the wait for its group to form)
-    if (c->hs) (void)hipEventElapsedTime(&c->ktimings[1], c->hash_timing.t0, c->hash_timing.t1);
+    if (c->hs && c->hash_timing.form != 4) (void)hipEventElapsedTime(&c->ktimings[1], c->hash_timing.t0, c->hash_timing.t1);
     else (void)hipEventElapsedTime(&c->ktimings[1], c->kev[0], c->kev[1]);
     (void)hipEventElapsedTime(&c->ktimings[2], c->kev[2], c->kev[3]);
     *proof_out = out;

@@ -87,6 +87,13 @@ void HashService::announce_big() {
     big_expected_++;
     big_active_++;
 }
+void HashService::set_big_queued(int n) {
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        big_queued_ = n;
+    }
+    cv_.notify_all();
+}
 void HashService::finish_big() {
     std::lock_guard<std::mutex> g(mu_);
     if (big_active_ > 0) big_active_--;
@@ -262,10 +269,10 @@ void HashService::run() {
         bool big_ready = !big_.empty();
         if (big_lane_ && !lane_share_ && !big_.empty()) {
             const double waited = (now_s() - big_.front()->t_arrive) * 1e3;
-            // a busy pool (five or more big proofs under way) always waits for a full group, bounded; a quiet one only for the proofs that
-            // are on their way to their commitment -- a lone proof is not held up
-            const bool busy = big_active_ >= (int)BIG_LANE_GROUP + 1;
-            big_ready = big_.size() >= BIG_LANE_GROUP || (!busy && big_expected_ <= 0) || waited >= big_gather_ms_ || stop_;
+            // A group goes out full.  Short of four it goes out when nobody else can join soon -- no big proof is on its way to its
+            // commitment and none is waiting to start -- or when the oldest request has waited `big_gather_ms_`; a lone proof is not held up.
+            const bool all_here = big_contexts_ > 0 && (int)big_.size() >= big_contexts_;  // every context's proof is waiting in this queue
+            big_ready = big_.size() >= BIG_LANE_GROUP || (big_expected_ <= 0 && big_queued_ <= 0) || all_here || waited >= big_gather_ms_ || stop_;
         }
         const bool take_big = big_ready && (!small_ready || !last_was_big_);
         if (take_big) {
@@ -422,6 +429,10 @@ struct Pool {
 
     double now() const { return now_s() - t0; }
 
+    void tell_big_queued() {  // under mu
+        if (hs) hs->set_big_queued((int)(q_big.size() + big_in_gen));
+    }
+
     void finish(Job* j, int rc) {
         std::lock_guard<std::mutex> g(mu);
         j->rc = rc;
@@ -511,6 +522,7 @@ struct Pool {
                     std::lock_guard<std::mutex> g(mu);
                     gen_running--;
                     if (j->big && big_in_gen > 0) big_in_gen--;
+                    tell_big_queued();
                     j->t[2] = now();
                 }
                 finish(j, rc);
@@ -538,6 +550,7 @@ struct Pool {
             (j->big ? q_big : q_small).push_back(j);
             cv_big.notify_all();
             cv_small.notify_all();
+            (void)0;  // (the count of big jobs that have not started is unchanged: from recording to queued)
         }
     }
 
@@ -618,6 +631,7 @@ struct Pool {
                 // (big jobs still queued for, or in, their recording count as waiting: with submit_witness they trickle into q_big
                 // one at a time, and q_big alone would make the FIRST wave look like the last)
                 urgent = big && stream_priority == 1 && q.size() + big_in_gen < big_ctx.size();
+                if (big) tell_big_queued();
             }
             if (big && stream_priority == 1) (void)ctx_set_urgent(c, urgent);
             int rc;
@@ -656,7 +670,10 @@ struct Pool {
     }
 };
 
-int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
+int pool_create(const starkhip_pool_config_t& cfg_in, Pool** out) {
+    starkhip_pool_config_t cfg = cfg_in;
+    if (const char* e = getenv("STARKHIP_POOL_PRIORITY"))  // experiments: overrides stream_priority
+        if (*e) cfg.stream_priority = (unsigned)atoi(e);
     std::unique_ptr<Pool> p(new Pool());
     p->device = cfg.device;
     p->t0 = now_s();
@@ -699,6 +716,7 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
     p->hs->policy = (int)cfg.commit_policy;
     p->hs->row_leaves_ = row_leaves;
     p->hs->big_lane_ = big_lane;
+    p->hs->big_contexts_ = (int)p->big_ctx.size();
     {
         const char* ls = getenv("STARKHIP_POOL_LANE_SHARE");
         p->hs->lane_share_ = big_lane && ls && *ls == '1';
@@ -706,6 +724,8 @@ int pool_create(const starkhip_pool_config_t& cfg, Pool** out) {
     {
         const char* lg = getenv("STARKHIP_POOL_LANE_GROUP");
         if (lg && *lg && atoi(lg) >= 2 && atoi(lg) <= 8) p->hs->BIG_LANE_GROUP = (unsigned)atoi(lg);
+        const char* bg = getenv("STARKHIP_POOL_BIG_GATHER_MS");
+        if (bg && *bg && atof(bg) > 0) p->hs->big_gather_ms_ = atof(bg);
     }
     if (cfg.commit_policy != 2) {  // 2: no commitment scheduling at all -- every context launches its own (A/B measurements)
         for (Ctx* c : p->big_ctx) ctx_attach_hash_service(c, p->hs.get());
@@ -777,6 +797,7 @@ static int pool_enqueue(Pool* p, Job* j, uint64_t* ticket) {
         (j->big ? p->q_big : p->q_small).push_back(j);
         (j->big ? p->cv_big : p->cv_small).notify_all();
     }
+    if (j->big) p->tell_big_queued();
     return STARKHIP_OK;
 }
 

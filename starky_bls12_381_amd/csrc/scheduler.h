@@ -24,6 +24,8 @@
 
 namespace starkhip {
 
+unsigned cpu_budget();  // CPUs this process may really use (cgroup quota, affinity mask; scheduler.cpp)
+
 class HashService {
   public:
     explicit HashService(int device);
@@ -61,12 +63,16 @@ class HashService {
     // beside a MillerLoop latency chain loses less than it would by waiting for it.
     int policy = 0;
     unsigned BIG_LANE_GROUP = 4;  // STARKHIP_POOL_LANE_GROUP: commitments per lane-form group (four fill the chip: two waves of 256 registers per SIMD)
-    double big_gather_ms_ = 150.0;  // lane form: how long a group of big commitments waits for announced ones to join
+    double big_gather_ms_ = 1000.0; // lane form: how long a group of big commitments waits at most for others to join (a group of three
+                                    // wastes a quarter of a 350 ms launch: full groups measured 6.46 against 6.2 - 6.3 proofs/s with a 150 ms bound)
+    void set_big_queued(int n);     // the pool's count of big jobs that have not started yet (queued, or their trace being recorded)
     bool big_lane_ = false;  // big commitments in groups, a group of two or more in the lane form (pools with five or more big contexts;
                              // STARKHIP_POOL_BIG_LANE=0 / 1 overrides)
     bool lane_share_ = false;  // STARKHIP_POOL_LANE_SHARE=1: big commitments go out one by one in the lane form, each launch taking half of every
                                // CU (launch_leaf_hash_lane share_cu): the LDE / quotient workgroups of the other proofs run beside them
     int big_expected_ = 0;   // big proofs that have started and not yet reached their commitment
+    int big_queued_ = 0;     // big jobs of the pool that have not started (under mu_)
+    int big_contexts_ = 0;   // the pool's number of big contexts (set once): when all of them wait here, nobody else can come
     int big_active_ = 0;     // big proofs being proved (before, in or after their commitment)  // STARKHIP_POOL_BIG_LANE=1: big commitments in the lane form (one lane per leaf)
     size_t row_leaves_ = 64;  // STARKHIP_POOL_ROW_LEAVES: small commitments of at most this many leaves go out in the row form, one launch each (0: never)
 

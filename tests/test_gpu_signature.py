@@ -74,7 +74,7 @@ def test_batch_of_eight_different_signatures_end_to_end():
         pool.close()
     assert sorted(results) == sorted(mine) and elapsed > 0
     assert all(np.array_equal(a, b) for s0, s1 in zip(sigs, sigs_seen) for a, b in zip(s0, s1))
-    assert pstats["big_commit_launches"] == 8 and pstats["small_commit_requests"] == 40
+    assert pstats["big_commit_launches"] == 8 and pstats["small_commit_requests"] == 32   # (the eight FP12Mul commitments are hashed on the host)
     assert pstats["max_merged_commitments"] >= 2   # small commitments shared launches
     for (_, name), (air, proof, cfg) in results.items():
         assert air == A.JOB_AIR[name]
