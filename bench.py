@@ -44,8 +44,24 @@ VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
 # VALU instructions of one permutation in the 4-lane form (ISA of poseidon_dev.h: 8 full rounds, 7 merged triples of
 # partial rounds, 1 single partial round)
 POSEIDON_QUAD_INSTRS = 7 * 261 + 204 + 7 * 309 + 152
-# issue slots of one permutation in the lane form, one permutation per lane (tools/gen_lane_round_asm.py --count)
-POSEIDON_LANE_SLOTS = 12900
+
+
+def poseidon_lane_slots():
+    """issue slots of one permutation in the lane form (one permutation per lane), from the block sizes tools/gen_lane_round_asm.py writes
+    into csrc/lane_round_asm.inc: 7 full rounds with the circulant layer on the matrix pipe, the capacity-only last round, 7 merged triples
+    of partial rounds, the lone partial round"""
+    import re
+    sizes = {}
+    for line in open(os.path.join(ROOT, "starky_bls12_381_amd", "csrc", "lane_round_asm.inc")):
+        m = re.match(r"// (.*?): (\d+) instructions", line)
+        if m:
+            sizes[m.group(1)] = int(m.group(2))
+    try:
+        return (7 * sizes["full round, circulant layer on the matrix pipe"] + sizes["last full round before an absorb: the capacity outputs only"]
+                + 7 * sizes["three partial rounds at once (poseidon_merged.h)"] + sizes["partial round, circulant layer on the matrix pipe"])
+    except KeyError:
+        return None
+
 KERNELS = ("lde_columns", "leaf_hash", "quotient_eval")
 PMC_NAMES = {"lde_columns": ("lde_columns_v2_kernel",), "leaf_hash": ("leaf_hash_kernel",), "leaf_hash_lane": ("leaf_hash_lane_kernel",),
              "quotient_eval": ("quotient_tiles_kernel", "quotient_eval_kernel")}
@@ -350,11 +366,13 @@ def main():
                     "durations": f"HIP events on the launch stream, the {len(timed_kernel_ms[dom])} launches of the timed region ({inflight} proofs in flight)",
                     "share_of_timed_kernel_time": {k: sum(v) for k, v in timed_kernel_ms.items()},
                     "limiter": "integer VALU issue" if dom.startswith("leaf_hash") else "see kernels"}
-        if dom == "leaf_hash_lane_kernel":
+        POSEIDON_LANE_SLOTS = poseidon_lane_slots()
+        if dom == "leaf_hash_lane_kernel" and POSEIDON_LANE_SLOTS:
             slots = perms / 64.0 * POSEIDON_LANE_SLOTS
             roofline["valu"] = {"issue_slots_per_launch": slots, "achieved_Gslots_per_s": slots * side / (dom_ms * 1e-3) / 1e9, "peak_Ginstr_per_s": VALU_PEAK_GINSTR,
                                 "frac": slots * side / (dom_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR,
-                                "basis": f"{POSEIDON_LANE_SLOTS} issue slots per permutation and lane (tools/gen_lane_round_asm.py), {perms} permutations / 64 lanes; peak = 256 CUs x 4 "
+                                "basis": f"{POSEIDON_LANE_SLOTS} issue slots per permutation and lane (block sizes in csrc/lane_round_asm.inc; the eight MFMAs of a matrix-pipe round "
+                                         f"counted as one slot each), {perms} permutations / 64 lanes; peak = 256 CUs x 4 "
                                          "SIMDs x 2.4 GHz / 4 cycles per integer VALU instruction (tools/valu_rate_bench.hip); some slots are 2-cycle instructions"}
 
         # ---- untimed: the same proof with the GPU to itself (one in flight): uncontended kernel and phase durations

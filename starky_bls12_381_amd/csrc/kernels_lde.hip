@@ -113,6 +113,11 @@ struct LdePlan {
 };
 
 __device__ __forceinline__ int lds_pad(int a) { return a + (a >> 4); }
+#ifdef STARKHIP_LDE_FULL_BARRIER
+__device__ __forceinline__ void lde_lds_barrier() { __syncthreads(); }
+#else
+__device__ __forceinline__ void lde_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // One Stockham pass on the 16 values a thread holds (element i' = column index t + i' * T).
 // P > 0: inputs come from the LDS image written by pass P-1.  Last pass: results stay in registers (natural index
@@ -144,7 +149,11 @@ __device__ __forceinline__ void lde_pass(gl_t (&v)[16], gl_t* __restrict__ lds, 
     SubNtts<R, INV, 0>::run(v);
     unscramble<R>(v);
     if constexpr (!LAST) {
-        __syncthreads();  // every thread of the column has read its inputs
+        // The two barriers of an exchange order LDS accesses only: they wait for this wave's LDS operations (lgkmcnt), NOT for its
+        // global ones -- __syncthreads() also waits vmcnt(0), i.e. for the sixteen result stores of the previous coset transform to reach
+        // memory, at the first exchange of every transform.  (Global data is never handed from thread to thread in this kernel: a
+        // thread re-reads only the coefficients it stored itself.)
+        lde_lds_barrier();  // every thread of the column has read its inputs
 #pragma unroll
         for (int m = 0; m < S; m++) {
             const int j = t + m * T;
@@ -157,7 +166,7 @@ __device__ __forceinline__ void lde_pass(gl_t (&v)[16], gl_t* __restrict__ lds, 
                 for (int k = 0; k < R; k++) lds[pbase + k * (NS + NS / 16)] = v[m + S * k];
             }
         }
-        __syncthreads();
+        lde_lds_barrier();
     }
 }
 
