@@ -356,7 +356,7 @@ __device__ __forceinline__ gl_t qt_fold_sums(const uint64_t (&S)[6]) {
 
 template <bool SMALL_N, unsigned DBG>
 __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(QTParams P) { STARKHIP_PRIO_ENTRY
-    __shared__ gl_t tile[2][QT_TILE_COLS * QT_TILE_ROWS];
+    __shared__ gl_t tile[2][(QT_TILE_COLS + 1) * QT_TILE_ROWS];  // + the column of ones (QT_ONES_SLOT: constant terms are plain records)
     __shared__ uint32_t rec_ring[QT_WAVES][3][32][4];  // per evaluating wave: three blocks of 16 records (32 x 16 bytes each)
     if (P.prio) __builtin_amdgcn_s_setprio(2);
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 .. QT_WAVES - 1 evaluate, QT_WAVES stages the tiles
@@ -380,6 +380,10 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
         // ---- producer: tile ti + 1 goes from HBM straight into the other LDS buffer (global_load_lds_dwordx4: no vector
         // registers, all 64 column loads of a tile in flight at once) while the eight evaluating waves work on tile ti.  Its
         // loads are the only ones it waits for, and nobody else waits for them: the evaluators meet it at the barrier.
+        for (unsigned buf = 0; buf < 2; buf++) {  // the column of ones of both buffers, once (visible after the first barrier)
+            tile[buf][QT_ONES_SLOT * QT_TILE_ROWS + lane] = 1;
+            if (lane < QT_TILE_ROWS - 64) tile[buf][QT_ONES_SLOT * QT_TILE_ROWS + 64 + lane] = 1;
+        }
         const uint32_t boff_next_last = __builtin_amdgcn_readlane(boff_next, 63);  // successor of the block's last point: row 64
         const uint32_t boff_block = __builtin_amdgcn_readfirstlane(boff_local);    // !SMALL_N: the 64 points are 512 contiguous bytes
         for (unsigned ti = 0; ti <= n_tiles; ti++) {
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
         const uint32_t d4 = ((const __attribute__((address_space(1))) uint32_t*)pc_addr)[4];
         const uint32_t dgate[4] = {d0.y, d0.z, d0.w, d4};
         piece_ctl = __builtin_amdgcn_readfirstlane(d0.x);
-        const uint32_t ng = (piece_ctl >> 2) & 7u;
+        const uint32_t ng = ((piece_ctl >> 2) & 7u) + ((piece_ctl >> QT_FOREIGN_SHIFT) & 7u);  // gates, then the absorbed pieces' cells (quotient_plan.h)
 #pragma unroll
         for (unsigned g = 0; g < 4; g++)
             if (g < ng) {
@@ -513,6 +517,7 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
     uint32_t b1 = 128;                    // ring offset of the group of four that holds record g + 4 (entry g % 4)
     unsigned next_block = 2, next_slot = 2;
     uint32_t n_plain = 0;                 // plain records known to follow (wave-uniform)
+    uint32_t n_pairs = 0;                 // fast pairs known to follow them (degree-2 monomials inside the tile: two records each)
     ring_read(0, 0, W0);
     ring_read(0, 1, W1);
     ring_read(0, 2, W2);
@@ -565,6 +570,19 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
         QT_MADS(W, X)                                                                                                 \
         QT_ADVANCE(U, W)                                                                                              \
     }
+    // a fast pair: record g = the first factor (nothing to do but keep its cell), record g + 1 = the second factor with the weights
+#define QT_PAIR_A(U, W, WC2, X2)                                                                                      \
+    {                                                                                                                 \
+        lds_read(WC2.a.x, X2);                                                                                        \
+        QT_ADVANCE(U, W)                                                                                              \
+    }
+#define QT_PAIR_B(U, W, X, XA, WC2, X2)                                                                               \
+    {                                                                                                                 \
+        lds_read(WC2.a.x, X2);                                                                                        \
+        const gl_t xp_ = gl_mul_nc(XA, X);                                                                            \
+        QT_MADS(W, xp_)                                                                                               \
+        QT_ADVANCE(U, W)                                                                                              \
+    }
     // any record: (W1c, X1) of record g + 1 as well (re-read when the tile changes)
 #define QT_GENERIC(U, W, X, WC1, X1, WC2, X2)                                                                         \
     {                                                                                                                 \
@@ -574,7 +592,9 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
             QT_MADS(W, X)                                                                                             \
         } else {                                                                                                      \
             const uint32_t ctl = __builtin_amdgcn_readfirstlane(W.a.x);                                               \
+            const uint32_t aux = __builtin_amdgcn_readfirstlane(W.a.y);                                               \
             n_plain = ctl >> QT_RUN_SHIFT;                                                                            \
+            n_pairs = (ctl & QT_SRC_GLOBAL) ? 0u : (aux & QT_AUX_PAIRS_MASK);                                         \
             gl_t x = X;                                                                                               \
             if ((ctl & QT_ODD_SOURCE) != 0) {                                                                         \
                 if (ctl & (QT_TILE | QT_STOP)) {                                                                      \
@@ -582,13 +602,20 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                 \
                     ti++;                                                                                             \
                     if ((ctl & QT_STOP) != 0 || ti >= n_tiles) goto stream_done;                                      \
-                    lds_cur = lds_local + (ti & 1u) * (uint32_t)(QT_TILE_COLS * QT_TILE_ROWS * sizeof(gl_t));         \
+                    lds_cur = lds_local + (ti & 1u) * (uint32_t)((QT_TILE_COLS + 1) * QT_TILE_ROWS * sizeof(gl_t));         \
                     lds_read(WC1.a.x, X1); /* the cells of the next two records live in the new tile */               \
                     lds_read(WC2.a.x, X2);                                                                            \
                     goto advance_##U;                                                                                 \
                 }                                                                                                     \
                 if (ctl & QT_SRC_ONE) x = 1;                                                                          \
-                if ((ctl & QT_SRC_GLOBAL) && !(DBG & 8u)) x = direct(__builtin_amdgcn_readfirstlane(W.a.y), ctl & QT_NEXT); \
+                if ((ctl & QT_SRC_GLOBAL) && !(DBG & 8u)) {                                                           \
+                    if (aux & QT_AUX_SLOT) { /* a cell requested with the piece's gates */                            \
+                        const uint32_t sl = aux & 3u;                                                                 \
+                        x = sl == 0 ? gate[0] : sl == 1 ? gate[1] : sl == 2 ? gate[2] : gate[3];                      \
+                    } else {                                                                                          \
+                        x = direct(aux, ctl & QT_NEXT);                                                               \
+                    }                                                                                                 \
+                }                                                                                                     \
                 if (ctl & QT_MULV) x = gl_mul_nc(v, x);                                                               \
                 if (ctl & QT_SETV) {                                                                                  \
                     v = x;                                                                                            \
@@ -597,7 +624,7 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
             }                                                                                                         \
             QT_MADS(W, x)                                                                                             \
             if ((ctl & QT_END) != 0 && !(DBG & 4u) && !(DBG & 2u)) {                                                  \
-                const uint32_t kind = piece_ctl & 3u, ng = (piece_ctl >> 2) & 7u, cm = piece_ctl >> 5;                \
+                const uint32_t kind = piece_ctl & 3u, ng = (piece_ctl >> 2) & 7u, cm = (piece_ctl >> 5) & 15u;        \
                 gl_t G = kind == KIND_PLAIN ? (gl_t)1 : kind == KIND_TRANSITION ? mask_tr : kind == KIND_FIRST ? mask_first : mask_last; \
                 _Pragma("unroll") for (unsigned q = 0; q < 4; q++) if (q < ng) {                                      \
                     gl_t gv = gate[q];                                                                                \
@@ -623,6 +650,14 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                 QT_PLAIN(3, W3, x3, W1, x1)
                 n_plain -= 4u;
             }
+            if (n_plain == 0u)
+                while (n_pairs >= 2u) {
+                    QT_PAIR_A(0, W0, W2, x2)
+                    QT_PAIR_B(1, W1, x1, x0, W3, x3)
+                    QT_PAIR_A(2, W2, W0, x0)
+                    QT_PAIR_B(3, W3, x3, x2, W1, x1)
+                    n_pairs -= 2u;
+                }
             QT_GENERIC(0, W0, x0, W1, x1, W2, x2)
             while (n_plain >= 4u) {
                 QT_PLAIN(1, W1, x1, W3, x3)
@@ -631,6 +666,14 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                 QT_PLAIN(0, W0, x0, W2, x2)
                 n_plain -= 4u;
             }
+            if (n_plain == 0u)
+                while (n_pairs >= 2u) {
+                    QT_PAIR_A(1, W1, W3, x3)
+                    QT_PAIR_B(2, W2, x2, x1, W0, x0)
+                    QT_PAIR_A(3, W3, W1, x1)
+                    QT_PAIR_B(0, W0, x0, x3, W2, x2)
+                    n_pairs -= 2u;
+                }
             QT_GENERIC(1, W1, x1, W2, x2, W3, x3)
             while (n_plain >= 4u) {
                 QT_PLAIN(2, W2, x2, W0, x0)
@@ -639,6 +682,14 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                 QT_PLAIN(1, W1, x1, W3, x3)
                 n_plain -= 4u;
             }
+            if (n_plain == 0u)
+                while (n_pairs >= 2u) {
+                    QT_PAIR_A(2, W2, W0, x0)
+                    QT_PAIR_B(3, W3, x3, x2, W1, x1)
+                    QT_PAIR_A(0, W0, W2, x2)
+                    QT_PAIR_B(1, W1, x1, x0, W3, x3)
+                    n_pairs -= 2u;
+                }
             QT_GENERIC(2, W2, x2, W3, x3, W0, x0)
             while (n_plain >= 4u) {
                 QT_PLAIN(3, W3, x3, W1, x1)
@@ -647,12 +698,22 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                 QT_PLAIN(2, W2, x2, W0, x0)
                 n_plain -= 4u;
             }
+            if (n_plain == 0u)
+                while (n_pairs >= 2u) {
+                    QT_PAIR_A(3, W3, W1, x1)
+                    QT_PAIR_B(0, W0, x0, x3, W2, x2)
+                    QT_PAIR_A(1, W1, W3, x3)
+                    QT_PAIR_B(2, W2, x2, x1, W0, x0)
+                    n_pairs -= 2u;
+                }
             QT_GENERIC(3, W3, x3, W0, x0, W1, x1)
         }
 stream_done:
 #undef QT_MADS
 #undef QT_ADVANCE
 #undef QT_PLAIN
+#undef QT_PAIR_A
+#undef QT_PAIR_B
 #undef QT_GENERIC
     // waves whose stream ended before the chunk's last tile (never by construction) would desynchronise the barrier count
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -23,6 +23,8 @@
 // Each wave reads its own stream of 32-byte wave-uniform records and a stream of piece descriptors.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <stdexcept>
@@ -35,6 +37,8 @@
 namespace starkhip {
 
 static const unsigned QT_TILE_COLS = 64;    // columns per LDS tile
+static const unsigned QT_ONES_SLOT = 64;     // = QT_TILE_COLS: one more "column" of every tile buffer that holds 1 in every row, so that a constant
+                                            // term is a PLAIN record (a cell read like any other) instead of a special one
 static const unsigned QT_TILE_ROWS = 66;    // 64 points + the successor of the last one (next-row reads are "lane + 1") + 8 bytes so
                                             // that every column starts on a 16-byte boundary (direct-to-LDS loads write 16 bytes per lane)
 static const unsigned QT_WAVES = 7;         // evaluating waves per workgroup (an eighth wave stages the tiles)
@@ -74,12 +78,23 @@ struct QTRec {
 };
 static_assert(sizeof(QTRec) == 32, "records are fetched as 8 dwords");
 
-// piece descriptor: ctl = kind | n_gates << 2 | complement mask << 5
+// piece descriptor: ctl = kind | n_gates << 2 | complement mask << 5 | n_foreign << 9
+// gate[0 .. n_gates) are the gate cells; gate[n_gates .. n_gates + n_foreign) are FOREIGN cells: the single cells of tiny pieces of the same
+// supergroup that lived in other tiles and were absorbed into this one (a piece end costs as much as fifteen records; 10 594 of FinalExp's
+// 32 850 closed a piece of exactly one record).  All of them are requested when the piece starts, so a foreign cell is in a register
+// long before its record (QT_SRC_GLOBAL with aux = QT_AUX_SLOT | slot) is evaluated.
 struct QTPiece {
     uint32_t ctl;
     uint32_t gate[4];  // cellrefs (column | REF_NEXT)
     uint32_t pad[3];
 };
+// A special record that is not QT_SRC_GLOBAL announces in `aux` (bits 15:0) how many FAST PAIRS follow the plain run it announces: a fast
+// pair is a degree-2 monomial with both cells in the tile -- record (QT_SETV, cell a) then record (QT_MULV, cell b, weights), no other flag --
+// and the kernel evaluates a run of them two pairs at a time without looking at their control words' flags (generic steps cost ~ 80 issue
+// slots per record, a pair in the fast path ~ 40).  Records inside a fast run carry no run length and no announcement.
+static const uint32_t QT_AUX_PAIRS_MASK = 0xFFFFu;
+static const uint32_t QT_AUX_SLOT = 0x80000000u;   // aux of a QT_SRC_GLOBAL record: the cell is descriptor slot (aux & 3), not column aux
+static const unsigned QT_FOREIGN_SHIFT = 9;
 static_assert(sizeof(QTPiece) == 32, "piece descriptors are fetched as 8 dwords");
 
 // one term's share of a record's weight: coefficient * alpha^e
@@ -102,6 +117,7 @@ struct QTPlan {
     std::vector<uint32_t> contrib_off;    // [recs.size() + 1]
     std::vector<QTContrib> contribs;
     // statistics
+    size_t n_absorbed = 0;  // tiny pieces whose cells ride in a bigger piece's descriptor
     size_t n_supergroups = 0, n_pieces = 0, n_piece_ends = 0, n_cell_records = 0, n_direct_loads = 0;  // n_piece_ends <= n_pieces: pieces carried across a tile boundary end once
     uint64_t cost_sum_max = 0, cost_sum_mean = 0, rec_sum_max = 0, rec_sum_total = 0, tile_phases = 0;  // per tile: the busiest wave's cost / the mean over the waves (model units)
 };
@@ -167,6 +183,25 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         }
     }
     if (k != K) throw std::runtime_error("quotient_plan: constraint count mismatch");
+    if (getenv("STARKHIP_PLAN_STATS")) {  // development aid: supergroups by (terms, gates)
+        std::vector<uint32_t> n_terms(sg_gates.size(), 0), max_deg(sg_gates.size(), 0);
+        for (const Term& t : terms) {
+            n_terms[t.sg]++;
+            uint32_t d = 0;
+            for (int f = 0; f < 3; f++) d += t.cells[f] != NONE;
+            max_deg[t.sg] = std::max(max_deg[t.sg], d);
+        }
+        size_t hist[6][5][4] = {{{0}}};
+        for (size_t g = 0; g < sg_gates.size(); g++) {
+            const uint32_t b = n_terms[g] <= 1 ? 0 : n_terms[g] <= 2 ? 1 : n_terms[g] <= 4 ? 2 : n_terms[g] <= 8 ? 3 : n_terms[g] <= 16 ? 4 : 5;
+            hist[b][std::min<size_t>(4, sg_gates[g].size())][std::min<uint32_t>(3, max_deg[g])]++;
+        }
+        const char* names[6] = {"1", "2", "3-4", "5-8", "9-16", ">16"};
+        for (int b = 0; b < 6; b++)
+            for (int g = 0; g < 5; g++)
+                for (int d = 0; d < 4; d++)
+                    if (hist[b][g][d]) fprintf(stderr, "supergroups with %s terms, %d gates, max degree %d: %zu\n", names[b], g, d, hist[b][g][d]);
+    }
 
     // ---- pass 2: merge terms with the same (supergroup, monomial) into records; order by (tile, supergroup, monomial)
     // the tile of a monomial is the tile of its first cell; constants go with the supergroup's first gate (or tile 0)
@@ -202,10 +237,12 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         uint32_t sg, tile;
         uint32_t m_begin, m_end;  // monomials
         uint32_t cost;
+        std::vector<uint32_t> foreign;  // monomials (single cells of other tiles) absorbed from tiny pieces of the same supergroup
     };
     std::vector<Mono> monos;
     std::vector<QTContrib> contribs;
     std::vector<Piece> pieces;
+    size_t Q_absorbed = 0;
     contribs.reserve(terms.size());
     for (size_t j = 0; j < order.size(); j++) {
         const Term& t = terms[order[j]];
@@ -213,7 +250,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         const bool same_piece = !pieces.empty() && pieces.back().sg == t.sg && pieces.back().tile == tl;
         const bool same_mono = same_piece && !monos.empty() && monos.back().cells[0] == t.cells[0] && monos.back().cells[1] == t.cells[1] &&
                                monos.back().cells[2] == t.cells[2] && pieces.back().m_end == monos.size();
-        if (!same_piece) pieces.push_back({t.sg, tl, (uint32_t)monos.size(), (uint32_t)monos.size(), 0});
+        if (!same_piece) pieces.push_back({t.sg, tl, (uint32_t)monos.size(), (uint32_t)monos.size(), 0, {}});
         if (!same_mono) {
             monos.push_back({{t.cells[0], t.cells[1], t.cells[2]}, (uint32_t)contribs.size(), (uint32_t)contribs.size()});
             pieces.back().m_end = (uint32_t)monos.size();
@@ -222,6 +259,56 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         monos.back().c_end = (uint32_t)contribs.size();
     }
     auto mono_records = [&](const Mono& m) -> uint32_t { return m.cells[0] == NONE ? 1u : m.cells[1] == NONE ? 1u : m.cells[2] == NONE ? 2u : 3u; };
+    // Inside a piece the order of the monomials is free (a sum): single cells first (they form the plain runs), then the degree-2
+    // monomials with both cells in the piece's tile (the fast pairs), then everything else (constants, factors in other tiles, degree 3).
+    {
+        auto klass = [&](const Mono& m, uint32_t tile) -> int {
+            if (m.cells[1] == NONE) return 0;   // one cell of the tile, or the constant (the tile's column of ones)
+            if (m.cells[1] != NONE && m.cells[2] == NONE && tile_of(m.cells[0]) == tile && tile_of(m.cells[1]) == tile) return 1;
+            return 2;
+        };
+        for (const Piece& p : pieces)
+            std::stable_sort(monos.begin() + p.m_begin, monos.begin() + p.m_end,
+                             [&](const Mono& a, const Mono& b) { return klass(a, p.tile) < klass(b, p.tile); });
+    }
+    // Tiny pieces go into the largest piece of their supergroup: a piece of one to three single-cell monomials costs a whole piece end
+    // (fold, gate product, descriptor, ~ 280 issue slots) for <= 3 records; as FOREIGN cells of the big piece they cost one record each and a
+    // descriptor slot (gates + foreign cells <= 4), and are requested with the gates when that piece starts.
+    {
+        std::vector<std::vector<uint32_t>> by_sg(sg_gates.size());
+        for (size_t j = 0; j < pieces.size(); j++) by_sg[pieces[j].sg].push_back((uint32_t)j);
+        std::vector<uint8_t> dead(pieces.size(), 0);
+        for (size_t sg = 0; sg < by_sg.size(); sg++) {
+            const std::vector<uint32_t>& ps = by_sg[sg];
+            if (ps.size() < 2) continue;
+            uint32_t big = ps[0];
+            auto n_monos = [&](uint32_t pi) { return pieces[pi].m_end - pieces[pi].m_begin; };
+            for (uint32_t pi : ps)
+                if (n_monos(pi) > n_monos(big)) big = pi;
+            // (the constant monomial of a supergroup used to get a piece of its own in the tile of the first gate: it needs no cell at
+            // all and goes along for nothing -- 8 178 of FinalExp's single-record pieces were that)
+            size_t room = 4 - sg_gates[sg].size();
+            for (uint32_t pi : ps) {
+                if (pi == big || n_monos(pi) > 3) continue;
+                size_t cells_needed = 0;
+                bool ok = true;
+                for (uint32_t b = pieces[pi].m_begin; b < pieces[pi].m_end; b++) {
+                    if (monos[b].cells[1] != NONE) ok = false;          // a product: stays where its factors are
+                    else if (monos[b].cells[0] != NONE) cells_needed++;
+                }
+                if (!ok || cells_needed > room) continue;
+                for (uint32_t b = pieces[pi].m_begin; b < pieces[pi].m_end; b++) pieces[big].foreign.push_back(b);
+                room -= cells_needed;
+                dead[pi] = 1;
+                Q_absorbed++;
+            }
+        }
+        std::vector<Piece> kept;
+        kept.reserve(pieces.size());
+        for (size_t j = 0; j < pieces.size(); j++)
+            if (!dead[j]) kept.push_back(std::move(pieces[j]));
+        pieces.swap(kept);
+    }
     // split big pieces (the contribution is linear in T, so a piece may be cut anywhere)
     {
         std::vector<Piece> cut;
@@ -231,13 +318,13 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
             for (; b < p.m_end; b++) {
                 const uint32_t r = mono_records(monos[b]);
                 if (recs + r > QT_MAX_PIECE && recs) {
-                    cut.push_back({p.sg, p.tile, start, b, 0});
+                    cut.push_back({p.sg, p.tile, start, b, 0, {}});
                     start = b;
                     recs = 0;
                 }
                 recs += r;
             }
-            cut.push_back({p.sg, p.tile, start, p.m_end, 0});
+            cut.push_back({p.sg, p.tile, start, p.m_end, 0, p.foreign});  // the absorbed cells go with the last part
         }
         pieces.swap(cut);
     }
@@ -245,6 +332,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
     for (Piece& p : pieces) {
         uint32_t recs = 0;
         for (uint32_t b = p.m_begin; b < p.m_end; b++) recs += mono_records(monos[b]);
+        recs += (uint32_t)p.foreign.size();
         p.cost = PIECE_COST + REC_COST * recs;
     }
 
@@ -269,6 +357,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
     Q.n_constraints = K;
     Q.n_supergroups = sg_gates.size();
     Q.n_pieces = pieces.size();
+    Q.n_absorbed = Q_absorbed;
     if (tiles.empty()) {  // a program without terms: one empty chunk
         Q.n_chunks = 1;
         Q.chunk_tile_off = {0, 0};
@@ -396,6 +485,10 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                     const std::vector<uint32_t>& gates = sg_gates[pc.sg];
                     const bool continues = pi == 0 && carry_in[t - t_lo][w];                                   // no descriptor of its own
                     const bool goes_on = pi + 1 == mine.size() && t + 1 < t_hi && carry_in[t + 1 - t_lo][w];  // no end of its own
+                    // a piece that goes on from the previous tile has no descriptor of its own: its foreign cells are loaded directly instead
+                    size_t foreign_cells = 0;
+                    for (uint32_t b : pc.foreign) foreign_cells += monos[b].cells[0] != NONE;
+                    const bool slots = !continues && gates.size() + foreign_cells <= 4;
                     if (!continues) {
                         QTPiece d = {0, {0, 0, 0, 0}, {0, 0, 0}};
                         uint32_t compl_mask = 0;
@@ -403,16 +496,50 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                             d.gate[g] = gates[g] & (REF_COL_MASK | REF_NEXT);
                             if (gates[g] & REF_COMPL) compl_mask |= 1u << g;
                         }
-                        d.ctl = sg_kind[pc.sg] | ((uint32_t)gates.size() << 2) | (compl_mask << 5);
+                        uint32_t n_foreign = 0;
+                        if (slots)
+                            for (uint32_t b : pc.foreign)
+                                if (monos[b].cells[0] != NONE) d.gate[gates.size() + n_foreign++] = monos[b].cells[0] & (REF_COL_MASK | REF_NEXT);
+                        d.ctl = sg_kind[pc.sg] | ((uint32_t)gates.size() << 2) | (compl_mask << 5) | (n_foreign << QT_FOREIGN_SHIFT);
                         Q.pieces.push_back(d);
-                        Q.n_direct_loads += gates.size();
+                        Q.n_direct_loads += gates.size() + n_foreign;
                         Q.n_piece_ends++;
                     }
-                    for (uint32_t b = pc.m_begin; b < pc.m_end; b++) {
+                    const size_t n_own = pc.m_end - pc.m_begin;
+                    size_t slot_at = gates.size();
+                    for (size_t fi = 0; fi < pc.foreign.size(); fi++) {
+                        const Mono& mo = monos[pc.foreign[fi]];
+                        const uint32_t cell = mo.cells[0];
+                        const bool last = n_own == 0 && fi + 1 == pc.foreign.size() && !goes_on;
+                        if (cell == NONE) {  // the constant term: the tile's column of ones
+                            push_rec(QT_ONES_SLOT * QT_TILE_ROWS * 8 | (last ? QT_END : 0u), 0, mo.c_begin, mo.c_end);
+                            continue;
+                        }
+                        uint32_t ctl = QT_SRC_GLOBAL | ((cell & REF_NEXT) ? QT_NEXT : 0u) | (last ? QT_END : 0u);
+                        push_rec(ctl, slots ? (QT_AUX_SLOT | (uint32_t)slot_at++) : (cell & REF_COL_MASK), mo.c_begin, mo.c_end);
+                        if (!slots) Q.n_direct_loads++;
+                    }
+                    // emission order: as stored (single cells, fast pairs, the rest) -- except that a piece whose last monomial would be a
+                    // fast pair ends on one of its single cells instead: the record that carries QT_END goes through the generic step,
+                    // and a plain record does that cheaply while a pair's two records do not
+                    std::vector<uint32_t> order_m;
+                    order_m.reserve(n_own);
+                    for (uint32_t b = pc.m_begin; b < pc.m_end; b++) order_m.push_back(b);
+                    if (n_own >= 2 && !goes_on) {
+                        const Mono& tail = monos[order_m.back()];
+                        const bool tail_is_pair = tail.cells[1] != NONE && tail.cells[2] == NONE && tile_of(tail.cells[0]) == tile && tile_of(tail.cells[1]) == tile;
+                        const Mono& head = monos[order_m.front()];
+                        if (tail_is_pair && head.cells[1] == NONE) {
+                            order_m.erase(order_m.begin());
+                            order_m.push_back(pc.m_begin);
+                        }
+                    }
+                    for (size_t oi = 0; oi < order_m.size(); oi++) {
+                        const uint32_t b = order_m[oi];
                         const Mono& mo = monos[b];
-                        const bool last = b + 1 == pc.m_end && !goes_on;
-                        if (mo.cells[0] == NONE) {
-                            push_rec(QT_SRC_ONE | (last ? QT_END : 0u), 0, mo.c_begin, mo.c_end);
+                        const bool last = oi + 1 == order_m.size() && !goes_on;
+                        if (mo.cells[0] == NONE) {  // the constant term: the tile's column of ones
+                            push_rec(QT_ONES_SLOT * QT_TILE_ROWS * 8 | (last ? QT_END : 0u), 0, mo.c_begin, mo.c_end);
                             continue;
                         }
                         // factors inside the tile first (LDS), direct loads after; the last factor carries the weights
@@ -428,7 +555,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                                 const uint32_t slot = (cell & REF_COL_MASK) - tile * QT_TILE_COLS;
                                 ctl = slot * QT_TILE_ROWS * 8 + ((cell & REF_NEXT) ? 8u : 0u);
                                 if (cell & REF_NEXT) ctl |= QT_NEXT;
-                                aux = slot;
+                                aux = 0;
                                 Q.n_cell_records++;
                             } else {
                                 ctl = QT_SRC_GLOBAL | ((cell & REF_NEXT) ? QT_NEXT : 0u);
@@ -449,47 +576,55 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                 push_rec(QT_TILE, 0, 0, 0);
             }
             push_rec(QT_STOP, 0, 0, 0);
-            // run lengths: walk the stream backwards; a run longer than QT_MAX_RUN is cut by more no-ops
+            // announcements: every special record says how many plain records follow it (QT_RUN_SHIFT) and, in aux, how many fast pairs
+            // follow those; a plain run longer than QT_MAX_RUN is cut by more no-ops (the last of them carries the pairs)
             {
+                const size_t n_in = Q.recs.size() - stream_first;
+                auto in = [&](size_t i) -> const QTRec& { return Q.recs[stream_first + i]; };
+                auto is_plain = [&](size_t i) { return (in(i).ctl & QT_SPECIAL) == 0; };
+                auto is_pair_a = [&](size_t i) { return (in(i).ctl & QT_SPECIAL) == QT_SETV; };   // first factor, a cell of the tile
+                auto is_pair_b = [&](size_t i) { return (in(i).ctl & QT_SPECIAL) == QT_MULV; };   // second factor, a cell of the tile, not the piece's last record
                 std::vector<QTRec> out;
                 std::vector<uint32_t> ocb, oce;
-                out.reserve(Q.recs.size() - stream_first + 8);
-                std::vector<uint32_t> run_after(Q.recs.size() - stream_first, 0);
-                uint32_t run = 0;
-                for (size_t r = Q.recs.size(); r-- > stream_first;) {
-                    if ((Q.recs[r].ctl & QT_SPECIAL) == 0) run++;
-                    else {
-                        run_after[r - stream_first] = run;
-                        run = 0;
-                    }
-                }
-                for (size_t r = stream_first; r < Q.recs.size(); r++) {
-                    QTRec rec = Q.recs[r];
-                    uint32_t left = (rec.ctl & QT_SPECIAL) ? run_after[r - stream_first] : 0;
-                    if (rec.ctl & QT_SPECIAL) {
-                        rec.ctl |= std::min<uint32_t>(left, QT_MAX_RUN) << QT_RUN_SHIFT;
-                        left -= std::min<uint32_t>(left, QT_MAX_RUN);
-                    }
+                out.reserve(n_in + 8);
+                auto emit = [&](const QTRec& rec, uint32_t cb, uint32_t ce) {
                     out.push_back(rec);
-                    ocb.push_back(rec_c_begin[r]);
-                    oce.push_back(rec_c_end[r]);
-                    // the plain records this special one announces follow; if the run is longer, a no-op goes in after QT_MAX_RUN of them
-                    size_t q = r + 1;
-                    for (uint32_t done = 0; (rec.ctl & QT_SPECIAL) && q < Q.recs.size() && (Q.recs[q].ctl & QT_SPECIAL) == 0; q++) {
+                    ocb.push_back(cb);
+                    oce.push_back(ce);
+                };
+                size_t i = 0;
+                while (i < n_in) {
+                    QTRec rec = in(i);
+                    if (is_plain(i)) throw std::runtime_error("quotient_plan: a plain record nobody announced");
+                    // what follows this special record: plains, then fast pairs
+                    size_t p_end = i + 1;
+                    while (p_end < n_in && is_plain(p_end)) p_end++;
+                    size_t q_end = p_end;
+                    while (q_end + 1 < n_in && is_pair_a(q_end) && is_pair_b(q_end + 1)) q_end += 2;
+                    uint32_t plains = (uint32_t)(p_end - i - 1), pairs = (uint32_t)((q_end - p_end) / 2);
+                    const bool can_announce_pairs = !(rec.ctl & QT_SRC_GLOBAL);   // its aux is a column (or a descriptor slot)
+                    if (!can_announce_pairs || pairs > QT_AUX_PAIRS_MASK) pairs = 0;
+                    uint32_t first = std::min<uint32_t>(plains, QT_MAX_RUN);
+                    rec.ctl |= first << QT_RUN_SHIFT;
+                    if (plains <= QT_MAX_RUN && can_announce_pairs) rec.aux = pairs;
+                    emit(rec, rec_c_begin[stream_first + i], rec_c_end[stream_first + i]);
+                    size_t at = i + 1;
+                    uint32_t left = plains - first;
+                    for (uint32_t done = 0; at < p_end; at++) {
                         if (done == QT_MAX_RUN) {
                             const uint32_t more = std::min<uint32_t>(left, QT_MAX_RUN);
-                            out.push_back({QT_SRC_ONE | QT_SETV | (more << QT_RUN_SHIFT), 0, {0, 0, 0, 0, 0, 0}});
-                            ocb.push_back(0);
-                            oce.push_back(0);
                             left -= more;
+                            emit({QT_SRC_ONE | QT_SETV | (more << QT_RUN_SHIFT), left == 0 ? pairs : 0u, {0, 0, 0, 0, 0, 0}}, 0, 0);
                             done = 0;
                         }
-                        out.push_back(Q.recs[q]);
-                        ocb.push_back(rec_c_begin[q]);
-                        oce.push_back(rec_c_end[q]);
+                        emit(in(at), rec_c_begin[stream_first + at], rec_c_end[stream_first + at]);
                         done++;
                     }
-                    r = q - 1;
+                    // the announced pairs go out as they are (their own control words announce nothing); unannounced ones are
+                    // ordinary special records and get their turn in this loop
+                    const size_t fast_end = p_end + 2 * (size_t)pairs;
+                    for (; at < fast_end; at++) emit(in(at), rec_c_begin[stream_first + at], rec_c_end[stream_first + at]);
+                    i = at;
                 }
                 Q.recs.resize(stream_first);
                 rec_c_begin.resize(stream_first);
@@ -566,16 +701,26 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
             bool in_product = false;
             gl_t v = 1;
             uint32_t announced = 0;  // plain records the last special record said would follow
+            uint32_t fast = 0;       // records of announced fast pairs still to come (two per pair): evaluated without a look at their flags
             if ((rec->ctl & QT_SPECIAL) == 0) return false;  // a stream opens with a special record (the kernel knows no run length before it)
             for (;; rec++) {
                 const uint32_t ctl = rec->ctl;
                 if ((ctl & QT_SPECIAL) == 0) {  // plain: must have been announced, and carries no run length itself
                     if (announced == 0 || (ctl >> QT_RUN_SHIFT) != 0) return false;
                     announced--;
+                } else if (announced == 0 && fast != 0) {
+                    // inside a fast run: exactly (SETV, cell in the tile) then (MULV, cell in the tile), nothing announced, not a piece's end
+                    const uint32_t want = (fast & 1u) ? QT_MULV : QT_SETV;
+                    if ((ctl & QT_SPECIAL) != want || (ctl >> QT_RUN_SHIFT) != 0 || rec->aux != 0) return false;
+                    fast--;
                 } else {
                     if (announced != 0) return false;  // a special record inside an announced run: the kernel would not look at its flags
                     announced = ctl >> QT_RUN_SHIFT;
                     if (announced > QT_MAX_RUN) return false;
+                    if (!(ctl & QT_SRC_GLOBAL)) {
+                        if (rec->aux & ~QT_AUX_PAIRS_MASK) return false;
+                        fast = 2 * rec->aux;
+                    }
                 }
                 if (ctl & QT_STOP) break;
                 if (ctl & QT_TILE) {
@@ -587,13 +732,23 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
                 const uint32_t tile = Q.tile_list[ti];
                 gl_t x;
                 if (ctl & QT_SRC_ONE) x = 1;
-                else if (ctl & QT_SRC_GLOBAL) x = ((ctl & QT_NEXT) ? next : local)[rec->aux];
+                else if ((ctl & QT_SRC_GLOBAL) && (rec->aux & QT_AUX_SLOT)) {  // a foreign cell: descriptor slot of the piece under way
+                    const uint32_t slot = rec->aux & 3u, ng = (pc->ctl >> 2) & 7u, nf = (pc->ctl >> QT_FOREIGN_SHIFT) & 7u;
+                    if ((rec->aux & ~(QT_AUX_SLOT | 3u)) != 0 || slot < ng || slot >= ng + nf || ng + nf > 4) return false;
+                    if (!!(pc->gate[slot] & REF_NEXT) != !!(ctl & QT_NEXT)) return false;
+                    x = ((pc->gate[slot] & REF_NEXT) ? next : local)[pc->gate[slot] & REF_COL_MASK];
+                } else if (ctl & QT_SRC_GLOBAL) x = ((ctl & QT_NEXT) ? next : local)[rec->aux];
                 else {
                     const uint32_t off = ctl & QT_OFF_MASK, slot = off / (QT_TILE_ROWS * 8), row = (off % (QT_TILE_ROWS * 8)) / 8;
-                    if (row > 1 || slot >= QT_TILE_COLS || (row == 1) != !!(ctl & QT_NEXT)) return false;
-                    const uint32_t col = tile * QT_TILE_COLS + slot;
-                    if (col >= Q.n_cols) return false;
-                    x = (row ? next : local)[col];
+                    if (row > 1 || slot > QT_ONES_SLOT || (row == 1) != !!(ctl & QT_NEXT)) return false;
+                    if (slot == QT_ONES_SLOT) {
+                        if (row) return false;
+                        x = 1;
+                    } else {
+                        const uint32_t col = tile * QT_TILE_COLS + slot;
+                        if (col >= Q.n_cols) return false;
+                        x = (row ? next : local)[col];
+                    }
                 }
                 if (ctl & QT_MULV) x = gl_mul(v, x);
                 if (ctl & QT_SETV) {
@@ -614,7 +769,7 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
                     }
                 if (++n_in_piece > QT_MAX_CHAIN) return false;  // the device fold's chains would wrap (see QT_MAX_CHAIN)
                 if (ctl & QT_END) {
-                    const uint32_t kind = pc->ctl & 3u, ng = (pc->ctl >> 2) & 7u, cm = pc->ctl >> 5;
+                    const uint32_t kind = pc->ctl & 3u, ng = (pc->ctl >> 2) & 7u, cm = (pc->ctl >> 5) & 15u;
                     gl_t G = masks[kind];
                     for (uint32_t g = 0; g < ng; g++) {
                         gl_t gv = ((pc->gate[g] & REF_NEXT) ? next : local)[pc->gate[g] & REF_COL_MASK];
@@ -629,7 +784,7 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
                     pc++;
                 }
             }
-            if (n_in_piece) return false;
+            if (n_in_piece || announced || fast) return false;
         }
     return true;
 }
