@@ -29,6 +29,25 @@ def test_fp12_mul_proof_is_bit_identical_to_oracle(prover, seed):
     assert proof.size == ref.size and np.array_equal(proof, ref)
 
 
+def test_fp12_mul_commitment_on_host_threads_and_on_the_device_give_the_same_proof():
+    """FP12Mul's trace commitment has 32 leaves: by default host threads hash them with the challenger's permutation
+    ("host_commit_leaves" = 64); with the option at 0 the device does (row form).  Same proof bytes, which are the oracle's."""
+    air = S.AIR_FP12_MUL
+    cfg = S.StarkConfig.for_air(air)
+    t, pis = S.trace_fp12_mul(random_fp12(0x5EED2200), random_fp12(0x5EED2201))
+    pv = S.Prover(0)
+    try:
+        on_host = pv.prove(air, cfg, t, pis)
+        pv.set_option("host_commit_leaves", 0)
+        on_device = pv.prove(air, cfg, t, pis)
+        with pytest.raises(S.StarkhipError):
+            pv.set_option("host_commit_leaves", 1 << 20)
+    finally:
+        pv.close()
+    assert np.array_equal(on_host, on_device)
+    assert np.array_equal(on_host, O.prove(S.air_program(air), cfg, S.trace_rows_to_poly_values(t), pis))
+
+
 def test_page_locked_trace_buffer_is_reused_across_proofs(prover):
     """starkhip_host_alloc hand-over: two different traces generated into the same page-locked buffer, each proof
     bit-identical to the oracle's; the buffer outlives views of it and is released afterwards."""
