@@ -272,12 +272,37 @@ void HashService::run() {
             // A group goes out full.  Short of four it goes out when nobody else can join soon -- no big proof is on its way to its
             // commitment and none is waiting to start -- or when the oldest request has waited `big_gather_ms_`; a lone proof is not held up.
             const bool all_here = big_contexts_ > 0 && (int)big_.size() >= big_contexts_;  // every context's proof is waiting in this queue
-            big_ready = big_.size() >= BIG_LANE_GROUP || (big_expected_ <= 0 && big_queued_ <= 0) || all_here || waited >= big_gather_ms_ || stop_;
+            // A request arrives when its proof has ENQUEUED its LDE, not when the LDE has run: launched then, the lane kernels of a group
+            // start one by one as their LDEs finish -- up to 170 ms apart in the kernel trace, the late LDEs starved by the lane waves that
+            // are already there -- and the group is not side by side.  So a commitment counts once its `ready` event has completed, and
+            // a group is the first four that have (the others keep their place).
+            size_t n_done = 0;
+            for (Req* r : big_) {
+                if (!r->lde_done) {
+                    r->lde_done = !align_groups_ || hipEventQuery(r->ready) == hipSuccess;
+                    (void)hipGetLastError();  // hipErrorNotReady is not an error
+                }
+                n_done += r->lde_done;
+            }
+            const bool nobody_else = (big_expected_ <= 0 && big_queued_ <= 0) || all_here || waited >= big_gather_ms_ || stop_;
+            big_ready = n_done >= BIG_LANE_GROUP || (nobody_else && n_done == big_.size()) || waited >= 2 * big_gather_ms_ || stop_;
+            big_poll_ = !big_ready;  // something is queued whose LDE is still running: look again shortly
         }
         const bool take_big = big_ready && (!small_ready || !last_was_big_);
         if (take_big) {
             std::vector<Req*> group;
-            while (!big_.empty() && group.size() < ((big_lane_ && !lane_share_) ? BIG_LANE_GROUP : 1u)) {
+            const size_t want = (big_lane_ && !lane_share_) ? BIG_LANE_GROUP : 1u;
+            if (big_lane_ && !lane_share_) {  // the ones whose LDE has run first, in arrival order
+                for (auto it = big_.begin(); it != big_.end() && group.size() < want;) {
+                    if ((*it)->lde_done) {
+                        group.push_back(*it);
+                        it = big_.erase(it);
+                    } else {
+                        ++it;
+                    }
+                }
+            }
+            while (!big_.empty() && group.size() < want && (group.empty() || stop_ || !(big_lane_ && !lane_share_))) {
                 group.push_back(big_.front());
                 big_.pop_front();
             }
@@ -317,6 +342,7 @@ void HashService::run() {
         double left_ms = 1e9;
         if (!small_.empty()) left_ms = std::min(left_ms, gather_ms - (now_s() - small_.front()->t_arrive) * 1e3);
         if (big_lane_ && !lane_share_ && !big_.empty()) left_ms = std::min(left_ms, big_gather_ms_ - (now_s() - big_.front()->t_arrive) * 1e3);
+        if (big_poll_ && !big_.empty()) left_ms = std::min(left_ms, 0.25);  // an LDE we are waiting for ends without telling us
         // (system_clock deadline = pthread_cond_timedwait: ThreadSanitizer of gcc 11 does not know pthread_cond_clockwait, which a
         // steady-clock wait_for uses, and then reports the mutex as still held)
         cv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds((long)(std::max(0.1, left_ms) * 1e3)));
@@ -724,6 +750,8 @@ int pool_create(const starkhip_pool_config_t& cfg_in, Pool** out) {
     {
         const char* lg = getenv("STARKHIP_POOL_LANE_GROUP");
         if (lg && *lg && atoi(lg) >= 2 && atoi(lg) <= 8) p->hs->BIG_LANE_GROUP = (unsigned)atoi(lg);
+        const char* al = getenv("STARKHIP_POOL_ALIGN");  // 1: a commitment joins a group only once its LDE has run (scheduler.h; A/B runs)
+        if (al && *al) p->hs->align_groups_ = *al == '1';
         const char* bg = getenv("STARKHIP_POOL_BIG_GATHER_MS");
         if (bg && *bg && atof(bg) > 0) p->hs->big_gather_ms_ = atof(bg);
     }
