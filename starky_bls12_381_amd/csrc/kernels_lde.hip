@@ -119,11 +119,32 @@ __device__ __forceinline__ void lde_lds_barrier() { __syncthreads(); }
 __device__ __forceinline__ void lde_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
 
+// The inter-pass twiddles of pass P for this thread: w_{NS*R}^{i * (j mod NS)}, j = t + m * T; the inverse transform's last pass also
+// carries n^-1 (row 0).  Uniform row base + 32-bit lane offset => scalar-base loads, no per-load address registers.  They depend on the
+// thread only, not on the data: the loads of pass P + 1 are issued BEFORE pass P's exchange barriers, so their L2 latency passes under the
+// LDS round trip instead of after it (17.10 -> 16.82 ms for FinalExp; -DSTARKHIP_LDE_NO_TW_PREFETCH loads them where they are used).
+template <int LOGN, int P, bool INV>
+__device__ __forceinline__ void lde_load_twiddles(gl_t (&w)[16], const gl_t* __restrict__ tw, int t) {
+    using PL = LdePlan<LOGN>;
+    if constexpr (P > 0 && P < PL::NP) {
+        constexpr int R = PL::radix(P), S = 16 / R, NS = PL::ns(P), T = PL::T;
+        constexpr bool LAST = P == PL::NP - 1;
+        constexpr int TW_OFF = PL::tw_off(P);  // constexpr variable: otherwise the recursive helper survives as a CALL in the 2^13 kernel
+        const gl_t* twp = tw + TW_OFF;
+#pragma unroll
+        for (int m = 0; m < S; m++) {
+            const uint32_t jj8 = (uint32_t)((t + m * T) % NS) * 8u;
+#pragma unroll
+            for (int i = (INV && LAST) ? 0 : 1; i < R; i++) w[m + S * i] = *(const gl_t*)((const char*)(twp + i * NS) + jj8);
+        }
+    }
+}
+
 // One Stockham pass on the 16 values a thread holds (element i' = column index t + i' * T).
 // P > 0: inputs come from the LDS image written by pass P-1.  Last pass: results stay in registers (natural index
 // t + i' * T); otherwise they are scattered to the LDS image for pass P+1.
 template <int LOGN, int P, bool INV>
-__device__ __forceinline__ void lde_pass(gl_t (&v)[16], gl_t* __restrict__ lds, const gl_t* __restrict__ tw, int t) {
+__device__ __forceinline__ void lde_pass(gl_t (&v)[16], gl_t (&w)[16], gl_t* __restrict__ lds, const gl_t* __restrict__ tw, int t) {
     using PL = LdePlan<LOGN>;
     constexpr int R = PL::radix(P), S = 16 / R, NS = PL::ns(P), T = PL::T;
     constexpr bool LAST = P == PL::NP - 1;
@@ -132,23 +153,21 @@ __device__ __forceinline__ void lde_pass(gl_t (&v)[16], gl_t* __restrict__ lds, 
         const int tpad = lds_pad(t);
 #pragma unroll
         for (int i = 0; i < 16; i++) v[i] = lds[tpad + i * (T + T / 16)];
-        // twiddles w_{NS*R}^{i * (j mod NS)}, j = t + m * T; the inverse transform's last pass also carries n^-1 (row 0).
-        // Uniform row base + 32-bit lane offset => scalar-base loads, no per-load address registers.
-        constexpr int TW_OFF = PL::tw_off(P);  // constexpr variable: otherwise the recursive helper survives as a CALL in the 2^13 kernel
-        const gl_t* twp = tw + TW_OFF;
+#ifdef STARKHIP_LDE_NO_TW_PREFETCH
+        lde_load_twiddles<LOGN, P, INV>(w, tw, t);
+#endif
 #pragma unroll
         for (int m = 0; m < S; m++) {
-            const uint32_t jj8 = (uint32_t)((t + m * T) % NS) * 8u;
 #pragma unroll
-            for (int i = (INV && LAST) ? 0 : 1; i < R; i++) {
-                const gl_t w = *(const gl_t*)((const char*)(twp + i * NS) + jj8);
-                v[m + S * i] = gl_mul_nc(v[m + S * i], w);
-            }
+            for (int i = (INV && LAST) ? 0 : 1; i < R; i++) v[m + S * i] = gl_mul_nc(v[m + S * i], w[m + S * i]);
         }
     }
     SubNtts<R, INV, 0>::run(v);
     unscramble<R>(v);
     if constexpr (!LAST) {
+#ifndef STARKHIP_LDE_NO_TW_PREFETCH
+        lde_load_twiddles<LOGN, P + 1, INV>(w, tw, t);
+#endif
         // The two barriers of an exchange order LDS accesses only: they wait for this wave's LDS operations (lgkmcnt), NOT for its
         // global ones -- __syncthreads() also waits vmcnt(0), i.e. for the sixteen result stores of the previous coset transform to reach
         // memory, at the first exchange of every transform.  (Global data is never handed from thread to thread in this kernel: a
@@ -173,8 +192,12 @@ __device__ __forceinline__ void lde_pass(gl_t (&v)[16], gl_t* __restrict__ lds, 
 template <int LOGN, int P, bool INV>
 struct LdePasses {
     static __device__ __forceinline__ void run(gl_t (&v)[16], gl_t* lds, const gl_t* tw, int t) {
-        lde_pass<LOGN, P, INV>(v, lds, tw, t);
-        if constexpr (P + 1 < LdePlan<LOGN>::NP) LdePasses<LOGN, P + 1, INV>::run(v, lds, tw, t);
+        gl_t w[16];
+        run_with(v, w, lds, tw, t);
+    }
+    static __device__ __forceinline__ void run_with(gl_t (&v)[16], gl_t (&w)[16], gl_t* lds, const gl_t* tw, int t) {
+        lde_pass<LOGN, P, INV>(v, w, lds, tw, t);
+        if constexpr (P + 1 < LdePlan<LOGN>::NP) LdePasses<LOGN, P + 1, INV>::run_with(v, w, lds, tw, t);
     }
 };
 

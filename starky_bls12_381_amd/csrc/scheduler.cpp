@@ -448,6 +448,7 @@ struct Pool {
     bool warm_device_traces = false;  // warm_up == 2: the caller's traces are column-major device memory: no trace buffers are reserved
     bool fifo = false;  // STARKHIP_POOL_FIFO=1: small jobs in arrival order (A/B measurements)
     int gen_nice = 10;  // STARKHIP_GEN_NICE: nice value of the generator threads (0: as the rest of the process)
+    size_t gen_ahead = 1;  // STARKHIP_POOL_GEN_AHEAD: FinalExp-class recordings made beyond the ones the contexts can take at once
     bool warm = false;        // contexts reserve the pipeline's AIRs when their threads start (pool_create waits for it)
     unsigned warmed = 0;
     int warm_rc = STARKHIP_OK;
@@ -506,7 +507,7 @@ struct Pool {
                 // leaf: MillerLoop 12 167, FP12Mul 7 536, PairingPrecomp 3 672), so that the batch does not end on one; recordings
                 // that cost nothing (FP12Mul: 16 rows) before all others -- their proofs are 2-wave chains that start at once.
                 auto it = q_gen.end();
-                const bool want_big = big_recordings_started < big_ctx.size() + 1;
+                const bool want_big = big_recordings_started < big_ctx.size() + gen_ahead;
                 for (auto k = q_gen.begin(); k != q_gen.end(); ++k)
                     if ((*k)->big == want_big && (it == q_gen.end() || (!want_big && !fifo && small_rank(*k) > small_rank(*it)))) it = k;
                 if (it == q_gen.end())  // none of the wanted class: the best of the other
@@ -729,6 +730,8 @@ int pool_create(const starkhip_pool_config_t& cfg_in, Pool** out) {
     {
         const char* e = getenv("STARKHIP_POOL_FIFO");
         p->fifo = e && *e == '1';
+        const char* ga = getenv("STARKHIP_POOL_GEN_AHEAD");
+        if (ga && *ga && atoi(ga) >= 0) p->gen_ahead = (size_t)atoi(ga);
         const char* n = getenv("STARKHIP_GEN_NICE");
         if (n && *n) p->gen_nice = atoi(n);
         const char* bl = getenv("STARKHIP_POOL_BIG_LANE");
