@@ -241,6 +241,8 @@ static int ensure_plan(Ctx* c, const AirInfo& air, size_t quotient_points) {
     const size_t blocks = (quotient_points + 63) / 64;
     unsigned want = (unsigned)std::min<size_t>(512, std::max<size_t>(1, (8192 + blocks - 1) / blocks));  // FinalExp: 4 chunks 29.8 ms, 8: 29.4, 16: 29.0, 32: 28.9
     if (c->opt_quotient_chunks > 0) want = (unsigned)c->opt_quotient_chunks;
+    else if (const char* e = getenv("STARKHIP_QUOTIENT_CHUNKS"))  // experiments
+        if (*e && atoi(e) > 0) want = (unsigned)atoi(e);
     for (auto& pd : c->plan_cache)
         if (pd->air == air.id && pd->want == want) {
             c->plan = pd.get();

@@ -236,7 +236,8 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
     struct Piece {
         uint32_t sg, tile;
         uint32_t m_begin, m_end;  // monomials
-        uint32_t cost;
+        uint32_t cost;      // issue slots (model) of its records, + PIECE_COST
+        uint32_t n_recs = 0;  // records (what the fold's overflow bound counts)
         std::vector<uint32_t> foreign;  // monomials (single cells of other tiles) absorbed from tiny pieces of the same supergroup
     };
     std::vector<Mono> monos;
@@ -250,7 +251,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         const bool same_piece = !pieces.empty() && pieces.back().sg == t.sg && pieces.back().tile == tl;
         const bool same_mono = same_piece && !monos.empty() && monos.back().cells[0] == t.cells[0] && monos.back().cells[1] == t.cells[1] &&
                                monos.back().cells[2] == t.cells[2] && pieces.back().m_end == monos.size();
-        if (!same_piece) pieces.push_back({t.sg, tl, (uint32_t)monos.size(), (uint32_t)monos.size(), 0, {}});
+        if (!same_piece) pieces.push_back({t.sg, tl, (uint32_t)monos.size(), (uint32_t)monos.size(), 0, 0, {}});
         if (!same_mono) {
             monos.push_back({{t.cells[0], t.cells[1], t.cells[2]}, (uint32_t)contribs.size(), (uint32_t)contribs.size()});
             pieces.back().m_end = (uint32_t)monos.size();
@@ -318,22 +319,33 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
             for (; b < p.m_end; b++) {
                 const uint32_t r = mono_records(monos[b]);
                 if (recs + r > QT_MAX_PIECE && recs) {
-                    cut.push_back({p.sg, p.tile, start, b, 0, {}});
+                    cut.push_back({p.sg, p.tile, start, b, 0, 0, {}});
                     start = b;
                     recs = 0;
                 }
                 recs += r;
             }
-            cut.push_back({p.sg, p.tile, start, p.m_end, 0, p.foreign});  // the absorbed cells go with the last part
+            cut.push_back({p.sg, p.tile, start, p.m_end, 0, 0, p.foreign});  // the absorbed cells go with the last part
         }
         pieces.swap(cut);
     }
-    const uint32_t PIECE_COST = 200, REC_COST = 18, TILE_COST = 150;  // vector instructions (ISA count): per piece end, per record
+    // Issue slots by kind of record (round-4 counters): a plain record 18, a degree-2 monomial inside the tile 40 for its two records, anything
+    // that goes through the generic step ~ 90 per record; a piece end ~ 150 on top of its last record's generic step.
+    const uint32_t PIECE_COST = 240, REC_COST = 18, PAIR_COST = 40, GENERIC_COST = 90, TILE_COST = 150;
     for (Piece& p : pieces) {
-        uint32_t recs = 0;
-        for (uint32_t b = p.m_begin; b < p.m_end; b++) recs += mono_records(monos[b]);
+        uint32_t recs = 0, cost = 0;
+        for (uint32_t b = p.m_begin; b < p.m_end; b++) {
+            const Mono& m = monos[b];
+            const uint32_t r = mono_records(m);
+            recs += r;
+            if (m.cells[1] == NONE) cost += REC_COST;
+            else if (m.cells[2] == NONE && tile_of(m.cells[0]) == p.tile && tile_of(m.cells[1]) == p.tile) cost += PAIR_COST;
+            else cost += GENERIC_COST * r;
+        }
         recs += (uint32_t)p.foreign.size();
-        p.cost = PIECE_COST + REC_COST * recs;
+        cost += GENERIC_COST * (uint32_t)p.foreign.size();
+        p.n_recs = recs;
+        p.cost = PIECE_COST + cost;
     }
 
     // ---- pass 3: tiles in walking order, cut into chunks of about equal cost
@@ -407,7 +419,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         // spans 2.4 tiles on average and a piece end costs as much as a dozen records)
         std::vector<std::vector<uint8_t>> carry_in(t_hi - t_lo, std::vector<uint8_t>(QT_WAVES, 0));
         std::vector<uint32_t> chain_recs(QT_WAVES, 0);  // records accumulated by the piece a wave ends the previous tile with
-        auto piece_recs = [&](uint32_t p) { return (pieces[p].cost - PIECE_COST) / REC_COST; };
+        auto piece_recs = [&](uint32_t p) { return pieces[p].n_recs; };
         for (uint32_t t = t_lo; t < t_hi; t++) {
             std::vector<uint32_t> ps;
             for (uint32_t p = tile_first_piece[t]; p < tile_first_piece[t + 1]; p++) ps.push_back(p);
