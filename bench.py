@@ -467,7 +467,7 @@ def main():
                     for t in [submit_one(i) for i in range(reps)]:
                         pool.wait(t, keep=False)
                     return reps / (time.perf_counter() - t0)
-                reps = 2 * inflight + 2
+                reps = 3 * inflight  # three waves of the pool per leg
                 if host_rows is None:
                     host_rows = helper.host_array((n, C))
                 _, pis0 = S.trace_final_exp(inputs[0], out=host_rows)
