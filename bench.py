@@ -178,7 +178,7 @@ def main():
                     help="proofs in flight per GPU (independent contexts on separate host threads and HIP streams); "
                          "1 = one proof at a time (latency); several hide the host-side Fiat-Shamir hashing and the launch gaps of "
                          "each proof behind the kernels of the others, and from five on the pool sends the trace commitments out in groups "
-                         "of four in the lane form of the leaf hash (~ 25 GB of HBM per context)")
+                         "of four in the lane form of the leaf hash (19.6 GB of HBM per context)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -214,7 +214,7 @@ def main():
         inflight = max(1, min(inflight, 8 // world))  # the rehearsing ranks share ONE card's memory
     # the in-flight proofs go through the library's own scheduler, as a caller of the C ABI would drive them: `inflight` FinalExp-class
     # contexts, one host thread each inside libstarkhip.so, generator threads that record the traces (a pool reserves every buffer of
-    # its contexts when it is created -- ~ 25 GB per FinalExp-class context; should eight ever not fit, fewer proofs in flight are
+    # its contexts when it is created -- 19.6 GB per FinalExp-class context; should eight ever not fit, fewer proofs in flight are
     # still a valid measurement of the same metric)
     pool = None
     for k in sorted({inflight, min(inflight, 6), min(inflight, 4)}, reverse=True):
@@ -322,7 +322,7 @@ def main():
 
     if rank == 0:
         steps = max(1, args.steps)
-        alg = {"lde_columns": 8.0 * C * (n + n + N),  # read values, write coeffs + LDE (IFFT and LDE fused in one kernel)
+        alg = {"lde_columns": 8.0 * C * (n + N),  # read values, write the LDE (IFFT and LDE fused in one kernel; round 4: no coefficients kept)
                "leaf_hash": 8.0 * C * N,              # read the LDE once
                "quotient_eval": 8.0 * C * N}          # read the LDE on the quotient coset once
         alg_by_kernel = {"lde_columns_v2_kernel": alg["lde_columns"], "quotient_tiles_kernel": alg["quotient_eval"]}

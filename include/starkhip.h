@@ -173,7 +173,7 @@ int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_
  * The reference's caller proves one AIR after the other on one thread (src/aggregate_proof.rs:304-370: pp1, ml1, pp2, ml2,
  * fp12_mul, final_exp; `aggregate_proof` :402-414) and lets rayon fill the cores inside each prove().  On a GPU several
  * proofs in flight are what fills the chip, so the library schedules them itself: a pool owns `big_contexts` prover contexts
- * for the 8192-row AIRs (FinalExp, ECCAgg: ~25 GB of buffers each) and `small_contexts` for the others, one host thread
+ * for the 8192-row AIRs (FinalExp, ECCAgg: 19.6 GB of buffers each) and `small_contexts` for the others, one host thread
  * per context, `generator_threads` host threads that record traces (starkhip_pool_submit_witness), and a commitment
  * scheduler: the trace commitments of small proofs that arrive together are hashed by ONE merged launch (and, by option, a
  * FinalExp-class commitment -- a one-shot grid that owns the chip -- never shares the chip with a small one).  Proofs are byte-identical to
@@ -183,7 +183,7 @@ int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_
 typedef struct {
     int device;
     unsigned big_contexts;      /* 0 = default (3).  Five or more: the trace commitments of these proofs go out in groups of up to four in the
-                                   lane form of the leaf hash (6.3 against 5.65 proofs/s on one MI355X; ~ 25 GB of HBM per context,
+                                   lane form of the leaf hash (6.3 against 5.65 proofs/s on one MI355X; 19.6 GB of HBM per context,
                                    starkhip_pool_reservation) */
     unsigned small_contexts;    /* 0 = default (16) */
     unsigned generator_threads; /* recordings under way at once; 0 = default (a quarter of the CPUs the process may use -- its
@@ -238,9 +238,9 @@ int starkhip_pool_submit_witness(void* pool, starkhip_air_t air, const starkhip_
 int starkhip_pool_wait(void* pool, uint64_t ticket, uint64_t** proof, size_t* proof_words, starkhip_ticket_info_t* info);
 int starkhip_pool_stats(void* pool, starkhip_pool_stats_t* out);
 /* What the pool has reserved (a warmed pool: everything its proofs will ever need; read it between proofs): device memory of all
- * contexts, page-locked upload staging, and the largest context of each class.  A FinalExp-class context holds the trace columns
- * (4.8 GB; the coefficients replace them in place), the LDE (19.3 GB; row-major uploads and recordings are staged in it before the
- * LDE kernel writes it) and ~ 0.5 GB of small buffers. */
+ * contexts, page-locked upload staging, and the largest context of each class.  A FinalExp-class context holds the LDE (19.3 GB; the trace
+ * columns wait for it inside that buffer, row-major uploads and recordings are staged in it before the LDE kernel writes it, and
+ * coefficients are not kept) and ~ 0.3 GB of small buffers. */
 typedef struct {
     uint64_t device_bytes, pinned_host_bytes, big_context_device_bytes, small_context_device_bytes;
     unsigned big_contexts, small_contexts;

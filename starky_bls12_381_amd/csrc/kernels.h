@@ -94,11 +94,14 @@ hipError_t launch_quotient_tiles_combine(const gl_t* partial, unsigned n_chunks,
 
 // kernels_fri.hip
 hipError_t launch_ext_powers(gl2_t* out, gl2_t base, size_t count, hipStream_t st);
-hipError_t launch_openings(const gl_t* coeffs, size_t n_polys, size_t n, const gl2_t* zpow, const gl2_t* gzpow, gl2_t* out_z, gl2_t* out_gz,
-                           hipStream_t st);
-hipError_t launch_fri_combine(const gl_t* coeffs, size_t n_polys, size_t n, const gl2_t* apow, size_t polys_per_chunk, size_t n_chunks,
-                              gl2_t* partial, hipStream_t st);
-hipError_t launch_ext_reduce(const gl2_t* partial, size_t n_chunks, size_t n, gl2_t* out, hipStream_t st);
+// weights of the evaluation at z (and, rotated by one, at w_n z) from values on coset 0 of the LDE; scale = (z^n - 7^n) / (n 7^n)
+hipError_t launch_coset_weights(gl2_t* wz, gl2_t* wgz, gl2_t z, gl2_t scale, unsigned log_n, hipStream_t st);
+// vectors of n words, `stride` words apart (coefficients: stride = n; coset 0 of an LDE: stride = 2^rate n)
+hipError_t launch_openings(const gl_t* coeffs, size_t stride, size_t n_polys, size_t n, const gl2_t* zpow, const gl2_t* gzpow, gl2_t* out_z,
+                           gl2_t* out_gz, hipStream_t st);
+hipError_t launch_fri_combine(const gl_t* coeffs, size_t stride, size_t n_polys, size_t n, const gl2_t* apow, size_t polys_per_chunk,
+                              size_t n_chunks, gl2_t* partial, hipStream_t st);
+hipError_t launch_ext_reduce(const gl2_t* partial, size_t n_chunks, size_t n, gl_t* out, hipStream_t st);  // two vectors of n words
 hipError_t launch_fri_leaves(const gl_t* vals, unsigned log_len, unsigned arity_bits, gl_t* rows, hipStream_t st);
 hipError_t launch_fri_fold(const gl_t* in, size_t len, unsigned arity_bits, gl2_t beta, gl_t* out, hipStream_t st);
 

@@ -15,13 +15,31 @@ __global__ void ext_powers_kernel(gl2_t* out, gl2_t base, size_t count) { STARKH
 }
 
 // ---------------------------------------------------------------- openings (App. A.7)
-// One workgroup per polynomial: out_z[c] = sum_k coeffs[c][k] * zpow[k], out_gz[c] likewise with gzpow.
-// coeffs is read exactly once; zpow / gzpow (n extension elements each) stay in L2.
-__global__ __launch_bounds__(256) void openings_kernel(const gl_t* __restrict__ coeffs, size_t n, const gl2_t* __restrict__ zpow,
+// The prover keeps no coefficients of the trace polynomials (a FinalExp context would hold 4.8 GB of them for these two sums): a
+// polynomial of degree < n is evaluated from its n values on coset 0 of the LDE, x_k = 7 w_n^k, by the interpolation formula
+//     p(z) = sum_k p(x_k) L_k(z),   L_k(z) = (z^n - 7^n) x_k / (n 7^n (z - x_k))
+// (Z(x) = x^n - 7^n vanishes on the coset and Z'(x_k) = n 7^n / x_k).  Exact field arithmetic: the same element of the extension as
+// sum_k c_k z^k, so the proof bytes are those of the reference's coefficient form (StarkOpeningSet::new -> eval).  L_k(w_n z) =
+// L_(k-1)(z): the weights of the next-row opening are the same vector rotated by one.  `scale` = (z^n - 7^n) / (n 7^n) from the host.
+__global__ void coset_weights_kernel(gl2_t* __restrict__ wz, gl2_t* __restrict__ wgz, gl2_t z, gl2_t scale, unsigned log_n) { STARKHIP_PRIO_ENTRY
+    const size_t n = (size_t)1 << log_n;
+    const size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const gl_t x = gl_mul(GL_GENERATOR, gl_pow(gl_root_of_unity(log_n), k));
+    const gl2_t d = gl2_sub(z, gl2_make(x, 0));
+    const gl2_t w = gl2_mul(gl2_mul_base(scale, x), gl2_inv(d));
+    wz[k] = w;
+    wgz[(k + 1) & (n - 1)] = w;
+}
+
+// One workgroup per polynomial: out_z[c] = sum_k vec[c * stride + k] * zpow[k], out_gz[c] likewise with gzpow.  vec = coefficients
+// and zpow = powers of z (the quotient polynomials), or vec = values on coset 0 and zpow = the weights above (the trace).
+// vec is read exactly once; zpow / gzpow (n extension elements each) stay in L2.
+__global__ __launch_bounds__(256) void openings_kernel(const gl_t* __restrict__ coeffs, size_t stride, size_t n, const gl2_t* __restrict__ zpow,
                                                        const gl2_t* __restrict__ gzpow, gl2_t* __restrict__ out_z,
                                                        gl2_t* __restrict__ out_gz) { STARKHIP_PRIO_ENTRY
     const size_t c = blockIdx.x;
-    const gl_t* col = coeffs + c * n;
+    const gl_t* col = coeffs + c * stride;
     gl2_t a = gl2_zero(), b = gl2_zero();
     for (size_t k = threadIdx.x; k < n; k += blockDim.x) {
         gl_t v = col[k];
@@ -46,8 +64,10 @@ __global__ __launch_bounds__(256) void openings_kernel(const gl_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------- FRI batch combine (App. A.8)
-// partial[jc][k] = sum_{j in chunk jc} apow[j0 + j] * coeffs[j][k]
-__global__ __launch_bounds__(256) void fri_combine_kernel(const gl_t* __restrict__ coeffs, size_t n_polys, size_t n,
+// partial[jc][k] = sum_{j in chunk jc} apow[j0 + j] * coeffs[j * stride + k]: linear, so it is taken on the trace's coset-0 values as
+// well as on coefficients (the quotient polynomials); the prover turns the sum of the former into coefficients with one inverse
+// coset transform of two vectors (prover.hip)
+__global__ __launch_bounds__(256) void fri_combine_kernel(const gl_t* __restrict__ coeffs, size_t stride, size_t n_polys, size_t n,
                                                           const gl2_t* __restrict__ apow, size_t polys_per_chunk,
                                                           gl2_t* __restrict__ partial) { STARKHIP_PRIO_ENTRY
     size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -55,16 +75,17 @@ __global__ __launch_bounds__(256) void fri_combine_kernel(const gl_t* __restrict
     size_t j0 = (size_t)blockIdx.y * polys_per_chunk;
     size_t j1 = j0 + polys_per_chunk < n_polys ? j0 + polys_per_chunk : n_polys;
     gl2_t acc = gl2_zero();
-    for (size_t j = j0; j < j1; j++) acc = gl2_add(acc, gl2_mul_base(apow[j], coeffs[j * n + k]));
+    for (size_t j = j0; j < j1; j++) acc = gl2_add(acc, gl2_mul_base(apow[j], coeffs[j * stride + k]));
     partial[(size_t)blockIdx.y * n + k] = acc;
 }
-// out[k] = sum_jc partial[jc][k]
-__global__ void ext_reduce_kernel(const gl2_t* __restrict__ partial, size_t n_chunks, size_t n, gl2_t* __restrict__ out) { STARKHIP_PRIO_ENTRY
+// out[k] = sum_jc partial[jc][k], as two vectors of base-field words: out[k], out[n + k] (what launch_ntt_global transforms)
+__global__ void ext_reduce_kernel(const gl2_t* __restrict__ partial, size_t n_chunks, size_t n, gl_t* __restrict__ out) { STARKHIP_PRIO_ENTRY
     size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (k >= n) return;
     gl2_t acc = gl2_zero();
     for (size_t c = 0; c < n_chunks; c++) acc = gl2_add(acc, partial[c * n + k]);
-    out[k] = acc;
+    out[k] = acc.a0;
+    out[n + k] = acc.a1;
 }
 
 // ---------------------------------------------------------------- FRI commit phase
@@ -94,19 +115,23 @@ hipError_t launch_ext_powers(gl2_t* out, gl2_t base, size_t count, hipStream_t s
     hipLaunchKernelGGL(ext_powers_kernel, dim3(nb(count, 256)), dim3(256), 0, st, out, base, count);
     return hipGetLastError();
 }
-hipError_t launch_openings(const gl_t* coeffs, size_t n_polys, size_t n, const gl2_t* zpow, const gl2_t* gzpow, gl2_t* out_z, gl2_t* out_gz,
-                           hipStream_t st) {
+hipError_t launch_coset_weights(gl2_t* wz, gl2_t* wgz, gl2_t z, gl2_t scale, unsigned log_n, hipStream_t st) {
+    hipLaunchKernelGGL(coset_weights_kernel, dim3(nb((size_t)1 << log_n, 256)), dim3(256), 0, st, wz, wgz, z, scale, log_n);
+    return hipGetLastError();
+}
+hipError_t launch_openings(const gl_t* coeffs, size_t stride, size_t n_polys, size_t n, const gl2_t* zpow, const gl2_t* gzpow, gl2_t* out_z,
+                           gl2_t* out_gz, hipStream_t st) {
     if (!n_polys) return hipSuccess;
-    hipLaunchKernelGGL(openings_kernel, dim3((unsigned)n_polys), dim3(256), 0, st, coeffs, n, zpow, gzpow, out_z, out_gz);
+    hipLaunchKernelGGL(openings_kernel, dim3((unsigned)n_polys), dim3(256), 0, st, coeffs, stride, n, zpow, gzpow, out_z, out_gz);
     return hipGetLastError();
 }
-hipError_t launch_fri_combine(const gl_t* coeffs, size_t n_polys, size_t n, const gl2_t* apow, size_t polys_per_chunk, size_t n_chunks,
-                              gl2_t* partial, hipStream_t st) {
-    hipLaunchKernelGGL(fri_combine_kernel, dim3(nb(n, 256), (unsigned)n_chunks), dim3(256), 0, st, coeffs, n_polys, n, apow, polys_per_chunk,
-                       partial);
+hipError_t launch_fri_combine(const gl_t* coeffs, size_t stride, size_t n_polys, size_t n, const gl2_t* apow, size_t polys_per_chunk,
+                              size_t n_chunks, gl2_t* partial, hipStream_t st) {
+    hipLaunchKernelGGL(fri_combine_kernel, dim3(nb(n, 256), (unsigned)n_chunks), dim3(256), 0, st, coeffs, stride, n_polys, n, apow,
+                       polys_per_chunk, partial);
     return hipGetLastError();
 }
-hipError_t launch_ext_reduce(const gl2_t* partial, size_t n_chunks, size_t n, gl2_t* out, hipStream_t st) {
+hipError_t launch_ext_reduce(const gl2_t* partial, size_t n_chunks, size_t n, gl_t* out, hipStream_t st) {
     hipLaunchKernelGGL(ext_reduce_kernel, dim3(nb(n, 256)), dim3(256), 0, st, partial, n_chunks, n, out);
     return hipGetLastError();
 }

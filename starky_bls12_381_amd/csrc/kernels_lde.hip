@@ -201,13 +201,17 @@ struct LdePasses {
     }
 };
 
-// values [C][n] (or coefficients when from_coeffs) -> coeffs [C][n] (nullable) and lde [C][2^rate][n], coset-major.
-// `coeffs` MAY BE `values` (the prover transforms a trace in place: values and coefficients are never both needed, 4.8 GB per
-// FinalExp context): a thread reads its 16 words of a column before it writes exactly those 16 back, and the closed-form branch
-// writes other words only after the workgroup's barriers -- so neither pointer is `__restrict__`.
+// values [C][n] (or coefficients when from_coeffs) -> lde [C][2^rate][n], coset-major, and the coefficients at coeffs[c * cf_stride + k].
+// The coefficients are the kernel's own scratch between the inverse transform and the coset transforms.  The prover does not keep them
+// (openings and the FRI combination read coset 0 of the LDE: kernels_fri.hip): it passes the LAST coset slot of the column's own LDE
+// block (cf_stride = 2^rate n, cf_keep = 0) -- a thread reads its 16 coefficient words for the last coset before it writes exactly those
+// 16 positions with that coset's values.  starkhip_lde_batch asks for them (cf_stride = n, cf_keep = 1), possibly in place of `values`.
+// `values` itself MAY lie inside `lde` (the prover parks a trace in the last quarter of the buffer the LDE is written to and launches
+// ranges of columns whose blocks cover only columns already transformed: prover.hip run_lde_trace); within a workgroup every input word
+// is in registers, behind a barrier in the closed-form branch, before any word is written -- so no pointer here is `__restrict__`.
 template <int LOGN>
-__global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kernel(const gl_t* values, gl_t* coeffs,
-                                                                                    gl_t* __restrict__ lde, unsigned n_cols, unsigned rate_bits,
+__global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kernel(const gl_t* values, gl_t* coeffs, unsigned cf_stride, int cf_keep,
+                                                                                    gl_t* lde, unsigned n_cols, unsigned rate_bits,
                                                                                     const gl_t* __restrict__ tw_fwd,
                                                                                     const gl_t* __restrict__ tw_inv, const gl_t* __restrict__ cs,
                                                                                     const gl_t* __restrict__ oh, int from_coeffs, int prio) { STARKHIP_PRIO_ENTRY
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kern
     // The coefficients are not held in registers across the coset transforms (16 x 64-bit more per lane would halve
     // the occupancy): each thread re-reads exactly the 16 words it stored itself, which are still in L2 / MALL.
     const char* cf_base = in_base;
+    uint32_t cf_off = in_off;
     if (!from_coeffs) {
 #pragma unroll
         for (int i = 0; i < 16; i++) v[i] = *(const gl_t*)(in_base + in_off + (uint32_t)(i * T * 8));
@@ -266,18 +271,20 @@ __global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kern
                 const bool is_const = (all_flags & 1u) == 0, is_unit = (all_flags & 2u) == 0 && all_ones == 1;
                 if (is_const || is_unit) {  // uniform over the workgroup
                     const unsigned n_cosets = 1u << rate_bits;
-                    char* cf_out = (char*)(coeffs + (size_t)col0 * n);
+                    char* cf_out = (char*)(coeffs + (size_t)col0 * cf_stride);  // one column per workgroup here
                     char* out_base = (char*)(lde + (size_t)col0 * n_cosets * n);
                     // 16-byte stores (two adjacent words per lane: 8-byte stores reach 0.5 - 0.7 of their rate): thread t owns words
                     // 2 t, 2 t + 1 of every block of 2 T
                     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
                     if (is_const) {
                         const gl_t c = gl_canon(first);
+                        if (cf_keep) {
 #pragma unroll
-                        for (int i = 0; i < 8; i++) {
-                            u64x2 w = {0, 0};
-                            if (t == 0 && i == 0) w.x = c;
-                            *(u64x2*)(cf_out + (uint32_t)((2 * t + i * 2 * T) * 8)) = w;
+                            for (int i = 0; i < 8; i++) {
+                                u64x2 w = {0, 0};
+                                if (t == 0 && i == 0) w.x = c;
+                                *(u64x2*)(cf_out + (uint32_t)((2 * t + i * 2 * T) * 8)) = w;
+                            }
                         }
                         const u64x2 cc = {c, c};
                         for (unsigned s = 0; s < n_cosets; s++) {
@@ -286,11 +293,13 @@ __global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kern
                         }
                     } else {
                         const unsigned r = cls[2];
+                        if (cf_keep) {
 #pragma unroll
-                        for (int i = 0; i < 8; i++) {
-                            const unsigned j = (unsigned)(2 * t + i * 2 * T);
-                            const u64x2 w = {oh[(r * j) & (unsigned)(n - 1)], oh[(r * (j + 1)) & (unsigned)(n - 1)]};
-                            *(u64x2*)(cf_out + (uint32_t)(j * 8)) = w;
+                            for (int i = 0; i < 8; i++) {
+                                const unsigned j = (unsigned)(2 * t + i * 2 * T);
+                                const u64x2 w = {oh[(r * j) & (unsigned)(n - 1)], oh[(r * (j + 1)) & (unsigned)(n - 1)]};
+                                *(u64x2*)(cf_out + (uint32_t)(j * 8)) = w;
+                            }
                         }
                         for (unsigned s = 0; s < n_cosets; s++) {
                             const gl_t* e0 = oh + n + (size_t)s * n;
@@ -307,10 +316,11 @@ __global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kern
             }
         }
         LdePasses<LOGN, 0, true>::run(v, lds, tw_inv, t);
-        char* cf_out = (char*)(coeffs + (size_t)col0 * n);
+        char* cf_out = (char*)(coeffs + (size_t)col0 * cf_stride);
+        cf_off = (uint32_t)(cib * cf_stride + t) * 8u;
         if (live) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) *(gl_t*)(cf_out + in_off + (uint32_t)(i * T * 8)) = gl_canon(v[i]);
+            for (int i = 0; i < 16; i++) *(gl_t*)(cf_out + cf_off + (uint32_t)(i * T * 8)) = gl_canon(v[i]);
         }
         cf_base = cf_out;
     }
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kern
         asm volatile("" : "+s"(cfb));  // opaque: keeps the re-read a load (no forwarding from the stores above, no hoisting out of the loop)
 #pragma unroll
         for (int i = 0; i < 16; i++)
-            v[i] = gl_mul_nc(*(const gl_t*)(cfb + in_off + (uint32_t)(i * T * 8)), *(const gl_t*)(cs_base + t8 + (uint32_t)(i * T * 8)));
+            v[i] = gl_mul_nc(*(const gl_t*)(cfb + cf_off + (uint32_t)(i * T * 8)), *(const gl_t*)(cs_base + t8 + (uint32_t)(i * T * 8)));
         LdePasses<LOGN, 0, false>::run(v, lds, tw_fwd, t);
         if (live) {
             const uint32_t out_off = (uint32_t)((cib * n_cosets + s) * n + t) * 8u;  // < CPB * 2^rate * n * 8 <= 2^22
@@ -367,8 +377,12 @@ static hipError_t launch_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, size_t 
         if (e != hipSuccess) return e;
     }
     const unsigned blocks = (unsigned)((n_cols + PL::CPB - 1) / PL::CPB);
-    hipLaunchKernelGGL(lde_columns_v2_kernel<LOGN>, dim3(blocks), dim3(PL::THREADS), lds_bytes, st, values, coeffs, lde, (unsigned)n_cols,
-                       rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs, (int)kernel_issue_priority());
+    // no coefficient output wanted: they pass through the last coset slot of the column's LDE block (see the kernel)
+    const bool keep = coeffs != nullptr;
+    gl_t* cf = keep ? coeffs : lde + (((size_t)1 << rate_bits) - 1) * PL::N;
+    const unsigned cf_stride = keep ? (unsigned)PL::N : (unsigned)PL::N << rate_bits;
+    hipLaunchKernelGGL(lde_columns_v2_kernel<LOGN>, dim3(blocks), dim3(PL::THREADS), lds_bytes, st, values, cf, cf_stride, keep ? 1 : 0, lde,
+                       (unsigned)n_cols, rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs, (int)kernel_issue_priority());
     return hipGetLastError();
 }
 
@@ -453,7 +467,6 @@ hipError_t lde_v2_upload_tables(unsigned log_n, unsigned rate_bits, gl_t* d_tw_f
 
 hipError_t launch_lde_columns_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, size_t n_cols, unsigned log_n, unsigned rate_bits,
                                  const gl_t* tw_fwd, const gl_t* tw_inv, const gl_t* cs, const gl_t* oh, int from_coeffs, hipStream_t st) {
-    if (!from_coeffs && !coeffs) return hipErrorInvalidValue;  // the coset transforms read the coefficients back from `coeffs`
     if (n_cols == 0) return hipSuccess;
     switch (log_n) {
         case 8: return launch_v2<8>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs, st);

@@ -133,11 +133,13 @@ struct Ctx {
     unsigned prog_slots = 0;
     std::vector<uint32_t> chunk_k_after;
     // work buffers
-    // `values` holds the trace columns and, after the inverse transforms, their coefficients IN PLACE (a column's values are dead once
-    // its coefficients exist; lde_columns_v2_kernel reads a column completely before it writes it).  Only a trace that already lies in
-    // the caller's device memory (layout 1, on_device) is left untouched: its coefficients go to `values` as a separate output.
-    // Upload staging (row-major rows before the transpose, a recording's words before the expansion) lives in `lde`, which nothing
-    // needs before the LDE kernel writes it.  Together: 4.8 + 19.3 GB per FinalExp context instead of 4.8 + 4.8 + 4.8 + 19.3.
+    // `lde` is the one big buffer (19.3 GB for FinalExp).  Before the LDE kernel writes it, it holds everything that waits for that
+    // kernel: the trace columns as its LAST quarter (the LDE goes out in launches that overwrite only columns already transformed:
+    // run_lde_trace) and, at its start, the upload staging (row-major rows before the transpose, a recording's words before the
+    // expansion).  Coefficients are the LDE kernel's scratch inside a column's own block and are not kept: openings and the FRI
+    // combination read coset 0 of the LDE (kernels_fri.hip).  `values` is the 1/64 of the columns the last LDE launch reads (75 MB), a
+    // whole trace only for rate_bits == 0, and starkhip_lde_batch's in-place values / coefficients.  Together 19.6 GB per FinalExp
+    // context; rounds 1-3: values + coefficients + staging + LDE = 33.7 GB.
     DevBuf staging, values, lde, digests, pis, apow, chunk_scale, partial, qvals, qcoef, qlde, qdigests, zpow, gzpow, open_local,
         open_next, open_q, ext_apow, comb_partial, comb_out, fri_coef, fri_vals, fri_rows[16], fri_digests[16], scale_tab, pow_state,
         pow_best, qidx, gather_t, gather_q;
@@ -206,6 +208,29 @@ static hipError_t run_lde(Ctx* c, const gl_t* values, gl_t* coeffs, gl_t* lde, s
                                      (c->opt_lde_closed_forms && lde_v2_oh_words(log_n, rate)) ? c->tab->lde2_oh.as<gl_t>() : nullptr, from_coeffs, c->st);
     return launch_lde_columns(values, coeffs, lde, cols, log_n, rate, c->tab->tw_fwd.as<gl_t>(), c->tab->tw_inv.as<gl_t>(), log_n + rate,
                               c->tab->coset_scale.as<gl_t>(), from_coeffs, c->st);
+}
+
+// The LDE of a trace whose columns are parked in the buffer the LDE goes to, as its last C n words (in_place): column c' lies at
+// (R - 1) C n + c' n, the LDE block of column c covers [R c n, R (c + 1) n), i.e. the parked columns R c - (R - 1) C + j, j < R.  A launch
+// over the columns [a, b) may overwrite only columns that an EARLIER launch has transformed (c' < a) -- workgroups of one launch run in
+// no particular order -- or a workgroup's own column (the last column's trace is the last slot of its own block, the slot the kernel
+// already uses for its coefficients): R b <= a + (R - 1) C.  So the launches cover 3/4, 3/16, 3/64 ... of the columns for R = 4.  Carried
+// to the end that is log_R(C) launches, the last of them a few columns wide and each as long as one column takes (10 launches, 17.6 ms
+// against 17.0 in one, for FinalExp's 73 527 columns); so the last lde_tail_columns(C) columns -- 1/64 of them for R = 4 -- are
+// copied aside (`tail`, 75 MB for FinalExp) and transformed from there in one launch: 4 launches.
+static size_t lde_tail_columns(size_t C) { return std::max<size_t>(C / 32, 64); }
+static hipError_t run_lde_trace(Ctx* c, const gl_t* values, gl_t* lde, gl_t* tail, size_t C, unsigned log_n, unsigned rate, bool in_place) {
+    if (!in_place) return run_lde(c, values, nullptr, lde, C, log_n, rate, 0);
+    const size_t n = (size_t)1 << log_n, R = (size_t)1 << rate;
+    size_t a = 0;
+    while (C - a > lde_tail_columns(C)) {
+        const size_t b = (a + (R - 1) * C) / R;  // > a while C - a >= 2
+        if (hipError_t e = run_lde(c, values + a * n, nullptr, lde + a * R * n, b - a, log_n, rate, 0); e != hipSuccess) return e;
+        a = b;
+    }
+    if (a == C) return hipSuccess;
+    if (hipError_t e = hipMemcpyAsync(tail, values + a * n, (C - a) * n * 8, hipMemcpyDeviceToDevice, c->st); e != hipSuccess) return e;
+    return run_lde(c, tail, nullptr, lde + a * R * n, C - a, log_n, rate, 0);
 }
 
 static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {
@@ -477,8 +502,20 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     const unsigned n_chunks = tiled ? c->plan->chunks : c->prog_chunks;
 
     // ---- buffers
-    HIPCHK(c->values.ensure(C * n * 8));
-    HIPCHK(c->lde.ensure(C * N * 8));
+    // The trace waits for the LDE INSIDE the buffer the LDE is written to, as its last C n words (trace_in_lde: run_lde_trace below);
+    // a separate buffer only when there is no room beside it (rate_bits == 0, or a recording longer than the rest of the buffer).
+    size_t park_words = 0;  // what the upload parks at the start of the LDE buffer, in 64-bit words
+    if (layout == 2) {
+        const TraceLog* log = (const TraceLog*)trace;
+        park_words = (log->total_words() + log->total_records() + log->total_late_zeros() + 2 + 1) / 2;
+    } else if (!on_device && layout == 0) {
+        park_words = C * n;
+    }
+    const bool trace_in_lde = r >= 1 && park_words <= (((size_t)1 << r) - 1) * C * n && !(on_device && layout == 1);
+    if (trace_in_lde) HIPCHK(c->values.ensure(lde_tail_columns(C) * n * 8));  // the columns the last LDE launch reads (run_lde_trace)
+    else if (!(on_device && layout == 1)) HIPCHK(c->values.ensure(C * n * 8));
+    HIPCHK(c->lde.ensure(std::max(C * N * 8, park_words * 8)));
+    gl_t* const d_trace = trace_in_lde ? c->lde.as<gl_t>() + (N - n) * C : c->values.as<gl_t>();
     HIPCHK(c->digests.ensure(digest_words(N) * 8));
     HIPCHK(c->pis.ensure(std::max<size_t>(1, n_pis) * 8));
     HIPCHK(c->apow.ensure(2 * (AIR_MAX_GROUP + 1) * 8));
@@ -488,8 +525,8 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(c->qcoef.ensure(Q * n * 8));
     HIPCHK(c->qlde.ensure(Q * N * 8));
     HIPCHK(c->qdigests.ensure(digest_words(N) * 8));
-    HIPCHK(c->zpow.ensure(n * 16));
-    HIPCHK(c->gzpow.ensure(n * 16));
+    HIPCHK(c->zpow.ensure(2 * n * 16));  // powers of zeta (the quotient polynomials' openings), then the coset-0 weights of zeta
+    HIPCHK(c->gzpow.ensure(n * 16));     // the weights of g zeta
     HIPCHK(c->open_local.ensure(C * 16));
     HIPCHK(c->open_next.ensure(C * 16));
     HIPCHK(c->open_q.ensure(Q * 16));
@@ -515,11 +552,10 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         const TraceLog* log = (const TraceLog*)trace;
         const size_t nw = log->total_words(), nr = log->total_records(), nz = log->total_late_zeros();
         if (log->rows != n || log->cols != C) return STARKHIP_ERR_BAD_SHAPE;
-        HIPCHK(c->lde.ensure(std::max(C * N * 8, (nw + nr + nz + 2) * 4)));  // the recording's words wait in the (still unused) LDE buffer
-        uint32_t* d_words = c->lde.as<uint32_t>();
+        uint32_t* d_words = c->lde.as<uint32_t>();  // the recording's words wait at the start of the (still unused) LDE buffer
         uint32_t* d_offsets = d_words + nw;
         uint32_t* d_zeros = d_offsets + nr;
-        HIPCHK(hipMemsetAsync(c->values.p, 0, C * n * 8, st));
+        HIPCHK(hipMemsetAsync(d_trace, 0, C * n * 8, st));
         {  // A log recorded by several threads comes in parts (trace_log.h): each part's words land at its base, its offsets
            // (already shifted by that base) and late zeros back to back.  The parts are gathered into ONE page-locked staging
            // buffer of the context and go up as ONE copy: a FinalExp recording has 53 parts x 3 arrays, and on a GPU that other
@@ -562,9 +598,9 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             for (std::thread& t : helpers) t.join();
             if (total) HIPCHK(hipMemcpyAsync(d_words, h, total * 4, hipMemcpyHostToDevice, st));
         }
-        if (nr) HIPCHK(launch_expand_trace(d_words, d_offsets, nr, c->values.as<gl_t>(), n, st));
-        if (nz) HIPCHK(launch_zero_cells(d_zeros, nz / 2, c->values.as<gl_t>(), n, st));
-        d_values = c->values.as<gl_t>();
+        if (nr) HIPCHK(launch_expand_trace(d_words, d_offsets, nr, d_trace, n, st));
+        if (nz) HIPCHK(launch_zero_cells(d_zeros, nz / 2, d_trace, n, st));
+        d_values = d_trace;
     } else if (layout == 3) {
         // The literal argument of starky's prove(): `Vec<PolynomialValues<F>>`, one heap allocation per column
         // (/root/reference/src/aggregate_proof.rs:168-175) -- `trace` is a table of C column pointers.  C separate pageable copies of
@@ -606,31 +642,31 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             }
             gather(0);
             for (std::thread& t : helpers) t.join();
-            HIPCHK(hipMemcpyAsync(c->values.as<gl_t>() + c0 * n, dst, cnt * col_bytes, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_trace + c0 * n, dst, cnt * col_bytes, hipMemcpyHostToDevice, st));
             HIPCHK(hipEventRecord(c->col_ev[h], st));
             used[h] = true;
         }
-        d_values = c->values.as<gl_t>();
+        d_values = d_trace;
     } else if (on_device && layout == 1) {
-        d_values = trace;  // the caller's memory: read only (the coefficients go to c->values)
+        d_values = trace;  // the caller's memory: read only
     } else if (on_device) {
-        HIPCHK(launch_transpose(trace, c->values.as<gl_t>(), n, C, st));
-        d_values = c->values.as<gl_t>();
+        HIPCHK(launch_transpose(trace, d_trace, n, C, st));
+        d_values = d_trace;
     } else if (layout == 1) {
-        HIPCHK(hipMemcpyAsync(c->values.p, trace, C * n * 8, hipMemcpyHostToDevice, st));
-        d_values = c->values.as<gl_t>();
+        HIPCHK(hipMemcpyAsync(d_trace, trace, C * n * 8, hipMemcpyHostToDevice, st));
+        d_values = d_trace;
     } else {
-        // row-major host rows: up into the LDE buffer (idle until the LDE kernel writes it), transposed from there
+        // row-major host rows: up into the start of the LDE buffer (idle until the LDE kernel writes it), transposed from there
         HIPCHK(hipMemcpyAsync(c->lde.p, trace, C * n * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(launch_transpose(c->lde.as<gl_t>(), c->values.as<gl_t>(), n, C, st));
-        d_values = c->values.as<gl_t>();
+        HIPCHK(launch_transpose(c->lde.as<gl_t>(), d_trace, n, C, st));
+        d_values = d_trace;
     }
     HIPCHK(hipEventRecord(c->ev[evi++], st));
     ranges.next("starkhip:ifft_lde");
 
     // ---- phase 1: IFFT + LDE (PolynomialBatch::from_values, App. A.3)
     HIPCHK(hipEventRecord(c->kev[4], st));
-    HIPCHK(run_lde(c, d_values, c->values.as<gl_t>(), c->lde.as<gl_t>(), C, log_n, r, 0));
+    HIPCHK(run_lde_trace(c, d_values, c->lde.as<gl_t>(), c->values.as<gl_t>(), C, log_n, r, trace_in_lde));
     HIPCHK(hipEventRecord(c->kev[5], st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
     ranges.next("starkhip:trace_merkle");
@@ -806,11 +842,17 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
 
     // ---- phase 5: openings (App. A.7)
     std::vector<gl2_t> op_local(C), op_next(C), op_q(Q);
+    // the trace polynomials from their values on coset 0 of the LDE (kernels_fri.hip: the context keeps no coefficients of them), the
+    // quotient polynomials from their coefficients
+    const gl_t shift_n = gl_pow(GL_GENERATOR, n);  // 7^n
+    const gl2_t zh = gl2_sub(gl2_pow(zeta, n), gl2_make(shift_n, 0));
+    if (gl2_eq(zh, gl2_zero())) return STARKHIP_ERR_ZETA_IN_SUBGROUP;  // zeta on the coset itself (as likely as the case above: 2^-115)
+    const gl2_t w_scale = gl2_mul_base(zh, gl_inv(gl_mul((gl_t)n, shift_n)));
     HIPCHK(launch_ext_powers(c->zpow.as<gl2_t>(), zeta, n, st));
-    HIPCHK(launch_ext_powers(c->gzpow.as<gl2_t>(), gzeta, n, st));
-    HIPCHK(launch_openings(c->values.as<gl_t>(), C, n, c->zpow.as<gl2_t>(), c->gzpow.as<gl2_t>(), c->open_local.as<gl2_t>(),
+    HIPCHK(launch_coset_weights(c->zpow.as<gl2_t>() + n, c->gzpow.as<gl2_t>(), zeta, w_scale, log_n, st));
+    HIPCHK(launch_openings(c->lde.as<gl_t>(), N, C, n, c->zpow.as<gl2_t>() + n, c->gzpow.as<gl2_t>(), c->open_local.as<gl2_t>(),
                            c->open_next.as<gl2_t>(), st));
-    HIPCHK(launch_openings(c->qcoef.as<gl_t>(), Q, n, c->zpow.as<gl2_t>(), nullptr, c->open_q.as<gl2_t>(), nullptr, st));
+    HIPCHK(launch_openings(c->qcoef.as<gl_t>(), n, Q, n, c->zpow.as<gl2_t>(), nullptr, c->open_q.as<gl2_t>(), nullptr, st));
     HIPCHK(hipMemcpyAsync(op_local.data(), c->open_local.p, C * 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(op_next.data(), c->open_next.p, C * 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(op_q.data(), c->open_q.p, Q * 16, hipMemcpyDeviceToHost, st));
@@ -828,15 +870,21 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     std::vector<gl2_t> fin(n);
     {
         HIPCHK(launch_ext_powers(c->ext_apow.as<gl2_t>(), fri_alpha, C + Q, st));
-        gl2_t* comb = c->comb_out.as<gl2_t>();
-        HIPCHK(launch_fri_combine(c->values.as<gl_t>(), C, n, c->ext_apow.as<gl2_t>(), comb_ppc, comb_chunks, c->comb_partial.as<gl2_t>(), st));
-        HIPCHK(launch_ext_reduce(c->comb_partial.as<gl2_t>(), comb_chunks, n, comb, st));  // sum_j alpha^j trace_j
-        HIPCHK(launch_fri_combine(c->qcoef.as<gl_t>(), Q, n, c->ext_apow.as<gl2_t>() + C, Q, 1, comb + n, st));  // alpha^(C+q) quotient_q
+        // sum_j alpha^j trace_j: the sum is taken on coset 0 of the LDE (n values a column) and turned into coefficients by ONE inverse
+        // coset transform of its two words -- linear, so these are the coefficients of the reference's sum of coefficient vectors
+        gl_t* comb_t = c->comb_out.as<gl_t>();                 // [2][n] words
+        gl2_t* comb_q = c->comb_out.as<gl2_t>() + n;           // [n] extension elements
+        HIPCHK(launch_fri_combine(c->lde.as<gl_t>(), N, C, n, c->ext_apow.as<gl2_t>(), comb_ppc, comb_chunks, c->comb_partial.as<gl2_t>(), st));
+        HIPCHK(launch_ext_reduce(c->comb_partial.as<gl2_t>(), comb_chunks, n, comb_t, st));
+        HIPCHK(launch_ntt_global(comb_t, 2, n, log_n, c->tab->tw_inv.as<gl_t>(), log_N, nullptr, c->tab->qshift_inv.as<gl_t>(), gl_inv((gl_t)n), st));
+        HIPCHK(launch_fri_combine(c->qcoef.as<gl_t>(), n, Q, n, c->ext_apow.as<gl2_t>() + C, Q, 1, comb_q, st));  // alpha^(C+q) quotient_q
+        std::vector<gl_t> F1w(2 * n);
         std::vector<gl2_t> F1(n), tailq(n), F0(n), q0(n), q1(n);
-        HIPCHK(hipMemcpyAsync(F1.data(), comb, n * 16, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(tailq.data(), comb + n, n * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(F1w.data(), comb_t, n * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(tailq.data(), comb_q, n * 16, hipMemcpyDeviceToHost, st));
         HIPCHK(stream_wait(c));
         host_other.start();
+        for (size_t k = 0; k < n; k++) F1[k] = gl2_make(F1w[k], F1w[n + k]);
         for (size_t k = 0; k < n; k++) F0[k] = gl2_add(F1[k], tailq[k]);
         divide_by_linear(F0.data(), n, zeta, q0.data());   // batch 0: trace ++ quotient at zeta
         divide_by_linear(F1.data(), n, gzeta, q1.data());  // batch 1: trace at g*zeta
@@ -1054,10 +1102,12 @@ int ctx_reserve(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, size_t
     pl.final_len = geo.final_poly_len; pl.n_pis = P.n_pis; pl.arity_bits = cfg.arity_bits; pl.n_challenges = 2;
     pl.compute();
     struct Want { DevBuf* b; size_t bytes; };
-    const Want wants[] = {{&c->values, C * n * 8}, {&c->lde, std::max(C * N * 8, log_bytes + 64)}, {&c->digests, digest_words(N) * 8},
+    // (`values`: a trace waits for its LDE inside the LDE buffer, prove() phase 0, but for the tail of run_lde_trace; rate_bits == 0 makes
+    // prove() grow it to a whole trace on demand)
+    const Want wants[] = {{&c->values, r >= 1 ? lde_tail_columns(C) * n * 8 : C * n * 8}, {&c->lde, std::max(C * N * 8, log_bytes + 64)}, {&c->digests, digest_words(N) * 8},
                           {&c->pis, std::max<size_t>(1, P.n_pis) * 8}, {&c->apow, 2 * (AIR_MAX_GROUP + 1) * 8}, {&c->chunk_scale, 2 * (size_t)n_chunks * 8},
                           {&c->partial, (size_t)n_chunks * 2 * size * 8}, {&c->qvals, 2 * size * 8}, {&c->qcoef, Q * n * 8}, {&c->qlde, Q * N * 8},
-                          {&c->qdigests, digest_words(N) * 8}, {&c->zpow, n * 16}, {&c->gzpow, n * 16}, {&c->open_local, C * 16}, {&c->open_next, C * 16},
+                          {&c->qdigests, digest_words(N) * 8}, {&c->zpow, 2 * n * 16}, {&c->gzpow, n * 16}, {&c->open_local, C * 16}, {&c->open_next, C * 16},
                           {&c->open_q, Q * 16}, {&c->ext_apow, (C + Q) * 16}, {&c->comb_partial, comb_chunks * n * 16}, {&c->comb_out, 2 * n * 16},
                           {&c->fri_coef, 2 * N * 8}, {&c->fri_vals, 2 * N * 8}, {&c->scale_tab, N * 8}, {&c->pow_state, 12 * 8}, {&c->pow_best, 8},
                           {&c->qidx, cfg.num_query_rounds * 4}, {&c->gather_t, cfg.num_query_rounds * pl.query_words * 8}};

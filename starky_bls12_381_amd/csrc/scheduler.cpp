@@ -589,7 +589,7 @@ struct Pool {
         // (growing them means hipFree + hipMalloc, and hipFree waits for every kernel on the device).  So a waiting job goes to
         // a context that proved its AIR last if one is idle; a context takes another AIR only when no idle one matches it.
         int last_air = -1;
-        bool urgent = false;
+        bool urgent = false, announce_big = false;
         if (warm) {  // every context brings up what the BLS pipeline's AIRs of its class need, all contexts in parallel
             // proof blobs: a context's last proof is usually still with the caller when the next one ends, hence two per big context;
             // the small contexts' MillerLoop-sized blob (69 MB) also serves FP12Mul (42 MB) -- blob_alloc takes the smallest that fits
@@ -658,14 +658,16 @@ struct Pool {
                 // (big jobs still queued for, or in, their recording count as waiting: with submit_witness they trickle into q_big
                 // one at a time, and q_big alone would make the FIRST wave look like the last)
                 urgent = big && stream_priority == 1 && q.size() + big_in_gen < big_ctx.size();
+                // announced BEFORE it stops counting as queued: between the two a waiting lane group would see nobody on the way
+                // and go out short, and this proof's commitment would follow it alone
+                announce_big = big && ctx_has_hash_service(c);
+                if (announce_big) hs->announce_big();
                 if (big) tell_big_queued();
             }
             if (big && stream_priority == 1) (void)ctx_set_urgent(c, urgent);
             int rc;
             const bool announce = !big && ctx_has_hash_service(c);
             if (announce) hs->announce_small();
-            const bool announce_big = big && ctx_has_hash_service(c);
-            if (announce_big) hs->announce_big();
             ctx_hash_request_reset(c);
             try {
                 const AirInfo* a = air_get(j->air);
