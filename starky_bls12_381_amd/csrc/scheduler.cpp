@@ -73,11 +73,6 @@ HashService::~HashService() {
 void HashService::announce_small() {
     std::lock_guard<std::mutex> g(mu_);
     announced_++;
-    small_active_++;
-}
-void HashService::finish_small() {
-    std::lock_guard<std::mutex> g(mu_);
-    if (small_active_ > 0) small_active_--;
 }
 void HashService::abandon_small() {
     {
@@ -146,9 +141,8 @@ void HashService::drain(std::vector<hipEvent_t>& evs) {
     evs.clear();
 }
 
-void HashService::launch_big(Req* r, bool lane, unsigned group, bool beside_small) {
+void HashService::launch_big(Req* r, bool lane, unsigned group) {
     hipStream_t s = (r->urgent && st_high_) ? st_high_ : st_;
-    if (!lane && st_masked_ && beside_small) s = st_masked_;
     hipError_t e = hipSuccess;
     if (lane) s = pick_small_stream(&e);  // lane-form grids are a quarter of the chip each: they must overlap, not queue in one stream
     if (e == hipSuccess) e = hipStreamWaitEvent(s, r->ready, 0);
@@ -257,15 +251,6 @@ void HashService::run() {
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
         hipStreamCreateWithPriority(&st_high_, hipStreamNonBlocking, greatest) != hipSuccess)
         st_high_ = nullptr;
-    if (reserve_cus_) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device_) == hipSuccess && (unsigned)prop.multiProcessorCount > 2 * reserve_cus_) {
-            std::vector<uint32_t> mask(((size_t)prop.multiProcessorCount + 31) / 32, 0);
-            for (unsigned cu = reserve_cus_; cu < (unsigned)prop.multiProcessorCount; cu++) mask[cu / 32] |= 1u << (cu % 32);
-            if (hipExtStreamCreateWithCUMask(&st_masked_, (uint32_t)mask.size(), mask.data()) != hipSuccess) st_masked_ = nullptr;
-        }
-        (void)hipGetLastError();
-    }
     std::unique_lock<std::mutex> lk(mu_);
     while (true) {
         cv_.wait(lk, [&] { return stop_ || !big_.empty() || !small_.empty(); });
@@ -323,10 +308,9 @@ void HashService::run() {
             }
             std::vector<hipEvent_t> wait_for;
             wait_for.swap(running_small_);
-            const bool beside_small = small_active_ > 0;
             lk.unlock();
             if (policy == 1) drain(wait_for);  // exclusive classes: the small window has left the chip
-            for (Req* r : group) launch_big(r, big_lane_ && (lane_share_ || group.size() >= 2), (unsigned)group.size(), beside_small);
+            for (Req* r : group) launch_big(r, big_lane_ && (lane_share_ || group.size() >= 2), (unsigned)group.size());
             lk.lock();
             for (Req* r : group) r->state = r->err == hipSuccess ? 1 : 2;
             stats_.big_launches += group.size();
@@ -364,7 +348,7 @@ void HashService::run() {
         cv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds((long)(std::max(0.1, left_ms) * 1e3)));
     }
     lk.unlock();
-    for (hipStream_t s : {st_, st_high_, st_masked_})
+    for (hipStream_t s : {st_, st_high_})
         if (s) {
             (void)hipStreamSynchronize(s);
             (void)hipStreamDestroy(s);
@@ -695,7 +679,6 @@ struct Pool {
                 rc = STARKHIP_ERR_BAD_SHAPE;
             }
             if (announce && !ctx_hash_requested(c)) hs->abandon_small();  // failed before its commitment: do not hold the window open
-            if (announce) hs->finish_small();
             if (announce_big && !ctx_hash_requested(c)) hs->abandon_big();
             if (announce_big) hs->finish_big();
             if (big) {
@@ -765,10 +748,6 @@ int pool_create(const starkhip_pool_config_t& cfg_in, Pool** out) {
     p->hs->row_leaves_ = row_leaves;
     p->hs->big_lane_ = big_lane;
     p->hs->big_contexts_ = (int)p->big_ctx.size();
-    {
-        const char* rc = getenv("STARKHIP_POOL_RESERVE_CUS");
-        if (rc && *rc) p->hs->reserve_cus_ = (unsigned)atoi(rc);
-    }
     {
         const char* ls = getenv("STARKHIP_POOL_LANE_SHARE");
         p->hs->lane_share_ = big_lane && ls && *ls == '1';

@@ -39,7 +39,6 @@ class HashService {
     void announce_big();   // a FinalExp-class proof has started: its commitment will come (lane-form groups wait for it)
     void abandon_big();
     void finish_big();     // that proof has ended
-    void finish_small();   // a small proof (announce_small) has ended
     void abandon_small();
     // Leaf digests of the coset-major LDE `mat` (kernels_hash.hip: launch_leaf_hash) into `digests`, ordered after everything
     // enqueued on `st` so far; when this returns, `st` has been made to wait for the launch (the caller goes on enqueueing).
@@ -74,10 +73,6 @@ class HashService {
                                 // proofs: from operands 6.34 / 6.37 aligned against 6.62 / 6.52, from resident traces 7.33 against 7.25: the lane
                                 // launches are 3 % shorter when they start together, but the early ones of a staggered group hash while the late
                                 // ones' LDEs still run, which is worth more when the traces arrive from the host
-    // reserve_cus_ > 0: a big commitment that goes out ALONE in the quad form while small proofs are in flight is launched on a stream
-    // whose CU mask leaves `reserve_cus_` CUs out (the lowest mask bits: spread evenly over the XCDs and shader engines), so that the
-    // small commitments' latency chains find wave slots at once instead of behind the big grid (scheduler.cpp: launch_big)
-    unsigned reserve_cus_ = 0;
     bool lane_share_ = false;  // STARKHIP_POOL_LANE_SHARE=1: big commitments go out one by one in the lane form, each launch taking half of every
                                // CU (launch_leaf_hash_lane share_cu): the LDE / quotient workgroups of the other proofs run beside them
     int big_expected_ = 0;   // big proofs that have started and not yet reached their commitment
@@ -106,14 +101,13 @@ class HashService {
         Timing* timing = nullptr;
     };
     void run();
-    void launch_big(Req* r, bool lane, unsigned group, bool beside_small);
+    void launch_big(Req* r, bool lane, unsigned group);
     void launch_small(std::vector<Req*>& reqs);
     void drain(std::vector<hipEvent_t>& evs);
     void track(std::vector<hipEvent_t>& evs, hipEvent_t done);
 
     int device_;
     hipStream_t st_ = nullptr, st_high_ = nullptr;  // big commitments: ordinary / urgent (high-priority stream)
-    hipStream_t st_masked_ = nullptr;
     // merged launches run side by side: each goes to a stream that is idle, so a window never queues behind an earlier one
     static const int N_SMALL_STREAMS = 12;
     hipStream_t small_st_[N_SMALL_STREAMS] = {};
@@ -123,7 +117,6 @@ class HashService {
     std::condition_variable cv_, cv_done_;
     std::deque<Req*> big_, small_;
     int announced_ = 0;  // small proofs that have started and not yet asked for their commitment
-    int small_active_ = 0;  // small proofs being proved (announce_small .. finish_small)
     bool stop_ = false, last_was_big_ = false, big_poll_ = false;
     std::vector<hipEvent_t> running_big_, running_small_;  // done events of launches that may still be executing
     Stats stats_;
