@@ -285,6 +285,11 @@ int starkhip_field_ops_batch(void* ctx, int op, const uint64_t* a, const uint64_
 /* CPU check (no GPU needed) of the constant tables the leaf-hash kernel uses for its merged partial rounds: replays the
  * merged formulation on n_states inputs against the plain permutation; returns the number of mismatches (0 = good) */
 int starkhip_selfcheck_hash_tables(unsigned n_states);
+/* The launch plan of a trace's LDE (no GPU needed).  The trace columns wait for the LDE inside the buffer the LDE is written to, as
+ * its last n_cols * n words, so the LDE goes out in several launches, each overwriting only parked columns that an earlier launch
+ * has read; the last one reads a copy of its columns (csrc/lde_ranges.h).  Writes up to `cap` launches as triples
+ * {first column, end column, 1 if it reads the copy} and returns how many the plan has. */
+size_t starkhip_lde_launch_ranges(size_t n_cols, unsigned rate_bits, uint64_t* triples, size_t cap);
 /* CPU check (no GPU needed) of the tiled constraint plan the quotient kernel executes (csrc/quotient_plan.h): builds the plan
  * of `air` with `want_chunks` chunks, derives the per-proof weights from random alphas / public inputs and replays the
  * record streams on one random frame with the kernel's own accumulators; the result must equal the plain fold

@@ -8,6 +8,7 @@
 #include "airs.h"
 #include "blob_arena.h"
 #include "kernels.h"
+#include "lde_ranges.h"
 #include "trace_log.h"
 
 #include <atomic>
@@ -391,6 +392,15 @@ int starkhip_field_ops_batch(void* ctx, int op, const uint64_t* a, const uint64_
     return field_ops((Ctx*)ctx, op, a, b, out, n);
 }
 int starkhip_selfcheck_hash_tables(unsigned n_states) { return quad_merged_tables_selfcheck(n_states); }
+size_t starkhip_lde_launch_ranges(size_t n_cols, unsigned rate_bits, uint64_t* triples, size_t cap) {
+    const std::vector<LdeLaunch> plan = lde_launch_plan(n_cols, rate_bits);
+    for (size_t i = 0; i < plan.size() && i < cap; i++) {
+        triples[3 * i] = plan[i].a;
+        triples[3 * i + 1] = plan[i].b;
+        triples[3 * i + 2] = plan[i].from_copy ? 1 : 0;
+    }
+    return plan.size();
+}
 void starkhip_poseidon_permute_host(uint64_t state[12]) { poseidon_permute_host(state); }
 /* n chained permutations with the challenger's host permutation (which = 0) or the portable reference loop (which = 1);
  * lets the tests compare the two and the benchmark report the host hashing rate */

@@ -19,6 +19,7 @@
 #include "airs.h"
 #include "blob_arena.h"
 #include "kernels.h"
+#include "lde_ranges.h"
 #include "trace_log.h"
 #include "poseidon.h"
 #include "proof.h"
@@ -210,27 +211,23 @@ static hipError_t run_lde(Ctx* c, const gl_t* values, gl_t* coeffs, gl_t* lde, s
                               c->tab->coset_scale.as<gl_t>(), from_coeffs, c->st);
 }
 
-// The LDE of a trace whose columns are parked in the buffer the LDE goes to, as its last C n words (in_place): column c' lies at
-// (R - 1) C n + c' n, the LDE block of column c covers [R c n, R (c + 1) n), i.e. the parked columns R c - (R - 1) C + j, j < R.  A launch
-// over the columns [a, b) may overwrite only columns that an EARLIER launch has transformed (c' < a) -- workgroups of one launch run in
-// no particular order -- or a workgroup's own column (the last column's trace is the last slot of its own block, the slot the kernel
-// already uses for its coefficients): R b <= a + (R - 1) C.  So the launches cover 3/4, 3/16, 3/64 ... of the columns for R = 4.  Carried
-// to the end that is log_R(C) launches, the last of them a few columns wide and each as long as one column takes (10 launches, 17.6 ms
-// against 17.0 in one, for FinalExp's 73 527 columns); so the last lde_tail_columns(C) columns -- 1/64 of them for R = 4 -- are
-// copied aside (`tail`, 75 MB for FinalExp) and transformed from there in one launch: 4 launches.
-static size_t lde_tail_columns(size_t C) { return std::max<size_t>(C / 32, 64); }
+// The LDE of a trace whose columns are parked in the buffer the LDE goes to, as its last C n words (in_place).  lde_ranges.h has the
+// launch plan and why it is safe: launches over 3/4, 3/16, 3/64 of the columns for R = 4, each overwriting only columns an earlier
+// launch has transformed, and the last lde_tail_columns(C) columns -- 1/64 of them, 75 MB for FinalExp -- from a copy (`tail`).  Carried
+// to the end the series would be log_R(C) launches, the last of them a few columns wide and each as long as one column takes; four
+// launches cost 0.07 ms of 17.5 against one (same box, alternating builds).
 static hipError_t run_lde_trace(Ctx* c, const gl_t* values, gl_t* lde, gl_t* tail, size_t C, unsigned log_n, unsigned rate, bool in_place) {
     if (!in_place) return run_lde(c, values, nullptr, lde, C, log_n, rate, 0);
     const size_t n = (size_t)1 << log_n, R = (size_t)1 << rate;
-    size_t a = 0;
-    while (C - a > lde_tail_columns(C)) {
-        const size_t b = (a + (R - 1) * C) / R;  // > a while C - a >= 2
-        if (hipError_t e = run_lde(c, values + a * n, nullptr, lde + a * R * n, b - a, log_n, rate, 0); e != hipSuccess) return e;
-        a = b;
+    for (const LdeLaunch& l : lde_launch_plan(C, rate)) {
+        const gl_t* in = values + l.a * n;
+        if (l.from_copy) {
+            if (hipError_t e = hipMemcpyAsync(tail, in, (l.b - l.a) * n * 8, hipMemcpyDeviceToDevice, c->st); e != hipSuccess) return e;
+            in = tail;
+        }
+        if (hipError_t e = run_lde(c, in, nullptr, lde + l.a * R * n, l.b - l.a, log_n, rate, 0); e != hipSuccess) return e;
     }
-    if (a == C) return hipSuccess;
-    if (hipError_t e = hipMemcpyAsync(tail, values + a * n, (C - a) * n * 8, hipMemcpyDeviceToDevice, c->st); e != hipSuccess) return e;
-    return run_lde(c, tail, nullptr, lde + a * R * n, C - a, log_n, rate, 0);
+    return hipSuccess;
 }
 
 static int ensure_program(Ctx* c, const AirInfo& air, size_t quotient_points) {

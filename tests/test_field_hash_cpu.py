@@ -163,3 +163,34 @@ def test_merged_partial_round_tables_reproduce_the_permutation():
     import starky_bls12_381_amd as S
     assert S.lib.starkhip_selfcheck_hash_tables(200) == 0
 
+
+
+def test_lde_launch_plan_never_overwrites_a_column_it_has_not_read():
+    """A trace waits for its LDE inside the buffer the LDE is written to, as its last C n words (prover.hip, csrc/lde_ranges.h): parked
+    column c' at words [(R - 1) C n + c' n, + n), the LDE block of column c at [R c n, R (c + 1) n).  Workgroups of one launch run in any
+    order, so a launch over [a, b) may touch only parked columns an earlier launch has read -- except the last launch, which reads a
+    COPY of its columns and may touch anything.  Checked on the plan the library actually launches from, for the five AIRs' shapes and
+    random ones, with plain interval arithmetic (n = 1: the row count scales both sides alike)."""
+    import starky_bls12_381_amd as S
+    f = S.lib.starkhip_lde_launch_ranges
+    f.restype = ctypes.c_size_t
+    f.argtypes = [ctypes.c_size_t, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t]
+    rng = np.random.default_rng(0x1DE)
+    shapes = [(73527, 2), (29376, 2), (97330, 1), (60285, 1), (2, 1), (3, 2), (1, 1), (64, 3), (65, 1), (4097, 3)]
+    shapes += [(int(rng.integers(1, 200000)), int(rng.integers(1, 4))) for _ in range(300)]
+    for C, r in shapes:
+        buf = (ctypes.c_uint64 * (3 * 64))()
+        k = f(C, r, buf, 64)
+        assert 1 <= k <= 64
+        plan = [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(k)]
+        R = 1 << r
+        assert plan[0][0] == 0 and plan[-1][1] == C and all(plan[i][1] == plan[i + 1][0] for i in range(k - 1))
+        assert all(a < b for a, b, _ in plan) and [c for _, _, c in plan] == [0] * (k - 1) + [1]
+        assert plan[-1][1] - plan[-1][0] <= max(C // 32, 64)          # what the copy buffer holds (ctx_reserve)
+        if C > 64:
+            assert k <= 2 + int(np.ceil(np.log(32) / np.log(R)))     # a handful of launches, not log_R(C)
+        for a, b, from_copy in plan:
+            if from_copy:
+                continue
+            # words the launch writes: [R a, R b); parked columns still unread: [a, C) at words (R - 1) C + [a, C)
+            assert R * b <= (R - 1) * C + a, (C, r, a, b)
