@@ -15,9 +15,10 @@ HDRS := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) include/starkhip.h
 
 all: $(OUT) oracle demo
 
+# FLAGS_<file>: compiler flags of ONE translation unit (e.g. FLAGS_kernels_lde), in the default and in the variant build
 build/%.hip.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(FLAGS_$*) -c $< -o $@
 build/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p build
 	$(HIPCC) -O2 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude $(EXTRA_DEFS) -c $< -o $@
@@ -71,7 +72,7 @@ NAME ?= variant
 VAR_OBJS := $(patsubst $(CSRC)/%.hip,build/$(NAME)/%.hip.o,$(wildcard $(CSRC)/*.hip))
 build/$(NAME)/%.hip.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/$(NAME)
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(DEFS) $(FLAGS_$*) -c $< -o $@
 variant: build/$(NAME)/libstarkhip_$(NAME).so
 build/$(NAME)/libstarkhip_$(NAME).so: $(VAR_OBJS) $(filter %.cpp.o,$(OBJS))
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread $(EXTRA_LIBS)
