@@ -8,6 +8,37 @@
 
 namespace starkhip {
 
+// Sums of products w_k * v_k (field elements) taken WITHOUT reducing each product: the 128-bit products are added into a 192-bit
+// accumulator (fewer than 2^64 terms fit) and the sum is reduced once -- ten to fifteen instructions per term where a reduced
+// multiply-add is fifty (gl_mul + gl_add: the openings and the FRI combination, 1.2 * 10^9 terms each for a FinalExp trace, were bound
+// by exactly those instructions).  2^128 = -2^32 (mod p).
+struct Acc192 {
+    uint64_t lo, mid, hi;
+};
+__device__ __forceinline__ void acc192_mad(Acc192& A, uint64_t w, uint64_t v) {
+    const uint64_t pl = w * v, ph = __umul64hi(w, v);
+    const uint64_t lo = A.lo + pl;
+    const uint64_t c0 = lo < pl ? 1u : 0u;
+    uint64_t mid = A.mid + ph;
+    uint64_t c1 = mid < ph ? 1u : 0u;
+    mid += c0;
+    c1 += mid < c0 ? 1u : 0u;
+    A.lo = lo;
+    A.mid = mid;
+    A.hi += c1;
+}
+__device__ __forceinline__ gl_t acc192_reduce(const Acc192& A) {  // hi < 2^32 (fewer than 2^32 terms)
+    return gl_sub(gl_reduce128(A.mid, A.lo), gl_reduce128(0, A.hi << 32));
+}
+struct Acc192x2 {  // an element of the extension: both words against the same base-field factor
+    Acc192 a0, a1;
+};
+__device__ __forceinline__ void acc192x2_mad(Acc192x2& A, gl2_t w, gl_t v) {
+    acc192_mad(A.a0, w.a0, v);
+    acc192_mad(A.a1, w.a1, v);
+}
+__device__ __forceinline__ gl2_t acc192x2_reduce(const Acc192x2& A) { return gl2_make(acc192_reduce(A.a0), acc192_reduce(A.a1)); }
+
 // out[i] = base^i in the extension, i < count (SoA-free: array of gl2_t)
 __global__ void ext_powers_kernel(gl2_t* out, gl2_t base, size_t count) { STARKHIP_PRIO_ENTRY
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -32,34 +63,63 @@ __global__ void coset_weights_kernel(gl2_t* __restrict__ wz, gl2_t* __restrict__
     wgz[(k + 1) & (n - 1)] = w;
 }
 
-// One workgroup per polynomial: out_z[c] = sum_k vec[c * stride + k] * zpow[k], out_gz[c] likewise with gzpow.  vec = coefficients
-// and zpow = powers of z (the quotient polynomials), or vec = values on coset 0 and zpow = the weights above (the trace).
-// vec is read exactly once; zpow / gzpow (n extension elements each) stay in L2.
-__global__ __launch_bounds__(256) void openings_kernel(const gl_t* __restrict__ coeffs, size_t stride, size_t n, const gl2_t* __restrict__ zpow,
-                                                       const gl2_t* __restrict__ gzpow, gl2_t* __restrict__ out_z,
-                                                       gl2_t* __restrict__ out_gz) { STARKHIP_PRIO_ENTRY
-    const size_t c = blockIdx.x;
-    const gl_t* col = coeffs + c * stride;
-    gl2_t a = gl2_zero(), b = gl2_zero();
-    for (size_t k = threadIdx.x; k < n; k += blockDim.x) {
-        gl_t v = col[k];
-        a = gl2_add(a, gl2_mul_base(zpow[k], v));
-        if (out_gz) b = gl2_add(b, gl2_mul_base(gzpow[k], v));
+// A workgroup takes OPEN_COLS polynomials: out_z[c] = sum_k vec[c * stride + k] * zpow[k], out_gz[c] likewise with gzpow.  vec =
+// coefficients and zpow = powers of z (the quotient polynomials), or vec = values on coset 0 and zpow = the weights above (the trace).
+// vec is read exactly once.  zpow / gzpow (32 bytes per k) come from L2 and are used for all OPEN_COLS columns: with one column per
+// workgroup they were four times the bytes of the column itself -- 19 GB through L2 for a FinalExp trace, 8 TB/s, the kernel's bound
+// (2.3 ms; 4.8 GB of HBM reads would take 1).
+static const unsigned OPEN_COLS = 4;
+__global__ __launch_bounds__(256) void openings_kernel(const gl_t* __restrict__ coeffs, size_t stride, size_t n_polys, size_t n,
+                                                       const gl2_t* __restrict__ zpow, const gl2_t* __restrict__ gzpow,
+                                                       gl2_t* __restrict__ out_z, gl2_t* __restrict__ out_gz) { STARKHIP_PRIO_ENTRY
+    const size_t c0 = (size_t)blockIdx.x * OPEN_COLS;
+    const unsigned nc = (unsigned)(n_polys - c0 < OPEN_COLS ? n_polys - c0 : OPEN_COLS);
+    const gl_t* col[OPEN_COLS];
+#pragma unroll
+    for (unsigned q = 0; q < OPEN_COLS; q++) col[q] = coeffs + (c0 + (q < nc ? q : 0)) * stride;  // (idle slots shadow the first column)
+    Acc192x2 sum_a[OPEN_COLS], sum_b[OPEN_COLS];
+#pragma unroll
+    for (unsigned q = 0; q < OPEN_COLS; q++) sum_a[q] = sum_b[q] = Acc192x2{{0, 0, 0}, {0, 0, 0}};
+    // every workgroup starts its walk through the rows at another offset: the columns lie a power of two apart (2^rate n words), and
+    // workgroups that start together would ask the same memory channels for the same rows of their columns at the same time
+    const size_t n_steps = (n + blockDim.x - 1) / blockDim.x, first = (blockIdx.x * 7u) % n_steps;
+    for (size_t it = 0; it < n_steps; it++) {
+        const size_t k = ((it + first) % n_steps) * blockDim.x + threadIdx.x;
+        if (k >= n) continue;
+        const gl2_t wz = zpow[k];
+        gl2_t wg = gl2_zero();
+        if (out_gz) wg = gzpow[k];
+#pragma unroll
+        for (unsigned q = 0; q < OPEN_COLS; q++) {
+            const gl_t v = col[q][k];
+            acc192x2_mad(sum_a[q], wz, v);
+            if (out_gz) acc192x2_mad(sum_b[q], wg, v);
+        }
+    }
+    gl2_t a[OPEN_COLS], b[OPEN_COLS];
+#pragma unroll
+    for (unsigned q = 0; q < OPEN_COLS; q++) {
+        a[q] = acc192x2_reduce(sum_a[q]);
+        b[q] = acc192x2_reduce(sum_b[q]);
     }
     __shared__ gl2_t sa[256], sb[256];
-    sa[threadIdx.x] = a;
-    sb[threadIdx.x] = b;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
-        if ((int)threadIdx.x < h) {
-            sa[threadIdx.x] = gl2_add(sa[threadIdx.x], sa[threadIdx.x + h]);
-            sb[threadIdx.x] = gl2_add(sb[threadIdx.x], sb[threadIdx.x + h]);
+#pragma unroll
+    for (unsigned q = 0; q < OPEN_COLS; q++) {  // (all of them, so that a[] and b[] stay in registers: the idle slots' sums are not stored)
+        sa[threadIdx.x] = a[q];
+        sb[threadIdx.x] = b[q];
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) {
+                sa[threadIdx.x] = gl2_add(sa[threadIdx.x], sa[threadIdx.x + h]);
+                sb[threadIdx.x] = gl2_add(sb[threadIdx.x], sb[threadIdx.x + h]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && q < nc) {
+            out_z[c0 + q] = sa[0];
+            if (out_gz) out_gz[c0 + q] = sb[0];
         }
         __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        out_z[c] = sa[0];
-        if (out_gz) out_gz[c] = sb[0];
     }
 }
 
@@ -74,9 +134,9 @@ __global__ __launch_bounds__(256) void fri_combine_kernel(const gl_t* __restrict
     if (k >= n) return;
     size_t j0 = (size_t)blockIdx.y * polys_per_chunk;
     size_t j1 = j0 + polys_per_chunk < n_polys ? j0 + polys_per_chunk : n_polys;
-    gl2_t acc = gl2_zero();
-    for (size_t j = j0; j < j1; j++) acc = gl2_add(acc, gl2_mul_base(apow[j], coeffs[j * stride + k]));
-    partial[(size_t)blockIdx.y * n + k] = acc;
+    Acc192x2 acc = {{0, 0, 0}, {0, 0, 0}};
+    for (size_t j = j0; j < j1; j++) acc192x2_mad(acc, apow[j], coeffs[j * stride + k]);
+    partial[(size_t)blockIdx.y * n + k] = acc192x2_reduce(acc);
 }
 // out[k] = sum_jc partial[jc][k], as two vectors of base-field words: out[k], out[n + k] (what launch_ntt_global transforms)
 __global__ void ext_reduce_kernel(const gl2_t* __restrict__ partial, size_t n_chunks, size_t n, gl_t* __restrict__ out) { STARKHIP_PRIO_ENTRY
@@ -122,7 +182,8 @@ hipError_t launch_coset_weights(gl2_t* wz, gl2_t* wgz, gl2_t z, gl2_t scale, uns
 hipError_t launch_openings(const gl_t* coeffs, size_t stride, size_t n_polys, size_t n, const gl2_t* zpow, const gl2_t* gzpow, gl2_t* out_z,
                            gl2_t* out_gz, hipStream_t st) {
     if (!n_polys) return hipSuccess;
-    hipLaunchKernelGGL(openings_kernel, dim3((unsigned)n_polys), dim3(256), 0, st, coeffs, stride, n, zpow, gzpow, out_z, out_gz);
+    hipLaunchKernelGGL(openings_kernel, dim3((unsigned)((n_polys + OPEN_COLS - 1) / OPEN_COLS)), dim3(256), 0, st, coeffs, stride, n_polys, n, zpow,
+                       gzpow, out_z, out_gz);
     return hipGetLastError();
 }
 hipError_t launch_fri_combine(const gl_t* coeffs, size_t stride, size_t n_polys, size_t n, const gl2_t* apow, size_t polys_per_chunk,
