@@ -80,20 +80,31 @@ __global__ __launch_bounds__(256) void openings_kernel(const gl_t* __restrict__ 
     Acc192x2 sum_a[OPEN_COLS], sum_b[OPEN_COLS];
 #pragma unroll
     for (unsigned q = 0; q < OPEN_COLS; q++) sum_a[q] = sum_b[q] = Acc192x2{{0, 0, 0}, {0, 0, 0}};
-    // every workgroup starts its walk through the rows at another offset: the columns lie a power of two apart (2^rate n words), and
-    // workgroups that start together would ask the same memory channels for the same rows of their columns at the same time
-    const size_t n_steps = (n + blockDim.x - 1) / blockDim.x, first = (blockIdx.x * 7u) % n_steps;
+    // the loads of step it + 1 are issued before the arithmetic of step it (hipcc keeps them inside their own iteration otherwise, and
+    // four waves per SIMD do not cover an HBM round trip per step)
+    const size_t n_steps = (n + blockDim.x - 1) / blockDim.x;
+    gl_t v_next[OPEN_COLS];
+    gl2_t wz_next = gl2_zero(), wg_next = gl2_zero();
+    auto fetch = [&](size_t it) {
+        const size_t k = it * blockDim.x + threadIdx.x;
+        const bool in = it < n_steps && k < n;
+        const size_t kk = in ? k : 0;
+        wz_next = zpow[kk];
+        if (out_gz) wg_next = gzpow[kk];
+#pragma unroll
+        for (unsigned q = 0; q < OPEN_COLS; q++) v_next[q] = in ? col[q][kk] : 0;  // a zero value adds nothing
+    };
+    fetch(0);
     for (size_t it = 0; it < n_steps; it++) {
-        const size_t k = ((it + first) % n_steps) * blockDim.x + threadIdx.x;
-        if (k >= n) continue;
-        const gl2_t wz = zpow[k];
-        gl2_t wg = gl2_zero();
-        if (out_gz) wg = gzpow[k];
+        const gl2_t wz = wz_next, wg = wg_next;
+        gl_t v[OPEN_COLS];
+#pragma unroll
+        for (unsigned q = 0; q < OPEN_COLS; q++) v[q] = v_next[q];
+        fetch(it + 1);
 #pragma unroll
         for (unsigned q = 0; q < OPEN_COLS; q++) {
-            const gl_t v = col[q][k];
-            acc192x2_mad(sum_a[q], wz, v);
-            if (out_gz) acc192x2_mad(sum_b[q], wg, v);
+            acc192x2_mad(sum_a[q], wz, v[q]);
+            if (out_gz) acc192x2_mad(sum_b[q], wg, v[q]);
         }
     }
     gl2_t a[OPEN_COLS], b[OPEN_COLS];
