@@ -33,6 +33,12 @@ import subprocess
 import sys
 import time
 
+# One hardware queue per in-flight proof and commitment stream.  The HIP runtime reads this once, when it is first used in the process:
+# starkhip_pool_create sets it for a process that has not touched HIP yet, but here torch does first (torch.cuda.set_device), and with
+# HIP's default of 4 queues the pool's streams share queues and kernels of different proofs wait behind each other (measured on one
+# box, 48 proofs: 6.61 / 6.76 proofs/s without it, 6.97 / 7.12 with it; 24 queues: 6.27 -- profiles/r04_ab_experiments.txt 17).
+# A host that embeds the pool beside other HIP users sets it the same way.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
