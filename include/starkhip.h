@@ -179,7 +179,10 @@ int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_
  * FinalExp-class commitment -- a one-shot grid that owns the chip -- never shares the chip with a small one).  Proofs are byte-identical to
  * starkhip_prove's.  submit returns at once with a ticket; wait blocks until that proof is done and hands it over
  * (starkhip_free), exactly once per ticket, from any thread.  Inputs of submit / submit_compact (trace, log, public inputs)
- * stay the caller's and must stay valid until the ticket has been waited for; submit_witness copies its operands. */
+ * stay the caller's and must stay valid until the ticket has been waited for; submit_witness copies its operands.
+ * Hardware queues: starkhip_pool_create sets GPU_MAX_HW_QUEUES=16 unless the variable exists, but the HIP runtime reads it only when
+ * the process first uses HIP -- a process that has used HIP before it creates its first pool exports the variable itself, earlier
+ * (with HIP's default of 4 queues the same pool is 6 % slower: INTEGRATION.md). */
 typedef struct {
     int device;
     unsigned big_contexts;      /* 0 = default (3).  Five or more: the trace commitments of these proofs go out in groups of up to four in the
