@@ -67,7 +67,7 @@ asan-pool-test: tests/tsan_pool_main.cpp $(ASAN_SRCS) $(HDRS)
 
 # Experiment builds of the device code for A/B runs on one box: `make variant NAME=x DEFS="-D..."` -> build/x/libstarkhip_x.so, selected
 # at run time with STARKHIP_LIBRARY=build/x/libstarkhip_x.so (e.g. NAME=nomfma DEFS=-DSTARKHIP_LANE_NO_MFMA: the lane-form leaf hash with every
-# round as multiply-add chains; NAME=prio DEFS=-DSTARKHIP_ALL_PRIO: every kernel but the lane-form hash at a raised issue priority)
+# round as multiply-add chains; NAME=noprio DEFS=-DSTARKHIP_NO_PRIO: no raised issue priority for the kernels beside the lane-form hash)
 NAME ?= variant
 VAR_OBJS := $(patsubst $(CSRC)/%.hip,build/$(NAME)/%.hip.o,$(wildcard $(CSRC)/*.hip))
 build/$(NAME)/%.hip.o: $(CSRC)/%.hip $(HDRS)

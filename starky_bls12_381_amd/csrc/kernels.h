@@ -5,9 +5,16 @@
 
 #include "gl.h"
 
-// First statement of every kernel except the lane-form leaf hash.  -DSTARKHIP_ALL_PRIO (an experiment build, `make prio`): every wave
-// of those kernels raises its issue priority, so that lane-form hash waves sharing a SIMD with them take only the slots they leave.
-#ifdef STARKHIP_ALL_PRIO
+// First statement of every kernel except the lane-form leaf hash: its waves raise their issue priority (s_setprio 2).  A lane-form group
+// of four saturates the SIMDs' issue slots for a third of a second; whatever else is resident beside it in that time -- the LDE and the
+// quotient of the proofs that are not in the group, Merkle levels, openings, the small AIRs' commitments -- would get the slots the
+// arbiter's round robin leaves them and crawl (an LDE measured 255 ms in flight against 17 alone).  At a raised priority those waves
+// issue first and the hash waves take every other slot: the same work, but the proofs outside the group reach THEIR commitment sooner
+// and the next group is ready when this one ends.  Measured on 16 hardware queues, 48 proofs from operands: 7.02 - 7.08 proofs/s without,
+// 7.57 - 7.58 with (profiles/r04_ab_experiments.txt 19; on HIP's default of four queues, where bench.py ran until the end of round 4,
+// the same build measured 5.79 against 5.90: kernels of different proofs waited behind each other in shared queues anyway).
+// -DSTARKHIP_NO_PRIO builds without it.
+#ifndef STARKHIP_NO_PRIO
 #define STARKHIP_PRIO_ENTRY __builtin_amdgcn_s_setprio(2);
 #else
 #define STARKHIP_PRIO_ENTRY
