@@ -172,7 +172,7 @@ def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=4096, bud
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary", action="store_true", help="skip the untimed legs (host rows, recorded trace, device-resident trace)")
