@@ -369,7 +369,9 @@ def main():
                     "achieved_is": ("algorithmic bytes per launch / average launch duration x the launches of a group that run side by side (a lane-form "
                                     "launch holds a quarter of the chip's registers; `achieved_per_launch` is the plain quotient)"
                                     if side > 1 else "algorithmic bytes per launch / average launch duration"),
-                    "durations": f"HIP events on the launch stream, the {len(timed_kernel_ms[dom])} launches of the timed region ({inflight} proofs in flight)",
+                    "durations": (f"HIP events on the launch stream, the {len(timed_kernel_ms[dom])} launches of the timed region ({inflight} proofs in flight); "
+                                  "the other proofs' kernels run beside these launches at a raised issue priority (csrc/kernels.h), so a launch is "
+                                  "longer than the same four launches with the chip to themselves (331-362 ms) while the proofs/s are higher"),
                     "share_of_timed_kernel_time": {k: sum(v) for k, v in timed_kernel_ms.items()},
                     "limiter": "integer VALU issue" if dom.startswith("leaf_hash") else "see kernels"}
         POSEIDON_LANE_SLOTS = poseidon_lane_slots()
