@@ -12,6 +12,9 @@ scaling, no data-path collective; torch.distributed is used only for the barrier
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts itself under torch.distributed.run as a CHILD
 process (before torch or the GPU is touched) and relays its output; launched by torchrun it just runs as a rank.
+`python bench.py --devices-in-process N` measures the same metric the way the reference's own caller would use a node: ONE process,
+a pool per device behind `starkhip_multipool_*` (no process group, no collective), N x steps proofs placed by the library; it prints
+the same JSON line (`config.parallelism` says which form ran).
 
 Prints ONE JSON line on rank 0.  What is measured where (DESIGN.md section 6 has every field):
 
@@ -25,6 +28,11 @@ Prints ONE JSON line on rank 0.  What is measured where (DESIGN.md section 6 has
                           (BASELINE.md section 4's literal hand-over); value_compact: a recorded trace; value_device_resident: the
                           column-major trace already in HBM (rounds 1-3's headline)
   cpu_baseline            rank 0 at N = 1: the CPU oracle on a bounded sample of the same workload, measured in this run
+  value_steady_state      proofs/s over the middle of the timed region only: completions after the first and before the last `inflight`
+                          per pool (the pool's start and tail dropped); null when the run is shorter than three waves
+  host                    what the host side had: CPUs granted, the pool's CPU budget and threads, process CPU-seconds per proof in the
+                          timed region -- so that a scaling curve that bends can be attributed to host or device
+  per_rank                --gpus N > 1: every rank's own proofs/s and CPU budget (value stays all ranks' proofs / the slowest rank's time)
 """
 import argparse
 import json
@@ -180,6 +188,10 @@ def main():
     ap.add_argument("--input", choices=("witness", "device"), default="witness",
                     help="what the TIMED region starts from: witness = the driver's operand on the host (generate_trace, upload and read-back inside; "
                          "the reference's boundary, the default); device = a column-major trace already in HBM (rounds 1-3's headline, for A/B runs)")
+    ap.add_argument("--devices-in-process", type=int, default=0,
+                    help="N > 0: ONE process drives N devices through starkhip_multipool_* (a pool per device, jobs placed by the library), the form the "
+                         "reference's single-process caller would use; N x steps proofs; no torch.distributed.  With STARKHIP_BENCH_REHEARSE=1 the N "
+                         "pools share device 0 (a rehearsal on a one-GPU box, not a measurement)")
     ap.add_argument("--inflight", type=int, default=8,
                     help="proofs in flight per GPU (independent contexts on separate host threads and HIP streams); "
                          "1 = one proof at a time (latency); several hide the host-side Fiat-Shamir hashing and the launch gaps of "
@@ -187,6 +199,9 @@ def main():
                          "of four in the lane form of the leaf hash (19.6 GB of HBM per context)")
     args = ap.parse_args()
 
+    n_dev = max(0, args.devices_in_process)
+    if n_dev and (args.gpus > 1 or args.input != "witness"):
+        raise SystemExit("--devices-in-process is its own launch form: without --gpus, from operands")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(sys.argv[1:], args.gpus))
 
@@ -223,9 +238,13 @@ def main():
     # its contexts when it is created -- 19.6 GB per FinalExp-class context; should eight ever not fit, fewer proofs in flight are
     # still a valid measurement of the same metric)
     pool = None
+    if n_dev and rehearse:
+        inflight = max(1, min(inflight, 8 // n_dev))  # the rehearsing pools share ONE card's memory
+    in_process_devices = ([0] * n_dev if rehearse else list(range(n_dev))) if n_dev else None
+    n_pools = max(1, n_dev)
     for k in sorted({inflight, min(inflight, 6), min(inflight, 4)}, reverse=True):
         try:
-            pool = S.ProofPool(local_rank, big_contexts=k, small_contexts=1, warm_up=1)
+            pool = S.ProofPool(local_rank, big_contexts=k, small_contexts=1, warm_up=1, devices=in_process_devices)
             inflight = k
             break
         except S.StarkhipError as e:
@@ -236,7 +255,8 @@ def main():
     reservation = pool.reservation()
 
     # synthetic statements, a different one per rank AND per context
-    seeds = [0x5EED0000 + 1 + rank * inflight + i for i in range(inflight)]
+    n_inputs = inflight * n_pools
+    seeds = [0x5EED0000 + 1 + rank * n_inputs + i for i in range(n_inputs)]
     inputs = [synthetic_final_exp_input(s) for s in seeds]
     helper = S.Prover(local_rank)  # page-locked staging for the host-rows leg / device traces
     host_rows = None
@@ -264,33 +284,38 @@ def main():
         if args.input == "device":
             d_cols, pis = device_work[i % inflight]
             return pool.submit_device(air, cfg, d_cols.data_ptr(), n, pis, layout=1)
-        return pool.submit_witness(air, inputs[i % inflight])
+        return pool.submit_witness(air, inputs[i % n_inputs])
 
     # warm-up: every context proves once (buffers, tables, plans); one proof in flight at a time gives the reference bytes of
     # each input, which the proofs of the timed region are compared with below
     solo_proofs = {}
-    for i in range(inflight):
+    for i in range(n_inputs):
         pr, _ = pool.wait(submit(i))
         solo_proofs[i] = pr
     for w in range(max(1, args.warmup)):
-        for t in [submit(i) for i in range(inflight)]:  # ... and all contexts at once
+        for t in [submit(i) for i in range(n_inputs)]:  # ... and all contexts at once
             pool.wait(t, keep=False)
     phase_ms = {k: 0.0 for k in S.PHASE_NAMES}
+    total_steps = args.steps * n_pools  # per process: `steps` per device
 
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
-    tickets = [submit(k) for k in range(args.steps)]
+    tickets = [submit(k) for k in range(total_steps)]
     timed_last = {}
+    done_by_slot = {}  # pool slot -> completion times of the timed proofs (seconds since that pool was created)
     timed_kernel_ms = {}  # kernel name -> launch durations of the trace-commitment / LDE / quotient kernels inside the timed region
     timed_groups = []
     gen_ms = []
     for k, t in enumerate(tickets):
-        keep = k >= args.steps - inflight  # the LAST proof of every input made inside the timed region is kept and checked below
+        keep = k >= total_steps - n_inputs  # the LAST proof of every input made inside the timed region is kept and checked below
+        slot = pool.slot_of(t)
         pr, info = pool.wait(t, keep=keep)
+        done_by_slot.setdefault(slot, []).append(info["timeline_s"][4])
         if keep:
-            timed_last[k % inflight] = pr
+            timed_last[k % n_inputs] = pr
         for name, v in info["phase_ms"].items():
             phase_ms[name] += v
         hk = FORM_KERNEL[info["leaf_hash_form"]]
@@ -304,8 +329,22 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = parallel.max_over_ranks(dist, elapsed, device=reduce_device)
+    elapsed_own = time.perf_counter() - t0
+    cpu_s_per_proof = (time.process_time() - cpu0) / max(1, total_steps)
+    elapsed = parallel.max_over_ranks(dist, elapsed_own, device=reduce_device)
+    # every rank's own rate and CPU budget, for rank 0's line (N > 1: a bent curve must be attributable to a rank and to host or device)
+    host_info = pool.host_info()
+    per_rank = parallel.gather_over_ranks(dist, [total_steps / elapsed_own, float(host_info[0]["cpu_budget"]), cpu_s_per_proof], device=reduce_device)
+    # steady state: per pool, the completions after its first `inflight` and up to its last `inflight` -- start-up and tail dropped
+    steady, steady_n = 0.0, 0
+    for times in done_by_slot.values():
+        times = sorted(times)
+        if len(times) >= 3 * inflight:
+            a, b = times[inflight - 1], times[len(times) - inflight - 1]
+            if b > a:
+                steady += (len(times) - 2 * inflight) / (b - a)
+                steady_n += 1
+    steady = parallel.sum_over_ranks(dist, steady if steady_n == len(done_by_slot) else float("nan"), device=reduce_device)
 
     # ---- untimed: what was timed is checked -- every kept proof of the timed region is accepted by the verifier and equals,
     # byte for byte, the proof of the same input made with nothing else in flight; rank 0's first input also has an oracle digest
@@ -313,7 +352,7 @@ def main():
     for i, pr in sorted(timed_last.items()):
         S.verify_stark_proof(air, cfg, pr)
         if not np.array_equal(pr, solo_proofs[i]):
-            raise SystemExit(f"proof of input {seeds[i]:#x} made with {inflight} in flight differs from the one made alone")
+            raise SystemExit(f"proof of input {seeds[i]:#x} made with {inflight} in flight per device differs from the one made alone")
         timed_verified += 1
     oracle_match = None
     if rank == 0 and 0 in timed_last:
@@ -369,9 +408,11 @@ def main():
                     "achieved_is": ("algorithmic bytes per launch / average launch duration x the launches of a group that run side by side (a lane-form "
                                     "launch holds a quarter of the chip's registers; `achieved_per_launch` is the plain quotient)"
                                     if side > 1 else "algorithmic bytes per launch / average launch duration"),
-                    "durations": (f"HIP events on the launch stream, the {len(timed_kernel_ms[dom])} launches of the timed region ({inflight} proofs in flight); "
+                    "durations": (f"HIP events on the launch stream, the {len(timed_kernel_ms[dom])} launches of the timed region ({inflight} proofs in flight per device); "
                                   "the other proofs' kernels run beside these launches at a raised issue priority (csrc/kernels.h), so a launch is "
-                                  "longer than the same four launches with the chip to themselves (331-362 ms) while the proofs/s are higher"),
+                                  "longer than the same launches with the chip to themselves while the proofs/s are higher"),
+                    "bound_note": ("`bound` names the contract's memory roofline; the limiter of this kernel is the SIMDs' instruction issue -- the `valu` block "
+                                   "is its fraction of that peak" if dom.startswith("leaf_hash") else None),
                     "share_of_timed_kernel_time": {k: sum(v) for k, v in timed_kernel_ms.items()},
                     "limiter": "integer VALU issue" if dom.startswith("leaf_hash") else "see kernels"}
         POSEIDON_LANE_SLOTS = poseidon_lane_slots()
@@ -426,21 +467,37 @@ def main():
         lh_ms = solo_ms["leaf_hash"]
         out = {
             "metric": "starky proofs/sec (FinalExponentiateStark 73527x8192)",
-            "value": world * args.steps / elapsed,
+            "value": world * total_steps / elapsed,
             "unit": "proofs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world * n_pools, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3,
+            "value_steady_state": None if steady != steady else steady,
+            "value_steady_state_is": (f"proofs/s over the middle of the timed region: per pool, the completions after its first {inflight} and up to its last "
+                                      f"{inflight} (start-up and tail of the pool dropped), summed over pools and ranks; null when a pool made fewer than "
+                                      f"{3 * inflight} proofs in the timed region"),
+            "host": {"cpus_granted": cpu_quota(), "cpu_budget_process": int(S.lib.starkhip_cpu_budget()), "pools": host_info,
+                     "cpu_seconds_per_proof": cpu_s_per_proof, "hw_queues_late": S.api.hw_queues_late(),
+                     "note": ("cpus_granted: cgroup quota / affinity mask of this process; cpu_budget_process: the library's figure (the same, divided by "
+                              "LOCAL_WORLD_SIZE under torch.distributed.run); pools[].cpu_budget: what each pool plans with (divided again by the pools of an "
+                              "in-process multi-device handle), its generator threads and the threads one FinalExp recording may use; cpu_seconds_per_proof: "
+                              "process CPU time over the timed region / proofs (recording, Fiat-Shamir hashing, upload gather, kernel launches)")},
+            "per_rank": ([{"rank": r, "proofs_per_s": v[0], "cpu_budget": int(v[1]), "cpu_seconds_per_proof": v[2]} for r, v in enumerate(per_rank)]
+                         if world > 1 else None),
+            "per_rank_min_max": ([min(v[0] for v in per_rank), max(v[0] for v in per_rank)] if world > 1 else None),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 (Goldilocks field)",
-            "data": "synthetic" + (" -- REHEARSAL: all ranks on one GPU over gloo, not a measurement" if rehearse else ""),
+            "data": "synthetic" + (" -- REHEARSAL: all ranks / pools on one GPU, not a measurement" if (rehearse and (world > 1 or n_dev > 1)) else ""),
             "config": {"workload": "FinalExponentiateStark 73527 cols x 8192 rows, rate_bits 2, 360800 constraints, "
                                    "standard_fast_config (84 queries, 16 pow bits); independent proofs, a different input per context and rank",
-                       "parallelism": f"proof-parallel x{world}", "proofs_in_flight_per_gpu": inflight,
+                       "parallelism": (f"proof-parallel x{n_pools}, ONE process: a pool per device behind starkhip_multipool_* (longest-job-first placement by the library, "
+                                       "no process group, no collective)" + (" -- REHEARSAL: the pools share device 0" if (n_dev and rehearse) else "")
+                                       if n_dev else f"proof-parallel x{world}"), "proofs_in_flight_per_gpu": inflight,
                        "timed_region": ("operand (one Fp12 on the host) -> generate_trace (recorded, 153 MB) -> upload -> expansion on the device -> prove -> proof bytes "
                                         "on the host: the reference's own boundary (src/aggregate_proof.rs:158-176)" if args.input == "witness"
                                         else "column-major trace resident in HBM -> prove -> proof bytes on the host (--input device)"),
-                       "driver": ("starkhip_pool_submit_witness" if args.input == "witness" else "starkhip_pool_submit (device pointer)")
-                                 + " / starkhip_pool_wait (in-flight scheduling inside libstarkhip.so)",
+                       "driver": (("starkhip_multipool_submit_witness / starkhip_multipool_wait" if n_dev else
+                                   "starkhip_pool_submit_witness / starkhip_pool_wait" if args.input == "witness" else "starkhip_pool_submit (device pointer) / starkhip_pool_wait")
+                                  + " (in-flight scheduling inside libstarkhip.so)"),
                        "pool_reservation_GB": {"device": reservation["device_bytes"] / 1e9, "per_final_exp_context": reservation["big_context_device_bytes"] / 1e9,
                                                "page_locked_host": reservation["pinned_host_bytes"] / 1e9}},
             "roofline": roofline,
@@ -465,7 +522,7 @@ def main():
                      "region, which include the time a kernel shares the CUs with the other contexts' kernels"),
             "reference_published": {"value": 1 / 92.0, "unit": "proofs/s", "hardware": "AWS r6a.8xlarge, 32-core EPYC 7R13 (reference README.md:39)"},
         }
-        if not args.no_boundary and world == 1:  # per-GPU figures, taken at N = 1 (other ranks would wait in the teardown meanwhile)
+        if not args.no_boundary and world == 1 and not n_dev:  # per-GPU figures, taken at N = 1 (other ranks would wait in the teardown meanwhile)
             # ---- untimed legs on the SAME pool, `inflight` in flight: the other hand-over forms of the same boundary
             try:
                 def leg(submit_one, reps):
@@ -495,7 +552,7 @@ def main():
                                             "in_flight": inflight, "what": "operand -> generate_trace -> upload -> proof -> D2H"}
             except Exception as e:  # never lose the main line to an auxiliary leg
                 out["value_host_rows"] = {"value": None, "error": str(e)}
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: other ranks would sit in the teardown barrier meanwhile
+        if not args.no_cpu_baseline and world == 1 and n_dev <= 1:  # rank 0 at N = 1 only: other ranks would sit in the teardown barrier meanwhile
             try:
                 out["cpu_baseline"] = cpu_baseline_sample(S, S.air_program(air), C, log_n, cfg.rate_bits)
             except Exception as e:  # the oracle is a checker, never a dependency of the measured path

@@ -165,6 +165,25 @@ extern "C" {
                                         pow_witness: u64, ticket: *mut u64) -> c_int;
     pub fn starkhip_pool_wait(pool: *mut c_void, ticket: u64, proof: *mut *mut u64, proof_words: *mut usize, info: *mut starkhip_ticket_info_t) -> c_int;
 
+    // one process, several devices: a pool per device behind one handle (`slot` = -1: the library places the job)
+    pub fn starkhip_multipool_create(devices: *const c_int, n_devices: usize, cfg: *const starkhip_pool_config_t, mpool: *mut *mut c_void) -> c_int;
+    pub fn starkhip_multipool_destroy(mpool: *mut c_void);
+    pub fn starkhip_multipool_size(mpool: *const c_void) -> usize;
+    pub fn starkhip_multipool_submit(mpool: *mut c_void, slot: c_int, air: Air, cfg: *const starkhip_config_t, trace: *const u64, n_rows: usize,
+                                     n_cols: usize, trace_layout: c_int, trace_on_device: c_int, public_inputs: *const u64, n_pis: usize,
+                                     pow_witness: u64, ticket: *mut u64) -> c_int;
+    pub fn starkhip_multipool_submit_columns(mpool: *mut c_void, slot: c_int, air: Air, cfg: *const starkhip_config_t, columns: *const *const u64,
+                                             n_rows: usize, n_cols: usize, public_inputs: *const u64, n_pis: usize, pow_witness: u64,
+                                             ticket: *mut u64) -> c_int;
+    pub fn starkhip_multipool_submit_witness(mpool: *mut c_void, slot: c_int, air: Air, cfg: *const starkhip_config_t, operands: *const u32,
+                                             n_limbs: usize, pow_witness: u64, ticket: *mut u64) -> c_int;
+    pub fn starkhip_multipool_submit_witness_batch(mpool: *mut c_void, n_jobs: usize, airs: *const Air, operands: *const *const u32,
+                                                   n_limbs: *const usize, pow_witness: u64, tickets: *mut u64, rcs: *mut c_int) -> c_int;
+    pub fn starkhip_multipool_ticket_slot(mpool: *const c_void, ticket: u64) -> c_int;
+    pub fn starkhip_multipool_wait(mpool: *mut c_void, ticket: u64, proof: *mut *mut u64, proof_words: *mut usize,
+                                   info: *mut starkhip_ticket_info_t) -> c_int;
+    pub fn starkhip_hw_queues_status() -> c_int;
+
     pub fn starkhip_last_timings(ctx: *mut c_void, ms: *mut f32) -> c_int;
     pub fn starkhip_host_alloc(ctx: *mut c_void, bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn starkhip_host_free(p: *mut c_void);
@@ -342,14 +361,26 @@ impl Prover {
 /// `generate_aggregate_proof` (src/aggregate_proof.rs:304-370).  `submit_*` returns at once with a ticket; the proofs of one
 /// signature -- or of many -- are in flight together, traces are generated on the pool's threads, and the library decides
 /// which Merkle commitments share a launch.
+///
+/// `Pool::new_multi(&[0, 1, .., 7], &cfg)` is the same object over SEVERAL devices (`starkhip_multipool_*`): the reference's
+/// caller is one process (src/aggregate_proof.rs:304-370, :402-414), and this gives that process a pool per GPU behind the same
+/// `submit_*` / `wait` -- every job goes to the pool with the least outstanding work, FinalExp jobs to the pool with the fewest
+/// of them (longest processing time first); no process group, no collective.
 pub struct Pool {
     pool: *mut c_void,
+    multi: bool,
 }
 unsafe impl Send for Pool {}
 unsafe impl Sync for Pool {} // submit / wait are thread-safe
 impl Drop for Pool {
     fn drop(&mut self) {
-        unsafe { starkhip_pool_destroy(self.pool) }
+        unsafe {
+            if self.multi {
+                starkhip_multipool_destroy(self.pool)
+            } else {
+                starkhip_pool_destroy(self.pool)
+            }
+        }
     }
 }
 /// A proof in flight.  The lifetime ties the ticket to the pool AND to everything the pool still reads for it: `submit_rows`
@@ -368,7 +399,7 @@ impl<'a> Drop for Ticket<'a> {
     fn drop(&mut self) {
         if !self.waited {
             // the library may still be reading the borrowed inputs: block until it is done with them, drop the proof
-            unsafe { starkhip_pool_wait(self.pool.pool, self.id, std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut()) };
+            unsafe { self.pool.raw_wait(self.id, std::ptr::null_mut(), std::ptr::null_mut()) };
         }
     }
 }
@@ -377,7 +408,48 @@ impl Pool {
     pub fn new(cfg: &starkhip_pool_config_t) -> Result<Pool, Error> {
         let mut pool = std::ptr::null_mut();
         check(unsafe { starkhip_pool_create(cfg, &mut pool) })?;
-        Ok(Pool { pool })
+        Ok(Pool { pool, multi: false })
+    }
+    /// One pool per entry of `devices` (an ordinal may repeat: two pools on one card), each configured by `cfg`
+    /// (`cfg.device` is ignored), the process's CPU budget split between them.
+    pub fn new_multi(devices: &[c_int], cfg: &starkhip_pool_config_t) -> Result<Pool, Error> {
+        let mut pool = std::ptr::null_mut();
+        check(unsafe { starkhip_multipool_create(devices.as_ptr(), devices.len(), cfg, &mut pool) })?;
+        Ok(Pool { pool, multi: true })
+    }
+    /// Pools behind this handle (1 for `new`).
+    pub fn devices(&self) -> usize {
+        if self.multi { unsafe { starkhip_multipool_size(self.pool) } } else { 1 }
+    }
+    /// Which of them a ticket's job went to.
+    pub fn slot_of(&self, ticket: &Ticket<'_>) -> usize {
+        if self.multi { unsafe { starkhip_multipool_ticket_slot(self.pool, ticket.id) }.max(0) as usize } else { 0 }
+    }
+    unsafe fn raw_wait(&self, id: u64, p: *mut *mut u64, w: *mut usize) -> c_int {
+        if self.multi {
+            starkhip_multipool_wait(self.pool, id, p, w, std::ptr::null_mut())
+        } else {
+            starkhip_pool_wait(self.pool, id, p, w, std::ptr::null_mut())
+        }
+    }
+    /// A whole batch of the reference's drivers at once -- BASELINE configs[3] / [4]: the six proofs of one signature, or the 48 of
+    /// eight -- placed longest first over the devices (on one pool: in the given order).  Tickets come back in the jobs' order.
+    pub fn submit_batch<'a>(&'a self, jobs: &[(Air, &[u32])]) -> Result<Vec<Ticket<'a>>, Error> {
+        if !self.multi {
+            return jobs.iter().map(|(air, ops)| self.submit(*air, ops)).collect();
+        }
+        let airs: Vec<Air> = jobs.iter().map(|j| j.0).collect();
+        let ptrs: Vec<*const u32> = jobs.iter().map(|j| j.1.as_ptr()).collect();
+        let lens: Vec<usize> = jobs.iter().map(|j| j.1.len()).collect();
+        let mut ids = vec![0u64; jobs.len()];
+        let rc = unsafe {
+            starkhip_multipool_submit_witness_batch(self.pool, jobs.len(), airs.as_ptr(), ptrs.as_ptr(), lens.as_ptr(), STARKHIP_POW_SEARCH,
+                                                    ids.as_mut_ptr(), std::ptr::null_mut())
+        };
+        // the jobs that were accepted are in flight: their tickets are made first, so that an error drops (= waits for) them
+        let tickets: Vec<Ticket<'a>> = jobs.iter().zip(ids.iter()).filter(|(_, id)| **id != 0).map(|(j, id)| self.ticket(j.0, *id)).collect();
+        check(rc)?;
+        Ok(tickets)
     }
     fn ticket<'a>(&'a self, air: Air, id: u64) -> Ticket<'a> {
         Ticket { air, id, pool: self, waited: false, _inputs: std::marker::PhantomData }
@@ -386,7 +458,13 @@ impl Pool {
     /// packed as `starkhip.h` says (e.g. MillerLoop: px, py, qx, qy, qz).  The operands are copied: nothing stays borrowed but the pool.
     pub fn submit<'a>(&'a self, air: Air, operands: &[u32]) -> Result<Ticket<'a>, Error> {
         let mut t = 0u64;
-        check(unsafe { starkhip_pool_submit_witness(self.pool, air, std::ptr::null(), operands.as_ptr(), operands.len(), STARKHIP_POW_SEARCH, &mut t) })?;
+        check(unsafe {
+            if self.multi {
+                starkhip_multipool_submit_witness(self.pool, -1, air, std::ptr::null(), operands.as_ptr(), operands.len(), STARKHIP_POW_SEARCH, &mut t)
+            } else {
+                starkhip_pool_submit_witness(self.pool, air, std::ptr::null(), operands.as_ptr(), operands.len(), STARKHIP_POW_SEARCH, &mut t)
+            }
+        })?;
         Ok(self.ticket(air, t))
     }
     /// The reference's own generator stays: hand over the rows `generate_trace` returned.  `trace` and `public_inputs` stay
@@ -394,8 +472,13 @@ impl Pool {
     pub fn submit_rows<'a, const COLUMNS: usize>(&'a self, air: Air, cfg: &Config, trace: &'a [[u64; COLUMNS]], public_inputs: &'a [u64]) -> Result<Ticket<'a>, Error> {
         let mut t = 0u64;
         check(unsafe {
-            starkhip_pool_submit(self.pool, air, cfg, trace.as_ptr() as *const u64, trace.len(), COLUMNS, 0, 0, public_inputs.as_ptr(),
-                                 public_inputs.len(), STARKHIP_POW_SEARCH, &mut t)
+            if self.multi {
+                starkhip_multipool_submit(self.pool, -1, air, cfg, trace.as_ptr() as *const u64, trace.len(), COLUMNS, 0, 0, public_inputs.as_ptr(),
+                                          public_inputs.len(), STARKHIP_POW_SEARCH, &mut t)
+            } else {
+                starkhip_pool_submit(self.pool, air, cfg, trace.as_ptr() as *const u64, trace.len(), COLUMNS, 0, 0, public_inputs.as_ptr(),
+                                     public_inputs.len(), STARKHIP_POW_SEARCH, &mut t)
+            }
         })?;
         Ok(self.ticket(air, t))
     }
@@ -411,8 +494,13 @@ impl Pool {
         let ptrs: Vec<*const u64> = columns.iter().map(|c| c.as_ptr()).collect();
         let mut t = 0u64;
         check(unsafe {
-            starkhip_pool_submit_columns(self.pool, air, cfg, ptrs.as_ptr(), n_rows, ptrs.len(), public_inputs.as_ptr(), public_inputs.len(),
-                                         STARKHIP_POW_SEARCH, &mut t)
+            if self.multi {
+                starkhip_multipool_submit_columns(self.pool, -1, air, cfg, ptrs.as_ptr(), n_rows, ptrs.len(), public_inputs.as_ptr(),
+                                                  public_inputs.len(), STARKHIP_POW_SEARCH, &mut t)
+            } else {
+                starkhip_pool_submit_columns(self.pool, air, cfg, ptrs.as_ptr(), n_rows, ptrs.len(), public_inputs.as_ptr(), public_inputs.len(),
+                                             STARKHIP_POW_SEARCH, &mut t)
+            }
         })?;
         Ok(self.ticket(air, t))
     }
@@ -420,7 +508,7 @@ impl Pool {
     pub fn wait(&self, mut ticket: Ticket<'_>) -> Result<Proof, Error> {
         let (mut p, mut w) = (std::ptr::null_mut::<u64>(), 0usize);
         ticket.waited = true; // starkhip_pool_wait consumes the ticket whatever it returns
-        check(unsafe { starkhip_pool_wait(self.pool, ticket.id, &mut p, &mut w, std::ptr::null_mut()) })?;
+        check(unsafe { self.raw_wait(ticket.id, &mut p, &mut w) })?;
         Ok(unsafe { Prover::take(p, w) })
     }
 }

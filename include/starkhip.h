@@ -60,7 +60,10 @@ typedef enum {
 enum {
     STARKHIP_OK = 0,
     STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE = -1, /* "Quotient has failed, the vanishing polynomial is not divisible by Z_H" */
-    STARKHIP_ERR_ZETA_IN_SUBGROUP = -2,
+    STARKHIP_ERR_ZETA_IN_SUBGROUP = -2, /* the challenge zeta lies in the trace subgroup H (starky fails there too: division by zeta - x) OR on the
+                                          coset 7 H (zeta^n == 7^n): the trace polynomials are opened from their values on that coset
+                                          (barycentric weights), which divides by zeta - 7 w^k.  The reference proves the
+                                          second case fine; probability 2^-115 per proof for either, deterministic for the input it hits */
     STARKHIP_ERR_BAD_SHAPE = -3,
     STARKHIP_ERR_HIP = -4,
     STARKHIP_ERR_OOM = -5,
@@ -164,6 +167,14 @@ int starkhip_trace_set_threads(int n);
 int starkhip_trace_log_end(void* log);
 void starkhip_trace_log_free(void* log);
 int starkhip_trace_log_info(const void* log, size_t* n_rows, size_t* n_cols, size_t* n_records, size_t* n_words);
+/* A finished log from explicit cell writes, (row, col, value) triples applied in order through the recorder's `set` (values < 2^32;
+ * a zero clears as the fillers' "selector(b) = 0" does).  For tests of the recorder's corner cases -- the generators are the
+ * product's way to make a log.  Release with starkhip_trace_log_free. */
+int starkhip_trace_log_from_writes(size_t n_rows, size_t n_cols, const uint64_t* writes, size_t n_writes, void** log);
+/* The two traces of the fillers' one overwriting idiom ("selector = 1 on rows a..b", then "selector(b) = 0") in a finished log:
+ * records whose run the clear took back to ZERO rows (a one-row run cleared again: the record stays in the log and stands for no
+ * cell -- kernels_trace.hip skips it) and cells cleared inside a longer run (zeroed after the expansion).  Tests. */
+int starkhip_trace_log_overwrites(const void* log, size_t* empty_runs, size_t* late_zeros);
 /* CPU replay into a row-major matrix (tests): *conflicts = cells that two records wrote with different values (must be 0) */
 int starkhip_trace_log_expand_host(const void* log, uint64_t* trace_rowmajor, size_t* conflicts);
 int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_t* cfg, const void* log, const uint64_t* public_inputs,
@@ -249,11 +260,65 @@ typedef struct {
     unsigned big_contexts, small_contexts;
 } starkhip_pool_reservation_t;
 int starkhip_pool_reservation(void* pool, starkhip_pool_reservation_t* out);
+/* The host side of a pool: the CPUs it plans with -- the process's budget (cgroup quota, else affinity mask, divided by
+ * LOCAL_WORLD_SIZE under torch.distributed.run and by the number of pools of a multi-device handle: starkhip_cpu_budget is the
+ * process's figure before that last division) --, its generator threads, the threads one recording of each class may use, and its
+ * prover threads (one per context; they launch kernels, hash the Fiat-Shamir transcript and gather uploads).  A scaling curve that
+ * bends for want of host CPUs shows here: a pool whose budget is 2 records one FinalExp trace at a time on one thread (212 ms). */
+typedef struct {
+    unsigned cpu_budget, generator_threads, trace_threads_big, trace_threads_small, prover_threads;
+    int device;
+} starkhip_pool_host_info_t;
+int starkhip_pool_host_info(void* pool, starkhip_pool_host_info_t* out);
+unsigned starkhip_cpu_budget(void);
 /* Proof blobs of a warmed pool are recycled page-locked buffers (the final device-to-host copy of 21 .. 69 MB runs at PCIe rate and
  * touches no fresh pages); starkhip_free() hands them back.  Process-wide counters: [0] blobs held, [1] of them with a caller,
  * [2] bytes held, [3] proofs served from them, [4] proofs served by malloc (no idle blob that fits).  STARKHIP_PINNED_PROOFS=0 in
  * the environment of starkhip_pool_create turns the reservation off. */
 void starkhip_proof_blob_stats(uint64_t out[5]);
+
+/* 0: GPU_MAX_HW_QUEUES was in the environment before the HIP runtime came up (the library's 16 or the caller's own value); 1: the
+ * runtime was already initialised when the first pool / multi-device handle of this process set it, so the pools run on HIP's default
+ * of 4 hardware queues (a line on stderr says so once).  Detected without touching HIP (the runtime's open /dev/kfd). */
+int starkhip_hw_queues_status(void);
+
+/* --- one caller, many devices -------------------------------------------------------------------------------------
+ * The reference's caller is ONE process: generate_aggregate_proof issues its six proves from one thread (src/aggregate_proof.rs:304-370,
+ * `aggregate_proof` :402-414).  A multi-device handle lets that caller use a node of GPUs as it is -- no process group, no collective
+ * (the proofs are independent; operands reach every pool through host memory): one proof pool per entry of
+ * `devices` (an ordinal may repeat: two pools on one card), each configured by `cfg` (cfg->device is ignored), the process's CPU budget
+ * split between them.  Jobs are placed longest processing time first: `slot` = -1 lets the library choose -- a FinalExp-class job goes
+ * to the pool with the fewest of them open, any job to the pool with the least outstanding cost (starkhip_air_cost), ties to the lowest
+ * slot -- and `slot` >= 0 names the pool (required for a trace in device memory: it lives on one device).  submit_witness_batch places a
+ * whole batch in order of decreasing cost (ties in the caller's order): BASELINE configs[3] (one signature's six proofs on six
+ * devices: each pool gets one) and configs[4] (48 proofs on 8: every device gets a FinalExp proof first, then two MillerLoop, ...).
+ * Tickets are the handle's own (they carry the slot); everything else -- proofs, ownership, errors, ticket info -- is as starkhip_pool_*.
+ * starkhip_multipool_pool hands out the pool of a slot for starkhip_pool_stats / _reservation (not for submit / wait / destroy). */
+int starkhip_multipool_create(const int* devices, size_t n_devices, const starkhip_pool_config_t* cfg, void** mpool);
+void starkhip_multipool_destroy(void* mpool); /* runs what is queued to the end first */
+size_t starkhip_multipool_size(const void* mpool);
+void* starkhip_multipool_pool(void* mpool, size_t slot);
+int starkhip_multipool_device(const void* mpool, size_t slot);
+int starkhip_multipool_submit(void* mpool, int slot, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows,
+                              size_t n_cols, int trace_layout, int trace_on_device, const uint64_t* public_inputs, size_t n_pis,
+                              uint64_t pow_witness, uint64_t* ticket);
+int starkhip_multipool_submit_columns(void* mpool, int slot, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* const* columns,
+                                      size_t n_rows, size_t n_cols, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness,
+                                      uint64_t* ticket);
+int starkhip_multipool_submit_compact(void* mpool, int slot, starkhip_air_t air, const starkhip_config_t* cfg, const void* log,
+                                      const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness, uint64_t* ticket);
+int starkhip_multipool_submit_witness(void* mpool, int slot, starkhip_air_t air, const starkhip_config_t* cfg, const uint32_t* operands,
+                                      size_t n_limbs, uint64_t pow_witness, uint64_t* ticket);
+/* operands[i] / n_limbs[i] as starkhip_pool_submit_witness takes them; tickets[i] = 0 and rcs[i] (may be NULL) != 0 for a job that was
+ * refused; returns the first failure */
+int starkhip_multipool_submit_witness_batch(void* mpool, size_t n_jobs, const starkhip_air_t* airs, const uint32_t* const* operands,
+                                            const size_t* n_limbs, uint64_t pow_witness, uint64_t* tickets, int* rcs);
+int starkhip_multipool_ticket_slot(const void* mpool, uint64_t ticket); /* -1: not a ticket of this handle */
+int starkhip_multipool_wait(void* mpool, uint64_t ticket, uint64_t** proof, size_t* proof_words, starkhip_ticket_info_t* info);
+/* the placement rule alone (no GPU needed): the slot each job of a batch gets on n_pools idle pools; starkhip_air_cost is the relative
+ * single-GPU proving cost the rule uses (FinalExp 92, MillerLoop 12.5, PairingPrecomp 4.5, ECCAgg 3, FP12Mul 0.22) */
+int starkhip_plan_lpt(size_t n_jobs, const starkhip_air_t* airs, size_t n_pools, int* slots);
+double starkhip_air_cost(starkhip_air_t air);
 
 /* per-phase device timings of the last prove on this ctx, milliseconds (HIP events):
  * [0] upload/transpose [1] ifft+lde [2] trace leaf hash + merkle [3] quotient [4] quotient commit
@@ -261,7 +326,8 @@ void starkhip_proof_blob_stats(uint64_t out[5]);
 #define STARKHIP_N_PHASES 11
 int starkhip_last_timings(void* ctx, float ms[STARKHIP_N_PHASES]);
 /* durations (ms, HIP events on the launch stream) of the three heavy kernels of the last prove:
- * [0] lde_columns_kernel (trace) [1] leaf_hash_kernel (trace) [2] quotient_eval_kernel */
+ * [0] lde_columns_v2_kernel (trace: the sum of its launches) [1] the trace commitment's leaf hash in the form it went out in
+ * (leaf_hash_kernel / _row_kernel / _lane_kernel / merged) [2] quotient_tiles_kernel */
 int starkhip_last_kernel_timings(void* ctx, float ms[3]);
 /* host time (ms, wall) inside the last prove: [0] Fiat-Shamir hashing -- the challenger's sequential Poseidon sponge over the
  * caps, the 2 (2 C + Q) opening words and the FRI data, on the proof's critical path (it falls inside the device phases
@@ -282,6 +348,8 @@ int starkhip_lde_batch(void* ctx, const uint64_t* values, size_t n_cols, unsigne
 /* Merkle cap of the matrix whose leaf j is the row bitrev(j) of an LDE given column-major natural order [C][N] */
 int starkhip_merkle_cap(void* ctx, const uint64_t* lde_colmajor, size_t n_cols, unsigned log_N, unsigned cap_height, uint64_t* cap_out);
 int starkhip_poseidon_permute_batch(void* ctx, uint64_t* states, size_t n_states);
+/* a finished log through the device's expansion kernels (csrc/kernels_trace.hip) into a host matrix, COLUMN-major [C][n_rows] */
+int starkhip_trace_log_expand_device(void* ctx, const void* log, uint64_t* trace_colmajor);
 /* device field arithmetic under test: out[i] = canonical(op(a[i], b[i])) with the lazy-reduction helpers the kernels use
  * (op codes: starky_bls12_381_amd/csrc/kernels_selftest.hip); lets the tests feed boundary operands */
 int starkhip_field_ops_batch(void* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

@@ -197,6 +197,10 @@ inline SignatureProofs prove_signature(Prover& pv, const uint32_t pk_x[12], cons
 // ---- the same on the library's proof pool (starkhip_pool_*): every driver becomes submit + wait, so the six proofs of one
 // signature -- or of a whole batch -- are in flight together; generate_trace runs on the pool's generator threads and the
 // pool's scheduler merges the small AIRs' trace commitments (starkhip.h).
+// Over SEVERAL devices (starkhip_multipool_*) it is the same object: the reference's caller is one process
+// (src/aggregate_proof.rs:304-370, :402-414), so `Pool(devices, cfg)` gives that process a pool per device behind the same
+// submit / wait -- jobs go to the pool with the least outstanding work, FinalExp-class jobs to the pool with the fewest of them
+// (longest processing time first).  No process group and no collective: the proofs are independent.
 class Pool {
   public:
     explicit Pool(const starkhip_pool_config_t& cfg) { check("starkhip_pool_create", starkhip_pool_create(&cfg, &pool_)); }
@@ -206,14 +210,42 @@ class Pool {
         cfg.device = device;
         check("starkhip_pool_create", starkhip_pool_create(&cfg, &pool_));
     }
-    ~Pool() { starkhip_pool_destroy(pool_); }
+    // one pool per entry of `devices` (an ordinal may repeat), each configured by `cfg`
+    Pool(const std::vector<int>& devices, const starkhip_pool_config_t& cfg) : multi_(true) {
+        check("starkhip_multipool_create", starkhip_multipool_create(devices.data(), devices.size(), &cfg, &pool_));
+    }
+    ~Pool() {
+        if (multi_) starkhip_multipool_destroy(pool_);
+        else starkhip_pool_destroy(pool_);
+    }
     Pool(const Pool&) = delete;
     Pool& operator=(const Pool&) = delete;
+    size_t devices() const { return multi_ ? starkhip_multipool_size(pool_) : 1; }
+    // which pool a ticket's job went to (0 on a single pool)
+    int slot_of(uint64_t ticket) const { return multi_ ? starkhip_multipool_ticket_slot(pool_, ticket) : 0; }
 
     // generate_trace + prove of one driver (src/aggregate_proof.rs:23-179) from its operands; returns the ticket
     uint64_t submit(starkhip_air_t air, const std::vector<uint32_t>& operands) {
         uint64_t t = 0;
-        check("starkhip_pool_submit_witness", starkhip_pool_submit_witness(pool_, air, nullptr, operands.data(), operands.size(), STARKHIP_POW_SEARCH, &t));
+        if (multi_)
+            check("starkhip_multipool_submit_witness",
+                  starkhip_multipool_submit_witness(pool_, -1, air, nullptr, operands.data(), operands.size(), STARKHIP_POW_SEARCH, &t));
+        else
+            check("starkhip_pool_submit_witness", starkhip_pool_submit_witness(pool_, air, nullptr, operands.data(), operands.size(), STARKHIP_POW_SEARCH, &t));
+        return t;
+    }
+    // a whole batch of drivers at once, placed longest first over the devices (on one pool: in the given order)
+    std::vector<uint64_t> submit_batch(const std::vector<starkhip_air_t>& airs, const std::vector<std::vector<uint32_t>>& operands) {
+        std::vector<uint64_t> t(airs.size(), 0);
+        if (!multi_) {
+            for (size_t i = 0; i < airs.size(); i++) t[i] = submit(airs[i], operands[i]);
+            return t;
+        }
+        std::vector<const uint32_t*> ptr;
+        std::vector<size_t> len;
+        for (const auto& o : operands) { ptr.push_back(o.data()); len.push_back(o.size()); }
+        check("starkhip_multipool_submit_witness_batch",
+              starkhip_multipool_submit_witness_batch(pool_, airs.size(), airs.data(), ptr.data(), len.data(), STARKHIP_POW_SEARCH, t.data(), nullptr));
         return t;
     }
     // the finished proof of `ticket`; verify = the reference's verify_stark_proof(..).unwrap() right after prove
@@ -223,21 +255,37 @@ class Pool {
         check("starkhip_config_for_air", starkhip_config_for_air(air, &p.config));
         uint64_t* blob = nullptr;
         size_t words = 0;
-        check("starkhip_pool_wait", starkhip_pool_wait(pool_, ticket, &blob, &words, &p.info));
+        if (multi_) check("starkhip_multipool_wait", starkhip_multipool_wait(pool_, ticket, &blob, &words, &p.info));
+        else check("starkhip_pool_wait", starkhip_pool_wait(pool_, ticket, &blob, &words, &p.info));
         if (info) *info = p.info;
         p.words = Words(blob, words);
         p.n_public_inputs = (size_t)starkhip_air_public_inputs(air);
         if (verify) check("starkhip_verify", starkhip_verify(air, &p.config, p.words.data(), p.words.size()));
         return p;
     }
-    starkhip_pool_stats_t stats() {
+    // launches of the commitment scheduler (summed over the devices' pools); slot >= 0: that device's pool alone
+    starkhip_pool_stats_t stats(int slot = -1) {
         starkhip_pool_stats_t s;
-        check("starkhip_pool_stats", starkhip_pool_stats(pool_, &s));
+        if (!multi_) {
+            check("starkhip_pool_stats", starkhip_pool_stats(pool_, &s));
+            return s;
+        }
+        memset(&s, 0, sizeof s);
+        for (size_t k = 0; k < devices(); k++) {
+            if (slot >= 0 && (size_t)slot != k) continue;
+            starkhip_pool_stats_t one;
+            check("starkhip_pool_stats", starkhip_pool_stats(starkhip_multipool_pool(pool_, k), &one));
+            s.big_commit_launches += one.big_commit_launches;
+            s.small_commit_launches += one.small_commit_launches;
+            s.small_commit_requests += one.small_commit_requests;
+            if (one.max_merged_commitments > s.max_merged_commitments) s.max_merged_commitments = one.max_merged_commitments;
+        }
         return s;
     }
 
   private:
     void* pool_ = nullptr;
+    bool multi_ = false;
 };
 
 namespace detail {

@@ -102,6 +102,9 @@ lib.starkhip_trace_set_threads.argtypes = [C.c_int]
 lib.starkhip_trace_log_free.argtypes = [C.c_void_p]
 lib.starkhip_trace_log_free.restype = None
 lib.starkhip_trace_log_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_size_t)] * 4
+lib.starkhip_trace_log_from_writes.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_void_p)]
+lib.starkhip_trace_log_expand_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+lib.starkhip_trace_log_overwrites.argtypes = [C.c_void_p] + [C.POINTER(C.c_size_t)] * 2
 lib.starkhip_trace_log_expand_host.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
 lib.starkhip_prove_compact.argtypes = [C.c_void_p, C.c_int, C.POINTER(StarkConfig), C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint64,
                                        C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t)]
@@ -242,6 +245,13 @@ class CompactTrace:
         self.n_records, self.nbytes = v[2].value, 4 * (v[3].value + v[2].value)
         self._fin = weakref.finalize(self, lib.starkhip_trace_log_free, handle)
 
+    def overwrites(self):
+        """(records whose run a later clear took back to zero rows, cells cleared inside a longer run) -- the traces of the fillers'
+        set-then-clear idiom (trace_log.h: TraceLog::set)."""
+        e, z = C.c_size_t(), C.c_size_t()
+        _chk(lib.starkhip_trace_log_overwrites(self._h, C.byref(e), C.byref(z)))
+        return e.value, z.value
+
     def expand(self):
         """(dense row-major trace, number of cells two records disagree on) -- CPU replay, for tests."""
         out = np.empty(self.shape, dtype=np.uint64)
@@ -298,6 +308,14 @@ def _trace_alloc(air, n_rows, out=None):
     elif out.shape != shape or out.dtype != np.uint64 or not out.flags.c_contiguous:
         raise ValueError(f"trace buffer must be C-contiguous uint64 {shape}, got {out.dtype} {out.shape}")
     return out, np.zeros(air_public_inputs(air), dtype=np.uint64), n_rows
+
+
+def trace_from_writes(n_rows, n_cols, writes):
+    """A CompactTrace from explicit (row, col, value) writes applied in order through the recorder (tests of its corner cases)."""
+    w = np.ascontiguousarray(writes, dtype=np.uint64).reshape(-1, 3)
+    h = C.c_void_p()
+    _chk(lib.starkhip_trace_log_from_writes(n_rows, n_cols, _p64(w), w.shape[0], C.byref(h)))
+    return CompactTrace(h)
 
 
 def trace_fibonacci(x0, x1, n_rows=None, out=None):
@@ -454,6 +472,13 @@ class Prover:
         lib.starkhip_free(out)
         return proof
 
+    def expand_trace(self, compact):
+        """A CompactTrace through the device's expansion kernels; returns the dense row-major [n][C] matrix (tests)."""
+        n, c = compact.shape
+        out = np.empty((c, n), dtype=np.uint64)
+        _chk(lib.starkhip_trace_log_expand_device(self._ctx, compact._h, _p64(out)))
+        return np.ascontiguousarray(out.T)
+
     def set_option(self, name, value):
         """Tuning knob of this context (starkhip_set_option)."""
         _chk(lib.starkhip_set_option(self._ctx, name.encode(), int(value)))
@@ -564,6 +589,53 @@ class PoolReservation(C.Structure):
 
 
 lib.starkhip_pool_reservation.argtypes = [C.c_void_p, C.POINTER(PoolReservation)]
+# a pool per device behind one handle (starkhip_multipool_*): the same submits with a `slot` argument after the handle
+lib.starkhip_multipool_create.argtypes = [C.POINTER(C.c_int), C.c_size_t, C.POINTER(PoolConfig), C.POINTER(C.c_void_p)]
+lib.starkhip_multipool_destroy.argtypes = [C.c_void_p]
+lib.starkhip_multipool_destroy.restype = None
+lib.starkhip_multipool_size.argtypes = [C.c_void_p]
+lib.starkhip_multipool_size.restype = C.c_size_t
+lib.starkhip_multipool_pool.argtypes = [C.c_void_p, C.c_size_t]
+lib.starkhip_multipool_pool.restype = C.c_void_p
+lib.starkhip_multipool_device.argtypes = [C.c_void_p, C.c_size_t]
+lib.starkhip_multipool_submit.argtypes = [C.c_void_p, C.c_int] + lib.starkhip_pool_submit.argtypes[1:]
+lib.starkhip_multipool_submit_compact.argtypes = [C.c_void_p, C.c_int] + lib.starkhip_pool_submit_compact.argtypes[1:]
+lib.starkhip_multipool_submit_witness.argtypes = [C.c_void_p, C.c_int] + lib.starkhip_pool_submit_witness.argtypes[1:]
+lib.starkhip_multipool_submit_columns.argtypes = [C.c_void_p, C.c_int] + lib.starkhip_pool_submit_columns.argtypes[1:]
+lib.starkhip_multipool_submit_witness_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(_u32p), C.POINTER(C.c_size_t), C.c_uint64,
+                                                        C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+lib.starkhip_multipool_ticket_slot.argtypes = [C.c_void_p, C.c_uint64]
+lib.starkhip_multipool_wait.argtypes = lib.starkhip_pool_wait.argtypes
+lib.starkhip_plan_lpt.argtypes = [C.c_size_t, C.POINTER(C.c_int), C.c_size_t, C.POINTER(C.c_int)]
+lib.starkhip_air_cost.argtypes = [C.c_int]
+lib.starkhip_air_cost.restype = C.c_double
+lib.starkhip_hw_queues_status.argtypes = []
+
+
+def plan_lpt(airs, n_pools):
+    """starkhip_plan_lpt: the slot each job of a batch gets on `n_pools` idle pools (longest processing time first)."""
+    a = (C.c_int * len(airs))(*[int(x) for x in airs])
+    out = (C.c_int * len(airs))()
+    _chk(lib.starkhip_plan_lpt(len(airs), a, n_pools, out))
+    return [int(x) for x in out]
+
+
+def air_cost(air):
+    return float(lib.starkhip_air_cost(int(air)))
+
+
+def hw_queues_late():
+    """True when the HIP runtime was up before the first pool could ask for its hardware queues (starkhip_hw_queues_status)."""
+    return bool(lib.starkhip_hw_queues_status())
+
+
+class PoolHostInfo(C.Structure):
+    _fields_ = [(n, C.c_uint) for n in ("cpu_budget", "generator_threads", "trace_threads_big", "trace_threads_small", "prover_threads")] + [("device", C.c_int)]
+
+
+lib.starkhip_pool_host_info.argtypes = [C.c_void_p, C.POINTER(PoolHostInfo)]
+lib.starkhip_cpu_budget.argtypes = []
+lib.starkhip_cpu_budget.restype = C.c_uint
 lib.starkhip_proof_blob_stats.argtypes = [C.POINTER(C.c_uint64)]
 lib.starkhip_proof_blob_stats.restype = None
 
@@ -607,15 +679,37 @@ class ProofPool:
     """
 
     def __init__(self, device=0, big_contexts=0, small_contexts=0, generator_threads=0, trace_threads=0, commit_policy=0, gather_ms=0.0,
-                 stream_priority=0, warm_up=0):
+                 stream_priority=0, warm_up=0, devices=None):
+        """`devices` (a list of ordinals, one pool each; an ordinal may repeat): ONE process on several GPUs through
+        starkhip_multipool_* -- the submits then take `slot` (-1: the library places the job, longest processing time first)."""
         cfg = PoolConfig(device, big_contexts, small_contexts, generator_threads, trace_threads, commit_policy, stream_priority, warm_up, gather_ms)
         self._h = C.c_void_p()
-        _chk(lib.starkhip_pool_create(C.byref(cfg), C.byref(self._h)))
+        self._multi = devices is not None
+        if self._multi:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _chk(lib.starkhip_multipool_create(devs, len(devices), C.byref(cfg), C.byref(self._h)))
+        else:
+            _chk(lib.starkhip_pool_create(C.byref(cfg), C.byref(self._h)))
         self._keep = {}  # ticket -> inputs that must outlive the proof
+
+    def _call(self, name, slot, *args):
+        if self._multi:
+            return getattr(lib, "starkhip_multipool_" + name)(self._h, slot, *args)
+        return getattr(lib, "starkhip_pool_" + name)(self._h, *args)
+
+    @property
+    def n_pools(self):
+        return int(lib.starkhip_multipool_size(self._h)) if self._multi else 1
+
+    def slot_of(self, ticket):
+        return int(lib.starkhip_multipool_ticket_slot(self._h, ticket)) if self._multi else 0
+
+    def _pools(self):
+        return [C.c_void_p(lib.starkhip_multipool_pool(self._h, k)) for k in range(self.n_pools)] if self._multi else [self._h]
 
     def close(self):
         if self._h:
-            lib.starkhip_pool_destroy(self._h)
+            (lib.starkhip_multipool_destroy if self._multi else lib.starkhip_pool_destroy)(self._h)
             self._h = C.c_void_p()
             self._keep.clear()
 
@@ -625,50 +719,71 @@ class ProofPool:
         except Exception:
             pass
 
-    def submit(self, air, config, trace, public_inputs, pow_witness=POW_SEARCH, layout=0):
+    def submit(self, air, config, trace, public_inputs, pow_witness=POW_SEARCH, layout=0, slot=-1):
         """As Prover.prove, asynchronously: `trace` a host array or a CompactTrace.  Returns the ticket."""
         pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         cfg = StarkConfig.from_buffer_copy(config)
         t = C.c_uint64()
         if isinstance(trace, CompactTrace):
-            _chk(lib.starkhip_pool_submit_compact(self._h, air, C.byref(cfg), trace._h, _p64(pis), pis.size, pow_witness, C.byref(t)))
+            _chk(self._call("submit_compact", slot, air, C.byref(cfg), trace._h, _p64(pis), pis.size, pow_witness, C.byref(t)))
         else:
             trace = np.ascontiguousarray(trace, dtype=np.uint64)
             if trace.ndim != 2 or layout not in (0, 1):
                 raise StarkhipError(ERR_BAD_SHAPE)
             n_rows, n_cols = trace.shape if layout == 0 else trace.shape[::-1]
-            _chk(lib.starkhip_pool_submit(self._h, air, C.byref(cfg), trace.ctypes.data_as(C.c_void_p), n_rows, n_cols, layout, 0, _p64(pis), pis.size,
-                                          pow_witness, C.byref(t)))
+            _chk(self._call("submit", slot, air, C.byref(cfg), trace.ctypes.data_as(C.c_void_p), n_rows, n_cols, layout, 0, _p64(pis), pis.size,
+                            pow_witness, C.byref(t)))
         self._keep[t.value] = (trace, pis, cfg)
         return t.value
 
-    def submit_device(self, air, config, trace_ptr, n_rows, public_inputs, pow_witness=POW_SEARCH, layout=1):
-        """`trace_ptr`: device address of a uint64 trace already resident in HBM (benchmark path)."""
+    def submit_device(self, air, config, trace_ptr, n_rows, public_inputs, pow_witness=POW_SEARCH, layout=1, slot=0):
+        """`trace_ptr`: device address of a uint64 trace already resident in HBM (benchmark path); on several devices `slot` names
+        the pool of the device the trace lives on."""
         pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         cfg = StarkConfig.from_buffer_copy(config)
         t = C.c_uint64()
-        _chk(lib.starkhip_pool_submit(self._h, air, C.byref(cfg), C.c_void_p(trace_ptr), n_rows, air_columns(air), layout, 1, _p64(pis), pis.size,
-                                      pow_witness, C.byref(t)))
+        _chk(self._call("submit", slot, air, C.byref(cfg), C.c_void_p(trace_ptr), n_rows, air_columns(air), layout, 1, _p64(pis), pis.size,
+                        pow_witness, C.byref(t)))
         self._keep[t.value] = (pis, cfg)
         return t.value
 
-    def submit_columns(self, air, config, columns, public_inputs, pow_witness=POW_SEARCH):
+    def submit_columns(self, air, config, columns, public_inputs, pow_witness=POW_SEARCH, slot=-1):
         """As Prover.prove_columns, asynchronously: one separately allocated array per trace column."""
         table, keep, n_rows = _column_table(columns)
         pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         cfg = StarkConfig.from_buffer_copy(config)
         t = C.c_uint64()
-        _chk(lib.starkhip_pool_submit_columns(self._h, air, C.byref(cfg), table, n_rows, len(keep), _p64(pis), pis.size, pow_witness, C.byref(t)))
+        _chk(self._call("submit_columns", slot, air, C.byref(cfg), table, n_rows, len(keep), _p64(pis), pis.size, pow_witness, C.byref(t)))
         self._keep[t.value] = (keep, pis, cfg)  # the table itself was copied by the library
         return t.value
 
-    def submit_witness(self, air, *generator_args, config=None, pow_witness=POW_SEARCH):
+    def submit_witness(self, air, *generator_args, config=None, pow_witness=POW_SEARCH, slot=-1):
         """generate_trace + prove inside the pool, from the arguments of `trace_<air>`."""
         ops = witness_operands(air, *generator_args)
         t = C.c_uint64()
         cfgp = C.byref(StarkConfig.from_buffer_copy(config)) if config is not None else None
-        _chk(lib.starkhip_pool_submit_witness(self._h, air, cfgp, _p32(ops), ops.size, pow_witness, C.byref(t)))
+        _chk(self._call("submit_witness", slot, air, cfgp, _p32(ops), ops.size, pow_witness, C.byref(t)))
         return t.value
+
+    def submit_witness_batch(self, jobs, pow_witness=POW_SEARCH):
+        """jobs: [(air, generator args...)]; on several devices the batch is placed longest processing time first
+        (starkhip_multipool_submit_witness_batch), on one pool in the given order.  Returns the tickets in the jobs' order."""
+        ops = [witness_operands(j[0], *j[1:]) for j in jobs]
+        if not self._multi:
+            out = []
+            for j, o in zip(jobs, ops):
+                t = C.c_uint64()
+                _chk(lib.starkhip_pool_submit_witness(self._h, j[0], None, _p32(o), o.size, pow_witness, C.byref(t)))
+                out.append(t.value)
+            return out
+        n = len(jobs)
+        airs = (C.c_int * n)(*[int(j[0]) for j in jobs])
+        ptrs = (_u32p * n)(*[_p32(o) for o in ops])
+        lens = (C.c_size_t * n)(*[o.size for o in ops])
+        tickets = (C.c_uint64 * n)()
+        rcs = (C.c_int * n)()
+        _chk(lib.starkhip_multipool_submit_witness_batch(self._h, n, airs, ptrs, lens, pow_witness, tickets, rcs))
+        return [int(t) for t in tickets]
 
     def wait(self, ticket, keep=True):
         """(proof, info) of `ticket`; raises StarkhipError with the proof's status if it failed.  info: phase_ms / kernel_ms
@@ -676,7 +791,7 @@ class ProofPool:
         out = _u64p()
         words = C.c_size_t()
         info = TicketInfo()
-        rc = lib.starkhip_pool_wait(self._h, ticket, C.byref(out), C.byref(words), C.byref(info))
+        rc = (lib.starkhip_multipool_wait if self._multi else lib.starkhip_pool_wait)(self._h, ticket, C.byref(out), C.byref(words), C.byref(info))
         self._keep.pop(ticket, None)
         _chk(rc)
         proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy() if keep else None
@@ -688,15 +803,37 @@ class ProofPool:
                        "leaf_hash_form": ("quad", "row", "merged", "lane", "host")[min(info.leaf_hash_form, 4)], "leaf_hash_group": int(info.leaf_hash_group)}
 
     def reservation(self):
-        """starkhip_pool_reservation: what the pool's contexts hold (bytes)."""
-        r = PoolReservation()
-        _chk(lib.starkhip_pool_reservation(self._h, C.byref(r)))
-        return {n: int(getattr(r, n)) for n, _ in PoolReservation._fields_}
+        """starkhip_pool_reservation: what the pool's contexts hold (bytes; summed over the devices' pools, the per-context figures the largest)."""
+        out = None
+        for h in self._pools():
+            r = PoolReservation()
+            _chk(lib.starkhip_pool_reservation(h, C.byref(r)))
+            one = {n: int(getattr(r, n)) for n, _ in PoolReservation._fields_}
+            if out is None:
+                out = one
+            else:
+                for n in one:
+                    out[n] = max(out[n], one[n]) if n.endswith("context_device_bytes") else out[n] + one[n]
+        return out
 
-    def stats(self):
-        s = PoolStats()
-        _chk(lib.starkhip_pool_stats(self._h, C.byref(s)))
-        return {n: int(getattr(s, n)) for n, _ in PoolStats._fields_}
+    def host_info(self):
+        """starkhip_pool_host_info of every pool behind this handle: the CPUs it plans with and its host threads."""
+        out = []
+        for h in self._pools():
+            r = PoolHostInfo()
+            _chk(lib.starkhip_pool_host_info(h, C.byref(r)))
+            out.append({n: int(getattr(r, n)) for n, _ in PoolHostInfo._fields_})
+        return out
+
+    def stats(self, per_pool=False):
+        each = []
+        for h in self._pools():
+            s = PoolStats()
+            _chk(lib.starkhip_pool_stats(h, C.byref(s)))
+            each.append({n: int(getattr(s, n)) for n, _ in PoolStats._fields_})
+        if per_pool:
+            return each
+        return {n: (max if n == "max_merged_commitments" else sum)(e[n] for e in each) for n in each[0]}
 
 
 def verify_stark_proof(air, config, proof):

@@ -1,6 +1,8 @@
 // extern "C" surface of libstarkhip.so (declared in include/starkhip.h).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <new>
 
@@ -249,6 +251,37 @@ int starkhip_trace_log_info(const void* log, size_t* n_rows, size_t* n_cols, siz
     if (n_words) *n_words = l->total_words();
     return STARKHIP_OK;
 }
+int starkhip_trace_log_from_writes(size_t n_rows, size_t n_cols, const uint64_t* writes, size_t n_writes, void** log) {
+    if (!log || (n_writes && !writes) || !n_rows || !n_cols) return STARKHIP_ERR_BAD_SHAPE;
+    *log = nullptr;
+    TraceLog* l = new (std::nothrow) TraceLog();
+    if (!l) return STARKHIP_ERR_OOM;
+    try {
+        l->reset(n_rows, n_cols);
+        for (size_t i = 0; i < n_writes; i++) l->set((size_t)writes[3 * i], (size_t)writes[3 * i + 1], writes[3 * i + 2]);
+    } catch (const std::bad_alloc&) {
+        delete l;
+        return STARKHIP_ERR_OOM;
+    } catch (const std::exception&) {  // a write outside the trace, a value of more than 32 bits
+        delete l;
+        return STARKHIP_ERR_BAD_SHAPE;
+    }
+    l->open.clear();
+    l->open.shrink_to_fit();
+    *log = l;
+    return STARKHIP_OK;
+}
+int starkhip_trace_log_overwrites(const void* log, size_t* empty_runs, size_t* late_zeros) {
+    if (!log) return STARKHIP_ERR_BAD_SHAPE;
+    const TraceLog* l = (const TraceLog*)log;
+    size_t empty = 0;
+    l->for_each_part([&](const TraceLog& part) {
+        for (uint32_t off : part.offsets) empty += part.words[off - part.base + 2] == 0;
+    });
+    if (empty_runs) *empty_runs = empty;
+    if (late_zeros) *late_zeros = l->total_late_zeros() / 2;
+    return STARKHIP_OK;
+}
 int starkhip_trace_log_expand_host(const void* log, uint64_t* trace_rowmajor, size_t* conflicts) {
     if (!log || !trace_rowmajor) return STARKHIP_ERR_BAD_SHAPE;
     const TraceLog* l = (const TraceLog*)log;
@@ -291,12 +324,43 @@ int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_
 }
 
 // ---- proof pool (scheduler.cpp)
+// One hardware queue per in-flight proof: with HIP's default of 4, streams share queues and kernels of different proofs serialise behind
+// each other (-6 % on the FinalExp pool).  The runtime reads GPU_MAX_HW_QUEUES ONCE, when the process first uses HIP, so setting it here
+// works only in a process that has not.  Whether it has is visible without touching HIP: initialising the runtime opens the compute
+// driver's device node, /dev/kfd.  0 = the variable was in the environment before the runtime came up (ours or the caller's own);
+// 1 = the runtime was already up when the first pool set it: the pools run on HIP's default, and the caller should export the variable
+// itself, earlier (bench.py does).
+static std::atomic<int> g_hw_queues_late(-1);
+static bool hip_runtime_is_up() {
+    char link[64], target[256];
+    for (int fd = 0; fd < 1024; fd++) {
+        snprintf(link, sizeof link, "/proc/self/fd/%d", fd);
+        const ssize_t n = readlink(link, target, sizeof target - 1);
+        if (n <= 0) continue;
+        target[n] = 0;
+        if (strcmp(target, "/dev/kfd") == 0) return true;
+    }
+    return false;
+}
+static void ask_for_hw_queues() {
+    if (g_hw_queues_late.load() >= 0) return;  // decided with the first pool
+    int late = 0;
+    if (!getenv("GPU_MAX_HW_QUEUES")) {
+        late = hip_runtime_is_up() ? 1 : 0;
+        setenv("GPU_MAX_HW_QUEUES", "16", 0);
+        if (late)
+            fprintf(stderr, "starkhip: the HIP runtime was initialised before the first pool could set GPU_MAX_HW_QUEUES=16; pools run on HIP's "
+                            "default of 4 hardware queues (about 6 %% slower). Export GPU_MAX_HW_QUEUES=16 before the process first uses HIP.\n");
+    }
+    int expected = -1;
+    g_hw_queues_late.compare_exchange_strong(expected, late);
+}
+int starkhip_hw_queues_status(void) { return std::max(0, g_hw_queues_late.load()); }
+
 int starkhip_pool_create(const starkhip_pool_config_t* cfg, void** pool) {
     if (!cfg || !pool) return STARKHIP_ERR_BAD_SHAPE;
     *pool = nullptr;
-    // one hardware queue per in-flight proof where the runtime has not been initialised yet: with HIP's default of 4, streams
-    // share queues and kernels of different proofs serialise behind each other
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    ask_for_hw_queues();
     Pool* p = nullptr;
     try {
         const int rc = pool_create(*cfg, &p);
@@ -343,10 +407,85 @@ int starkhip_pool_reservation(void* pool, starkhip_pool_reservation_t* out) {
     if (!pool || !out) return STARKHIP_ERR_BAD_SHAPE;
     return pool_reservation((Pool*)pool, out);
 }
+int starkhip_pool_host_info(void* pool, starkhip_pool_host_info_t* out) {
+    if (!pool || !out) return STARKHIP_ERR_BAD_SHAPE;
+    return pool_host_info((Pool*)pool, out);
+}
+unsigned starkhip_cpu_budget(void) { return cpu_budget(); }
 int starkhip_pool_stats(void* pool, starkhip_pool_stats_t* out) {
     if (!pool || !out) return STARKHIP_ERR_BAD_SHAPE;
     return pool_stats((Pool*)pool, out);
 }
+
+// ---- a pool per device behind one handle (scheduler.cpp)
+int starkhip_multipool_create(const int* devices, size_t n_devices, const starkhip_pool_config_t* cfg, void** mpool) {
+    if (!devices || !n_devices || !cfg || !mpool) return STARKHIP_ERR_BAD_SHAPE;
+    *mpool = nullptr;
+    ask_for_hw_queues();
+    MultiPool* mp = nullptr;
+    try {
+        const int rc = multipool_create(devices, n_devices, *cfg, &mp);
+        *mpool = mp;
+        return rc;
+    } catch (const std::bad_alloc&) {
+        return STARKHIP_ERR_OOM;
+    } catch (const std::exception&) {
+        return STARKHIP_ERR_HIP;
+    }
+}
+void starkhip_multipool_destroy(void* mpool) { multipool_destroy((MultiPool*)mpool); }
+size_t starkhip_multipool_size(const void* mpool) { return mpool ? multipool_size((const MultiPool*)mpool) : 0; }
+void* starkhip_multipool_pool(void* mpool, size_t slot) { return mpool ? (void*)multipool_pool((MultiPool*)mpool, slot) : nullptr; }
+int starkhip_multipool_device(const void* mpool, size_t slot) { return mpool ? multipool_device((const MultiPool*)mpool, slot) : -1; }
+int starkhip_multipool_submit(void* mpool, int slot, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows,
+                              size_t n_cols, int trace_layout, int trace_on_device, const uint64_t* public_inputs, size_t n_pis,
+                              uint64_t pow_witness, uint64_t* ticket) {
+    if (!mpool) return STARKHIP_ERR_NO_DEVICE;
+    return multipool_submit((MultiPool*)mpool, slot, air, cfg, trace, n_rows, n_cols, trace_layout, trace_on_device, public_inputs, n_pis, pow_witness,
+                            ticket);
+}
+int starkhip_multipool_submit_columns(void* mpool, int slot, starkhip_air_t air, const starkhip_config_t* cfg, const uint64_t* const* columns,
+                                      size_t n_rows, size_t n_cols, const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness,
+                                      uint64_t* ticket) {
+    if (!mpool) return STARKHIP_ERR_NO_DEVICE;
+    return multipool_submit_columns((MultiPool*)mpool, slot, air, cfg, columns, n_rows, n_cols, public_inputs, n_pis, pow_witness, ticket);
+}
+int starkhip_multipool_submit_compact(void* mpool, int slot, starkhip_air_t air, const starkhip_config_t* cfg, const void* log,
+                                      const uint64_t* public_inputs, size_t n_pis, uint64_t pow_witness, uint64_t* ticket) {
+    if (!mpool) return STARKHIP_ERR_NO_DEVICE;
+    if (log && armed_trace_log() == (const TraceLog*)log) return STARKHIP_ERR_BAD_SHAPE;
+    return multipool_submit_compact((MultiPool*)mpool, slot, air, cfg, log, public_inputs, n_pis, pow_witness, ticket);
+}
+int starkhip_multipool_submit_witness(void* mpool, int slot, starkhip_air_t air, const starkhip_config_t* cfg, const uint32_t* operands,
+                                      size_t n_limbs, uint64_t pow_witness, uint64_t* ticket) {
+    if (!mpool) return STARKHIP_ERR_NO_DEVICE;
+    try {
+        return multipool_submit_witness((MultiPool*)mpool, slot, air, cfg, operands, n_limbs, pow_witness, ticket);
+    } catch (const std::bad_alloc&) {
+        return STARKHIP_ERR_OOM;
+    }
+}
+int starkhip_multipool_submit_witness_batch(void* mpool, size_t n_jobs, const starkhip_air_t* airs, const uint32_t* const* operands,
+                                            const size_t* n_limbs, uint64_t pow_witness, uint64_t* tickets, int* rcs) {
+    if (!mpool) return STARKHIP_ERR_NO_DEVICE;
+    static_assert(sizeof(starkhip_air_t) == sizeof(int), "air ids travel as int");
+    try {
+        return multipool_submit_witness_batch((MultiPool*)mpool, n_jobs, (const int*)airs, operands, n_limbs, pow_witness, tickets, rcs);
+    } catch (const std::bad_alloc&) {
+        return STARKHIP_ERR_OOM;
+    }
+}
+int starkhip_multipool_ticket_slot(const void* mpool, uint64_t ticket) { return mpool ? multipool_ticket_slot((const MultiPool*)mpool, ticket) : -1; }
+int starkhip_multipool_wait(void* mpool, uint64_t ticket, uint64_t** proof, size_t* proof_words, starkhip_ticket_info_t* info) {
+    if (!mpool) return STARKHIP_ERR_NO_DEVICE;
+    return multipool_wait((MultiPool*)mpool, ticket, proof, proof_words, info);
+}
+int starkhip_plan_lpt(size_t n_jobs, const starkhip_air_t* airs, size_t n_pools, int* slots) {
+    if ((n_jobs && (!airs || !slots)) || !n_pools) return STARKHIP_ERR_BAD_SHAPE;
+    plan_lpt(n_jobs, (const int*)airs, n_pools, slots);
+    return STARKHIP_OK;
+}
+double starkhip_air_cost(starkhip_air_t air) { return air_cost((int)air); }
 
 int starkhip_last_timings(void* ctx, float ms[STARKHIP_N_PHASES]) {
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;
@@ -382,6 +521,15 @@ int starkhip_lde_batch(void* ctx, const uint64_t* values, size_t n_cols, unsigne
 int starkhip_merkle_cap(void* ctx, const uint64_t* lde_colmajor, size_t n_cols, unsigned log_N, unsigned cap_height, uint64_t* cap_out) {
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;
     return merkle_cap((Ctx*)ctx, lde_colmajor, n_cols, log_N, cap_height, cap_out);
+}
+int starkhip_trace_log_expand_device(void* ctx, const void* log, uint64_t* trace_colmajor) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    if (!log || !trace_colmajor || armed_trace_log() == (const TraceLog*)log) return STARKHIP_ERR_BAD_SHAPE;
+    try {
+        return expand_log((Ctx*)ctx, (const TraceLog*)log, trace_colmajor);
+    } catch (const std::bad_alloc&) {
+        return STARKHIP_ERR_OOM;
+    }
 }
 int starkhip_poseidon_permute_batch(void* ctx, uint64_t* states, size_t n_states) {
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;

@@ -28,17 +28,19 @@ static bool fake_device() {
 }
 
 struct Ctx {
+    int device = 0;
     HashService* hs = nullptr;
     bool hash_requested = false, urgent = false;
     float timings[STARKHIP_N_PHASES] = {0}, ktimings[3] = {0}, htimings[2] = {0};
     std::set<int> blob_airs;
 };
-int ctx_create(int, Ctx** out, int) {
-    if (!fake_device()) {
+int ctx_create(int device, Ctx** out, int) {
+    if (!fake_device() || device < 0 || device >= 8) {  // the pretended node has eight devices
         *out = nullptr;
         return STARKHIP_ERR_NO_DEVICE;
     }
     *out = new Ctx();
+    (*out)->device = device;
     return STARKHIP_OK;
 }
 void ctx_destroy(Ctx* c) {
@@ -84,7 +86,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     if (pow_witness == 0xBAD2) return STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE;     // a job that fails after its commitment
     uint64_t* out = blob_alloc((4 + n_pis) * 8);
     if (!out) return STARKHIP_ERR_OOM;
-    out[0] = 0xFA4EULL; out[1] = (uint64_t)air.id; out[2] = n_rows; out[3] = c->urgent;
+    out[0] = 0xFA4EULL; out[1] = (uint64_t)air.id; out[2] = n_rows; out[3] = (uint64_t)c->urgent | ((uint64_t)c->device << 8);
     if (n_pis) memcpy(out + 4, pis, n_pis * 8);
     *proof_out = out;
     *proof_words = 4 + n_pis;
@@ -94,6 +96,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
 int lde_batch(Ctx*, const uint64_t*, size_t, unsigned, unsigned, uint64_t*, uint64_t*) { return STARKHIP_ERR_NO_DEVICE; }
 int merkle_cap(Ctx*, const uint64_t*, size_t, unsigned, unsigned, uint64_t*) { return STARKHIP_ERR_NO_DEVICE; }
 int permute_batch(Ctx*, uint64_t*, size_t) { return STARKHIP_ERR_NO_DEVICE; }
+int expand_log(Ctx*, const TraceLog*, uint64_t*) { return STARKHIP_ERR_NO_DEVICE; }
 int field_ops(Ctx*, int, const uint64_t*, const uint64_t*, uint64_t*, size_t) { return STARKHIP_ERR_NO_DEVICE; }
 int host_alloc(Ctx*, size_t, void**) { return STARKHIP_ERR_NO_DEVICE; }
 void host_free(void*) {}
@@ -103,7 +106,7 @@ int quad_merged_tables_selfcheck(unsigned) { return 0; }  // the real one is com
 static std::atomic<unsigned long> g_fake_launches(0), g_fake_merged(0);
 hipError_t launch_leaf_hash(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t) { g_fake_launches++; return hipSuccess; }
 hipError_t launch_leaf_hash_row(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t) { g_fake_launches++; return hipSuccess; }
-hipError_t launch_leaf_hash_lane(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t, bool) { g_fake_launches++; return hipSuccess; }
+hipError_t launch_leaf_hash_lane(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t) { g_fake_launches++; return hipSuccess; }
 hipError_t launch_leaf_hash_multi(const LeafHashBatch&, unsigned count, size_t, unsigned, unsigned, hipStream_t) {
     g_fake_launches++;
     g_fake_merged += count;

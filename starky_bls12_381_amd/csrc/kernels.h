@@ -21,9 +21,6 @@
 #endif
 
 namespace starkhip {
-// STARKHIP_KERNEL_PRIO (read once): != 0 = the LDE and quotient kernels run their waves at a raised issue priority (s_setprio 2), so that a
-// leaf-hash wave sharing their SIMD (launch_leaf_hash_lane share_cu) fills the slots they leave instead of taking them
-unsigned kernel_issue_priority();
 struct QOp;  // quotient_ops.h
 struct QTRec;  // quotient_plan.h
 struct QTPiece;
@@ -67,10 +64,7 @@ hipError_t launch_leaf_hash_multi(const LeafHashBatch& B, unsigned count, size_t
 hipError_t launch_leaf_hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st);
 // the same digests from the row form (16 lanes per leaf): shorter chain per leaf, 4x the lane-instructions -- for a lone commitment of few leaves
 // the same digests from the lane form (one lane per leaf): fewest instructions per permutation, but 1/4 of the waves -- for big commitments when several are in flight
-// share_cu: the launch reserves just over half a CU's LDS per workgroup, so that every CU holds ONE of its workgroups -- one 256-register
-// wave per SIMD -- and the other half of the SIMDs' registers and of the LDS stays free for another proof's LDE / quotient workgroup
-// (kernels_hash.hip)
-hipError_t launch_leaf_hash_lane(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st, bool share_cu = false);
+hipError_t launch_leaf_hash_lane(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st);
 hipError_t launch_leaf_hash_row(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st);
 hipError_t launch_leaf_hash_rows(const gl_t* rows, size_t width, size_t n_leaves, gl_t* digests, hipStream_t st);
 hipError_t launch_merkle_levels(gl_t* digests, unsigned log_leaves, unsigned cap_h, hipStream_t st);

@@ -603,22 +603,10 @@ hipError_t launch_leaf_hash_row(const gl_t* mat, size_t n_cols, unsigned log_n, 
     hipLaunchKernelGGL(leaf_hash_row_kernel, dim3(nblocks(16 * N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
     return hipGetLastError();
 }
-// share_cu: a lane-form workgroup is four waves of 256 registers, one per SIMD; two of them own a CU's register file, and a group of four
-// commitments owns the chip's -- the 512-thread LDE / quotient workgroups of the other proofs in flight then wait for the group to end
-// (17 -> 50 ms and 27 -> 73 ms on average in the kernel trace) and the two kinds of work alternate, each leaving issue slots empty that the
-// other could fill (the LDE issues vector instructions 71 % of the time, the quotient about 80 %).  With an LDS reservation of just over
-// half a CU's 160 KB per workgroup a CU takes ONE lane workgroup: 256 registers per SIMD and 78 KB of LDS stay free -- exactly one LDE
-// workgroup (8 waves x <= 128 registers, 69.6 KB) or one quotient workgroup (78.3 KB) fits beside it.
-static constexpr unsigned LANE_SHARE_LDS = 82944;  // > 163 840 / 2; + the quotient's 78 336 bytes <= 163 840
-hipError_t launch_leaf_hash_lane(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st, bool share_cu) {
+hipError_t launch_leaf_hash_lane(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st) {
     size_t N = (size_t)1 << (log_n + rate_bits);
     if (hipError_t e = ensure_lane_tables(); e != hipSuccess) return e;
-    unsigned dyn = 0;
-    if (share_cu) {
-        dyn = LANE_SHARE_LDS - (unsigned)sizeof(LaneTables);
-        if (hipError_t e = hipFuncSetAttribute((const void*)leaf_hash_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(leaf_hash_lane_kernel, dim3(nblocks(N, 256)), dim3(256), dyn, st, mat, n_cols, log_n, rate_bits, digests);
+    hipLaunchKernelGGL(leaf_hash_lane_kernel, dim3(nblocks(N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
     return hipGetLastError();
 }
 hipError_t launch_leaf_hash_multi(const LeafHashBatch& B, unsigned count, size_t n_cols, unsigned log_n, unsigned rate_bits, hipStream_t st) {

@@ -214,10 +214,9 @@ __global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kern
                                                                                     gl_t* lde, unsigned n_cols, unsigned rate_bits,
                                                                                     const gl_t* __restrict__ tw_fwd,
                                                                                     const gl_t* __restrict__ tw_inv, const gl_t* __restrict__ cs,
-                                                                                    const gl_t* __restrict__ oh, int from_coeffs, int prio) { STARKHIP_PRIO_ENTRY
+                                                                                    const gl_t* __restrict__ oh, int from_coeffs) { STARKHIP_PRIO_ENTRY
     using PL = LdePlan<LOGN>;
     constexpr int T = PL::T, n = PL::N;
-    if (prio) __builtin_amdgcn_s_setprio(2);
     extern __shared__ gl_t lds_all[];
     __shared__ unsigned cls[3];  // closed-form classes (below): [0] flags, [1] number of ones, [2] row of a one
     if constexpr (PL::CPB == 1) {
@@ -382,16 +381,8 @@ static hipError_t launch_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, size_t 
     gl_t* cf = keep ? coeffs : lde + (((size_t)1 << rate_bits) - 1) * PL::N;
     const unsigned cf_stride = keep ? (unsigned)PL::N : (unsigned)PL::N << rate_bits;
     hipLaunchKernelGGL(lde_columns_v2_kernel<LOGN>, dim3(blocks), dim3(PL::THREADS), lds_bytes, st, values, cf, cf_stride, keep ? 1 : 0, lde,
-                       (unsigned)n_cols, rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs, (int)kernel_issue_priority());
+                       (unsigned)n_cols, rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs);
     return hipGetLastError();
-}
-
-unsigned kernel_issue_priority() {
-    static const unsigned prio = [] {
-        const char* e = getenv("STARKHIP_KERNEL_PRIO");
-        return (e && *e) ? (unsigned)atoi(e) : 0u;
-    }();
-    return prio;
 }
 
 bool lde_v2_supported(unsigned log_n) { return log_n >= 8 && log_n <= 13; }

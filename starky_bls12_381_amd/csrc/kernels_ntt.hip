@@ -82,7 +82,8 @@ __device__ __forceinline__ void lds_ntt_dit(gl_t* a, const gl_t* __restrict__ tw
 // LDS: COLS_PER_BLOCK * n * 8 bytes (64 KiB at n = 8192).
 template <int LOGN, int COLS_PER_BLOCK, int THREADS>
 __global__ __launch_bounds__(THREADS) void lde_columns_kernel(const gl_t* values, gl_t* coeffs,  // coeffs may be values (in place): every word of a column is in LDS, behind a barrier, before any is written
-                                                               gl_t* __restrict__ lde, size_t n_cols, unsigned rate_bits,
+                                                               gl_t* lde,  // not restrict: the trace columns wait inside the LDE buffer (prover.hip: trace_in_lde), so `values` may alias it
+                                                               size_t n_cols, unsigned rate_bits,
                                                                const gl_t* __restrict__ tw_fwd, const gl_t* __restrict__ tw_inv,
                                                                unsigned tw_log, const gl_t* __restrict__ coset_scale, int from_coeffs) { STARKHIP_PRIO_ENTRY
     constexpr int n = 1 << LOGN;

@@ -290,7 +290,6 @@ struct QTParams {
     gl_t* partial;                    // [n_chunks][2][size]
     unsigned log_n, rate_bits, qdb, n_cols;
     unsigned dbg;  // profiling only: 1 = the producer loads nothing, 2 = the evaluators skip the arithmetic (results are garbage)
-    unsigned prio; // != 0: the waves raise their issue priority (s_setprio): beside a co-resident leaf-hash wave they issue first
 };
 
 // (hi:lo) += (xh:xl) as one carry chain (the sums involved stay far below 2^128)
@@ -358,7 +357,6 @@ template <bool SMALL_N, unsigned DBG>
 __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(QTParams P) { STARKHIP_PRIO_ENTRY
     __shared__ gl_t tile[2][(QT_TILE_COLS + 1) * QT_TILE_ROWS];  // + the column of ones (QT_ONES_SLOT: constant terms are plain records)
     __shared__ uint32_t rec_ring[QT_WAVES][3][32][4];  // per evaluating wave: three blocks of 16 records (32 x 16 bytes each)
-    if (P.prio) __builtin_amdgcn_s_setprio(2);
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 .. QT_WAVES - 1 evaluate, QT_WAVES stages the tiles
     const unsigned lane = threadIdx.x & 63u;
     const size_t n = (size_t)1 << P.log_n, size = n << P.qdb;
@@ -795,7 +793,6 @@ hipError_t launch_quotient_tiles(const QTRec* recs, const QTPiece* pieces, const
                                  unsigned rate_bits, unsigned qdb, unsigned n_cols, unsigned dbg, hipStream_t st) {
     QTParams P;
     P.dbg = dbg;
-    P.prio = kernel_issue_priority();
     P.recs = recs; P.pieces = pieces; P.streams = streams; P.chunk_tile_off = chunk_tile_off; P.tile_list = tile_list;
     P.lde = lde; P.tab = tab; P.partial = partial; P.log_n = log_n; P.rate_bits = rate_bits; P.qdb = qdb; P.n_cols = n_cols;
     const size_t size = (size_t)1 << (log_n + qdb);

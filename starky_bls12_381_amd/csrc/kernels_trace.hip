@@ -24,6 +24,7 @@ __global__ __launch_bounds__(64) void expand_trace_kernel(const uint32_t* __rest
         if (r >= n_records) return;  // wave-uniform
         const uint32_t* rec = words + offsets[r];
         const uint32_t col = rec[0], row0 = rec[1], run = rec[2], n = rec[3];
+        if (run == 0 || n == 0) continue;  // wave-uniform: a one-row run whose only cell the filler cleared again (TraceLog::set takes the row back)
         // lane -> (limb, row) ONCE per record: a run shorter than the wave packs 64 / run limbs side by side (rows fastest, so a limb's
         // run is one contiguous piece of its column) and steps that many limbs per store; a long run walks the rows of one limb after
         // the other.  (The first version divided by the run length for every cell: 25 of its 40 instructions per store.)

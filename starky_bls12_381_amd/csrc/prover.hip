@@ -263,8 +263,6 @@ static int ensure_plan(Ctx* c, const AirInfo& air, size_t quotient_points) {
     const size_t blocks = (quotient_points + 63) / 64;
     unsigned want = (unsigned)std::min<size_t>(512, std::max<size_t>(1, (8192 + blocks - 1) / blocks));  // FinalExp: 4 chunks 29.8 ms, 8: 29.4, 16: 29.0, 32: 28.9
     if (c->opt_quotient_chunks > 0) want = (unsigned)c->opt_quotient_chunks;
-    else if (const char* e = getenv("STARKHIP_QUOTIENT_CHUNKS"))  // experiments
-        if (*e && atoi(e) > 0) want = (unsigned)atoi(e);
     for (auto& pd : c->plan_cache)
         if (pd->air == air.id && pd->want == want) {
             c->plan = pd.get();
@@ -1152,6 +1150,32 @@ int lde_batch(Ctx* c, const uint64_t* values, size_t n_cols, unsigned log_n, uns
             for (size_t s = 0; s < R; s++)
                 for (size_t k = 0; k < n; k++) lde_out[col * N + k * R + s] = tmp[col * N + s * n + k];
     }
+    return STARKHIP_OK;
+}
+
+// kernel-level test entry: a recorded trace through expand_trace_kernel + zero_cells_kernel, handed back column-major [C][rows]
+int expand_log(Ctx* c, const TraceLog* log, uint64_t* out_colmajor) {
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nw = log->total_words(), nr = log->total_records(), nz = log->total_late_zeros();
+    std::vector<uint32_t> h(nw + nr + nz);
+    size_t at_r = 0, at_z = 0;
+    log->for_each_part([&](const TraceLog& part) {
+        std::copy(part.words.begin(), part.words.end(), h.begin() + part.base);
+        std::copy(part.offsets.begin(), part.offsets.end(), h.begin() + nw + at_r);
+        std::copy(part.late_zeros.begin(), part.late_zeros.end(), h.begin() + nw + nr + at_z);
+        at_r += part.offsets.size();
+        at_z += part.late_zeros.size();
+    });
+    const size_t cells = log->rows * log->cols;
+    HIPCHK(c->values.ensure(cells * 8));
+    HIPCHK(c->staging.ensure(std::max<size_t>(h.size(), 1) * 4));
+    uint32_t* d = c->staging.as<uint32_t>();
+    if (!h.empty()) HIPCHK(hipMemcpyAsync(d, h.data(), h.size() * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemsetAsync(c->values.p, 0, cells * 8, c->st));
+    if (nr) HIPCHK(launch_expand_trace(d, d + nw, nr, c->values.as<gl_t>(), log->rows, c->st));
+    if (nz) HIPCHK(launch_zero_cells(d + nw + nr, nz / 2, c->values.as<gl_t>(), log->rows, c->st));
+    HIPCHK(hipMemcpyAsync(out_colmajor, c->values.p, cells * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(stream_wait(c));
     return STARKHIP_OK;
 }
 

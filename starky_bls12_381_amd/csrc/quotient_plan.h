@@ -183,6 +183,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         }
     }
     if (k != K) throw std::runtime_error("quotient_plan: constraint count mismatch");
+#ifdef STARKHIP_DEBUG
     if (getenv("STARKHIP_PLAN_STATS")) {  // development aid: supergroups by (terms, gates)
         std::vector<uint32_t> n_terms(sg_gates.size(), 0), max_deg(sg_gates.size(), 0);
         for (const Term& t : terms) {
@@ -202,6 +203,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                 for (int d = 0; d < 4; d++)
                     if (hist[b][g][d]) fprintf(stderr, "supergroups with %s terms, %d gates, max degree %d: %zu\n", names[b], g, d, hist[b][g][d]);
     }
+#endif
 
     // ---- pass 2: merge terms with the same (supergroup, monomial) into records; order by (tile, supergroup, monomial)
     // the tile of a monomial is the tile of its first cell; constants go with the supergroup's first gate (or tile 0)

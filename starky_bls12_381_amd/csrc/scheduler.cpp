@@ -151,7 +151,7 @@ void HashService::launch_big(Req* r, bool lane, unsigned group) {
         r->timing->group = group;
         if (e == hipSuccess && r->timing->t0) e = hipEventRecord(r->timing->t0, s);
     }
-    if (e == hipSuccess) e = lane ? launch_leaf_hash_lane(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s, lane_share_)
+    if (e == hipSuccess) e = lane ? launch_leaf_hash_lane(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s)
                                   : launch_leaf_hash(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s);
     if (e == hipSuccess && r->timing && r->timing->t1) e = hipEventRecord(r->timing->t1, s);
     if (e == hipSuccess) e = hipEventRecord(r->done, s);
@@ -244,6 +244,11 @@ void HashService::launch_small(std::vector<Req*>& reqs) {
     }
 }
 
+// Somebody who has STARTED is on the way to the commitment (its upload and LDE are tens of milliseconds): the full bound.  Only jobs that
+// have not started could still join -- a recording under way, or every context busy with a proof past its commitment: the soonest of them
+// needs a recording's end, an upload and an LDE, so waiting much longer than that for a fuller group costs more than the group gains.
+double HashService::big_wait_bound() const { return big_expected_ > 0 ? big_gather_ms_ : std::min(big_gather_ms_, big_queued_wait_ms_); }
+
 void HashService::run() {
     (void)hipSetDevice(device_);
     int least = 0, greatest = 0;
@@ -267,42 +272,20 @@ void HashService::run() {
         // GROUPS: a group waits (bounded) while big proofs that have started have not reached their commitment; a commitment that ends
         // up alone goes out in the quad form.
         bool big_ready = !big_.empty();
-        if (big_lane_ && !lane_share_ && !big_.empty()) {
+        if (big_lane_ && !big_.empty()) {
             const double waited = (now_s() - big_.front()->t_arrive) * 1e3;
             // A group goes out full.  Short of four it goes out when nobody else can join soon -- no big proof is on its way to its
-            // commitment and none is waiting to start -- or when the oldest request has waited `big_gather_ms_`; a lone proof is not held up.
+            // commitment and none is waiting to start -- or when the oldest request has waited its bound; a lone proof is not held up.
+            // (A request joins as soon as its proof has ENQUEUED its LDE: the early launches of a staggered group hash while the late
+            // ones' LDEs still run, which measured better than holding the group until every LDE has run -- profiles/r04_ab_experiments.txt.)
             const bool all_here = big_contexts_ > 0 && (int)big_.size() >= big_contexts_;  // every context's proof is waiting in this queue
-            // A request arrives when its proof has ENQUEUED its LDE, not when the LDE has run: launched then, the lane kernels of a group
-            // start one by one as their LDEs finish -- up to 170 ms apart in the kernel trace, the late LDEs starved by the lane waves that
-            // are already there -- and the group is not side by side.  So a commitment counts once its `ready` event has completed, and
-            // a group is the first four that have (the others keep their place).
-            size_t n_done = 0;
-            for (Req* r : big_) {
-                if (!r->lde_done) {
-                    r->lde_done = !align_groups_ || hipEventQuery(r->ready) == hipSuccess;
-                    (void)hipGetLastError();  // hipErrorNotReady is not an error
-                }
-                n_done += r->lde_done;
-            }
-            const bool nobody_else = (big_expected_ <= 0 && big_queued_ <= 0) || all_here || waited >= big_gather_ms_ || stop_;
-            big_ready = n_done >= BIG_LANE_GROUP || (nobody_else && n_done == big_.size()) || waited >= 2 * big_gather_ms_ || stop_;
-            big_poll_ = !big_ready;  // something is queued whose LDE is still running: look again shortly
+            big_ready = big_.size() >= BIG_LANE_GROUP || (big_expected_ <= 0 && big_queued_ <= 0) || all_here || waited >= big_wait_bound() || stop_;
         }
         const bool take_big = big_ready && (!small_ready || !last_was_big_);
         if (take_big) {
             std::vector<Req*> group;
-            const size_t want = (big_lane_ && !lane_share_) ? BIG_LANE_GROUP : 1u;
-            if (big_lane_ && !lane_share_) {  // the ones whose LDE has run first, in arrival order
-                for (auto it = big_.begin(); it != big_.end() && group.size() < want;) {
-                    if ((*it)->lde_done) {
-                        group.push_back(*it);
-                        it = big_.erase(it);
-                    } else {
-                        ++it;
-                    }
-                }
-            }
-            while (!big_.empty() && group.size() < want && (group.empty() || stop_ || !(big_lane_ && !lane_share_))) {
+            const size_t want = big_lane_ ? BIG_LANE_GROUP : 1u;
+            while (!big_.empty() && group.size() < want) {  // in arrival order
                 group.push_back(big_.front());
                 big_.pop_front();
             }
@@ -310,7 +293,7 @@ void HashService::run() {
             wait_for.swap(running_small_);
             lk.unlock();
             if (policy == 1) drain(wait_for);  // exclusive classes: the small window has left the chip
-            for (Req* r : group) launch_big(r, big_lane_ && (lane_share_ || group.size() >= 2), (unsigned)group.size());
+            for (Req* r : group) launch_big(r, big_lane_ && group.size() >= 2, (unsigned)group.size());
             lk.lock();
             for (Req* r : group) r->state = r->err == hipSuccess ? 1 : 2;
             stats_.big_launches += group.size();
@@ -341,8 +324,7 @@ void HashService::run() {
         // requests are pending but their window is still gathering: wake up when something arrives or its time is up
         double left_ms = 1e9;
         if (!small_.empty()) left_ms = std::min(left_ms, gather_ms - (now_s() - small_.front()->t_arrive) * 1e3);
-        if (big_lane_ && !lane_share_ && !big_.empty()) left_ms = std::min(left_ms, big_gather_ms_ - (now_s() - big_.front()->t_arrive) * 1e3);
-        if (big_poll_ && !big_.empty()) left_ms = std::min(left_ms, 0.25);  // an LDE we are waiting for ends without telling us
+        if (big_lane_ && !big_.empty()) left_ms = std::min(left_ms, big_wait_bound() - (now_s() - big_.front()->t_arrive) * 1e3);
         // (system_clock deadline = pthread_cond_timedwait: ThreadSanitizer of gcc 11 does not know pthread_cond_clockwait, which a
         // steady-clock wait_for uses, and then reports the mutex as still held)
         cv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds((long)(std::max(0.1, left_ms) * 1e3)));
@@ -362,6 +344,20 @@ void HashService::run() {
 
 // ------------------------------------------------------------------------------------------------ pool
 extern void set_thread_trace_threads(int n);  // capi.cpp: trace_threads() of the calling thread (0 = the process-wide setting)
+
+// Relative single-GPU proving cost per AIR, for placing jobs on the pools of a multi-device handle (longest processing time first):
+// FinalExp dominates (the reference's README.md:36-39 has the same ordering on its CPU; here 135 ms per proof in a full pool against
+// 20 / 7 ms per MillerLoop / PairingPrecomp proof).  The same table as the Python plan (parallel.AIR_COST).
+double air_cost(int air) {
+    switch (air) {
+        case STARKHIP_AIR_FINAL_EXP: return 92.0;
+        case STARKHIP_AIR_MILLER_LOOP: return 12.5;
+        case STARKHIP_AIR_PAIRING_PRECOMP: return 4.5;
+        case STARKHIP_AIR_ECC_AGGREGATE: return 3.0;
+        case STARKHIP_AIR_FP12_MUL: return 0.22;
+        default: return 0.01;
+    }
+}
 
 namespace {
 
@@ -383,6 +379,7 @@ struct Job {
     void* own_log = nullptr;          // witness jobs: the recording, freed when proven
     std::vector<uint64_t> own_pis, own_rows;  // own_rows: the toy AIR's generator writes plain rows (it does not record)
     bool big = false;
+    double cost = 0;  // relative proving cost (air_cost): what the job adds to its pool's load until it is done
     // result
     int state = 0;  // 0 queued for generation / proving, 1 running, 2 done
     int rc = STARKHIP_OK;
@@ -442,13 +439,14 @@ struct Pool {
     unsigned gen_threads = 0, trace_threads_cfg = 0, gen_running = 0, cpus = 1;
     size_t big_recordings_started = 0, big_proofs_done = 0;  // under mu
     size_t big_in_gen = 0;  // FinalExp-class witness jobs queued for, or in, their recording (under mu)
+    double load = 0;        // sum of air_cost over the jobs that are not done (under mu): what a multi-device handle balances
+    unsigned big_open = 0;  // FinalExp-class jobs that are not done (under mu)
     unsigned waiters = 0;   // callers inside pool_wait (under mu): pool_destroy lets them leave before it frees anything
     std::map<int, int> idle_big, idle_small;                 // idle contexts by the AIR they proved last (under mu)
     unsigned stream_priority = 0;
     bool warm_device_traces = false;  // warm_up == 2: the caller's traces are column-major device memory: no trace buffers are reserved
-    bool fifo = false;  // STARKHIP_POOL_FIFO=1: small jobs in arrival order (A/B measurements)
     int gen_nice = 10;  // STARKHIP_GEN_NICE: nice value of the generator threads (0: as the rest of the process)
-    size_t gen_ahead = 1;  // STARKHIP_POOL_GEN_AHEAD: FinalExp-class recordings made beyond the ones the contexts can take at once
+    static constexpr size_t gen_ahead = 1;  // FinalExp-class recordings made beyond the ones the contexts can take at once
     bool warm = false;        // contexts reserve the pipeline's AIRs when their threads start (pool_create waits for it)
     unsigned warmed = 0;
     int warm_rc = STARKHIP_OK;
@@ -465,6 +463,8 @@ struct Pool {
         j->rc = rc;
         j->state = 2;
         j->t[4] = now();
+        load = std::max(0.0, load - j->cost);
+        if (j->big && big_open > 0) big_open--;
         cv_done.notify_all();
     }
 
@@ -509,10 +509,10 @@ struct Pool {
                 auto it = q_gen.end();
                 const bool want_big = big_recordings_started < big_ctx.size() + gen_ahead;
                 for (auto k = q_gen.begin(); k != q_gen.end(); ++k)
-                    if ((*k)->big == want_big && (it == q_gen.end() || (!want_big && !fifo && small_rank(*k) > small_rank(*it)))) it = k;
+                    if ((*k)->big == want_big && (it == q_gen.end() || (!want_big && small_rank(*k) > small_rank(*it)))) it = k;
                 if (it == q_gen.end())  // none of the wanted class: the best of the other
                     for (auto k = q_gen.begin(); k != q_gen.end(); ++k)
-                        if (it == q_gen.end() || (want_big && !fifo && small_rank(*k) > small_rank(*it))) it = k;
+                        if (it == q_gen.end() || (want_big && small_rank(*k) > small_rank(*it))) it = k;
                 j = *it;
                 q_gen.erase(it);
                 if (j->big) big_recordings_started++;
@@ -630,8 +630,8 @@ struct Pool {
                             for (auto k = q.begin(); k != q.end(); ++k) {
                                 auto f = idle.find((*k)->air);
                                 if (f != idle.end() && f->second != 0) continue;  // somebody idle knows this AIR better
-                                if (it == q.end() || (!big && !fifo && small_rank(*k) > small_rank(*it))) it = k;  // the longest proof first
-                                if (big || fifo) break;
+                                if (it == q.end() || (!big && small_rank(*k) > small_rank(*it))) it = k;  // the longest proof first
+                                if (big) break;
                             }
                         if (it != q.end()) {
                             j = *it;
@@ -699,17 +699,15 @@ struct Pool {
     }
 };
 
-int pool_create(const starkhip_pool_config_t& cfg_in, Pool** out) {
+int pool_create(const starkhip_pool_config_t& cfg_in, Pool** out, unsigned cpu_share) {
     starkhip_pool_config_t cfg = cfg_in;
-    if (const char* e = getenv("STARKHIP_POOL_PRIORITY"))  // experiments: overrides stream_priority
-        if (*e) cfg.stream_priority = (unsigned)atoi(e);
     std::unique_ptr<Pool> p(new Pool());
     p->device = cfg.device;
     p->t0 = now_s();
     const unsigned n_big = cfg.big_contexts ? cfg.big_contexts : 3, n_small = cfg.small_contexts ? cfg.small_contexts : 16;
     // recording is host work the GPU waits for, but the CPU budget is shared with the prover threads (Fiat-Shamir hashing, kernel
     // launches): a quarter of the budget in recordings at once (at least 3), each on a few threads (trace_threads_for_call)
-    p->cpus = cpu_budget();
+    p->cpus = std::max(1u, cpu_budget() / std::max(1u, cpu_share));  // cpu_share: pools of one multi-device handle share the process's CPUs
     p->gen_threads = cfg.generator_threads ? cfg.generator_threads : std::min(12u, std::max(3u, p->cpus / 4));
     p->trace_threads_cfg = cfg.trace_threads;
     int rc = STARKHIP_OK;
@@ -730,10 +728,6 @@ int pool_create(const starkhip_pool_config_t& cfg_in, Pool** out) {
     bool big_lane = false;
     size_t row_leaves = 64;  // a commitment this small is a handful of waves in either form: the shorter chain costs nothing (FP12Mul: 32 leaves)
     {
-        const char* e = getenv("STARKHIP_POOL_FIFO");
-        p->fifo = e && *e == '1';
-        const char* ga = getenv("STARKHIP_POOL_GEN_AHEAD");
-        if (ga && *ga && atoi(ga) >= 0) p->gen_ahead = (size_t)atoi(ga);
         const char* n = getenv("STARKHIP_GEN_NICE");
         if (n && *n) p->gen_nice = atoi(n);
         const char* bl = getenv("STARKHIP_POOL_BIG_LANE");
@@ -749,14 +743,8 @@ int pool_create(const starkhip_pool_config_t& cfg_in, Pool** out) {
     p->hs->big_lane_ = big_lane;
     p->hs->big_contexts_ = (int)p->big_ctx.size();
     {
-        const char* ls = getenv("STARKHIP_POOL_LANE_SHARE");
-        p->hs->lane_share_ = big_lane && ls && *ls == '1';
-    }
-    {
         const char* lg = getenv("STARKHIP_POOL_LANE_GROUP");
         if (lg && *lg && atoi(lg) >= 2 && atoi(lg) <= 8) p->hs->BIG_LANE_GROUP = (unsigned)atoi(lg);
-        const char* al = getenv("STARKHIP_POOL_ALIGN");  // 1: a commitment joins a group only once its LDE has run (scheduler.h; A/B runs)
-        if (al && *al) p->hs->align_groups_ = *al == '1';
         const char* bg = getenv("STARKHIP_POOL_BIG_GATHER_MS");
         if (bg && *bg && atof(bg) > 0) p->hs->big_gather_ms_ = atof(bg);
     }
@@ -820,6 +808,9 @@ static int pool_enqueue(Pool* p, Job* j, uint64_t* ticket) {
     }
     j->id = p->next_id++;
     j->t[0] = p->now();
+    j->cost = air_cost(j->air);
+    p->load += j->cost;
+    if (j->big) p->big_open++;
     p->jobs[j->id] = j;
     *ticket = j->id;
     if (j->kind == JOB_WITNESS) {
@@ -947,6 +938,17 @@ int pool_reservation(Pool* p, starkhip_pool_reservation_t* out) {
     return STARKHIP_OK;
 }
 
+int pool_host_info(Pool* p, starkhip_pool_host_info_t* out) {
+    memset(out, 0, sizeof *out);
+    out->cpu_budget = p->cpus;
+    out->generator_threads = p->gen_threads;
+    out->trace_threads_big = (unsigned)p->trace_threads_for_call(true);
+    out->trace_threads_small = (unsigned)p->trace_threads_for_call(false);
+    out->prover_threads = (unsigned)(p->big_ctx.size() + p->small_ctx.size());
+    out->device = p->device;
+    return STARKHIP_OK;
+}
+
 int pool_stats(Pool* p, starkhip_pool_stats_t* out) {
     const HashService::Stats s = p->hs->stats();
     out->big_commit_launches = s.big_launches;
@@ -954,6 +956,174 @@ int pool_stats(Pool* p, starkhip_pool_stats_t* out) {
     out->small_commit_requests = s.small_requests;
     out->max_merged_commitments = s.max_merged;
     return STARKHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ many devices, one caller
+// The reference's caller is ONE process that issues its proves from one thread (/root/reference/src/aggregate_proof.rs:304-370,
+// :402-414).  For that caller to use a node of GPUs it needs no process group and no collective -- the proofs are independent
+//  -- only a pool per device and a rule that says which pool a job goes to.  The rule is the Python plan's
+// (signature.plan_batch): longest processing time first -- a job goes to the pool with the least outstanding cost (air_cost), a batch is
+// placed in order of decreasing cost, so every device gets whole FinalExp proofs first and the small proofs fill the gaps.
+struct MultiPool {
+    std::vector<Pool*> pools;
+    std::vector<int> devices;
+    std::mutex mu;  // placement + enqueue are one step: two submitting threads see each other's jobs
+};
+
+static const unsigned TICKET_SLOT_SHIFT = 48;  // ticket of a multi-device handle = (slot + 1) << 48 | the pool's own ticket
+
+int multipool_create(const int* devices, size_t n, const starkhip_pool_config_t& cfg, MultiPool** out) {
+    if (!devices || n == 0 || n > 64) return STARKHIP_ERR_BAD_SHAPE;
+    std::unique_ptr<MultiPool> mp(new MultiPool());
+    // The pools come up side by side (a warmed FinalExp pool allocates 160 GB and builds its plans: seconds per device)
+    std::vector<Pool*> made(n, nullptr);
+    std::vector<int> rcs(n, STARKHIP_OK);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < n; i++)
+        th.emplace_back([&, i] {
+            starkhip_pool_config_t c = cfg;
+            c.device = devices[i];
+            try {
+                rcs[i] = pool_create(c, &made[i], (unsigned)n);
+            } catch (const std::bad_alloc&) {
+                rcs[i] = STARKHIP_ERR_OOM;
+            } catch (const std::exception&) {
+                rcs[i] = STARKHIP_ERR_HIP;
+            }
+        });
+    for (std::thread& t : th) t.join();
+    int rc = STARKHIP_OK;
+    for (size_t i = 0; i < n; i++)
+        if (rcs[i] != STARKHIP_OK && rc == STARKHIP_OK) rc = rcs[i];
+    if (rc != STARKHIP_OK) {
+        for (Pool* p : made)
+            if (p) pool_destroy(p);
+        return rc;
+    }
+    mp->pools = made;
+    mp->devices.assign(devices, devices + n);
+    *out = mp.release();
+    return STARKHIP_OK;
+}
+
+void multipool_destroy(MultiPool* mp) {
+    if (!mp) return;
+    std::vector<std::thread> th;  // every pool runs what it has queued to the end: side by side
+    for (Pool* p : mp->pools) th.emplace_back([p] { pool_destroy(p); });
+    for (std::thread& t : th) t.join();
+    delete mp;
+}
+
+size_t multipool_size(const MultiPool* mp) { return mp->pools.size(); }
+Pool* multipool_pool(MultiPool* mp, size_t slot) { return slot < mp->pools.size() ? mp->pools[slot] : nullptr; }
+int multipool_device(const MultiPool* mp, size_t slot) { return slot < mp->devices.size() ? mp->devices[slot] : -1; }
+
+// the pool a job of `air` goes to (under mp->mu): for a FinalExp-class job the pool with the fewest of them open, then -- and for every
+// other job -- the least outstanding cost, then the lowest slot
+static size_t multipool_pick(MultiPool* mp, int air) {
+    const AirInfo* a = air_get(air);
+    starkhip_config_t cfg;
+    bool big = false;
+    if (a && starkhip_config_for_air((starkhip_air_t)air, &cfg) == STARKHIP_OK) {
+        unsigned log_n = 0;
+        while (((size_t)1 << log_n) < (size_t)a->default_rows) log_n++;
+        big = HashService::is_big(log_n, cfg.rate_bits);
+    }
+    size_t best = 0;
+    double best_load = 0;
+    unsigned best_big = 0;
+    for (size_t i = 0; i < mp->pools.size(); i++) {
+        Pool* p = mp->pools[i];
+        double load;
+        unsigned open;
+        {
+            std::lock_guard<std::mutex> g(p->mu);
+            load = p->load;
+            open = p->big_open;
+        }
+        const bool better = i == 0 || (big && open != best_big ? open < best_big : load < best_load);
+        if (better) {
+            best = i;
+            best_load = load;
+            best_big = open;
+        }
+    }
+    return best;
+}
+
+template <class Submit>
+static int multipool_place(MultiPool* mp, int air, int slot, uint64_t* ticket, Submit submit) {
+    if (!ticket || slot >= (int)mp->pools.size()) return STARKHIP_ERR_BAD_SHAPE;
+    std::lock_guard<std::mutex> g(mp->mu);
+    const size_t at = slot >= 0 ? (size_t)slot : multipool_pick(mp, air);
+    uint64_t inner = 0;
+    const int rc = submit(mp->pools[at], &inner);
+    if (rc == STARKHIP_OK) *ticket = ((uint64_t)(at + 1) << TICKET_SLOT_SHIFT) | inner;
+    return rc;
+}
+
+int multipool_submit(MultiPool* mp, int slot, int air, const starkhip_config_t* cfg, const uint64_t* trace, size_t n_rows, size_t n_cols, int layout,
+                     int on_device, const uint64_t* pis, size_t n_pis, uint64_t pow, uint64_t* ticket) {
+    if (on_device && slot < 0) return STARKHIP_ERR_BAD_SHAPE;  // device memory belongs to one device: the caller says which
+    return multipool_place(mp, air, slot, ticket,
+                           [&](Pool* p, uint64_t* t) { return pool_submit(p, air, cfg, trace, n_rows, n_cols, layout, on_device, pis, n_pis, pow, t); });
+}
+int multipool_submit_columns(MultiPool* mp, int slot, int air, const starkhip_config_t* cfg, const uint64_t* const* columns, size_t n_rows, size_t n_cols,
+                             const uint64_t* pis, size_t n_pis, uint64_t pow, uint64_t* ticket) {
+    return multipool_place(mp, air, slot, ticket,
+                           [&](Pool* p, uint64_t* t) { return pool_submit_columns(p, air, cfg, columns, n_rows, n_cols, pis, n_pis, pow, t); });
+}
+int multipool_submit_compact(MultiPool* mp, int slot, int air, const starkhip_config_t* cfg, const void* log, const uint64_t* pis, size_t n_pis,
+                             uint64_t pow, uint64_t* ticket) {
+    return multipool_place(mp, air, slot, ticket, [&](Pool* p, uint64_t* t) { return pool_submit_compact(p, air, cfg, log, pis, n_pis, pow, t); });
+}
+int multipool_submit_witness(MultiPool* mp, int slot, int air, const starkhip_config_t* cfg, const uint32_t* operands, size_t n_limbs, uint64_t pow,
+                             uint64_t* ticket) {
+    return multipool_place(mp, air, slot, ticket, [&](Pool* p, uint64_t* t) { return pool_submit_witness(p, air, cfg, operands, n_limbs, pow, t); });
+}
+
+// A whole batch of witness jobs, placed longest first (ties in the caller's order).  All or nothing is not promised: tickets[i] == 0 and
+// rcs[i] != OK for a job that was refused; the return value is the first failure.
+int multipool_submit_witness_batch(MultiPool* mp, size_t n, const int* airs, const uint32_t* const* operands, const size_t* n_limbs, uint64_t pow,
+                                   uint64_t* tickets, int* rcs) {
+    if (!airs || !operands || !n_limbs || !tickets) return STARKHIP_ERR_BAD_SHAPE;
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return air_cost(airs[a]) > air_cost(airs[b]); });
+    int first = STARKHIP_OK;
+    for (size_t i : order) {
+        tickets[i] = 0;
+        const int rc = multipool_submit_witness(mp, -1, airs[i], nullptr, operands[i], n_limbs[i], pow, &tickets[i]);
+        if (rcs) rcs[i] = rc;
+        if (rc != STARKHIP_OK && first == STARKHIP_OK) first = rc;
+    }
+    return first;
+}
+
+int multipool_ticket_slot(const MultiPool* mp, uint64_t ticket) {
+    const uint64_t s = ticket >> TICKET_SLOT_SHIFT;
+    return (s >= 1 && s <= mp->pools.size()) ? (int)(s - 1) : -1;
+}
+
+int multipool_wait(MultiPool* mp, uint64_t ticket, uint64_t** proof, size_t* words, starkhip_ticket_info_t* info) {
+    const int slot = multipool_ticket_slot(mp, ticket);
+    if (slot < 0) return STARKHIP_ERR_BAD_SHAPE;
+    return pool_wait(mp->pools[(size_t)slot], ticket & (((uint64_t)1 << TICKET_SLOT_SHIFT) - 1), proof, words, info);
+}
+
+// the plan alone, for tests and for callers that want to see it: slot per job of a batch placed on `n_pools` idle pools
+void plan_lpt(size_t n, const int* airs, size_t n_pools, int* slots) {
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return air_cost(airs[a]) > air_cost(airs[b]); });
+    std::vector<double> load(n_pools, 0.0);
+    for (size_t i : order) {
+        size_t best = 0;
+        for (size_t k = 1; k < n_pools; k++)
+            if (load[k] < load[best]) best = k;
+        slots[i] = (int)best;
+        load[best] += air_cost(airs[i]);
+    }
 }
 
 }  // namespace starkhip

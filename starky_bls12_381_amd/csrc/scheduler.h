@@ -63,18 +63,14 @@ class HashService {
     // beside a MillerLoop latency chain loses less than it would by waiting for it.
     int policy = 0;
     unsigned BIG_LANE_GROUP = 4;  // STARKHIP_POOL_LANE_GROUP: commitments per lane-form group (four fill the chip: two waves of 256 registers per SIMD)
-    double big_gather_ms_ = 1000.0; // lane form: how long a group of big commitments waits at most for others to join (a group of three
+    double big_gather_ms_ = 1000.0; // lane form: how long a group of big commitments waits at most for proofs that HAVE STARTED to join (a group of three
                                     // wastes a quarter of a 350 ms launch: full groups measured 6.46 against 6.2 - 6.3 proofs/s with a 150 ms bound)
+    double big_queued_wait_ms_ = 300.0;  // ... and for jobs that have not started (queued, or being recorded) when nobody who has started is on the
+                                         // way: a recording plus upload plus LDE -- what the soonest of them needs -- not the full bound (a short batch,
+                                         // or the tail of one, would otherwise hold a commitment for several proof lengths)
     void set_big_queued(int n);     // the pool's count of big jobs that have not started yet (queued, or their trace being recorded)
     bool big_lane_ = false;  // big commitments in groups, a group of two or more in the lane form (pools with five or more big contexts;
                              // STARKHIP_POOL_BIG_LANE=0 / 1 overrides)
-    bool align_groups_ = false; // STARKHIP_POOL_ALIGN=1: a big commitment joins a group only once its LDE has RUN on the device, so that the four
-                                // launches start together (default: as soon as it is requested -- its LDE may still be queued).  Measured on one box, 40
-                                // proofs: from operands 6.34 / 6.37 aligned against 6.62 / 6.52, from resident traces 7.33 against 7.25: the lane
-                                // launches are 3 % shorter when they start together, but the early ones of a staggered group hash while the late
-                                // ones' LDEs still run, which is worth more when the traces arrive from the host
-    bool lane_share_ = false;  // STARKHIP_POOL_LANE_SHARE=1: big commitments go out one by one in the lane form, each launch taking half of every
-                               // CU (launch_leaf_hash_lane share_cu): the LDE / quotient workgroups of the other proofs run beside them
     int big_expected_ = 0;   // big proofs that have started and not yet reached their commitment
     int big_queued_ = 0;     // big jobs of the pool that have not started (under mu_)
     int big_contexts_ = 0;   // the pool's number of big contexts (set once): when all of them wait here, nobody else can come
@@ -97,10 +93,10 @@ class HashService {
         int state = 0;  // 0 queued, 1 launched, 2 failed
         hipError_t err = hipSuccess;
         double t_arrive = 0;
-        bool lde_done = false;  // its `ready` event has completed (big commitments: run())
         Timing* timing = nullptr;
     };
     void run();
+    double big_wait_bound() const;  // under mu_: how long the oldest queued big commitment waits at most for its group to fill
     void launch_big(Req* r, bool lane, unsigned group);
     void launch_small(std::vector<Req*>& reqs);
     void drain(std::vector<hipEvent_t>& evs);
@@ -117,7 +113,7 @@ class HashService {
     std::condition_variable cv_, cv_done_;
     std::deque<Req*> big_, small_;
     int announced_ = 0;  // small proofs that have started and not yet asked for their commitment
-    bool stop_ = false, last_was_big_ = false, big_poll_ = false;
+    bool stop_ = false, last_was_big_ = false;
     std::vector<hipEvent_t> running_big_, running_small_;  // done events of launches that may still be executing
     Stats stats_;
     std::thread th_;

@@ -68,6 +68,18 @@ def max_over_ranks(dist, value, device="cpu"):
     return float(t.item())
 
 
+def gather_over_ranks(dist, values, device="cpu"):
+    """Every rank's list of floats, on every rank: [[rank 0's values], [rank 1's], ...] (one all_gather of a small tensor)."""
+    vals = [float(v) for v in values]
+    if dist is None:
+        return [vals]
+    import torch
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o.cpu()] for o in out]
+
+
 def sum_over_ranks(dist, value, device="cpu"):
     if dist is None:
         return float(value)

@@ -226,6 +226,49 @@ def test_two_contexts_prove_concurrently_and_agree_with_sequential(prover):
         assert np.array_equal(got[i], want[i])
 
 
+def test_a_log_with_empty_records_and_late_zeros_expands_to_the_dense_trace(prover):
+    """The recorder's set-then-clear corner cases on the device (kernels_trace.hip): a one-row run that was cleared again stays in
+    the log as a record of ZERO rows -- the expansion's lane -> (limb, row) mapping divides by the run length and must skip it -- and a
+    clear inside a longer run is a late zero.  The FP12Mul trace is replayed cell by cell through the recorder with both idioms put
+    on columns that are zero in the trace; the device's expansion must equal the host replay and the matrix the writes stand for.
+    The generators' own logs of all five AIRs go the same way (their proofs are compared elsewhere; here the cells)."""
+    dense, _ = S.trace_fp12_mul(random_fp12(0x5EED2210), random_fp12(0x5EED2211))
+    rows, cols = dense.shape
+    zero_cols = np.flatnonzero(~dense.any(axis=0))
+    c0, c1, c2 = (int(c) for c in zero_cols[:3])
+    writes = [(5, c0, 1), (5, c0, 0)]                                   # empty record, first in the log
+    writes += [(r, c1, 1) for r in range(2, 9)] + [(8, c1, 0), (7, c1, 0), (4, c1, 0)]  # shrinks twice, then a late zero
+    r_idx, c_idx = np.nonzero(dense)
+    order = np.lexsort((r_idx, c_idx))  # column by column, rows ascending: runs are extended as the generators extend them
+    writes += [(int(r), int(c), int(dense[r, c])) for r, c in zip(r_idx[order], c_idx[order])]
+    writes += [(0, c2, 9), (0, c2, 0)]                                  # another empty record, last in the log
+    log = S.trace_from_writes(rows, cols, writes)
+    assert log.overwrites() == (2, 1)
+    expected = dense.copy()
+    expected[2:7, c1] = 1
+    expected[4, c1] = 0
+    host, conflicts = log.expand()
+    assert conflicts == 0 and np.array_equal(host, expected)
+    assert np.array_equal(prover.expand_trace(log), expected)
+    # a long run (>= 64 rows) taken back row by row to nothing, and records of many limbs beside it
+    rows2, cols2 = 256, 40
+    w2 = [(r, 3, 1) for r in range(100)] + [(r, 3, 0) for r in range(99, -1, -1)]
+    w2 += [(r, c, 1 + c) for r in range(10, 200) for c in range(8, 30)]
+    log2 = S.trace_from_writes(rows2, cols2, w2)
+    want2 = np.zeros((rows2, cols2), dtype=np.uint64)
+    for r, c, v in w2:
+        want2[r, c] = v
+    assert log2.overwrites()[0] == 1
+    assert np.array_equal(prover.expand_trace(log2), want2)
+    from bls_util import fp_arr
+    b = _bls()
+    hm = (fp_arr(b["hm_x1"], b["hm_x2"]), fp_arr(b["hm_y1"], b["hm_y2"]), fp_arr(b["hm_z1"], b["hm_z2"]))
+    for fn, args in [(S.trace_fp12_mul, (random_fp12(0x5EED2212), random_fp12(0x5EED2213))), (S.trace_pairing_precomp, hm)]:
+        d, _ = fn(*args)
+        c, _ = fn(*args, compact=True)
+        assert np.array_equal(prover.expand_trace(c), d)
+
+
 def test_one_compact_trace_is_proven_by_several_contexts_at_once_and_recorded_on_threads(prover):
     """A finished trace log is immutable: four contexts on four host threads prove the same one concurrently (the bench's
     shape), and four threads record different traces at the same time (recording is armed per thread)."""

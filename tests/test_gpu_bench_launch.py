@@ -25,3 +25,46 @@ def test_bench_gpus_2_starts_itself_and_prints_one_line_for_two_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
     assert d["timed_proofs_verified"] == 2 and "REHEARSAL" in d["data"]
     assert d["config"]["parallelism"] == "proof-parallel x2"
+    assert d["per_rank"] and len(d["per_rank"]) == 2 and all(r["proofs_per_s"] > 0 and r["cpu_budget"] >= 1 for r in d["per_rank"])
+    lo, hi = d["per_rank_min_max"]
+    assert lo <= hi and lo > 0
+
+
+def _bench(args, env_extra=None, prefix=()):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env.update(env_extra or {})
+    r = subprocess.run(list(prefix) + [sys.executable, os.path.join(ROOT, "bench.py")] + [str(a) for a in args], capture_output=True, text=True, timeout=900,
+                       env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_devices_in_process_prints_the_same_line_from_one_process():
+    """`bench.py --devices-in-process 2`: the reference's single-process caller shape -- one process, a pool per device behind
+    starkhip_multipool_* -- rehearsed with both pools on the one card.  Same JSON line, both pools prove, every timed proof verifies and
+    equals the proof made alone."""
+    d = _bench(["--devices-in-process", 2, "--steps", 4, "--warmup", 1, "--inflight", 2, "--no-cpu-baseline", "--no-solo"], {"STARKHIP_BENCH_REHEARSE": "1"})
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and "REHEARSAL" in d["data"]
+    assert "ONE process" in d["config"]["parallelism"] and "starkhip_multipool" in d["config"]["driver"]
+    assert d["timed_proofs_verified"] == 4                      # 2 in flight x 2 pools: the last proof of each of the four inputs
+    assert len(d["host"]["pools"]) == 2 and all(p["cpu_budget"] >= 1 for p in d["host"]["pools"])
+    assert d["host"]["pools"][0]["cpu_budget"] <= max(1, d["host"]["cpu_budget_process"] // 2)   # the process's CPUs are split between its pools
+    assert d["roofline"]["frac"] > 0 and d["per_rank"] is None
+
+
+def test_bench_under_a_two_cpu_mask_reports_the_budget_and_still_verifies():
+    """A host with two CPUs for the process (plain `taskset` on the command -- NOT under rocprofv3): the line must say so (cpus_granted, the
+    pool's budget and threads, CPU-seconds per proof) and the proofs must still verify and match; the rate is whatever two CPUs feed."""
+    cpus = sorted(os.sched_getaffinity(0))
+    if len(cpus) < 2:
+        pytest.skip("fewer than two CPUs")
+    mask = ",".join(str(c) for c in cpus[:2])
+    d = _bench(["--steps", 16, "--warmup", 1, "--no-cpu-baseline", "--no-boundary", "--no-solo"], prefix=("taskset", "-c", mask))
+    h = d["host"]
+    assert h["cpus_granted"] == 2 and h["cpu_budget_process"] == 2 and h["pools"][0]["cpu_budget"] == 2
+    assert h["pools"][0]["generator_threads"] >= 1 and h["pools"][0]["trace_threads_big"] == 1     # 3/4 of two CPUs: one thread per FinalExp recording
+    assert 0.05 < h["cpu_seconds_per_proof"] < 2.0
+    assert d["timed_proofs_verified"] == 8 and d["oracle_digest_match"] is True
+    assert d["value"] > 0.5 and d["value_steady_state"] is None    # 16 proofs are two waves of the eight-context pool: no middle to speak of

@@ -189,6 +189,67 @@ def test_final_exp_in_lane_form_groups_match_the_oracle_digest(monkeypatch):
     assert stats["big_commit_launches"] == 8
 
 
+def test_failures_of_final_exp_class_jobs_inside_lane_groups():
+    """scheduler.cpp's announce / withdraw / group logic for the 8192-row class with REAL kernels (the sanitizer harness runs it against
+    a fake device): a pool of five big contexts sends FinalExp-class commitments out in lane-form groups that wait for proofs which
+    have started.  (FinalExp itself -- degree 5 at blow-up 4, quotient_degree_factor == blow-up -- has no quotient chunk that must
+    vanish, so like starky's prove() it cannot notice a broken trace; the 8192-row AIR that can is ECCAgg, degree 4: its commitment
+    joins the same groups.)
+      1. two proofs on five contexts are not held for a group that cannot fill (the scheduler's bound for jobs that have not started);
+      2. three good FinalExp jobs + one whose public input is not canonical: that one fails BEFORE its commitment (ERR_BAD_SHAPE) and
+         withdraws; the group of three goes out without waiting its bound for it;
+      3. four good FinalExp jobs + an ECCAgg job with a changed trace cell: it fails AFTER its commitment (the quotient's top chunk:
+         ERR_QUOTIENT_NOT_DIVISIBLE), having been a member of a group;
+    every good proof hashes to the CPU oracle's digest of the benchmark's first seeded input, and the pool proves on afterwards."""
+    from test_ecc_aggregate_cpu import pack, reference_vector
+    air = S.AIR_FINAL_EXP
+    cfg = S.StarkConfig.for_air(air)
+    want = open(os.path.join(GOLDEN, "final_exp_seed_5eed0001_proof.sha256")).read().split()[0]
+    x = random_fp12(0x5EED0001)
+    compact, pis = S.trace_final_exp(x, compact=True)
+    pis_bad = pis.copy()
+    pis_bad[3] = np.uint64(S.P)   # not a canonical field element
+    pts, bits, _ = reference_vector()
+    ecc_cfg = S.StarkConfig.for_air(S.AIR_ECC_AGGREGATE)
+    ecc_t, ecc_pis = S.trace_ecc_aggregate(*pack(pts, bits))
+    ecc_bad = ecc_t.copy()
+    ecc_bad[4000, 1200] = (int(ecc_bad[4000, 1200]) + 1) % S.P
+    sha = lambda pr: hashlib.sha256(pr.tobytes()).hexdigest()  # noqa: E731
+    pool = S.ProofPool(0, big_contexts=5, small_contexts=1, generator_threads=3, warm_up=1)
+    try:
+        # 1.
+        got = [pool.wait(t) for t in [pool.submit_witness(air, x) for _ in range(2)]]
+        assert [sha(p) for p, _ in got] == [want] * 2
+        assert all(i["timeline_s"][4] - i["timeline_s"][0] < 1.0 for _, i in got), [i["timeline_s"] for _, i in got]
+        # 2.
+        t_good = [pool.submit(air, cfg, compact, pis) for _ in range(3)]
+        t_bad = pool.submit(air, cfg, compact, pis_bad)
+        with pytest.raises(S.StarkhipError) as e:
+            pool.wait(t_bad)
+        assert e.value.code == S.ERR_BAD_SHAPE
+        got = [pool.wait(t) for t in t_good]
+        assert [sha(p) for p, _ in got] == [want] * 3
+        assert {i["leaf_hash_form"] for _, i in got} == {"lane"} and {i["leaf_hash_group"] for _, i in got} == {3}
+        assert all(i["timeline_s"][4] - i["timeline_s"][3] < 1.0 for _, i in got), [i["timeline_s"] for _, i in got]   # nobody waited 1 s for the one that withdrew
+        # 3.
+        t_ecc = pool.submit(S.AIR_ECC_AGGREGATE, ecc_cfg, ecc_bad, ecc_pis)
+        t_good = [pool.submit(air, cfg, compact, pis) for _ in range(4)]
+        with pytest.raises(S.StarkhipError) as e:
+            pool.wait(t_ecc)
+        assert e.value.code == S.ERR_QUOTIENT_NOT_DIVISIBLE
+        got = [pool.wait(t) for t in t_good]
+        assert [sha(p) for p, _ in got] == [want] * 4
+        assert all(i["timeline_s"][4] - i["timeline_s"][3] < 1.5 for _, i in got)
+        stats = pool.stats()
+        assert stats["big_commit_launches"] == 2 + 3 + 5   # the ECCAgg job reached its commitment, the bad-input job did not
+        # the pool goes on: the same ECCAgg statement with its real trace, and one more FinalExp proof
+        ok = pool.wait(pool.submit(S.AIR_ECC_AGGREGATE, ecc_cfg, ecc_t, ecc_pis))[0]
+        S.verify_stark_proof(S.AIR_ECC_AGGREGATE, ecc_cfg, ok)
+        assert sha(pool.wait(pool.submit_witness(air, x))[0]) == want
+    finally:
+        pool.close()
+
+
 def _signature_points(count, seed):
     """`count` different valid (pk, H(m), signature) triples on the curve (signature.synthetic_signatures over the reference's vector)."""
     from bls_util import native_vectors

@@ -89,3 +89,66 @@ def test_batch_of_eight_different_signatures_end_to_end():
         digests.add(bytes(six["final_exp"][1][16:80]))
     assert len(digests) == batch   # eight different FinalExp proofs (different trace caps)
     assert stats["wall_s"] < stats["generate_s"] + stats["prove_s"]   # generation overlapped proving
+
+
+def _demo(*args, timeout=900):
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "build", "signature_demo")
+    if not os.path.exists(exe):
+        pytest.skip("build/signature_demo not built (make demo)")
+    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_one_process_two_pools_gives_the_one_pool_proofs():
+    """starkhip_multipool_*: the reference's single-process caller (src/aggregate_proof.rs:304-370) on several devices.  On the
+    one-GPU box the two "devices" are two pools on the same card (`--devices 0,0`): a batch of eight different signatures = 48
+    proofs, every one verified, linked and bound to its statement, and BYTE-EQUAL to the proofs one pool makes of the same
+    operands (proof bytes do not depend on the device, pool or context); both pools proved FinalExp proofs -- four each."""
+    import os
+    ops = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "signature_operands_8.bin")
+    common = ["--batch", 8, "--operands", ops, "--steps", 1, "--warmup", 0, "--digests"]
+    one = _demo(*common, "--big", 6, "--small", 12)
+    two = _demo(*common, "--devices", "0,0", "--big", 3, "--small", 6)
+    assert one["pools"] == 1 and two["pools"] == 2
+    for r in (one, two):
+        assert r["proofs_verified_after_timing"] == 48 and r["signatures_valid_linked_bound"] == 8 and len(r["proof_digests"]) == 48
+    assert one["proof_digests"] == two["proof_digests"]
+    assert len(set(one["proof_digests"])) == 48
+    assert [p["big"] for p in two["commit_launches_per_pool"]] == [4, 4]          # FinalExp-class proofs: longest first, spread evenly
+    assert all(p["small_requests"] > 0 for p in two["commit_launches_per_pool"])
+    assert two["hw_queues_late"] == 0   # a process of its own: the library's GPU_MAX_HW_QUEUES was in time
+
+
+def test_multi_device_handle_from_python_places_jobs_and_matches_single_pool_bytes():
+    """The same handle through ctypes: a batch of one signature's six jobs on THREE pools of the one card -- the plan is
+    starkhip_plan_lpt's (FinalExp alone on slot 0, the two MillerLoops on slots 1 and 2, the rest behind the shorter queue) --,
+    jobs named to a slot stay there, and the proofs equal those of a plain pool."""
+    _, pk, hm, sig = _bls_points()
+    jobs, natives = A.signature_jobs(pk, hm, sig)
+    batch = [(A.JOB_AIR[name],) + tuple(jobs[name][1]) for name in A.JOB_ORDER]
+    plan = S.api.plan_lpt([b[0] for b in batch], 3)
+    ref = S.ProofPool(0, big_contexts=1, small_contexts=4, warm_up=1)
+    try:
+        want = [ref.wait(t)[0] for t in ref.submit_witness_batch(batch)]
+    finally:
+        ref.close()
+    mp = S.ProofPool(big_contexts=1, small_contexts=2, warm_up=1, devices=[0, 0, 0])
+    try:
+        assert mp.n_pools == 3
+        tickets = mp.submit_witness_batch(batch)
+        assert [mp.slot_of(t) for t in tickets] == plan
+        assert plan[A.JOB_ORDER.index("final_exp")] == 0 and sorted(plan[A.JOB_ORDER.index(n)] for n in ("ml1", "ml2")) == [1, 2]
+        pinned = mp.submit_witness(batch[0][0], *batch[0][1:], slot=2)
+        assert mp.slot_of(pinned) == 2
+        got = [mp.wait(t)[0] for t in tickets]
+        assert np.array_equal(mp.wait(pinned)[0], want[0])
+        per_pool = mp.stats(per_pool=True)
+    finally:
+        mp.close()
+    for name, a, b in zip(A.JOB_ORDER, got, want):
+        assert np.array_equal(a, b), name
+    assert per_pool[0]["big_commit_launches"] == 1 and per_pool[1]["big_commit_launches"] == 0

@@ -89,3 +89,25 @@ def test_recording_is_one_generator_call_per_log_and_per_thread():
     out, words = C.POINTER(C.c_uint64)(), C.c_size_t()
     assert S.lib.starkhip_prove_compact(None, S.AIR_FP12_MUL, C.byref(cfg), c._h, S.api._p64(cpis), cpis.size, S.POW_SEARCH, C.byref(out),
                                         C.byref(words)) == S.ERR_NO_DEVICE
+
+
+def test_a_one_row_run_that_is_cleared_again_leaves_an_empty_record():
+    """TraceLog::set takes the row back from the run that just wrote it ("selector = 1 on rows a..b", then "selector(b) = 0"): a ONE-row
+    run ends up with zero rows and its record stays in the log.  Such a record stands for no cell -- the host replay and the device
+    expansion (kernels_trace.hip: the lane -> (limb, row) mapping divides by the run length) must skip it."""
+    rows, cols = 8, 3
+    writes = [(r, 0, 1 + r) for r in range(rows)]
+    writes += [(2, 1, 1), (2, 1, 0)]                 # one-row run, cleared again: empty record
+    writes += [(r, 2, 1) for r in range(3, 7)] + [(6, 2, 0)]   # "rows 3..6", then the last one cleared: the run shrinks to 3..5
+    writes += [(r, 1, 7) for r in range(4, 8)] + [(5, 1, 0)]   # a clear inside the latest run: a late zero
+    log = S.trace_from_writes(rows, cols, writes)
+    assert log.overwrites() == (1, 1)
+    dense = np.zeros((rows, cols), dtype=np.uint64)
+    for r, c, v in writes:
+        dense[r, c] = v
+    got, conflicts = log.expand()
+    assert conflicts == 0 and np.array_equal(got, dense)
+    with pytest.raises(S.StarkhipError):
+        S.trace_from_writes(rows, cols, [(rows, 0, 1)])       # outside the trace
+    with pytest.raises(S.StarkhipError):
+        S.trace_from_writes(rows, cols, [(0, 0, 1 << 32)])    # a cell of more than 32 bits

@@ -8,6 +8,10 @@
 //                                       BASELINE configs[4]: B different signatures = 6 B proofs per step on the pool; prints
 //                                       signatures/s with trace generation and natives INSIDE the timed region; afterwards every
 //                                       proof of the last step is verified and checked against its statement
+//   signature_demo --batch 8 --devices 0,1,2,3,4,5,6,7
+//                                       the same from ONE process on several GPUs (starkhip_multipool_*: a pool per listed device --
+//                                       an ordinal may repeat --, jobs placed longest first); --digests adds a digest of every proof
+//                                       of the last step (the bytes do not depend on which device, pool or context made a proof)
 // Exit code 0 = every proof verified, the public inputs chain, and final_exponentiate(ml1 * ml2) == 1 for every signature.
 // Operand file: B records of 120 little-endian u32 limbs -- pk x, y (12 each), H(m) x, y (24 each), signature x, y (24 each);
 // Z = (1, 0) is implied (tools/make_signature_operands.py derives them from the reference vector).  Build: make demo
@@ -15,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 
 #include "starkhip_driver.hpp"
@@ -67,7 +72,8 @@ static double seconds_since(std::chrono::steady_clock::time_point t0) { return s
 
 int main(int argc, char** argv) {
     size_t batch = 0, steps = 3, warmup = 1, pipeline = 1;
-    bool use_pool = false, timeline = false;
+    bool use_pool = false, timeline = false, digests = false;
+    std::vector<int> devices;
     const char* operands = nullptr;
     starkhip_pool_config_t cfg;
     memset(&cfg, 0, sizeof cfg);
@@ -92,6 +98,15 @@ int main(int argc, char** argv) {
         else if (a == "--warm") cfg.warm_up = (unsigned)strtoul(val(), nullptr, 0);
         else if (a == "--gather-ms") cfg.gather_ms = (float)atof(val());
         else if (a == "--device") cfg.device = atoi(val());
+        else if (a == "--devices") {  // one pool per listed ordinal, in one process
+            use_pool = true;
+            for (const char* p = val(); *p;) {
+                char* end = nullptr;
+                devices.push_back((int)strtol(p, &end, 10));
+                if (end == p) { fprintf(stderr, "signature_demo: --devices wants a comma-separated list of ordinals\n"); return 2; }
+                p = *end == ',' ? end + 1 : end;
+            }
+        } else if (a == "--digests") digests = true;
         else {
             fprintf(stderr, "signature_demo: unknown option %s\n", a.c_str());
             return 2;
@@ -124,7 +139,8 @@ int main(int argc, char** argv) {
             if (!cfg.small_contexts) cfg.small_contexts = 12;
         }
         starkhip_driver::tune_host_allocator();
-        starkhip_driver::Pool pool(cfg);
+        std::unique_ptr<starkhip_driver::Pool> pool_owner(devices.empty() ? new starkhip_driver::Pool(cfg) : new starkhip_driver::Pool(devices, cfg));
+        starkhip_driver::Pool& pool = *pool_owner;
         std::vector<SignatureProofs> proofs;
         double total = 0, best = 1e30;
         std::string step_ms;
@@ -201,13 +217,33 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        // FNV-1a over each proof's words, and which device slot proved it
+        std::string digest_json, per_device_json;
+        if (digests) {
+            for (size_t i = 0; i < proofs.size(); i++) {
+                const starkhip_driver::Proof* ps[] = {&proofs[i].pp1, &proofs[i].ml1, &proofs[i].pp2, &proofs[i].ml2, &proofs[i].fp12_mul, &proofs[i].final_exp};
+                for (int k = 0; k < 6; k++) {
+                    uint64_t h = 0xcbf29ce484222325ULL;
+                    for (size_t w = 0; w < ps[k]->words.size(); w++) h = (h ^ ps[k]->words[w]) * 0x100000001b3ULL;
+                    char buf[40];
+                    snprintf(buf, sizeof buf, "%s\"%016llx\"", digest_json.empty() ? "" : ", ", (unsigned long long)h);
+                    digest_json += buf;
+                }
+            }
+        }
+        for (size_t k = 0; k < pool.devices(); k++) {
+            const starkhip_pool_stats_t one = pool.stats((int)k);
+            char buf[96];
+            snprintf(buf, sizeof buf, "%s{\"big\": %lu, \"small_requests\": %lu}", k ? ", " : "", one.big_commit_launches, one.small_commit_requests);
+            per_device_json += buf;
+        }
         const starkhip_pool_stats_t st = pool.stats();
         printf("{\"metric\": \"BLS signature checks/s, end to end from compiled host code (operands -> natives -> trace generation -> 6 STARK proofs each)\", "
                "\"value\": %.4f, \"unit\": \"signatures/s\", \"batch\": %zu, \"steps\": %zu, \"warmup\": %zu, \"ms_per_step\": %.1f, \"best_ms\": %.1f, \"step_ms\": [%s], "
                "\"batches_in_flight\": %zu, \"proofs_per_step\": %zu, \"proofs_verified_after_timing\": %zu, \"verify_s\": %.2f, \"signatures_valid_linked_bound\": %zu, "
-               "\"commit_launches\": {\"big\": %lu, \"small_merged\": %lu, \"small_requests\": %lu, \"max_merged\": %lu}, \"operands\": \"%s\"}\n",
+               "\"commit_launches\": {\"big\": %lu, \"small_merged\": %lu, \"small_requests\": %lu, \"max_merged\": %lu}, \"pools\": %zu, \"commit_launches_per_pool\": [%s], \"hw_queues_late\": %d, \"proof_digests\": [%s], \"operands\": \"%s\"}\n",
                batch / per_step, batch, steps, warmup, per_step * 1e3, best * 1e3, step_ms.c_str(), pipeline, 6 * batch, verified, seconds_since(tv), ok, st.big_commit_launches,
-               st.small_commit_launches, st.small_commit_requests, st.max_merged_commitments, operands ? operands : "reference vector (src/native.rs:1480-1498)");
+               st.small_commit_launches, st.small_commit_requests, st.max_merged_commitments, pool.devices(), per_device_json.c_str(), starkhip_hw_queues_status(), digest_json.c_str(), operands ? operands : "reference vector (src/native.rs:1480-1498)");
         return verified == 6 * batch && ok == batch ? 0 : 1;
     } catch (const std::exception& e) {
         fprintf(stderr, "signature_demo: %s\n", e.what());
