@@ -50,6 +50,11 @@ size_t lde_v2_oh_words(unsigned log_n, unsigned rate_bits);  // closed-form tabl
 hipError_t lde_v2_upload_tables(unsigned log_n, unsigned rate_bits, gl_t* d_tw_fwd, gl_t* d_tw_inv, gl_t* d_cs, gl_t* d_oh, hipStream_t st);
 hipError_t launch_lde_columns_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, size_t n_cols, unsigned log_n, unsigned rate_bits,
                                  const gl_t* tw_fwd, const gl_t* tw_inv, const gl_t* cs, const gl_t* oh, int from_coeffs, hipStream_t st);
+// 2^13 rows, values -> LDE only (no coefficient output): the wave-resident kernel (kernels_lde.hip; tools/lde_wave_model.py)
+bool lde_wave_supported(unsigned log_n);
+size_t lde_wave_table_words(unsigned rate_bits);
+hipError_t lde_wave_upload_tables(unsigned rate_bits, gl_t* d_tab, hipStream_t st);
+hipError_t launch_lde_columns_wave(const gl_t* values, gl_t* lde, size_t n_cols, unsigned rate_bits, const gl_t* d_tab, const gl_t* oh, hipStream_t st);
 hipError_t launch_ntt_global(gl_t* data, size_t n_vecs, size_t vec_stride, unsigned log_n, const gl_t* tw, unsigned tw_log,
                              const gl_t* pre_scale, const gl_t* post_scale, gl_t final_mul, hipStream_t st);
 

@@ -343,6 +343,255 @@ __global__ __launch_bounds__(LdePlan<LOGN>::THREADS, 4) void lde_columns_v2_kern
     }
 }
 
+// ---------------------------------------------------------------- wave-resident transforms for 2^13 rows
+// The kernel the FinalExp-class traces take (tools/lde_wave_model.py is its executable specification: every index map, LDS address
+// function and table below is checked there against a plain NTT and against the LDS banking rules).
+//
+// lde_columns_v2_kernel<13> moves a column through the WHOLE workgroup's LDS image three times per transform, each time between two
+// s_barriers of eight waves: thirty barriers per column, waves of a workgroup in lock step, and the 17/16 padding conflict-free for the
+// first exchange only.  Here a column's 13 index bits are split 4 (registers) + 6 (lanes) + 3 (waves) so that
+//   * only ONE exchange per transform crosses waves (it has to: the three wave bits must reach the registers once), and its image is
+//     laid out by READER -- after it every wave reads its own eighth of the LDS only;
+//   * the other exchange moves bits between registers and LANES: it stays inside the wave's own eighth, needs no barrier, and waves run
+//     at their own pace between the two barriers of the crossing exchange;
+//   * the last index bit is a lane bit (lane ^ 32): v_permlane32_swap_b32 pairs the registers of the two half-waves, no LDS at all;
+//   * the inverse transform ENDS in the layout the forward transforms START from, so a coefficient never leaves the thread that made
+//     it: the first coset is transformed from registers, the others re-read the thread's own sixteen words (thread-major scratch in
+//     the column's last coset slot, raw representatives, no canonicalisation);
+//   * every LDS access pattern is conflict-free by construction (unit strides, or a 5-bit XOR swizzle inside 32-word rows);
+//   * n^-1 is folded into the coset table.
+// Two LDS exchanges and two barriers per transform instead of three and six; the forward transform's stores are two runs of 32
+// consecutive points per wave and register (256 B each).
+struct LdeWaveTables {
+    const gl_t* tw1_inv;  // [16][512]  w_n^(-j2 k1), j2 = thread
+    const gl_t* tw1_fwd;  // [16][512]  w_n^(+j2 k1), j2 = the low nine bits of the coefficient index a thread holds
+    const gl_t* tw2_inv;  // [16][32]   w_512^(-b k2)
+    const gl_t* tw2_fwd;  // [16][32]
+    const gl_t* cs;       // [2^rate][16][512]  n^-1 (7 w_N^s)^c, c = the coefficient register i of thread t holds
+};
+static constexpr int LDE_WAVE_LOGN = 13;
+
+template <bool INV>
+__device__ __forceinline__ void lde_dft16(gl_t (&v)[16]) {
+    SubNtts<16, INV, 0>::run(v);
+    unscramble<16>(v);
+}
+// LDS operations of ONE wave execute in order, so a wave's reads see its own earlier writes; what has to be kept is the compiler's order
+__device__ __forceinline__ void lde_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// exponent E of the radix-2 step's twiddle 2^E = w_32^(+-k4): w_64 = 2^39, so w_32 = 2^78 and its inverse 2^114
+template <bool INV>
+constexpr int lde_w32_exp(int k4) { return ((INV ? 114 : 78) * k4) % 192; }
+
+// (A, B) <- (A + B', A - B') where B' = B * 2^E was formed WITHOUT its sign (2^96 = -1): E >= 96 swaps the outputs.  The element in B
+// has k4 = K_LO in the lower half-wave and K_HI in the upper one.
+template <bool INV, int K_LO, int K_HI>
+__device__ __forceinline__ void lde_last_bfly(gl_t& A, gl_t& B, bool hi) {
+    constexpr bool NEG_LO = lde_w32_exp<INV>(K_LO) >= 96, NEG_HI = lde_w32_exp<INV>(K_HI) >= 96;
+    const gl_t bc = gl_canon(B);
+    const gl_t s = gl_add_nc(A, bc), d = gl_sub_nc(A, bc);
+    if constexpr (NEG_LO == NEG_HI) {
+        A = NEG_LO ? d : s;
+        B = NEG_LO ? s : d;
+    } else {
+        const bool neg = hi ? NEG_HI : NEG_LO;
+        A = neg ? d : s;
+        B = neg ? s : d;
+    }
+}
+template <bool INV, int K>
+__device__ __forceinline__ void lde_w32_twiddles(gl_t (&v)[16]) {  // v[k4] *= |w_32^(+-k4)| (sign left to lde_last_bfly)
+    v[K] = gl_mul_pow2_nn(v[K], lde_w32_exp<INV>(K) % 96);
+    if constexpr (K + 1 < 16) lde_w32_twiddles<INV, K + 1>(v);
+}
+// rows 2, 3 of `a` <-> rows 0, 1 of `b` (one row = 16 lanes): afterwards the lower half-wave holds (own a, the upper half's a) in
+// (a, b), the upper half-wave (the lower half's b, own b)
+__device__ __forceinline__ void lde_swap_halves(gl_t& a, gl_t& b) {
+    // (the builtin, not inline assembly: v_permlane32_swap_b32 needs two wait states after a VALU write of its operands, which the
+    // compiler's hazard recogniser inserts for the builtin and does not look for inside an asm block)
+    const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)a, (uint32_t)b, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(a >> 32), (uint32_t)(b >> 32), false, false);
+    a = ((uint64_t)hi[0] << 32) | lo[0];
+    b = ((uint64_t)hi[1] << 32) | lo[1];
+}
+
+__global__ __launch_bounds__(512, 4) void lde_columns_wave_kernel(const gl_t* values, gl_t* lde, unsigned n_cols, unsigned rate_bits, LdeWaveTables tb,
+                                                                   const gl_t* __restrict__ oh) { STARKHIP_PRIO_ENTRY
+    constexpr int n = 1 << LDE_WAVE_LOGN, T = n / 16;
+    extern __shared__ gl_t lds_all[];  // 8192 words, no padding
+    __shared__ unsigned cls[3];
+    if (threadIdx.x == 0) cls[0] = cls[1] = 0;
+    const unsigned t = threadIdx.x, w = t >> 6, l = t & 63;
+    const bool hi = l >= 32;
+    const unsigned col = blockIdx.x;
+    const unsigned n_cosets = 1u << rate_bits;
+    const char* in_base = (const char*)(values + (size_t)col * n);
+    char* out_base = (char*)(lde + (size_t)col * n_cosets * n);
+    const uint32_t t8 = t * 8u;
+    gl_t v[16], tw[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = *(const gl_t*)(in_base + t8 + (uint32_t)(i * T * 8));
+#pragma unroll
+    for (int k = 1; k < 16; k++) tw[k] = *(const gl_t*)((const char*)tb.tw1_inv + t8 + (uint32_t)(k * T * 8));
+
+    // ---- closed forms (constant and unit-vector columns), as in lde_columns_v2_kernel: exact values, no transforms
+    if (oh != nullptr) {
+        const gl_t first = *(const gl_t*)in_base;  // uniform
+        unsigned flags = 0, ones = 0, row = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            flags |= v[i] != first ? 1u : 0u;
+            flags |= v[i] > 1 ? 2u : 0u;
+            if (v[i] == 1) {
+                ones++;
+                row = t + (unsigned)i * T;
+            }
+        }
+        __syncthreads();  // cls[] cleared
+        if (flags) atomicOr(&cls[0], flags);
+        if (ones) {
+            atomicAdd(&cls[1], ones);
+            cls[2] = row;
+        }
+        __syncthreads();
+        const unsigned all_flags = cls[0], all_ones = cls[1];
+        const bool is_const = (all_flags & 1u) == 0, is_unit = (all_flags & 2u) == 0 && all_ones == 1;
+        if (is_const || is_unit) {  // uniform over the workgroup
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            if (is_const) {
+                const gl_t c = gl_canon(first);
+                const u64x2 cc = {c, c};
+                for (unsigned s = 0; s < n_cosets; s++) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) *(u64x2*)(out_base + (uint32_t)((s * n + 2 * t + i * 2 * T) * 8)) = cc;
+                }
+            } else {
+                const unsigned r = cls[2];
+                for (unsigned s = 0; s < n_cosets; s++) {
+                    const gl_t* e0 = oh + n + (size_t)s * n;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const unsigned j = 2 * t + (unsigned)i * 2 * T;
+                        const u64x2 wv = {e0[(j - r) & (unsigned)(n - 1)], e0[(j + 1 - r) & (unsigned)(n - 1)]};
+                        *(u64x2*)(out_base + (uint32_t)((s * n + j) * 8)) = wv;
+                    }
+                }
+            }
+            return;
+        }
+    }
+
+    char* lds = (char*)lds_all;
+    // ================================================================ inverse transform
+    lde_dft16<true>(v);  // j12..9 -> k1
+#pragma unroll
+    for (int k = 1; k < 16; k++) v[k] = gl_mul_nc(v[k], tw[k]);
+    {  // next twiddles: w_512^(-b k2), b = l & 31
+        const uint32_t b8 = (l & 31u) * 8u;
+#pragma unroll
+        for (int k = 1; k < 16; k++) tw[k] = *(const gl_t*)((const char*)tb.tw2_inv + b8 + (uint32_t)(k * 32 * 8));
+    }
+    lde_lds_barrier();  // (nothing of this workgroup is in the image yet; kept: one code path for the crossing exchange)
+#pragma unroll
+    for (int k = 0; k < 16; k++) *(gl_t*)(lds + t8 + (uint32_t)(k * 512 * 8)) = v[k];  // image[k1][j2]
+    lde_lds_barrier();
+    {   // this thread's k1 = 2 w + (l >> 5), b = l & 31; register a = j8..5
+        const uint32_t base = ((2u * w + (l >> 5)) * 512u + (l & 31u)) * 8u;
+#pragma unroll
+        for (int a = 0; a < 16; a++) v[a] = *(const gl_t*)(lds + base + (uint32_t)(a * 32 * 8));
+    }
+    lde_dft16<true>(v);  // j8..5 -> k2
+#pragma unroll
+    for (int k = 1; k < 16; k++) v[k] = gl_mul_nc(v[k], tw[k]);
+    {   // exchange inside the wave's slice: word b * 32 + ((2 k2 + k1bit) ^ b)
+        const uint32_t b = l & 31u, k1bit = l >> 5;
+        const uint32_t wbase = ((w * 1024u + b * 32u) | (k1bit ^ b)) * 8u;
+#pragma unroll
+        for (int k = 0; k < 16; k++) *(gl_t*)(lds + (wbase ^ (uint32_t)(2 * k * 8))) = v[k];
+        lde_wave_sync();
+        // now: k1bit = l & 1, k2 = (l >> 1) & 15, e = l >> 5; register d = j4..1, b = 2 d + e
+        const uint32_t e = l >> 5, m5 = l & 31u;
+        const uint32_t rbase = ((w * 1024u + e * 32u) | (m5 ^ e)) * 8u;
+#pragma unroll
+        for (int d = 0; d < 16; d++) v[d] = *(const gl_t*)(lds + ((rbase ^ (uint32_t)(2 * d * 8)) + (uint32_t)(d * 64 * 8)));
+    }
+    lde_dft16<true>(v);  // j4..1 -> k4
+    if (hi) lde_w32_twiddles<true, 0>(v);  // the e = 1 elements
+    // registers (2 m, 2 m + 1) of the two half-waves -> (e = 0, e = 1) of k4 = 2 m + hi; radix 2 -> k5
+#define LDE_INV_LAST(M) lde_swap_halves(v[2 * M], v[2 * M + 1]); lde_last_bfly<true, 2 * M, 2 * M + 1>(v[2 * M], v[2 * M + 1], hi);
+    LDE_INV_LAST(0) LDE_INV_LAST(1) LDE_INV_LAST(2) LDE_INV_LAST(3) LDE_INV_LAST(4) LDE_INV_LAST(5) LDE_INV_LAST(6) LDE_INV_LAST(7)
+#undef LDE_INV_LAST
+    // coefficient register i = k5 * 8 + m is v[2 m + k5]; thread-major scratch in the column's last coset slot
+    char* cf = out_base + (size_t)(n_cosets - 1) * n * 8;
+    if (n_cosets > 1) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) *(gl_t*)(cf + t8 + (uint32_t)(i * T * 8)) = v[2 * (i & 7) + (i >> 3)];
+    }
+    // ================================================================ forward transforms
+    // coefficient index bits of this thread: c0 = l0, c7..4 = l4..1, c8 = l5, c3..1 = w
+    const uint32_t c0 = l & 1u, a_in = ((l >> 5) << 3) | ((l >> 2) & 7u), c4 = (l >> 1) & 1u;
+    const uint32_t fw_wbase = ((w * 1024u + ((a_in << 1) | c0) * 32u) | (c4 ^ ((c0 << 1) | ((a_in & 3u) << 2)))) * 8u;
+    // after the exchange: k1 = l & 15, c4 = (l >> 4) & 1, c0 = l >> 5
+    const uint32_t r_c0 = l >> 5, r_c4 = (l >> 4) & 1u, r_k1 = l & 15u;
+    const uint32_t fw_rbase = ((w * 1024u + r_c0 * 32u) | (((r_k1 << 1) | r_c4) ^ (r_c0 << 1))) * 8u;
+    const uint32_t fw_b = (r_c4 << 4) | (w << 1) | r_c0;                     // low five bits of the 512-point sub-transform's index
+    const uint32_t fx_wbase = (fw_b * 32u + r_k1) * 8u;                      // + (k2 >> 1) * 1024 + (k2 & 1) * 16
+    const uint32_t fx_rbase = (w * 1024u + (l >> 5) * 32u + (l & 31u)) * 8u; // + d * 64
+    const uint32_t st_off = ((l & 31u) | (w << 5) | ((l >> 5) << 11)) * 8u;  // + (reg & 7) * 256 + (reg >> 3) * 4096
+    {   // the first coset straight from the registers: v[i] <- coefficient i * cs[0][i]
+#pragma unroll
+        for (int i = 0; i < 16; i++) tw[i] = *(const gl_t*)((const char*)tb.cs + t8 + (uint32_t)(i * T * 8));
+        gl_t c[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) c[i] = gl_mul_nc(v[2 * (i & 7) + (i >> 3)], tw[i]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = c[i];
+    }
+    for (unsigned s = 0; s < n_cosets; s++) {
+#pragma unroll
+        for (int k = 1; k < 16; k++) tw[k] = *(const gl_t*)((const char*)tb.tw1_fwd + t8 + (uint32_t)(k * T * 8));
+        lde_dft16<false>(v);  // c12..9 -> k1
+#pragma unroll
+        for (int k = 1; k < 16; k++) v[k] = gl_mul_nc(v[k], tw[k]);
+        {
+            const uint32_t b8 = fw_b * 8u;
+#pragma unroll
+            for (int k = 1; k < 16; k++) tw[k] = *(const gl_t*)((const char*)tb.tw2_fwd + b8 + (uint32_t)(k * 32 * 8));
+        }
+        // exchange inside the wave's slice: row (2 a + c0), word ((2 k1 + c4) ^ g), g = 2 c0 + 4 (a & 3)
+#pragma unroll
+        for (int k = 0; k < 16; k++) *(gl_t*)(lds + (fw_wbase ^ (uint32_t)(2 * k * 8))) = v[k];
+        lde_wave_sync();
+#pragma unroll
+        for (int a = 0; a < 16; a++) v[a] = *(const gl_t*)(lds + ((fw_rbase ^ (uint32_t)(((a & 3) << 2) * 8)) + (uint32_t)(a * 64 * 8)));
+        lde_dft16<false>(v);  // c8..5 -> k2
+#pragma unroll
+        for (int k = 1; k < 16; k++) v[k] = gl_mul_nc(v[k], tw[k]);
+        lde_lds_barrier();  // every wave is done with its slice
+#pragma unroll
+        for (int k = 0; k < 16; k++) *(gl_t*)(lds + fx_wbase + (uint32_t)(((k >> 1) * 1024 + (k & 1) * 16) * 8)) = v[k];
+        lde_lds_barrier();
+#pragma unroll
+        for (int d = 0; d < 16; d++) v[d] = *(const gl_t*)(lds + fx_rbase + (uint32_t)(d * 64 * 8));
+        lde_dft16<false>(v);  // c4..1 -> k4
+        if (hi) lde_w32_twiddles<false, 0>(v);
+#define LDE_FWD_LAST(R) lde_swap_halves(v[R], v[R + 8]); lde_last_bfly<false, R, R + 8>(v[R], v[R + 8], hi);
+        LDE_FWD_LAST(0) LDE_FWD_LAST(1) LDE_FWD_LAST(2) LDE_FWD_LAST(3) LDE_FWD_LAST(4) LDE_FWD_LAST(5) LDE_FWD_LAST(6) LDE_FWD_LAST(7)
+#undef LDE_FWD_LAST
+        char* ob = out_base + (size_t)s * n * 8;
+#pragma unroll
+        for (int r = 0; r < 16; r++) *(gl_t*)(ob + st_off + (uint32_t)(((r & 7) * 256 + (r >> 3) * 4096) * 8)) = gl_canon(v[r]);
+        if (s + 1 < n_cosets) {  // the next coset: the thread's own sixteen words back from the scratch, times that coset's powers
+            const char* cs_base = (const char*)(tb.cs + (size_t)(s + 1) * n);
+            const char* cfb = cf;
+            asm volatile("" : "+s"(cfb));  // opaque: keeps the re-read a load (no forwarding from the stores above)
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = gl_mul_nc(*(const gl_t*)(cfb + t8 + (uint32_t)(i * T * 8)), *(const gl_t*)(cs_base + t8 + (uint32_t)(i * T * 8)));
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host side
 template <int LOGN>
 static void fill_tw(std::vector<gl_t>& out, bool inv) {
@@ -468,6 +717,64 @@ hipError_t launch_lde_columns_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, si
         case 13: return launch_v2<13>(values, coeffs, lde, n_cols, rate_bits, tw_fwd, tw_inv, cs, oh, from_coeffs, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+// ---- wave-resident kernel (2^13 rows): tables as tools/lde_wave_model.py builds them
+bool lde_wave_supported(unsigned log_n) { return log_n == (unsigned)LDE_WAVE_LOGN; }
+size_t lde_wave_table_words(unsigned rate_bits) { return 2 * 16 * 512 + 2 * 16 * 32 + ((size_t)16 * 512 << rate_bits); }
+
+static unsigned lde_wave_coef_index(unsigned t, unsigned i) {
+    const unsigned w = t >> 6, l = t & 63;
+    return (i << 9) | ((l >> 5) << 8) | (((l >> 1) & 15) << 4) | (w << 1) | (l & 1);
+}
+
+hipError_t lde_wave_upload_tables(unsigned rate_bits, gl_t* d_tab, hipStream_t st) {
+    constexpr unsigned n = 1u << LDE_WAVE_LOGN, T = n / 16;
+    std::vector<gl_t> tab(lde_wave_table_words(rate_bits));
+    gl_t* tw1[2] = {tab.data(), tab.data() + 16 * T};            // inverse, forward
+    gl_t* tw2[2] = {tab.data() + 2 * 16 * T, tab.data() + 2 * 16 * T + 16 * 32};
+    gl_t* cs = tab.data() + 2 * 16 * T + 2 * 16 * 32;
+    const gl_t wn = gl_root_of_unity(LDE_WAVE_LOGN);
+    for (int dir = 0; dir < 2; dir++) {
+        const gl_t w = dir == 0 ? gl_inv(wn) : wn;
+        std::vector<gl_t> pw(n);  // w^e
+        pw[0] = 1;
+        for (unsigned e = 1; e < n; e++) pw[e] = gl_mul(pw[e - 1], w);
+        for (unsigned t = 0; t < T; t++) {
+            const unsigned j2 = dir == 0 ? t : (lde_wave_coef_index(t, 0) & 511u);
+            for (unsigned k1 = 0; k1 < 16; k1++) tw1[dir][k1 * T + t] = pw[(j2 * k1) & (n - 1)];
+        }
+        for (unsigned k2 = 0; k2 < 16; k2++)
+            for (unsigned b = 0; b < 32; b++) tw2[dir][k2 * 32 + b] = pw[(16 * b * k2) & (n - 1)];
+    }
+    const gl_t wN = gl_root_of_unity(LDE_WAVE_LOGN + rate_bits), ninv = gl_inv((gl_t)n);
+    for (unsigned s = 0; s < (1u << rate_bits); s++) {
+        const gl_t shift = gl_mul(GL_GENERATOR, gl_pow(wN, s));
+        std::vector<gl_t> sp(n);  // n^-1 shift^c
+        sp[0] = ninv;
+        for (unsigned c = 1; c < n; c++) sp[c] = gl_mul(sp[c - 1], shift);
+        for (unsigned i = 0; i < 16; i++)
+            for (unsigned t = 0; t < T; t++) cs[(size_t)s * n + i * T + t] = sp[lde_wave_coef_index(t, i)];
+    }
+    hipError_t e = hipMemcpyAsync(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(st);  // the host vector goes out of scope
+}
+
+// values [C][8192] -> lde [C][2^rate][8192]; `oh`: the closed-form tables of lde_v2_upload_tables (or null: every column is transformed)
+hipError_t launch_lde_columns_wave(const gl_t* values, gl_t* lde, size_t n_cols, unsigned rate_bits, const gl_t* d_tab, const gl_t* oh, hipStream_t st) {
+    if (n_cols == 0) return hipSuccess;
+    constexpr size_t T = (1u << LDE_WAVE_LOGN) / 16, lds_bytes = (size_t)8 << LDE_WAVE_LOGN;
+    hipError_t e = hipFuncSetAttribute((const void*)lde_columns_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  // per device: not cached
+    if (e != hipSuccess) return e;
+    LdeWaveTables tb;
+    tb.tw1_inv = d_tab;
+    tb.tw1_fwd = d_tab + 16 * T;
+    tb.tw2_inv = d_tab + 2 * 16 * T;
+    tb.tw2_fwd = tb.tw2_inv + 16 * 32;
+    tb.cs = tb.tw2_fwd + 16 * 32;
+    hipLaunchKernelGGL(lde_columns_wave_kernel, dim3((unsigned)n_cols), dim3(512), lds_bytes, st, values, lde, (unsigned)n_cols, rate_bits, tb, oh);
+    return hipGetLastError();
 }
 
 }  // namespace starkhip

@@ -112,6 +112,7 @@ struct Ctx {
         int log_n = -1, rate = -1, qdb = -1;
         DevBuf tw_fwd, tw_inv, coset_scale, qtab, qshift_inv;
         DevBuf lde2_fwd, lde2_inv, lde2_cs, lde2_oh;  // kernels_lde.hip tables (log_n >= 8)
+        DevBuf lde_wave;                               // ... and of its wave-resident kernel (log_n == 13)
     };
     struct PlanDev {  // tiled plan (quotient_plan.h) of one AIR on the device
         int air = -1;
@@ -124,6 +125,7 @@ struct Ctx {
     Tables* tab = nullptr;    // the current shape's (ensure_tables)
     PlanDev* plan = nullptr;  // the current AIR's (ensure_plan)
     long opt_leaf_hash_form = 0;     // 0: row form for a lone context's commitments of <= 4096 leaves, quad form otherwise; 1: quad always; 2: row always
+    long opt_lde_impl = 0;           // 0: 8192-row traces take lde_columns_wave_kernel; 1: lde_columns_v2_kernel for every shape (the cross-check)
     long opt_lde_closed_forms = 1;   // constant / unit-vector columns skip their transforms (kernels_lde.hip); 0: every column is transformed
     long opt_host_commit_leaves = 64; // trace commitments of at most this many leaves (and >= 64 columns) are hashed by host threads (0: never)
     std::vector<gl_t> host_lde;      // their LDE on the host
@@ -169,7 +171,7 @@ static int ensure_tables(Ctx* c, unsigned log_n, unsigned rate, unsigned qdb) {
         Ctx::Tables* t;
         ~Release() {
             if (!t) return;
-            for (DevBuf* b : {&t->tw_fwd, &t->tw_inv, &t->coset_scale, &t->qtab, &t->qshift_inv, &t->lde2_fwd, &t->lde2_inv, &t->lde2_cs, &t->lde2_oh}) b->release();
+            for (DevBuf* b : {&t->tw_fwd, &t->tw_inv, &t->coset_scale, &t->qtab, &t->qshift_inv, &t->lde2_fwd, &t->lde2_inv, &t->lde2_cs, &t->lde2_oh, &t->lde_wave}) b->release();
         }
     } guard{T};
     const unsigned log_N = log_n + rate;
@@ -191,6 +193,10 @@ static int ensure_tables(Ctx* c, unsigned log_n, unsigned rate, unsigned qdb) {
         HIPCHK(T->lde2_cs.ensure(N * 8));
         HIPCHK(T->lde2_oh.ensure(std::max<size_t>(1, lde_v2_oh_words(log_n, rate)) * 8));
         HIPCHK(lde_v2_upload_tables(log_n, rate, T->lde2_fwd.as<gl_t>(), T->lde2_inv.as<gl_t>(), T->lde2_cs.as<gl_t>(), T->lde2_oh.as<gl_t>(), c->st));
+        if (lde_wave_supported(log_n)) {
+            HIPCHK(T->lde_wave.ensure(lde_wave_table_words(rate) * 8));
+            HIPCHK(lde_wave_upload_tables(rate, T->lde_wave.as<gl_t>(), c->st));
+        }
     }
     T->log_n = log_n;
     T->rate = rate;
@@ -203,6 +209,10 @@ static int ensure_tables(Ctx* c, unsigned log_n, unsigned rate, unsigned qdb) {
 
 // IFFT + coset LDE of `cols` columns with the tables of ensure_tables(log_n, rate, .)
 static hipError_t run_lde(Ctx* c, const gl_t* values, gl_t* coeffs, gl_t* lde, size_t cols, unsigned log_n, unsigned rate, int from_coeffs) {
+    // 8192-row traces (FinalExp, ECCAgg): values -> LDE with nothing kept in between goes through the wave-resident kernel
+    if (lde_wave_supported(log_n) && !coeffs && !from_coeffs && c->opt_lde_impl == 0)
+        return launch_lde_columns_wave(values, lde, cols, rate, c->tab->lde_wave.as<gl_t>(),
+                                       (c->opt_lde_closed_forms && lde_v2_oh_words(log_n, rate)) ? c->tab->lde2_oh.as<gl_t>() : nullptr, c->st);
     if (lde_v2_supported(log_n))
         return launch_lde_columns_v2(values, coeffs, lde, cols, log_n, rate, c->tab->lde2_fwd.as<gl_t>(), c->tab->lde2_inv.as<gl_t>(),
                                      c->tab->lde2_cs.as<gl_t>(),
@@ -366,7 +376,7 @@ void ctx_destroy(Ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->st);
     for (auto& t : c->table_cache)
-        for (DevBuf* b : {&t->tw_fwd, &t->tw_inv, &t->coset_scale, &t->qtab, &t->qshift_inv, &t->lde2_fwd, &t->lde2_inv, &t->lde2_cs, &t->lde2_oh}) b->release();
+        for (DevBuf* b : {&t->tw_fwd, &t->tw_inv, &t->coset_scale, &t->qtab, &t->qshift_inv, &t->lde2_fwd, &t->lde2_inv, &t->lde2_cs, &t->lde2_oh, &t->lde_wave}) b->release();
     for (auto& d : c->plan_cache)
         for (DevBuf* b : {&d->q_recs, &d->q_pieces, &d->q_streams, &d->q_chunk_tile_off, &d->q_tile_list, &d->q_contrib_off, &d->q_contribs, &d->q_consts, &d->q_apow}) b->release();
     DevBuf* bufs[] = {&c->d_ops, &c->d_loads, &c->d_chunk_off, &c->staging,
@@ -422,6 +432,7 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
     else if (k == "quotient_debug" && value >= 0 && value <= 9) c->opt_quotient_debug = value;
 #endif
     else if (k == "lde_closed_forms" && (value == 0 || value == 1)) c->opt_lde_closed_forms = value;
+    else if (k == "lde_impl" && (value == 0 || value == 1)) c->opt_lde_impl = value;
     else if (k == "host_commit_leaves" && value >= 0 && value <= 4096) c->opt_host_commit_leaves = value;
     else if (k == "leaf_hash_form" && value >= 0 && value <= 3) c->opt_leaf_hash_form = value;
     else if (k == "quotient_chunks" && value >= 0 && value <= 4096) c->opt_quotient_chunks = value;  // plans are cached by (AIR, chunks)
@@ -431,7 +442,7 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
 size_t ctx_device_bytes(Ctx* c) {
     size_t total = 0;
     for (auto& t : c->table_cache)
-        for (DevBuf* b : {&t->tw_fwd, &t->tw_inv, &t->coset_scale, &t->qtab, &t->qshift_inv, &t->lde2_fwd, &t->lde2_inv, &t->lde2_cs, &t->lde2_oh}) total += b->cap;
+        for (DevBuf* b : {&t->tw_fwd, &t->tw_inv, &t->coset_scale, &t->qtab, &t->qshift_inv, &t->lde2_fwd, &t->lde2_inv, &t->lde2_cs, &t->lde2_oh, &t->lde_wave}) total += b->cap;
     for (auto& d : c->plan_cache)
         for (DevBuf* b : {&d->q_recs, &d->q_pieces, &d->q_streams, &d->q_chunk_tile_off, &d->q_tile_list, &d->q_contrib_off, &d->q_contribs, &d->q_consts, &d->q_apow}) total += b->cap;
     DevBuf* bufs[] = {&c->d_ops, &c->d_loads, &c->d_chunk_off, &c->staging, &c->values, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial,
@@ -1138,13 +1149,27 @@ int lde_batch(Ctx* c, const uint64_t* values, size_t n_cols, unsigned log_n, uns
     HIPCHK(c->values.ensure(n_cols * n * 8));
     HIPCHK(c->lde.ensure(n_cols * N * 8));
     HIPCHK(hipMemcpyAsync(c->values.p, values, n_cols * n * 8, hipMemcpyHostToDevice, c->st));
-    HIPCHK(run_lde(c, c->values.as<gl_t>(), c->values.as<gl_t>(), c->lde.as<gl_t>(), n_cols, log_n, rate_bits, 0));
+    // the LDE comes from the kernel prove() uses for this shape: for 8192 rows the wave-resident one, which keeps no coefficients --
+    // those, when asked for, come from the other kernel afterwards (in place of the values, which the first run leaves untouched)
+    const bool wave = lde_wave_supported(log_n) && c->opt_lde_impl == 0;
+    std::vector<gl_t> tmp;
+    if (wave) {
+        HIPCHK(run_lde(c, c->values.as<gl_t>(), nullptr, c->lde.as<gl_t>(), n_cols, log_n, rate_bits, 0));
+        if (lde_out) {
+            tmp.resize(n_cols * N);
+            HIPCHK(hipMemcpyAsync(tmp.data(), c->lde.p, n_cols * N * 8, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(stream_wait(c));
+        }
+    }
+    if (!wave || coeffs_out) HIPCHK(run_lde(c, c->values.as<gl_t>(), c->values.as<gl_t>(), c->lde.as<gl_t>(), n_cols, log_n, rate_bits, 0));
     if (coeffs_out) HIPCHK(hipMemcpyAsync(coeffs_out, c->values.p, n_cols * n * 8, hipMemcpyDeviceToHost, c->st));  // in place
     HIPCHK(stream_wait(c));
     if (lde_out) {
         // device layout is coset-major; hand back NATURAL point order i = k * R + s
-        std::vector<gl_t> tmp(n_cols * N);
-        HIPCHK(hipMemcpy(tmp.data(), c->lde.p, n_cols * N * 8, hipMemcpyDeviceToHost));
+        if (!wave) {
+            tmp.resize(n_cols * N);
+            HIPCHK(hipMemcpy(tmp.data(), c->lde.p, n_cols * N * 8, hipMemcpyDeviceToHost));
+        }
         const size_t R = (size_t)1 << rate_bits;
         for (size_t col = 0; col < n_cols; col++)
             for (size_t s = 0; s < R; s++)

@@ -38,6 +38,33 @@ def test_lde_matches_oracle(prover, log_n, rate_bits, ncols):
     assert np.array_equal(lde, olde_rows.T)
 
 
+@pytest.mark.parametrize("rate_bits,ncols", [(0, 3), (1, 5), (2, 17), (3, 4)])
+def test_lde_8192_rows_in_both_kernels(prover, rate_bits, ncols):
+    """8192-row columns take the wave-resident kernel (lde_columns_wave_kernel: one exchange across waves per transform, the others
+    inside a wave, the last index bit by v_permlane32_swap; tools/lde_wave_model.py is its index model) when nothing but the LDE is
+    asked for; "lde_impl" = 1 sends them through lde_columns_v2_kernel like every other shape.  Both give the oracle's values for
+    random columns, columns of boundary values, and with the closed forms off (every column transformed)."""
+    n = 1 << 13
+    rng = np.random.default_rng(4000 + rate_bits)
+    vals = _rand(rng, (ncols, n))
+    vals[0] = 0
+    vals[1] = P - 1
+    vals[2, ::2] = P - 1
+    vals[2, 1::2] = 1
+    ocoeffs, olde_rows = O.lde_rows(vals, rate_bits)
+    for impl in (0, 1):
+        for closed in (1, 0):
+            prover.set_option("lde_impl", impl)
+            prover.set_option("lde_closed_forms", closed)
+            try:
+                coeffs, lde = prover.lde_batch(vals, rate_bits)
+            finally:
+                prover.set_option("lde_impl", 0)
+                prover.set_option("lde_closed_forms", 1)
+            assert np.array_equal(lde, olde_rows.T), (impl, closed)
+            assert np.array_equal(coeffs, ocoeffs), (impl, closed)
+
+
 @pytest.mark.parametrize("log_n,rate_bits", [(13, 2), (12, 2), (12, 1), (13, 1)])
 def test_lde_closed_forms_match_oracle(prover, log_n, rate_bits):
     """Columns the LDE kernel does NOT transform (kernels_lde.hip: one workgroup per column, 2^12 and 2^13 rows): constant
