@@ -348,6 +348,13 @@ int starkhip_lde_batch(void* ctx, const uint64_t* values, size_t n_cols, unsigne
 /* Merkle cap of the matrix whose leaf j is the row bitrev(j) of an LDE given column-major natural order [C][N] */
 int starkhip_merkle_cap(void* ctx, const uint64_t* lde_colmajor, size_t n_cols, unsigned log_N, unsigned cap_height, uint64_t* cap_out);
 int starkhip_poseidon_permute_batch(void* ctx, uint64_t* states, size_t n_states);
+/* micro-benchmark: the values -> LDE kernel prove() uses for this shape on n_cols synthetic columns already in HBM, `const_per_64` of
+ * every 64 of them constant (these take a closed form; a FinalExp trace has 11 in 64), `reps` launches between two HIP events; average
+ * milliseconds per launch.  const_per_64 + 256: unit vectors instead of constants.  device_values != NULL: the caller's own column-major
+ * matrix in device memory (n_cols x 2^log_n words) instead of the synthetic one.  reps == 0: one launch with no warm-up launch in front
+ * of it.  each_ms (may be NULL): min(reps, 16) durations, launch by launch */
+int starkhip_lde_bench(void* ctx, size_t n_cols, unsigned log_n, unsigned rate_bits, unsigned reps, unsigned const_per_64, const uint64_t* device_values,
+                       float* ms_per_launch, float* each_ms);
 /* a finished log through the device's expansion kernels (csrc/kernels_trace.hip) into a host matrix, COLUMN-major [C][n_rows] */
 int starkhip_trace_log_expand_device(void* ctx, const void* log, uint64_t* trace_colmajor);
 /* device field arithmetic under test: out[i] = canonical(op(a[i], b[i])) with the lazy-reduction helpers the kernels use

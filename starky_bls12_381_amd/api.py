@@ -103,6 +103,7 @@ lib.starkhip_trace_log_free.argtypes = [C.c_void_p]
 lib.starkhip_trace_log_free.restype = None
 lib.starkhip_trace_log_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_size_t)] * 4
 lib.starkhip_trace_log_from_writes.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_void_p)]
+lib.starkhip_lde_bench.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
 lib.starkhip_trace_log_expand_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
 lib.starkhip_trace_log_overwrites.argtypes = [C.c_void_p] + [C.POINTER(C.c_size_t)] * 2
 lib.starkhip_trace_log_expand_host.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
@@ -471,6 +472,13 @@ class Prover:
         proof = np.ctypeslib.as_array(out, shape=(words.value,)).copy()
         lib.starkhip_free(out)
         return proof
+
+    def lde_bench(self, n_cols, log_n, rate_bits, reps=5, const_per_64=0, device_ptr=None, each=False):
+        """starkhip_lde_bench: average milliseconds of one values -> LDE launch over `n_cols` synthetic columns."""
+        ms = C.c_float()
+        per = (C.c_float * 16)()
+        _chk(lib.starkhip_lde_bench(self._ctx, n_cols, log_n, rate_bits, reps, const_per_64, C.c_void_p(device_ptr) if device_ptr else None, C.byref(ms), per))
+        return [round(float(x), 2) for x in per[:max(1, min(reps, 16))]] if each else float(ms.value)
 
     def expand_trace(self, compact):
         """A CompactTrace through the device's expansion kernels; returns the dense row-major [n][C] matrix (tests)."""

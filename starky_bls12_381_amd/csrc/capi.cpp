@@ -522,6 +522,11 @@ int starkhip_merkle_cap(void* ctx, const uint64_t* lde_colmajor, size_t n_cols, 
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;
     return merkle_cap((Ctx*)ctx, lde_colmajor, n_cols, log_N, cap_height, cap_out);
 }
+int starkhip_lde_bench(void* ctx, size_t n_cols, unsigned log_n, unsigned rate_bits, unsigned reps, unsigned const_per_64, const uint64_t* device_values, float* ms_per_launch, float* each_ms) {
+    if (!ctx) return STARKHIP_ERR_NO_DEVICE;
+    if (!ms_per_launch) return STARKHIP_ERR_BAD_SHAPE;
+    return lde_bench((Ctx*)ctx, n_cols, log_n, rate_bits, reps, const_per_64, device_values, ms_per_launch, each_ms);
+}
 int starkhip_trace_log_expand_device(void* ctx, const void* log, uint64_t* trace_colmajor) {
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;
     if (!log || !trace_colmajor || armed_trace_log() == (const TraceLog*)log) return STARKHIP_ERR_BAD_SHAPE;

@@ -97,6 +97,7 @@ int lde_batch(Ctx*, const uint64_t*, size_t, unsigned, unsigned, uint64_t*, uint
 int merkle_cap(Ctx*, const uint64_t*, size_t, unsigned, unsigned, uint64_t*) { return STARKHIP_ERR_NO_DEVICE; }
 int permute_batch(Ctx*, uint64_t*, size_t) { return STARKHIP_ERR_NO_DEVICE; }
 int expand_log(Ctx*, const TraceLog*, uint64_t*) { return STARKHIP_ERR_NO_DEVICE; }
+int lde_bench(Ctx*, size_t, unsigned, unsigned, unsigned, unsigned, const uint64_t*, float*, float*) { return STARKHIP_ERR_NO_DEVICE; }
 int field_ops(Ctx*, int, const uint64_t*, const uint64_t*, uint64_t*, size_t) { return STARKHIP_ERR_NO_DEVICE; }
 int host_alloc(Ctx*, size_t, void**) { return STARKHIP_ERR_NO_DEVICE; }
 void host_free(void*) {}

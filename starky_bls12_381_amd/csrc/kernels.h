@@ -54,7 +54,8 @@ hipError_t launch_lde_columns_v2(const gl_t* values, gl_t* coeffs, gl_t* lde, si
 bool lde_wave_supported(unsigned log_n);
 size_t lde_wave_table_words(unsigned rate_bits);
 hipError_t lde_wave_upload_tables(unsigned rate_bits, gl_t* d_tab, hipStream_t st);
-hipError_t launch_lde_columns_wave(const gl_t* values, gl_t* lde, size_t n_cols, unsigned rate_bits, const gl_t* d_tab, const gl_t* oh, hipStream_t st);
+hipError_t launch_lde_columns_wave(const gl_t* values, gl_t* lde, size_t n_cols, unsigned rate_bits, const gl_t* d_tab, const gl_t* oh, unsigned* next,
+                                   hipStream_t st);
 hipError_t launch_ntt_global(gl_t* data, size_t n_vecs, size_t vec_stride, unsigned log_n, const gl_t* tw, unsigned tw_log,
                              const gl_t* pre_scale, const gl_t* post_scale, gl_t final_mul, hipStream_t st);
 

@@ -371,6 +371,12 @@ struct LdeWaveTables {
 };
 static constexpr int LDE_WAVE_LOGN = 13;
 
+// Development builds only (make variant DEFS=-DSTARKHIP_LDE_ABLATE=mask): leave out one kind of work to see what the rest costs -- wrong
+// results.  1: table loads become constants, 2: no coefficient re-read, 4: no result stores, 8: no LDS exchanges, 16: no barriers.
+#ifndef STARKHIP_LDE_ABLATE
+#define STARKHIP_LDE_ABLATE 0
+#endif
+#define LDE_TABLE_LOAD(expr) ((STARKHIP_LDE_ABLATE & 1) ? (gl_t)(0x9E3779B97F4A7C15ULL + threadIdx.x) : (expr))
 template <bool INV>
 __device__ __forceinline__ void lde_dft16(gl_t (&v)[16]) {
     SubNtts<16, INV, 0>::run(v);
@@ -378,6 +384,13 @@ __device__ __forceinline__ void lde_dft16(gl_t (&v)[16]) {
 }
 // LDS operations of ONE wave execute in order, so a wave's reads see its own earlier writes; what has to be kept is the compiler's order
 __device__ __forceinline__ void lde_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lde_x_barrier() {
+    if (!(STARKHIP_LDE_ABLATE & 16)) lde_lds_barrier();
+}
+__device__ __forceinline__ void lde_lds_put(char* p, gl_t x) {
+    if (!(STARKHIP_LDE_ABLATE & 8)) *(gl_t*)p = x;
+}
+__device__ __forceinline__ gl_t lde_lds_get(const char* p, gl_t keep) { return (STARKHIP_LDE_ABLATE & 8) ? keep : *(const gl_t*)p; }
 
 // exponent E of the radix-2 step's twiddle 2^E = w_32^(+-k4): w_64 = 2^39, so w_32 = 2^78 and its inverse 2^114
 template <bool INV>
@@ -415,24 +428,35 @@ __device__ __forceinline__ void lde_swap_halves(gl_t& a, gl_t& b) {
     b = ((uint64_t)hi[1] << 32) | lo[1];
 }
 
+// The grid is PERSISTENT: a workgroup takes its first column from its index and every further one from a counter (`next`, zero at
+// launch), so a launch is 2 workgroups per CU however many columns it has: no workgroup turnover (LDS allocation, wave launch, the
+// first loads' HBM latency with nothing to hide behind) between columns, and short columns (closed forms) even out by themselves.
 __global__ __launch_bounds__(512, 4) void lde_columns_wave_kernel(const gl_t* values, gl_t* lde, unsigned n_cols, unsigned rate_bits, LdeWaveTables tb,
-                                                                   const gl_t* __restrict__ oh) { STARKHIP_PRIO_ENTRY
+                                                                   const gl_t* __restrict__ oh, unsigned* next) { STARKHIP_PRIO_ENTRY
     constexpr int n = 1 << LDE_WAVE_LOGN, T = n / 16;
     extern __shared__ gl_t lds_all[];  // 8192 words, no padding
-    __shared__ unsigned cls[3];
-    if (threadIdx.x == 0) cls[0] = cls[1] = 0;
-    const unsigned t = threadIdx.x, w = t >> 6, l = t & 63;
-    const bool hi = l >= 32;
-    const unsigned col = blockIdx.x;
+    __shared__ unsigned cls[3], next_col;
     const unsigned n_cosets = 1u << rate_bits;
+    gl_t v[16], tw[16];
+    unsigned col = blockIdx.x;
+  while (col < n_cols) {  // uniform over the workgroup
+    // (the thread index is made opaque per column: otherwise every per-lane table and image address below is an invariant of this loop,
+    // hoisted out of it and kept in registers across it -- 140 spilled registers)
+    unsigned t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const unsigned w = t >> 6, l = t & 63;
+    const bool hi = l >= 32;
+    const uint32_t t8 = t * 8u;
+    if (t == 0) {
+        cls[0] = cls[1] = 0;
+        next_col = gridDim.x + atomicAdd(next, 1u);  // read by everybody behind a barrier further down
+    }
     const char* in_base = (const char*)(values + (size_t)col * n);
     char* out_base = (char*)(lde + (size_t)col * n_cosets * n);
-    const uint32_t t8 = t * 8u;
-    gl_t v[16], tw[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) v[i] = *(const gl_t*)(in_base + t8 + (uint32_t)(i * T * 8));
 #pragma unroll
-    for (int k = 1; k < 16; k++) tw[k] = *(const gl_t*)((const char*)tb.tw1_inv + t8 + (uint32_t)(k * T * 8));
+    for (int k = 1; k < 16; k++) tw[k] = LDE_TABLE_LOAD(*(const gl_t*)((const char*)tb.tw1_inv + t8 + (uint32_t)(k * T * 8)));
 
     // ---- closed forms (constant and unit-vector columns), as in lde_columns_v2_kernel: exact values, no transforms
     if (oh != nullptr) {
@@ -477,7 +501,9 @@ __global__ __launch_bounds__(512, 4) void lde_columns_wave_kernel(const gl_t* va
                     }
                 }
             }
-            return;
+            col = next_col;  // (written before the two barriers above)
+            __syncthreads();  // nobody is still reading cls[] / next_col when thread 0 writes them again
+            continue;
         }
     }
 
@@ -489,16 +515,16 @@ __global__ __launch_bounds__(512, 4) void lde_columns_wave_kernel(const gl_t* va
     {  // next twiddles: w_512^(-b k2), b = l & 31
         const uint32_t b8 = (l & 31u) * 8u;
 #pragma unroll
-        for (int k = 1; k < 16; k++) tw[k] = *(const gl_t*)((const char*)tb.tw2_inv + b8 + (uint32_t)(k * 32 * 8));
+        for (int k = 1; k < 16; k++) tw[k] = LDE_TABLE_LOAD(*(const gl_t*)((const char*)tb.tw2_inv + b8 + (uint32_t)(k * 32 * 8)));
     }
-    lde_lds_barrier();  // (nothing of this workgroup is in the image yet; kept: one code path for the crossing exchange)
+    lde_x_barrier();  // (nothing of this workgroup is in the image yet; kept: one code path for the crossing exchange)
 #pragma unroll
-    for (int k = 0; k < 16; k++) *(gl_t*)(lds + t8 + (uint32_t)(k * 512 * 8)) = v[k];  // image[k1][j2]
-    lde_lds_barrier();
+    for (int k = 0; k < 16; k++) lde_lds_put(lds + t8 + (uint32_t)(k * 512 * 8), v[k]);  // image[k1][j2]
+    lde_x_barrier();
     {   // this thread's k1 = 2 w + (l >> 5), b = l & 31; register a = j8..5
         const uint32_t base = ((2u * w + (l >> 5)) * 512u + (l & 31u)) * 8u;
 #pragma unroll
-        for (int a = 0; a < 16; a++) v[a] = *(const gl_t*)(lds + base + (uint32_t)(a * 32 * 8));
+        for (int a = 0; a < 16; a++) v[a] = lde_lds_get(lds + base + (uint32_t)(a * 32 * 8), v[a]);
     }
     lde_dft16<true>(v);  // j8..5 -> k2
 #pragma unroll
@@ -507,13 +533,13 @@ __global__ __launch_bounds__(512, 4) void lde_columns_wave_kernel(const gl_t* va
         const uint32_t b = l & 31u, k1bit = l >> 5;
         const uint32_t wbase = ((w * 1024u + b * 32u) | (k1bit ^ b)) * 8u;
 #pragma unroll
-        for (int k = 0; k < 16; k++) *(gl_t*)(lds + (wbase ^ (uint32_t)(2 * k * 8))) = v[k];
+        for (int k = 0; k < 16; k++) lde_lds_put(lds + (wbase ^ (uint32_t)(2 * k * 8)), v[k]);
         lde_wave_sync();
         // now: k1bit = l & 1, k2 = (l >> 1) & 15, e = l >> 5; register d = j4..1, b = 2 d + e
         const uint32_t e = l >> 5, m5 = l & 31u;
         const uint32_t rbase = ((w * 1024u + e * 32u) | (m5 ^ e)) * 8u;
 #pragma unroll
-        for (int d = 0; d < 16; d++) v[d] = *(const gl_t*)(lds + ((rbase ^ (uint32_t)(2 * d * 8)) + (uint32_t)(d * 64 * 8)));
+        for (int d = 0; d < 16; d++) v[d] = lde_lds_get(lds + ((rbase ^ (uint32_t)(2 * d * 8)) + (uint32_t)(d * 64 * 8)), v[d]);
     }
     lde_dft16<true>(v);  // j4..1 -> k4
     if (hi) lde_w32_twiddles<true, 0>(v);  // the e = 1 elements
@@ -540,7 +566,7 @@ __global__ __launch_bounds__(512, 4) void lde_columns_wave_kernel(const gl_t* va
     const uint32_t st_off = ((l & 31u) | (w << 5) | ((l >> 5) << 11)) * 8u;  // + (reg & 7) * 256 + (reg >> 3) * 4096
     {   // the first coset straight from the registers: v[i] <- coefficient i * cs[0][i]
 #pragma unroll
-        for (int i = 0; i < 16; i++) tw[i] = *(const gl_t*)((const char*)tb.cs + t8 + (uint32_t)(i * T * 8));
+        for (int i = 0; i < 16; i++) tw[i] = LDE_TABLE_LOAD(*(const gl_t*)((const char*)tb.cs + t8 + (uint32_t)(i * T * 8)));
         gl_t c[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) c[i] = gl_mul_nc(v[2 * (i & 7) + (i >> 3)], tw[i]);
@@ -549,30 +575,32 @@ __global__ __launch_bounds__(512, 4) void lde_columns_wave_kernel(const gl_t* va
     }
     for (unsigned s = 0; s < n_cosets; s++) {
 #pragma unroll
-        for (int k = 1; k < 16; k++) tw[k] = *(const gl_t*)((const char*)tb.tw1_fwd + t8 + (uint32_t)(k * T * 8));
+        for (int k = 1; k < 16; k++) tw[k] = LDE_TABLE_LOAD(*(const gl_t*)((const char*)tb.tw1_fwd + t8 + (uint32_t)(k * T * 8)));
         lde_dft16<false>(v);  // c12..9 -> k1
 #pragma unroll
         for (int k = 1; k < 16; k++) v[k] = gl_mul_nc(v[k], tw[k]);
         {
             const uint32_t b8 = fw_b * 8u;
 #pragma unroll
-            for (int k = 1; k < 16; k++) tw[k] = *(const gl_t*)((const char*)tb.tw2_fwd + b8 + (uint32_t)(k * 32 * 8));
+            for (int k = 1; k < 16; k++) tw[k] = LDE_TABLE_LOAD(*(const gl_t*)((const char*)tb.tw2_fwd + b8 + (uint32_t)(k * 32 * 8)));
         }
         // exchange inside the wave's slice: row (2 a + c0), word ((2 k1 + c4) ^ g), g = 2 c0 + 4 (a & 3)
 #pragma unroll
-        for (int k = 0; k < 16; k++) *(gl_t*)(lds + (fw_wbase ^ (uint32_t)(2 * k * 8))) = v[k];
+        for (int k = 0; k < 16; k++) lde_lds_put(lds + (fw_wbase ^ (uint32_t)(2 * k * 8)), v[k]);
         lde_wave_sync();
 #pragma unroll
-        for (int a = 0; a < 16; a++) v[a] = *(const gl_t*)(lds + ((fw_rbase ^ (uint32_t)(((a & 3) << 2) * 8)) + (uint32_t)(a * 64 * 8)));
+        for (int a = 0; a < 16; a++) v[a] = lde_lds_get(lds + ((fw_rbase ^ (uint32_t)(((a & 3) << 2) * 8)) + (uint32_t)(a * 64 * 8)), v[a]);
         lde_dft16<false>(v);  // c8..5 -> k2
 #pragma unroll
         for (int k = 1; k < 16; k++) v[k] = gl_mul_nc(v[k], tw[k]);
-        lde_lds_barrier();  // every wave is done with its slice
+        lde_x_barrier();  // every wave is done with its slice
+        const unsigned nxt = next_col;  // between the two barriers: thread 0 cannot have gone on to the next column's counter yet
 #pragma unroll
-        for (int k = 0; k < 16; k++) *(gl_t*)(lds + fx_wbase + (uint32_t)(((k >> 1) * 1024 + (k & 1) * 16) * 8)) = v[k];
-        lde_lds_barrier();
+        for (int k = 0; k < 16; k++) lde_lds_put(lds + fx_wbase + (uint32_t)(((k >> 1) * 1024 + (k & 1) * 16) * 8), v[k]);
+        lde_x_barrier();
+
 #pragma unroll
-        for (int d = 0; d < 16; d++) v[d] = *(const gl_t*)(lds + fx_rbase + (uint32_t)(d * 64 * 8));
+        for (int d = 0; d < 16; d++) v[d] = lde_lds_get(lds + fx_rbase + (uint32_t)(d * 64 * 8), v[d]);
         lde_dft16<false>(v);  // c4..1 -> k4
         if (hi) lde_w32_twiddles<false, 0>(v);
 #define LDE_FWD_LAST(R) lde_swap_halves(v[R], v[R + 8]); lde_last_bfly<false, R, R + 8>(v[R], v[R + 8], hi);
@@ -580,16 +608,23 @@ __global__ __launch_bounds__(512, 4) void lde_columns_wave_kernel(const gl_t* va
 #undef LDE_FWD_LAST
         char* ob = out_base + (size_t)s * n * 8;
 #pragma unroll
-        for (int r = 0; r < 16; r++) *(gl_t*)(ob + st_off + (uint32_t)(((r & 7) * 256 + (r >> 3) * 4096) * 8)) = gl_canon(v[r]);
+        for (int r = 0; r < 16; r++) {
+            if ((STARKHIP_LDE_ABLATE & 4) && v[r] != 12345) continue;  // (data-dependent, so the arithmetic stays)
+            *(gl_t*)(ob + st_off + (uint32_t)(((r & 7) * 256 + (r >> 3) * 4096) * 8)) = gl_canon(v[r]);
+        }
         if (s + 1 < n_cosets) {  // the next coset: the thread's own sixteen words back from the scratch, times that coset's powers
             const char* cs_base = (const char*)(tb.cs + (size_t)(s + 1) * n);
             const char* cfb = cf;
             asm volatile("" : "+s"(cfb));  // opaque: keeps the re-read a load (no forwarding from the stores above)
 #pragma unroll
             for (int i = 0; i < 16; i++)
-                v[i] = gl_mul_nc(*(const gl_t*)(cfb + t8 + (uint32_t)(i * T * 8)), *(const gl_t*)(cs_base + t8 + (uint32_t)(i * T * 8)));
+                v[i] = gl_mul_nc((STARKHIP_LDE_ABLATE & 2) ? v[i] : *(const gl_t*)(cfb + t8 + (uint32_t)(i * T * 8)),
+                                 LDE_TABLE_LOAD(*(const gl_t*)(cs_base + t8 + (uint32_t)(i * T * 8))));
+        } else {
+            col = nxt;
         }
     }
+  }
 }
 
 // ---------------------------------------------------------------- host side
@@ -761,8 +796,9 @@ hipError_t lde_wave_upload_tables(unsigned rate_bits, gl_t* d_tab, hipStream_t s
     return hipStreamSynchronize(st);  // the host vector goes out of scope
 }
 
-// values [C][8192] -> lde [C][2^rate][8192]; `oh`: the closed-form tables of lde_v2_upload_tables (or null: every column is transformed)
-hipError_t launch_lde_columns_wave(const gl_t* values, gl_t* lde, size_t n_cols, unsigned rate_bits, const gl_t* d_tab, const gl_t* oh, hipStream_t st) {
+// values [C][8192] -> lde [C][2^rate][8192]; `next`: a device word holding 0 (the launch's column counter); `oh`: the closed-form tables of lde_v2_upload_tables (or null: every column is transformed)
+hipError_t launch_lde_columns_wave(const gl_t* values, gl_t* lde, size_t n_cols, unsigned rate_bits, const gl_t* d_tab, const gl_t* oh, unsigned* next,
+                                   hipStream_t st) {
     if (n_cols == 0) return hipSuccess;
     constexpr size_t T = (1u << LDE_WAVE_LOGN) / 16, lds_bytes = (size_t)8 << LDE_WAVE_LOGN;
     hipError_t e = hipFuncSetAttribute((const void*)lde_columns_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  // per device: not cached
@@ -773,7 +809,11 @@ hipError_t launch_lde_columns_wave(const gl_t* values, gl_t* lde, size_t n_cols,
     tb.tw2_inv = d_tab + 2 * 16 * T;
     tb.tw2_fwd = tb.tw2_inv + 16 * 32;
     tb.cs = tb.tw2_fwd + 16 * 32;
-    hipLaunchKernelGGL(lde_columns_wave_kernel, dim3((unsigned)n_cols), dim3(512), lds_bytes, st, values, lde, (unsigned)n_cols, rate_bits, tb, oh);
+    // two workgroups fit a CU (64 KB of LDS each); `next` must be zero (the caller clears it on the same stream)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)std::min<size_t>(n_cols, (size_t)2 * (size_t)std::max(cus, 1));
+    hipLaunchKernelGGL(lde_columns_wave_kernel, dim3(grid), dim3(512), lds_bytes, st, values, lde, (unsigned)n_cols, rate_bits, tb, oh, next);
     return hipGetLastError();
 }
 

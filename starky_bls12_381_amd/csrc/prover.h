@@ -71,6 +71,7 @@ int merkle_cap(Ctx* c, const uint64_t* lde_natural, size_t n_cols, unsigned log_
 int permute_batch(Ctx* c, uint64_t* states, size_t n);
 struct TraceLog;
 int expand_log(Ctx* c, const TraceLog* log, uint64_t* out_colmajor);
+int lde_bench(Ctx* c, size_t n_cols, unsigned log_n, unsigned rate_bits, unsigned reps, unsigned const_per_64, const uint64_t* device_values, float* ms_out, float* each_ms = nullptr);
 int field_ops(Ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int host_alloc(Ctx* c, size_t bytes, void** out);
 void host_free(void* p);

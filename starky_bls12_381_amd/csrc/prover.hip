@@ -194,7 +194,7 @@ static int ensure_tables(Ctx* c, unsigned log_n, unsigned rate, unsigned qdb) {
         HIPCHK(T->lde2_oh.ensure(std::max<size_t>(1, lde_v2_oh_words(log_n, rate)) * 8));
         HIPCHK(lde_v2_upload_tables(log_n, rate, T->lde2_fwd.as<gl_t>(), T->lde2_inv.as<gl_t>(), T->lde2_cs.as<gl_t>(), T->lde2_oh.as<gl_t>(), c->st));
         if (lde_wave_supported(log_n)) {
-            HIPCHK(T->lde_wave.ensure(lde_wave_table_words(rate) * 8));
+            HIPCHK(T->lde_wave.ensure((lde_wave_table_words(rate) + 1) * 8));  // + the launches' column counter
             HIPCHK(lde_wave_upload_tables(rate, T->lde_wave.as<gl_t>(), c->st));
         }
     }
@@ -210,9 +210,13 @@ static int ensure_tables(Ctx* c, unsigned log_n, unsigned rate, unsigned qdb) {
 // IFFT + coset LDE of `cols` columns with the tables of ensure_tables(log_n, rate, .)
 static hipError_t run_lde(Ctx* c, const gl_t* values, gl_t* coeffs, gl_t* lde, size_t cols, unsigned log_n, unsigned rate, int from_coeffs) {
     // 8192-row traces (FinalExp, ECCAgg): values -> LDE with nothing kept in between goes through the wave-resident kernel
-    if (lde_wave_supported(log_n) && !coeffs && !from_coeffs && c->opt_lde_impl == 0)
+    if (lde_wave_supported(log_n) && !coeffs && !from_coeffs && c->opt_lde_impl == 0) {
+        // the launch's column counter: the last word of the table buffer, cleared in stream order before every launch
+        unsigned* next = (unsigned*)(c->tab->lde_wave.as<gl_t>() + lde_wave_table_words(rate));
+        if (hipError_t e = hipMemsetAsync(next, 0, sizeof(unsigned), c->st); e != hipSuccess) return e;
         return launch_lde_columns_wave(values, lde, cols, rate, c->tab->lde_wave.as<gl_t>(),
-                                       (c->opt_lde_closed_forms && lde_v2_oh_words(log_n, rate)) ? c->tab->lde2_oh.as<gl_t>() : nullptr, c->st);
+                                       (c->opt_lde_closed_forms && lde_v2_oh_words(log_n, rate)) ? c->tab->lde2_oh.as<gl_t>() : nullptr, next, c->st);
+    }
     if (lde_v2_supported(log_n))
         return launch_lde_columns_v2(values, coeffs, lde, cols, log_n, rate, c->tab->lde2_fwd.as<gl_t>(), c->tab->lde2_inv.as<gl_t>(),
                                      c->tab->lde2_cs.as<gl_t>(),
@@ -1175,6 +1179,52 @@ int lde_batch(Ctx* c, const uint64_t* values, size_t n_cols, unsigned log_n, uns
             for (size_t s = 0; s < R; s++)
                 for (size_t k = 0; k < n; k++) lde_out[col * N + k * R + s] = tmp[col * N + s * n + k];
     }
+    return STARKHIP_OK;
+}
+
+// micro-benchmark entry: the trace LDE of `n_cols` synthetic columns (powers of a generator: no constant or unit column, so every
+// column is transformed unless const_per_64 says otherwise), `reps` launches timed with HIP events on the context's stream; average milliseconds per launch
+int lde_bench(Ctx* c, size_t n_cols, unsigned log_n, unsigned rate_bits, unsigned reps, unsigned const_per_64, const uint64_t* device_values, float* ms_out, float* each_ms) {
+    if (log_n < 1 || log_n > 13 || !n_cols) return STARKHIP_ERR_BAD_SHAPE;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_tables(c, log_n, rate_bits, 0))) return rc;
+    const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+    HIPCHK(c->values.ensure(n_cols * n * 8));
+    HIPCHK(c->lde.ensure(n_cols * N * 8));
+    const gl_t* in = device_values ? (const gl_t*)device_values : c->values.as<gl_t>();  // the caller's own column-major matrix, or the synthetic one
+    if (device_values) const_per_64 = 0;
+    else HIPCHK(launch_fill_powers(c->values.as<gl_t>(), 3, GL_GENERATOR, n_cols * n, c->st));
+    // `const_per_64` of every 64 columns constant (a FinalExp trace: 11 of 64 take a closed form), in runs of up to 12 as its Fp12 blocks are
+    // (+ 256: unit vectors instead -- one 1 per column, at a different row each -- the other closed form: FinalExp's 8192 row selectors)
+    const bool unit = (const_per_64 & 256u) != 0;
+    const_per_64 &= 255u;
+    for (size_t c0 = 0; const_per_64 && c0 < n_cols; c0 += 64) {
+        const size_t cnt = std::min<size_t>(const_per_64, n_cols - c0);
+        HIPCHK(hipMemsetAsync(c->values.as<gl_t>() + c0 * n, unit ? 0 : 1, cnt * n * 8, c->st));
+        for (size_t k = 0; unit && k < cnt; k++) HIPCHK(hipMemsetAsync(c->values.as<gl_t>() + (c0 + k) * n + ((c0 + k) * 37) % n, 1, 1, c->st));
+    }
+    const bool cold = reps == 0;  // reps == 0: ONE launch with no warm-up launch in front of it
+    if (cold) reps = 1;
+    reps = std::min(reps, 16u);
+    std::vector<hipEvent_t> ev(reps + 1, nullptr);
+    hipError_t err = hipSuccess;
+    for (hipEvent_t& e : ev)
+        if (err == hipSuccess) err = hipEventCreate(&e);
+    if (err == hipSuccess) err = cold ? hipStreamSynchronize(c->st) : run_lde(c, in, nullptr, c->lde.as<gl_t>(), n_cols, log_n, rate_bits, 0);  // warm-up
+    if (err == hipSuccess) err = hipEventRecord(ev[0], c->st);
+    for (unsigned r = 0; r < reps && err == hipSuccess; r++) {
+        err = run_lde(c, in, nullptr, c->lde.as<gl_t>(), n_cols, log_n, rate_bits, 0);
+        if (err == hipSuccess) err = hipEventRecord(ev[r + 1], c->st);
+    }
+    if (err == hipSuccess) err = hipEventSynchronize(ev[reps]);
+    float ms = 0;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, ev[0], ev[reps]);
+    for (unsigned r = 0; r < reps && err == hipSuccess && each_ms; r++) err = hipEventElapsedTime(&each_ms[r], ev[r], ev[r + 1]);
+    for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
+    HIPCHK(err);
+    *ms_out = ms / reps;
     return STARKHIP_OK;
 }
 

@@ -1,0 +1,20 @@
+#!/bin/bash
+# SQ counters of the two LDE kernels side by side (tools/experiments/lde_ab.py proves FinalExp with each in turn, one proof in flight).
+# Run on the GPU box from the repo root; CSV rows land in gpurun_out/${TAG}_lde_sq{1,2,3}.csv
+TAG=${1:-lde}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python3 $R/tools/experiments/lde_ab.py 2"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d $OUT/pmc1_$TAG -o p -- $CMD > $OUT/pmc1_$TAG.log 2>&1 || { tail -5 $OUT/pmc1_$TAG.log; exit 1; }
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_ACTIVE_INST_MISC -d $OUT/pmc2_$TAG -o p -- $CMD > $OUT/pmc2_$TAG.log 2>&1 || { tail -5 $OUT/pmc2_$TAG.log; exit 1; }
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_IFETCH SQ_INST_LEVEL_VMEM -d $OUT/pmc3_$TAG -o p -- $CMD > $OUT/pmc3_$TAG.log 2>&1 || { tail -5 $OUT/pmc3_$TAG.log; }
+cd $R
+for k in 1 2 3; do
+  db=$(find $OUT/pmc${k}_$TAG -name "*results.db" | head -1)
+  [ -n "$db" ] && python3 tools/rocprof_export.py pmc $db $OUT/${TAG}_lde_sq$k.csv
+  rm -rf $OUT/pmc${k}_$TAG
+done
+head -1 $OUT/${TAG}_lde_sq1.csv
+grep -hE "lde_columns" $OUT/${TAG}_lde_sq1.csv $OUT/${TAG}_lde_sq2.csv $OUT/${TAG}_lde_sq3.csv
