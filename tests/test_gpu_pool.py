@@ -213,7 +213,7 @@ def test_failures_of_final_exp_class_jobs_inside_lane_groups():
     ecc_cfg = S.StarkConfig.for_air(S.AIR_ECC_AGGREGATE)
     ecc_t, ecc_pis = S.trace_ecc_aggregate(*pack(pts, bits))
     ecc_bad = ecc_t.copy()
-    ecc_bad[4000, 1200] = (int(ecc_bad[4000, 1200]) + 1) % S.P
+    ecc_bad[4000, 2000] = (int(ecc_bad[4000, 2000]) + 1) % S.P   # a cell the constraints of rows 3999 and 4000 read (not every cell is constrained on every row)
     sha = lambda pr: hashlib.sha256(pr.tobytes()).hexdigest()  # noqa: E731
     pool = S.ProofPool(0, big_contexts=5, small_contexts=1, generator_threads=3, warm_up=1)
     try:
