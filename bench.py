@@ -77,7 +77,7 @@ def poseidon_lane_slots():
         return None
 
 KERNELS = ("lde_columns", "leaf_hash", "quotient_eval")
-PMC_NAMES = {"lde_columns": ("lde_columns_v2_kernel",), "leaf_hash": ("leaf_hash_kernel",), "leaf_hash_lane": ("leaf_hash_lane_kernel",),
+PMC_NAMES = {"lde_columns": ("lde_columns_wave_kernel", "lde_columns_v2_kernel"), "leaf_hash": ("leaf_hash_kernel",), "leaf_hash_lane": ("leaf_hash_lane_kernel",),
              "quotient_eval": ("quotient_tiles_kernel", "quotient_eval_kernel")}
 FORM_KERNEL = {"quad": "leaf_hash_kernel", "lane": "leaf_hash_lane_kernel", "row": "leaf_hash_row_kernel", "merged": "leaf_hash_multi_kernel",
                "host": "host threads"}
@@ -302,6 +302,7 @@ def main():
     if dist is not None:
         dist.barrier()
     cpu0 = time.process_time()
+    host_cpu0 = S.api.host_cpu_seconds()
     t0 = time.perf_counter()
     tickets = [submit(k) for k in range(total_steps)]
     timed_last = {}
@@ -320,7 +321,7 @@ def main():
             phase_ms[name] += v
         hk = FORM_KERNEL[info["leaf_hash_form"]]
         timed_kernel_ms.setdefault(hk, []).append(info["kernel_ms"]["leaf_hash"])
-        timed_kernel_ms.setdefault("lde_columns_v2_kernel", []).append(info["kernel_ms"]["lde_columns"])
+        timed_kernel_ms.setdefault("lde_columns_wave_kernel", []).append(info["kernel_ms"]["lde_columns"])
         timed_kernel_ms.setdefault("quotient_tiles_kernel", []).append(info["kernel_ms"]["quotient_eval"])
         if info["leaf_hash_form"] == "lane":
             timed_groups.append(info["leaf_hash_group"])
@@ -331,6 +332,9 @@ def main():
         dist.barrier()
     elapsed_own = time.perf_counter() - t0
     cpu_s_per_proof = (time.process_time() - cpu0) / max(1, total_steps)
+    host_cpu1 = S.api.host_cpu_seconds()
+    cpu_split = {k: (host_cpu1[k] - host_cpu0[k]) / max(1, total_steps) for k in host_cpu1}
+    cpu_split["runtime_and_caller"] = cpu_s_per_proof - cpu_split["recording"] - cpu_split["proving"]
     elapsed = parallel.max_over_ranks(dist, elapsed_own, device=reduce_device)
     # every rank's own rate and CPU budget, for rank 0's line (N > 1: a bent curve must be attributable to a rank and to host or device)
     host_info = pool.host_info()
@@ -370,7 +374,7 @@ def main():
         alg = {"lde_columns": 8.0 * C * (n + N),  # read values, write the LDE (IFFT and LDE fused in one kernel; round 4: no coefficients kept)
                "leaf_hash": 8.0 * C * N,              # read the LDE once
                "quotient_eval": 8.0 * C * N}          # read the LDE on the quotient coset once
-        alg_by_kernel = {"lde_columns_v2_kernel": alg["lde_columns"], "quotient_tiles_kernel": alg["quotient_eval"]}
+        alg_by_kernel = {"lde_columns_wave_kernel": alg["lde_columns"], "quotient_tiles_kernel": alg["quotient_eval"]}
         for kname in FORM_KERNEL.values():
             alg_by_kernel[kname] = alg["leaf_hash"]
         perms = (C + 7) // 8 * N
@@ -398,7 +402,7 @@ def main():
         dom_ms = sum(timed_kernel_ms[dom]) / len(timed_kernel_ms[dom])
         side = (sum(timed_groups) / len(timed_groups)) if (dom == "leaf_hash_lane_kernel" and timed_groups) else 1.0
         per_launch_gbs = alg_by_kernel[dom] / (dom_ms * 1e-3) / 1e9
-        pmc_key = {"leaf_hash_lane_kernel": "leaf_hash_lane", "leaf_hash_kernel": "leaf_hash", "lde_columns_v2_kernel": "lde_columns",
+        pmc_key = {"leaf_hash_lane_kernel": "leaf_hash_lane", "leaf_hash_kernel": "leaf_hash", "lde_columns_wave_kernel": "lde_columns",
                    "quotient_tiles_kernel": "quotient_eval"}.get(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": per_launch_gbs * side, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": per_launch_gbs * side / HBM_PEAK_GBS, "traffic": pmc.get(pmc_key),
@@ -476,11 +480,13 @@ def main():
                                       f"{inflight} (start-up and tail of the pool dropped), summed over pools and ranks; null when a pool made fewer than "
                                       f"{3 * inflight} proofs in the timed region"),
             "host": {"cpus_granted": cpu_quota(), "cpu_budget_process": int(S.lib.starkhip_cpu_budget()), "pools": host_info,
-                     "cpu_seconds_per_proof": cpu_s_per_proof, "hw_queues_late": S.api.hw_queues_late(),
+                     "cpu_seconds_per_proof": cpu_s_per_proof, "cpu_seconds_per_proof_by_role": cpu_split, "hw_queues_late": S.api.hw_queues_late(),
                      "note": ("cpus_granted: cgroup quota / affinity mask of this process; cpu_budget_process: the library's figure (the same, divided by "
                               "LOCAL_WORLD_SIZE under torch.distributed.run); pools[].cpu_budget: what each pool plans with (divided again by the pools of an "
                               "in-process multi-device handle), its generator threads and the threads one FinalExp recording may use; cpu_seconds_per_proof: "
-                              "process CPU time over the timed region / proofs (recording, Fiat-Shamir hashing, upload gather, kernel launches)")},
+                              "process CPU time over the timed region / proofs; by_role: recording = inside starkhip_trace_* on the generator threads and their helpers, "
+                              "proving = the context threads inside prove() (launches, Fiat-Shamir sponge, upload gather), runtime_and_caller = the rest (the HIP "
+                              "runtime's own threads, this script)")},
             "per_rank": ([{"rank": r, "proofs_per_s": v[0], "cpu_budget": int(v[1]), "cpu_seconds_per_proof": v[2]} for r, v in enumerate(per_rank)]
                          if world > 1 else None),
             "per_rank_min_max": ([min(v[0] for v in per_rank), max(v[0] for v in per_rank)] if world > 1 else None),

@@ -271,6 +271,11 @@ typedef struct {
 } starkhip_pool_host_info_t;
 int starkhip_pool_host_info(void* pool, starkhip_pool_host_info_t* out);
 unsigned starkhip_cpu_budget(void);
+/* Where the pools' host CPU time goes, process-wide and cumulative (seconds of CPU, not of wall): [0] recording traces (the generator
+ * threads inside starkhip_trace_* and the helper threads of multi-threaded recordings), [1] the context threads inside prove() (kernel
+ * launches, the challenger's Fiat-Shamir sponge, gathering uploads, the FRI batches' host arithmetic), [2] the part of [1] spent INSIDE the waits for the device (an event wait that sleeps costs next to nothing).  What a process's
+ * total CPU time holds beyond these two is the HIP runtime's own threads and the caller. */
+void starkhip_host_cpu_seconds(double out[3]);
 /* Proof blobs of a warmed pool are recycled page-locked buffers (the final device-to-host copy of 21 .. 69 MB runs at PCIe rate and
  * touches no fresh pages); starkhip_free() hands them back.  Process-wide counters: [0] blobs held, [1] of them with a caller,
  * [2] bytes held, [3] proofs served from them, [4] proofs served by malloc (no idle blob that fits).  STARKHIP_PINNED_PROOFS=0 in

@@ -642,10 +642,19 @@ class PoolHostInfo(C.Structure):
 
 
 lib.starkhip_pool_host_info.argtypes = [C.c_void_p, C.POINTER(PoolHostInfo)]
+lib.starkhip_host_cpu_seconds.argtypes = [C.POINTER(C.c_double)]
+lib.starkhip_host_cpu_seconds.restype = None
 lib.starkhip_cpu_budget.argtypes = []
 lib.starkhip_cpu_budget.restype = C.c_uint
 lib.starkhip_proof_blob_stats.argtypes = [C.POINTER(C.c_uint64)]
 lib.starkhip_proof_blob_stats.restype = None
+
+
+def host_cpu_seconds():
+    """starkhip_host_cpu_seconds: cumulative CPU seconds of the pools' host work -- {"recording", "proving"}."""
+    out = (C.c_double * 3)()
+    lib.starkhip_host_cpu_seconds(out)
+    return {"recording": float(out[0]), "proving": float(out[1]), "of_proving_in_device_waits": float(out[2])}
 
 
 def proof_blob_stats():

@@ -412,6 +412,9 @@ int starkhip_pool_host_info(void* pool, starkhip_pool_host_info_t* out) {
     return pool_host_info((Pool*)pool, out);
 }
 unsigned starkhip_cpu_budget(void) { return cpu_budget(); }
+void starkhip_host_cpu_seconds(double out[3]) {
+    if (out) host_cpu_seconds(out);
+}
 int starkhip_pool_stats(void* pool, starkhip_pool_stats_t* out) {
     if (!pool || !out) return STARKHIP_ERR_BAD_SHAPE;
     return pool_stats((Pool*)pool, out);

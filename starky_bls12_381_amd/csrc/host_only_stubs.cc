@@ -21,6 +21,7 @@
 #include "trace_log.h"
 
 namespace starkhip {
+std::atomic<uint64_t> g_wait_cpu_ns(0);
 
 static bool fake_device() {
     const char* e = getenv("STARKHIP_FAKE_DEVICE");

@@ -40,6 +40,7 @@ int pool_stats(Pool* p, starkhip_pool_stats_t* out);
 int pool_reservation(Pool* p, starkhip_pool_reservation_t* out);
 int pool_host_info(Pool* p, starkhip_pool_host_info_t* out);
 unsigned cpu_budget();  // scheduler.cpp: CPUs this process may really use
+void host_cpu_seconds(double out[3]);
 // a pool per device behind one handle (scheduler.cpp): placement by outstanding cost, longest job first
 struct MultiPool;
 double air_cost(int air);

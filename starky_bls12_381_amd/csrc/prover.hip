@@ -3,6 +3,9 @@
 // SURVEY.md App. A.5 step by step; every heavy step is one of the kernels in kernels_*.hip, the host
 // only runs the Fiat-Shamir challenger, two length-n synthetic divisions and the proof assembly.
 #include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -96,6 +99,14 @@ struct Ctx {
     hipEvent_t hash_ready = nullptr, hash_done = nullptr;
     HashService::Timing hash_timing;  // pooled: the commitment kernel's own start / stop on ITS launch stream, its form and group
     hipEvent_t wait_ev = nullptr;  // hipEventBlockingSync: see stream_wait()
+    // Read-backs (caps, openings, FRI batches, the nonce) land in a page-locked arena and are copied to where prove() wants them when the
+    // host next waits for the stream (read_back() / stream_wait()): hipMemcpyAsync into PAGEABLE memory does not return until the copy has
+    // run, and the runtime waits for it spinning -- every context thread of a pool burned a CPU for as long as its proof's kernels ran
+    // (0.84 CPU-seconds per FinalExp proof with eight in flight against 0.27 with the arena; bench.py: host.cpu_seconds_per_proof_by_role).
+    void* rb = nullptr;
+    size_t rb_cap = 0, rb_used = 0;
+    struct Pending { void* dst; const void* src; size_t bytes; };
+    std::vector<Pending> rb_pending;
     void* host_staging = nullptr;  // page-locked: a recording's parts gathered for one upload (prove(), layout 2); scattered columns (layout 3)
     size_t host_staging_cap = 0;
     hipEvent_t col_ev[2] = {nullptr, nullptr};  // layout 3: the two halves of host_staging, each free again when its copy has run
@@ -125,7 +136,11 @@ struct Ctx {
     Tables* tab = nullptr;    // the current shape's (ensure_tables)
     PlanDev* plan = nullptr;  // the current AIR's (ensure_plan)
     long opt_leaf_hash_form = 0;     // 0: row form for a lone context's commitments of <= 4096 leaves, quad form otherwise; 1: quad always; 2: row always
+#ifdef STARKHIP_LDE_V2_DEFAULT      // A/B builds (make variant NAME=ldev2 DEFS=-DSTARKHIP_LDE_V2_DEFAULT): pooled contexts cannot be given an option from outside
+    long opt_lde_impl = 1;
+#else
     long opt_lde_impl = 0;           // 0: 8192-row traces take lde_columns_wave_kernel; 1: lde_columns_v2_kernel for every shape (the cross-check)
+#endif
     long opt_lde_closed_forms = 1;   // constant / unit-vector columns skip their transforms (kernels_lde.hip); 0: every column is transformed
     long opt_host_commit_leaves = 64; // trace commitments of at most this many leaves (and >= 64 columns) are hashed by host threads (0: never)
     std::vector<gl_t> host_lde;      // their LDE on the host
@@ -153,10 +168,49 @@ struct Ctx {
 // its stream most of the time; hipStreamSynchronize spins by default (hipDeviceScheduleAuto on a many-core host), and spinning
 // threads eat the CPUs -- in a container with a CPU quota, the quota -- that trace generation and the other proofs' Fiat-Shamir
 // hashing need.  Per event, so nothing about the device's scheduling flags changes for other libraries in the process (RCCL).
+// Waiting for an event WITHOUT a CPU: hipEventSynchronize on a hipEventBlockingSync event does not sleep on this runtime -- measured with
+// eight proofs in flight, 0.80 of the 0.84 CPU-seconds a context thread spends per FinalExp proof were inside that call (it yields, so it
+// only shows where CPUs are idle; where they are not, it takes them from the recordings, which run at nice 10).  The device phases it
+// waits for are milliseconds long, so: look a few times, then sleep in steps that grow from 20 to 200 microseconds.
+static hipError_t event_wait_sleeping(hipEvent_t ev) {
+    for (int spin = 0; spin < 8; spin++) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q != hipErrorNotReady) return q;
+    }
+    (void)hipGetLastError();  // hipErrorNotReady is not an error (and must not surface at the next launch)
+    timespec ts = {0, 20000};
+    for (;;) {
+        nanosleep(&ts, nullptr);
+        const hipError_t q = hipEventQuery(ev);
+        if (q != hipErrorNotReady) return q;
+        (void)hipGetLastError();
+        if (ts.tv_nsec < 200000) ts.tv_nsec += ts.tv_nsec / 2;
+    }
+}
+
+uint64_t thread_cpu_ns();                      // trace_tasks.cpp
+std::atomic<uint64_t> g_wait_cpu_ns(0);       // CPU time the context threads spend INSIDE their waits for the device (should be next to nothing)
 static hipError_t stream_wait(Ctx* c) {
+    const uint64_t cpu0 = thread_cpu_ns();
     hipError_t e = hipEventRecord(c->wait_ev, c->st);
-    if (e != hipSuccess) return e;
-    return hipEventSynchronize(c->wait_ev);
+    if (e == hipSuccess) e = event_wait_sleeping(c->wait_ev);
+    g_wait_cpu_ns.fetch_add(thread_cpu_ns() - cpu0);
+    for (const Ctx::Pending& p : c->rb_pending)  // the read-backs requested since the last wait have landed in the arena
+        if (e == hipSuccess) memcpy(p.dst, p.src, p.bytes);
+    c->rb_pending.clear();
+    c->rb_used = 0;
+    return e;
+}
+
+// device -> host on the context's stream, complete after the next stream_wait(c); `dst` may be pageable
+static hipError_t read_back(Ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (!c->rb || c->rb_used + need > c->rb_cap || st != c->st) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);  // does not fit: the direct (blocking) way
+    void* slot = (char*)c->rb + c->rb_used;
+    c->rb_used += need;
+    const hipError_t e = hipMemcpyAsync(slot, src, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) c->rb_pending.push_back({dst, slot, bytes});
+    return e;
 }
 
 static int ensure_tables(Ctx* c, unsigned log_n, unsigned rate, unsigned qdb) {
@@ -357,7 +411,10 @@ int ctx_create(int device, Ctx** out, int priority) {
     ok = ok && hipEventCreateWithFlags(&c->hash_done, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
     ok = ok && hipEventCreate(&c->hash_timing.t0) == hipSuccess && hipEventCreate(&c->hash_timing.t1) == hipSuccess;
+    if (ok && hipHostMalloc(&c->rb, (size_t)8 << 20, hipHostMallocDefault) == hipSuccess) c->rb_cap = (size_t)8 << 20;  // (without it read-backs go the direct way)
+    else c->rb = nullptr;
     if (!ok) {  // release whatever was created
+        if (c->rb) (void)hipHostFree(c->rb);
         if (c->hash_ready) (void)hipEventDestroy(c->hash_ready);
         if (c->hash_done) (void)hipEventDestroy(c->hash_done);
         if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
@@ -393,6 +450,7 @@ void ctx_destroy(Ctx* c) {
     for (auto& b : c->fri_digests) b.release();
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& e : c->kev) (void)hipEventDestroy(e);
+    if (c->rb) (void)hipHostFree(c->rb);
     (void)hipEventDestroy(c->hash_ready);
     (void)hipEventDestroy(c->hash_done);
     (void)hipEventDestroy(c->wait_ev);
@@ -458,7 +516,7 @@ size_t ctx_device_bytes(Ctx* c) {
     for (auto& b : c->fri_digests) total += b.cap;
     return total;
 }
-size_t ctx_pinned_bytes(Ctx* c) { return c->host_staging_cap; }
+size_t ctx_pinned_bytes(Ctx* c) { return c->host_staging_cap + c->rb_cap; }
 const float* ctx_timings(Ctx* c) { return c->timings; }
 const float* ctx_kernel_timings(Ctx* c) { return c->ktimings; }
 const float* ctx_host_timings(Ctx* c) { return c->htimings; }
@@ -488,6 +546,13 @@ struct HostWatch {  // accumulates wall time of the host-side stretches of prove
 
 int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64_t* trace, size_t n_rows, int layout, int on_device,
           const uint64_t* pis_host, size_t n_pis, uint64_t pow_witness, uint64_t** proof_out, size_t* proof_words) {
+    struct ReadBackGuard {  // an early return between a read_back() and its stream_wait() must not leave destinations of this call behind
+        Ctx* c;
+        ~ReadBackGuard() {
+            c->rb_pending.clear();
+            c->rb_used = 0;
+        }
+    } read_back_guard{c};
     const AirProgram& P = air.prog;
     unsigned log_n = 0;
     while (((size_t)1 << log_n) < n_rows) log_n++;
@@ -637,7 +702,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         for (size_t c0 = 0; c0 < C; c0 += per_half, h ^= 1) {
             const size_t cnt = std::min(per_half, C - c0);
             char* dst = (char*)c->host_staging + (size_t)h * half_bytes;
-            if (used[h]) HIPCHK(hipEventSynchronize(c->col_ev[h]));  // the copy that last read this half has run
+            if (used[h]) HIPCHK(event_wait_sleeping(c->col_ev[h]));  // the copy that last read this half has run
             const unsigned n_thr = cnt * col_bytes > ((size_t)8 << 20) ? 4 : 1;
             auto gather = [&](unsigned w) {
                 for (size_t i = w; i < cnt; i += n_thr) memcpy(dst + i * col_bytes, cols[c0 + i], col_bytes);
@@ -745,7 +810,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(hipEventRecord(c->kev[1], st));
     HIPCHK(launch_merkle_levels(c->digests.as<gl_t>(), log_N, cap_h, st));
     std::vector<gl_t> trace_cap(4 * ncap), quot_cap(4 * ncap);
-    HIPCHK(hipMemcpyAsync(trace_cap.data(), c->digests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), 4 * ncap * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(read_back(c, trace_cap.data(), c->digests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), 4 * ncap * 8, st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
     ranges.next("starkhip:quotient");
     HIPCHK(stream_wait(c));
@@ -793,7 +858,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             int rc2;
             if ((rc2 = ensure_plan(c, air, size))) return rc2;
             std::vector<gl_t> ref(2 * size), got(2 * size);
-            HIPCHK(hipMemcpyAsync(ref.data(), c->qvals.p, 2 * size * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(read_back(c, ref.data(), c->qvals.p, 2 * size * 8, st));
             HIPCHK(c->partial.ensure((size_t)std::max(n_chunks, c->plan->chunks) * 2 * size * 8));
             HIPCHK(launch_quotient_weights(c->plan->q_recs.as<QTRec>(), c->plan->q_contrib_off.as<uint32_t>(), c->plan->q_contribs.as<QTContrib>(), c->plan->recs,
                                            c->plan->q_apow.as<gl_t>(), P.n_constraints, c->plan->q_consts.as<gl_t>(), c->pis.as<gl_t>(), alphas[0], alphas[1], st));
@@ -801,7 +866,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
                                          c->plan->q_chunk_tile_off.as<uint32_t>(), c->plan->q_tile_list.as<uint32_t>(), c->plan->chunks, c->lde.as<gl_t>(),
                                          c->tab->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, 0, st));
             HIPCHK(launch_quotient_tiles_combine(c->partial.as<gl_t>(), c->plan->chunks, c->tab->qtab.as<gl_t>(), log_n, qdb, c->comb_partial.as<gl_t>(), st));
-            HIPCHK(hipMemcpyAsync(got.data(), c->comb_partial.p, 2 * size * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(read_back(c, got.data(), c->comb_partial.p, 2 * size * 8, st));
             HIPCHK(stream_wait(c));
             size_t bad = 0;
             size_t last_blk = (size_t)-1;
@@ -822,8 +887,8 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         if (size > (size_t)factor * n) {
             tail.resize(2 * (size - factor * n));
             for (int j = 0; j < 2; j++)
-                HIPCHK(hipMemcpyAsync(tail.data() + j * (size - factor * n), c->qvals.as<gl_t>() + j * size + factor * n,
-                                      (size - factor * n) * 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(read_back(c, tail.data() + j * (size - factor * n), c->qvals.as<gl_t>() + j * size + factor * n,
+                                      (size - factor * n) * 8, st));
         }
         for (int j = 0; j < 2; j++)
             HIPCHK(hipMemcpyAsync(c->qcoef.as<gl_t>() + (size_t)j * factor * n, c->qvals.as<gl_t>() + j * size, (size_t)factor * n * 8,
@@ -839,7 +904,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(run_lde(c, c->qcoef.as<gl_t>(), nullptr, c->qlde.as<gl_t>(), Q, log_n, r, 1));
     HIPCHK(launch_leaf_hash(c->qlde.as<gl_t>(), Q, log_n, r, c->qdigests.as<gl_t>(), st));
     HIPCHK(launch_merkle_levels(c->qdigests.as<gl_t>(), log_N, cap_h, st));
-    HIPCHK(hipMemcpyAsync(quot_cap.data(), c->qdigests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), 4 * ncap * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(read_back(c, quot_cap.data(), c->qdigests.as<gl_t>() + 4 * level_off(N, log_N - cap_h), 4 * ncap * 8, st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
     ranges.next("starkhip:openings");
     HIPCHK(stream_wait(c));
@@ -863,9 +928,9 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     HIPCHK(launch_openings(c->lde.as<gl_t>(), N, C, n, c->zpow.as<gl2_t>() + n, c->gzpow.as<gl2_t>(), c->open_local.as<gl2_t>(),
                            c->open_next.as<gl2_t>(), st));
     HIPCHK(launch_openings(c->qcoef.as<gl_t>(), n, Q, n, c->zpow.as<gl2_t>(), nullptr, c->open_q.as<gl2_t>(), nullptr, st));
-    HIPCHK(hipMemcpyAsync(op_local.data(), c->open_local.p, C * 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(op_next.data(), c->open_next.p, C * 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(op_q.data(), c->open_q.p, Q * 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(read_back(c, op_local.data(), c->open_local.p, C * 16, st));
+    HIPCHK(read_back(c, op_next.data(), c->open_next.p, C * 16, st));
+    HIPCHK(read_back(c, op_q.data(), c->open_q.p, Q * 16, st));
     HIPCHK(hipEventRecord(c->ev[evi++], st));
     ranges.next("starkhip:fri_combine");
     HIPCHK(stream_wait(c));
@@ -890,8 +955,8 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         HIPCHK(launch_fri_combine(c->qcoef.as<gl_t>(), n, Q, n, c->ext_apow.as<gl2_t>() + C, Q, 1, comb_q, st));  // alpha^(C+q) quotient_q
         std::vector<gl_t> F1w(2 * n);
         std::vector<gl2_t> F1(n), tailq(n), F0(n), q0(n), q1(n);
-        HIPCHK(hipMemcpyAsync(F1w.data(), comb_t, n * 16, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(tailq.data(), comb_q, n * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(read_back(c, F1w.data(), comb_t, n * 16, st));
+        HIPCHK(read_back(c, tailq.data(), comb_q, n * 16, st));
         HIPCHK(stream_wait(c));
         host_other.start();
         for (size_t k = 0; k < n; k++) F1[k] = gl2_make(F1w[k], F1w[n + k]);
@@ -938,8 +1003,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             HIPCHK(launch_merkle_levels(c->fri_digests[l].as<gl_t>(), log_len - ab, cap_h, st));
             // leaves and digests stay on the device (the query phase gathers from them); only the cap feeds the transcript
             gl_t* cap = fri_caps.data() + l * 4 * ncap;
-            HIPCHK(hipMemcpyAsync(cap, c->fri_digests[l].as<gl_t>() + 4 * level_off(n_leaves, log_len - ab - cap_h), 4 * ncap * 8,
-                                  hipMemcpyDeviceToHost, st));
+            HIPCHK(read_back(c, cap, c->fri_digests[l].as<gl_t>() + 4 * level_off(n_leaves, log_len - ab - cap_h), 4 * ncap * 8, st));
             HIPCHK(stream_wait(c));
             fs.start();
             ch.observe_many(cap, 4 * ncap);
@@ -954,8 +1018,8 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
         }
         // final polynomial: truncate to len >> rate_bits; the dropped coefficients must be zero
         std::vector<gl_t> fc(2 * len);
-        HIPCHK(hipMemcpyAsync(fc.data(), coef, len * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(fc.data() + len, coef + len, len * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(read_back(c, fc.data(), coef, len * 8, st));
+        HIPCHK(read_back(c, fc.data() + len, coef + len, len * 8, st));
         HIPCHK(stream_wait(c));
         if ((len >> r) != geo.final_poly_len) return STARKHIP_ERR_BAD_SHAPE;
         for (size_t k = 0; k < len; k++) {
@@ -984,7 +1048,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
                 if (start >= GL_P - batch) return STARKHIP_ERR_HIP;
                 HIPCHK(hipMemcpyAsync(c->pow_best.p, &best, 8, hipMemcpyHostToDevice, st));
                 HIPCHK(launch_pow_grind(c->pow_state.as<gl_t>(), ch.n_in, cfg.proof_of_work_bits, start, batch, c->pow_best.as<unsigned long long>(), st));
-                HIPCHK(hipMemcpyAsync(&best, c->pow_best.p, 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(read_back(c, &best, c->pow_best.p, 8, st));
                 HIPCHK(stream_wait(c));
             }
             pow_witness = best;
@@ -1197,7 +1261,7 @@ int lde_bench(Ctx* c, size_t n_cols, unsigned log_n, unsigned rate_bits, unsigne
     else HIPCHK(launch_fill_powers(c->values.as<gl_t>(), 3, GL_GENERATOR, n_cols * n, c->st));
     // `const_per_64` of every 64 columns constant (a FinalExp trace: 11 of 64 take a closed form), in runs of up to 12 as its Fp12 blocks are
     // (+ 256: unit vectors instead -- one 1 per column, at a different row each -- the other closed form: FinalExp's 8192 row selectors)
-    const bool unit = (const_per_64 & 256u) != 0, prewarm = (const_per_64 & 1024u) != 0;  // + 1024 (with reps == 0): see below
+    const bool unit = (const_per_64 & 256u) != 0, prewarm = (const_per_64 & 1024u) != 0, touch = (const_per_64 & 2048u) != 0;  // + 1024 / + 2048 (with reps == 0): see below
     const_per_64 &= 255u;
     for (size_t c0 = 0; const_per_64 && c0 < n_cols; c0 += 64) {
         const size_t cnt = std::min<size_t>(const_per_64, n_cols - c0);
@@ -1211,6 +1275,7 @@ int lde_bench(Ctx* c, size_t n_cols, unsigned log_n, unsigned rate_bits, unsigne
     hipError_t err = hipSuccess;
     for (hipEvent_t& e : ev)
         if (err == hipSuccess) err = hipEventCreate(&e);
+    if (err == hipSuccess && cold && touch) err = hipMemsetAsync(c->lde.p, 0, n_cols * N * 8, c->st);  // every page of the output written once just before
     if (err == hipSuccess && cold && prewarm)  // a few milliseconds of the same arithmetic on a small footprint, then the launch that is timed
         for (int k = 0; k < 4 && err == hipSuccess; k++) err = run_lde(c, in, nullptr, c->lde.as<gl_t>(), std::min<size_t>(n_cols, 4096), log_n, rate_bits, 0);
     if (err == hipSuccess) err = cold ? hipStreamSynchronize(c->st) : run_lde(c, in, nullptr, c->lde.as<gl_t>(), n_cols, log_n, rate_bits, 0);  // warm-up

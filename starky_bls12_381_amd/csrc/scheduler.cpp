@@ -56,6 +56,16 @@ unsigned cpu_budget() {
     return hw;
 }
 
+uint64_t thread_cpu_ns();                                 // trace_tasks.cpp
+extern std::atomic<uint64_t> g_trace_worker_cpu_ns;       // CPU time of the recordings' helper threads
+extern std::atomic<uint64_t> g_wait_cpu_ns;               // prover.hip: CPU time inside the context threads' waits for the device
+static std::atomic<uint64_t> g_gen_cpu_ns(0), g_prove_cpu_ns(0);  // ... of the generator threads inside a recording, of the context threads inside prove()
+void host_cpu_seconds(double out[3]) {
+    out[0] = (double)(g_gen_cpu_ns.load() + g_trace_worker_cpu_ns.load()) * 1e-9;
+    out[1] = (double)g_prove_cpu_ns.load() * 1e-9;
+    out[2] = (double)g_wait_cpu_ns.load() * 1e-9;
+}
+
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ------------------------------------------------------------------------------------------------ HashService
@@ -521,6 +531,7 @@ struct Pool {
                 j->t[1] = now();
             }
             int rc = STARKHIP_OK;
+            const uint64_t cpu0 = thread_cpu_ns();
             try {
                 set_thread_trace_threads(tt);
                 const AirInfo* a = air_get(j->air);
@@ -542,6 +553,7 @@ struct Pool {
             } catch (const std::exception&) {
                 rc = STARKHIP_ERR_BAD_SHAPE;
             }
+            g_gen_cpu_ns.fetch_add(thread_cpu_ns() - cpu0);
             if (rc != STARKHIP_OK) {
                 if (j->own_log) starkhip_trace_log_free(j->own_log);
                 j->own_log = nullptr;
@@ -669,6 +681,7 @@ struct Pool {
             const bool announce = !big && ctx_has_hash_service(c);
             if (announce) hs->announce_small();
             ctx_hash_request_reset(c);
+            const uint64_t cpu0 = thread_cpu_ns();
             try {
                 const AirInfo* a = air_get(j->air);
                 rc = prove(c, *a, j->cfg, j->trace, j->n_rows, j->kind == JOB_COMPACT ? 2 : j->kind == JOB_COLUMNS ? 3 : j->layout, j->on_device, j->pis,
@@ -678,6 +691,7 @@ struct Pool {
             } catch (const std::exception&) {
                 rc = STARKHIP_ERR_BAD_SHAPE;
             }
+            g_prove_cpu_ns.fetch_add(thread_cpu_ns() - cpu0);
             if (announce && !ctx_hash_requested(c)) hs->abandon_small();  // failed before its commitment: do not hold the window open
             if (announce_big && !ctx_hash_requested(c)) hs->abandon_big();
             if (announce_big) hs->finish_big();

@@ -11,9 +11,20 @@
 #include <thread>
 #include <vector>
 
+#include <time.h>
+
 #include "gadgets.h"
 
 namespace starkhip {
+
+// CPU time of the calling thread, and the process-wide tally of what recording costs on the helper threads below (they end with their
+// recording, so nothing else can read their clocks afterwards): starkhip_host_cpu_seconds
+uint64_t thread_cpu_ns() {
+    timespec ts;
+    if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) != 0) return 0;
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+std::atomic<uint64_t> g_trace_worker_cpu_ns(0);
 
 void fill_tasks(Trace& t, size_t n_tasks, const std::function<void(Trace&, size_t)>& fill) {
     const int threads = t.log ? trace_threads() : 1;
@@ -38,8 +49,12 @@ void fill_tasks(Trace& t, size_t n_tasks, const std::function<void(Trace&, size_
         }
     };
     std::vector<std::thread> pool;
+    auto helper = [&] {
+        worker();
+        g_trace_worker_cpu_ns.fetch_add(thread_cpu_ns());  // a fresh thread: its clock started at zero
+    };
     try {
-        for (int w = 1; w < threads && (size_t)w < n_tasks; w++) pool.emplace_back(worker);
+        for (int w = 1; w < threads && (size_t)w < n_tasks; w++) pool.emplace_back(helper);
     } catch (const std::system_error&) {
         // no more threads to be had: the ones that started and this one share the tasks
     }

@@ -4,4 +4,4 @@ import starky_bls12_381_amd as S
 pv = S.Prover(0)
 print("eight launches after a warm-up launch:", pv.lde_bench(73527, 13, 2, 8, 11, each=True))
 print("one launch, nothing in front:         ", [pv.lde_bench(73527, 13, 2, 0, 11, each=True)[0] for _ in range(3)])
-print("one launch after 4 launches over 4096 columns:", [pv.lde_bench(73527, 13, 2, 0, 11 + 1024, each=True)[0] for _ in range(3)])
+print("one launch after a memset of the whole output buffer:", [pv.lde_bench(73527, 13, 2, 0, 11 + 2048, each=True)[0] for _ in range(3)])

@@ -11,6 +11,7 @@ KERNEL_SOURCES = {
     "leaf_hash_lane_kernel": ("kernels_hash.hip", "poseidon_dev.h", "poseidon_merged.h", "gl_dev.h", "lane_round_asm.inc"),
     "quotient_tiles_kernel": ("kernels_quotient.hip", "quotient_plan.h", "gl_dev.h"),
     "lde_columns_v2_kernel": ("kernels_lde.hip", "gl_dev.h"),
+    "lde_columns_wave_kernel": ("kernels_lde.hip", "gl_dev.h"),
 }
 
 

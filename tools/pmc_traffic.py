@@ -20,7 +20,7 @@ def main():
         seen = {}
         for f, ctr in ((dbs[pair], "FETCH_SIZE"), (dbs[pair + 1], "WRITE_SIZE")):
             cur = sqlite3.connect(f).cursor()
-            for k in ("leaf_hash_lane_kernel", "leaf_hash_kernel", "quotient_tiles_kernel", "lde_columns_v2_kernel"):
+            for k in ("leaf_hash_lane_kernel", "leaf_hash_kernel", "quotient_tiles_kernel", "lde_columns_wave_kernel", "lde_columns_v2_kernel"):
                 rows = list(cur.execute("select value, duration from counters_collection where kernel_name like ? and counter_name = ? order by duration desc",
                                         ("%" + k + "%", ctr)))
                 if not rows:
@@ -28,7 +28,9 @@ def main():
                 big = [r for r in rows if r[1] > 0.5 * rows[0][1]]
                 # a trace's LDE is SEVERAL launches (3/4, 3/16, 3/64 and the last 1/64 of the columns: prover.hip run_lde_trace): the bytes
                 # of all of them per proof (the quotient commitment's four-column launches are in the sum too: 0.005 % of it)
-                part = rows if k == "lde_columns_v2_kernel" else big
+                # (lde_columns_wave_kernel: every launch of a trace has the same persistent grid; the first launch of a proof -- 3/4 of the
+                # columns -- is the `big` one, so len(big) = proofs)
+                part = rows if k.startswith("lde_columns") else big
                 seen.setdefault(k, {})[ctr] = (sum(r[0] for r in part) / len(big), len(big), sum(r[1] for r in part) / len(big) / 1e6)
         for k, v in seen.items():
             if k not in res and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
