@@ -471,12 +471,16 @@ __global__ __launch_bounds__(512, 4) void lde_columns_wave_kernel(const gl_t* va
                 row = t + (unsigned)i * T;
             }
         }
+        // per WAVE first (ballots), then one LDS atomic per wave: 512 lanes' atomics on one address serialise -- in a real trace nearly
+        // every thread holds a cell that differs from the first and a cell that is 1 (2 x 512 conflicting LDS operations per column)
+        const bool w_differs = __ballot(flags & 1u) != 0, w_big = __ballot(flags & 2u) != 0;
+        const unsigned w_ones = (unsigned)__popcll(__ballot(ones == 1)) + 2u * (unsigned)(__ballot(ones > 1) != 0);  // exact while it matters (<= 1)
         __syncthreads();  // cls[] cleared
-        if (flags) atomicOr(&cls[0], flags);
-        if (ones) {
-            atomicAdd(&cls[1], ones);
-            cls[2] = row;
+        if (l == 0) {
+            if (w_differs || w_big) atomicOr(&cls[0], (w_differs ? 1u : 0u) | (w_big ? 2u : 0u));
+            if (w_ones) atomicAdd(&cls[1], w_ones);
         }
+        if (w_ones == 1 && ones == 1) cls[2] = row;  // one lane of the wave
         __syncthreads();
         const unsigned all_flags = cls[0], all_ones = cls[1];
         const bool is_const = (all_flags & 1u) == 0, is_unit = (all_flags & 2u) == 0 && all_ones == 1;

@@ -1,9 +1,11 @@
 """Host side of the end-to-end signature driver (starky_bls12_381_amd/signature.py) without a GPU: synthetic valid
 signatures, the batch plan, and the generate -> prove pipeline with a stand-in prover (real compact trace generators)."""
 import numpy as np
+import pytest
 
 import starky_bls12_381_amd as S
 from starky_bls12_381_amd import aggregate as A
+from starky_bls12_381_amd import parallel
 from starky_bls12_381_amd import signature as G
 from bls_util import native_vectors
 
@@ -165,3 +167,42 @@ def test_pool_driver_submits_every_job_with_the_operands_its_generator_takes():
     fe = results[(1, "final_exp")][1][-288:]
     assert np.array_equal(fe[:144], natives[1]["product"].astype(np.uint64)) and np.array_equal(fe[144:], natives[1]["final"].astype(np.uint64))
     assert stats["generate_s"] >= 0 and elapsed > 0
+
+
+def test_compiled_placement_rule_is_the_python_plan():
+    """starkhip_plan_lpt (what starkhip_multipool_submit_witness_batch applies inside ONE process) places a batch exactly as
+    signature.plan_batch / parallel.assign_jobs place it across torchrun ranks: same cost table, longest first, ties to the lowest index.
+    BASELINE configs[3]: one signature on six devices -- one proof each; configs[4]: 48 proofs on eight -- a FinalExp proof per device
+    first, then two MillerLoop, two PairingPrecomp and an FP12Mul each."""
+    for air, cost in parallel.AIR_COST.items():
+        assert S.api.air_cost(air) == cost
+    for batch, world in ((1, 6), (8, 8), (8, 6), (3, 2), (5, 8)):
+        jobs = [(i, name) for i in range(batch) for name in A.JOB_ORDER]
+        airs = [A.JOB_AIR[name] for _, name in jobs]
+        slots = S.api.plan_lpt(airs, world)
+        want = [None] * len(jobs)
+        for rank, mine in enumerate(G.plan_batch(batch, world)):
+            for j in mine:
+                want[jobs.index(j)] = rank
+        assert slots == want, (batch, world)
+    one = S.api.plan_lpt([A.JOB_AIR[n] for n in A.JOB_ORDER], 6)
+    assert sorted(one) == list(range(6)) and one[A.JOB_ORDER.index("final_exp")] == 0
+    eight = S.api.plan_lpt([A.JOB_AIR[n] for _ in range(8) for n in A.JOB_ORDER], 8)
+    per_dev = [sorted(A.JOB_AIR[A.JOB_ORDER[k % 6]] for k, s in enumerate(eight) if s == d) for d in range(8)]
+    assert all(p == sorted(A.JOB_AIR[n] for n in A.JOB_ORDER) for p in per_dev)   # every device: a FinalExp, two MillerLoop, two PairingPrecomp, an FP12Mul
+
+
+def test_multi_device_handle_without_a_gpu_fails_loudly():
+    """No CPU fallback: without a device the handle cannot be created, and a null handle is refused by every entry point."""
+    import ctypes as C
+    with pytest.raises(S.StarkhipError) as e:
+        S.ProofPool(devices=[0, 1])
+    assert e.value.code == S.ERR_NO_DEVICE
+    t = C.c_uint64()
+    ops = (C.c_uint32 * 144)()
+    assert S.lib.starkhip_multipool_submit_witness(None, -1, S.AIR_FINAL_EXP, None, ops, 144, S.POW_SEARCH, C.byref(t)) == S.ERR_NO_DEVICE
+    assert S.lib.starkhip_multipool_wait(None, 1, None, None, None) == S.ERR_NO_DEVICE
+    assert S.lib.starkhip_multipool_size(None) == 0 and S.lib.starkhip_multipool_ticket_slot(None, 1 << 48) == -1
+    assert S.api.hw_queues_late() is False   # nothing in this process has initialised HIP behind the library's back
+    cpu = S.api.host_cpu_seconds()
+    assert set(cpu) == {"recording", "proving", "of_proving_in_device_waits"} and all(v >= 0 for v in cpu.values())
