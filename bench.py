@@ -409,6 +409,7 @@ def main():
                     "traffic_source": pmc_src, "traffic_stale_for": pmc_stale or None,
                     "algorithmic_bytes_per_launch": alg_by_kernel[dom], "avg_launch_ms": dom_ms, "launches_timed": len(timed_kernel_ms[dom]),
                     "launches_side_by_side": side, "achieved_per_launch": per_launch_gbs,
+                    "group_sizes": ({str(k): timed_groups.count(k) for k in sorted(set(timed_groups))} if timed_groups else None),
                     "achieved_is": ("algorithmic bytes per launch / average launch duration x the launches of a group that run side by side (a lane-form "
                                     "launch holds a quarter of the chip's registers; `achieved_per_launch` is the plain quotient)"
                                     if side > 1 else "algorithmic bytes per launch / average launch duration"),

@@ -456,7 +456,10 @@ struct Pool {
     unsigned stream_priority = 0;
     bool warm_device_traces = false;  // warm_up == 2: the caller's traces are column-major device memory: no trace buffers are reserved
     int gen_nice = 10;  // STARKHIP_GEN_NICE: nice value of the generator threads (0: as the rest of the process)
-    static constexpr size_t gen_ahead = 1;  // FinalExp-class recordings made beyond the ones the contexts can take at once
+#ifndef STARKHIP_GEN_AHEAD
+#define STARKHIP_GEN_AHEAD 1
+#endif
+    static constexpr size_t gen_ahead = STARKHIP_GEN_AHEAD;  // FinalExp-class recordings made beyond the ones the contexts can take at once
     bool warm = false;        // contexts reserve the pipeline's AIRs when their threads start (pool_create waits for it)
     unsigned warmed = 0;
     int warm_rc = STARKHIP_OK;

@@ -146,6 +146,17 @@ def test_multi_device_handle_from_python_places_jobs_and_matches_single_pool_byt
         assert mp.slot_of(pinned) == 2
         got = [mp.wait(t)[0] for t in tickets]
         assert np.array_equal(mp.wait(pinned)[0], want[0])
+        # the other hand-over forms through the handle: a recorded trace, dense rows, separately allocated columns
+        air = A.JOB_AIR["pp1"]
+        cfg = S.StarkConfig.for_air(air)
+        args = jobs["pp1"][1]
+        compact, cpis = S.trace_pairing_precomp(*args, compact=True)
+        dense, pis = S.trace_pairing_precomp(*args)
+        cols = [np.ascontiguousarray(dense[:, c]) for c in range(dense.shape[1])]
+        t_forms = [mp.submit(air, cfg, compact, cpis), mp.submit(air, cfg, dense, pis, slot=1), mp.submit_columns(air, cfg, cols, pis)]
+        assert mp.slot_of(t_forms[1]) == 1
+        for t in t_forms:
+            assert np.array_equal(mp.wait(t)[0], want[A.JOB_ORDER.index("pp1")])
         per_pool = mp.stats(per_pool=True)
     finally:
         mp.close()
