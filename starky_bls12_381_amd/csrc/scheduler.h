@@ -65,7 +65,10 @@ class HashService {
     unsigned BIG_LANE_GROUP = 4;  // STARKHIP_POOL_LANE_GROUP: commitments per lane-form group (four fill the chip: two waves of 256 registers per SIMD)
     double big_gather_ms_ = 1000.0; // lane form: how long a group of big commitments waits at most for proofs that HAVE STARTED to join (a group of three
                                     // wastes a quarter of a 350 ms launch: full groups measured 6.46 against 6.2 - 6.3 proofs/s with a 150 ms bound)
-    double big_queued_wait_ms_ = 300.0;  // ... and for jobs that have not started (queued, or being recorded) when nobody who has started is on the
+#ifndef STARKHIP_QUEUED_WAIT_MS
+#define STARKHIP_QUEUED_WAIT_MS 300.0
+#endif
+    double big_queued_wait_ms_ = STARKHIP_QUEUED_WAIT_MS;  // ... and for jobs that have not started (queued, or being recorded) when nobody who has started is on the
                                          // way: a recording plus upload plus LDE -- what the soonest of them needs -- not the full bound (a short batch,
                                          // or the tail of one, would otherwise hold a commitment for several proof lengths)
     void set_big_queued(int n);     // the pool's count of big jobs that have not started yet (queued, or their trace being recorded)
