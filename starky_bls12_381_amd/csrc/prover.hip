@@ -173,6 +173,9 @@ struct Ctx {
 // only shows where CPUs are idle; where they are not, it takes them from the recordings, which run at nice 10).  The device phases it
 // waits for are milliseconds long, so: look a few times, then sleep in steps that grow from 20 to 200 microseconds.
 static hipError_t event_wait_sleeping(hipEvent_t ev) {
+#ifdef STARKHIP_RUNTIME_WAIT  // A/B builds: the runtime's own wait (rounds 3-4)
+    return hipEventSynchronize(ev);
+#endif
     for (int spin = 0; spin < 8; spin++) {
         const hipError_t q = hipEventQuery(ev);
         if (q != hipErrorNotReady) return q;
