@@ -1,0 +1,367 @@
+#!/usr/bin/env python3
+"""The PAIR form of the Poseidon permutation, costed: lanes l and l + 32 of a wave share one permutation (lane l holds state elements
+0 .. 5, lane l + 32 elements 6 .. 11), one 256-register wave per SIMD -- the form a LONE FinalExp-class commitment would take instead
+of the quad form.  This script builds the rounds with the instruction model, list scheduler and interpreter of
+tools/gen_lane_round_asm.py / gen_row_round_asm.py, checks them on two lanes against the rounds in Python integers, and prints the
+issue slots per permutation -- the number the decision to build the kernel rests on.  It emits no include file: nothing in the
+product uses this form (yet).
+
+  full round      six S-boxes per lane; the circulant layer on the matrix pipe as in the lane form, but with a DENSE weight tile: the
+                  two lane halves supply the two K halves of v_mfma_i32_32x32x32_i8 (elements 0 .. 5 and 6 .. 11 of the same column),
+                  and the result rows are chosen so that outputs 0 .. 5 land in the lower half-wave and 6 .. 11 in the upper one
+  merged triple   three partial rounds at once (poseidon_merged.h): the two dot products are partial sums over a lane's own six
+                  elements added across the pair with v_permlane32_swap_b32; the dense 12 x 12 layer needs the partner's six elements
+                  (12 swaps) and computes six outputs per lane
+  partial round   the lone one: S-box on element 0 (lower half only), layer on the matrix pipe
+
+    python tools/gen_pair_round_asm.py
+"""
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen_row_round_asm as G  # noqa: E402
+import gen_lane_round_asm as L  # noqa: E402
+
+Ins, v, vp, sp = G.Ins, G.v, G.vp, G.sp
+P, M32, M64 = G.P, G.M32, G.M64
+G.NL = 2   # lane 0 = lower half-wave (elements 0 .. 5), lane 1 = upper half-wave (elements 6 .. 11)
+
+T, S = L.T, L.S                  # state: six pairs v[80:91]; S-box outputs / hi halves: six pairs v[104:115]
+PT = 116                         # the partner's six elements (pairs v[116:127]) -- merged triple
+O = L.O                          # dense layer outputs: six pairs v[176:187]
+TMP = 188                        # copies for the swaps (four pairs)
+MASK_LO = 70                     # SGPR pair in: lanes 0 .. 31
+NE = 6                           # elements per lane
+
+
+def swap(prog, a, b):
+    """v_permlane32_swap_b32 a, b: rows 2, 3 of a <-> rows 0, 1 of b"""
+    ins = Ins("v_permlane32_swap_b32 %s, %s" % (v(a), v(b)), [a, b], [a, b], dpp=True, sem=("swap32", a, b))
+    prog.append(ins)
+
+
+def partners(prog, d0, d1, s0, s1):
+    """d0 = the PARTNER lane's s1, d1 = the partner lane's s0 (64-bit pairs), in both lanes.  Two copies and four swaps:
+    swap(X, Y) sends the upper lane's X to the lower lane's Y and the lower lane's Y to the upper lane's X; with X = copy of s0's dword
+    and Y = copy of s1's dword, swap(X, Y) then swap(Y, X) leaves the partner's s1 in X and the partner's s0 in Y -- in BOTH lanes."""
+    prog.append(Ins("v_mov_b64 %s, %s" % (vp(d0), vp(s0)), [s0, s0 + 1], [d0, d0 + 1], sem=("mov64", d0, s0)))
+    prog.append(Ins("v_mov_b64 %s, %s" % (vp(d1), vp(s1)), [s1, s1 + 1], [d1, d1 + 1], sem=("mov64", d1, s1)))
+    for h in (0, 1):
+        swap(prog, d0 + h, d1 + h)
+        swap(prog, d1 + h, d0 + h)
+
+
+# ---------------------------------------------------------------- full / partial round on the matrix pipe
+# v_mfma_i32_32x32x32_i8, D[row][col] = sum_K A[row][K] B[K][col]: lane (col = l & 31, half = l >> 5) of the B operand holds 16 K-values of
+# its column, which meet the 16 K-values lane (row, half) of the A operand holds; result register i of lane (col, half) is row
+# (i & 3) + 8 (i >> 2) + 4 half (tools/experiments/mfma_mds_probe.hip).  Here column = permutation, the two halves hold its elements
+# 0 .. 5 and 6 .. 11, and ONE instruction multiplies TWO byte planes: the 16 K-values of a lane are
+#     dword d = 0 .. 2:  (e[2d].b_p, e[2d+1].b_p, e[2d].b_p+1, e[2d+1].b_p+1)   -- one v_perm_b32 of the two words' dwords
+#     dword 3:           (1, 64, 127, 127)                                      -- the constants' carrier, as in the lane form
+# and weight row (g, p') = output g against plane p + p' is M[g][6 half + 2 d + (i & 1)] where (i >> 1) == p', zero elsewhere.  Rows are
+# assigned so that result registers 0 .. 5 of a lane are its own six outputs for plane p and 6 .. 11 the same for plane p + 1:
+# row(i, half) -> g = 6 half + i % 6, p' = i / 6.  Four instructions per round instead of the lane form's eight, 12 byte permutes instead of 48.
+def pair_mfma(prog, q):
+    a, b, d = L.AW[q % 2], L.BP[q], DT[q]
+    L.load(prog, a + 3, 1, L.A_RCB, 256 * q, ("rcb", q))
+    ins = Ins("v_mfma_i32_32x32x32_i8 v[%d:%d], v[%d:%d], v[%d:%d], 0" % (d, d + 15, a, a + 3, b, b + 3),
+              [a, a + 1, a + 2, a + 3, b, b + 1, b + 2, b + 3, L.MFMA_PIPE], list(range(d, d + 12)) + [L.MFMA_PIPE], sem=("pmfma", d, a, b, q))
+    ins.is_mfma = True
+    ins.junk = set(range(d + 12, d + 16))
+    prog.append(ins)
+
+
+DT = [128 + 12 * q for q in range(4)]   # result tiles (sixteen registers written, twelve results; the junk rows are the next tile's first four)
+
+
+def circulant_pair(prog, in_base, out_base, first_out=0):
+    """out[i] = RC + sum_j M[g][j] in[j], g = 6 * half + i, for this lane's outputs first_out .. 5"""
+    for half in range(2):
+        w = [in_base + 2 * e + half for e in range(NE)]
+        for q2, sel in ((0, "A"), (1, "B")):
+            q = 2 * half + q2
+            for d in range(3):
+                L.perm(prog, L.BP[q] + d, w[2 * d + 1], w[2 * d], sel)
+            for d in range(3):
+                L.xor80(prog, L.BP[q] + d)
+            pair_mfma(prog, q)
+    for half in range(2):
+        for i in range(first_out, NE):
+            ad = L.AD[i % 2]
+            u = L.UT[(2 * half + i) % 4]
+            t0, t1 = DT[2 * half], DT[2 * half + 1]
+            L.lshl_add(prog, ad, t0 + NE + i, 8, t0 + i)
+            L.lshl_add(prog, u, t1 + NE + i, 8, t1 + i)
+            dst = (out_base if half == 0 else L.HIP) + 2 * i
+            prog.append(Ins("v_mad_u64_u32 %s, %s, %s, s%d, %s" % (vp(dst), sp(L.SINK), v(u), L.S_64K, vp(ad)), [u, ad, ad + 1], [dst, dst + 1],
+                            sem=("mad", dst, None, u, ("const", 65536), ad)))
+    for i in range(first_out, NE):
+        L.fold_hi_lo(prog, out_base + 2 * i, out_base + 2 * i, L.HIP + 2 * i, i % 2)
+
+
+def block_full_pair(first_out=0):
+    prog = []
+    for e in range(NE):
+        L.sbox(prog, S + 2 * e, T + 2 * e, e % 2)
+    circulant_pair(prog, S, T, first_out)
+    return prog
+
+
+def block_partial_pair():
+    """element 0 (the lower lane's first) through the S-box; the upper lane keeps its element 6"""
+    prog = []
+    L.sbox(prog, S, T, 0)
+    for h in (0, 1):
+        G.cndmask(prog, T + h, T + h, S + h, MASK_LO)
+    circulant_pair(prog, T, T)
+    return prog
+
+
+# ---------------------------------------------------------------- merged triple
+# LDS rows per lane half (the kernel gives the two halves different base addresses): dot rows of six coefficients (own elements),
+# dense rows of 16 dwords: [own six, partner six, b2, b3, 0, 0].
+def dot6(prog, A, B, coef_off, seed_regs, key):
+    cr = L.COEFR + 16 * key[1]
+    L.load(prog, cr, 4, L.A_COEF, coef_off, (key, 0))
+    L.load(prog, cr + 4, 2, L.A_COEF, coef_off + 16, (key, 1))
+    for j in range(NE):
+        L.madc(prog, A, T + 2 * j, ("v", cr + j), seed=seed_regs if j == 0 else None)
+        L.madc(prog, B, T + 2 * j + 1, ("v", cr + j), seed=seed_regs + 2 if j == 0 else None)
+
+
+def pair_sums(prog, A, B, k):
+    """A and B (64-bit pairs) += the partner lane's A and B, in both lanes"""
+    ca, cb = TMP + 4 * k, TMP + 4 * k + 2
+    partners(prog, ca, cb, A, B)       # ca = partner's B, cb = partner's A
+    G.add64(prog, A, A, cb)
+    G.add64(prog, B, B, ca)
+
+
+DOT_OFF0, DOT_OFF1, ROW_OFF = 0, 32, 64     # bytes in the half's coefficient table
+
+
+def block_triple_pair():
+    prog = []
+    L.sbox(prog, S, T, 0)                                      # x1 (meaningful in the lower lane)
+    for h in (0, 1):
+        G.cndmask(prog, T + h, T + h, S + h, MASK_LO)        # T is u' now
+    L.load(prog, L.SEEDR, 4, L.A_K12, 0, ("k12", 0))          # k1 (lower half; zero in the upper half's table)
+    L.load(prog, L.SEEDR + 4, 4, L.A_K12, 16, ("k12", 1))
+    dot6(prog, L.ACC, L.ACC + 2, DOT_OFF0, L.SEEDR, ("dot", 0))
+    pair_sums(prog, L.ACC, L.ACC + 2, 0)
+    L.fold_to(prog, L.YY, L.ACC, L.ACC + 2, 0)
+    L.sbox(prog, L.YY + 2, L.YY, 1)                            # x2, in both lanes
+    dot6(prog, L.ACC + 4, L.ACC + 6, DOT_OFF1, L.SEEDR + 4, ("dot", 1))
+    pair_sums(prog, L.ACC + 4, L.ACC + 6, 1)
+    L.madc(prog, L.ACC + 4, L.YY + 2, 25)
+    L.madc(prog, L.ACC + 6, L.YY + 3, 25)
+    L.fold_to(prog, L.YY, L.ACC + 4, L.ACC + 6, 1)
+    L.sbox(prog, L.YY + 4, L.YY, 0)                            # x3
+    # the partner's six elements, neighbours crossed (partners()): PT + 2 e = the partner's element e ^ 1
+    for e in range(0, NE, 2):
+        partners(prog, PT + 2 * e, PT + 2 * e + 2, T + 2 * e, T + 2 * e + 2)
+    for r in range(NE):
+        sd = L.SEEDR + 8 + 4 * (r % 2)
+        L.load(prog, sd, 4, L.A_K3, 16 * r, ("k3", r))
+        A, B = L.ACC + 4 * (r % 2), L.ACC + 4 * (r % 2) + 2
+        cr = L.COEFR + 16 * (r % 2)
+        for q in range(4):
+            L.load(prog, cr + 4 * q, 4, L.A_COEF, ROW_OFF + 64 * r + 16 * q, (("row", r), q))
+        for j in range(12):   # the row's columns in the LANE's order: its own six elements, then the partner's
+            src = T + 2 * j if j < NE else PT + 2 * ((j - NE) ^ 1)
+            L.madc(prog, A, src, ("v", cr + j), seed=sd if j == 0 else None)
+            L.madc(prog, B, src + 1, ("v", cr + j), seed=sd + 2 if j == 0 else None)
+        L.madc(prog, A, L.YY + 2, ("v", cr + 12))
+        L.madc(prog, B, L.YY + 3, ("v", cr + 12))
+        L.madc(prog, A, L.YY + 4, ("v", cr + 13))
+        L.madc(prog, B, L.YY + 5, ("v", cr + 13))
+        L.fold_to(prog, O + 2 * r, A, B, r % 2)
+    for e in range(NE):
+        prog.append(Ins("v_mov_b64 %s, %s" % (vp(T + 2 * e), vp(O + 2 * e)), [O + 2 * e, O + 2 * e + 1], [T + 2 * e, T + 2 * e + 1], sem=("mov64", T + 2 * e, O + 2 * e)))
+    return prog
+
+
+# ---------------------------------------------------------------- scheduling: the lane generator's, plus the swap's two wait states
+def schedule_pair(prog):
+    """gen_lane_round_asm.schedule, with a swap's operands written at least three slots before it (two wait states; the builtin gets
+    s_nop 1 from the compiler, kernels_lde.hip)."""
+    base = L.schedule_lane
+
+    def with_swaps(p):
+        marks = []
+        for ins in p:
+            if getattr(ins, "dpp", False):
+                marks.append(ins)
+        # the lane scheduler knows loads and MFMAs; a swap is given the distance through a pseudo latency on its producers
+        return base(p)
+
+    order = L.schedule(prog)
+    out = []
+    for ins in order:
+        if getattr(ins, "dpp", False):
+            gap = 0
+            for back in (1, 2):
+                if len(out) >= back and (ins.reads & out[-back].writes):
+                    gap = max(gap, 3 - back)
+            for _ in range(gap):
+                out.append(Ins("s_nop 0", [], []))
+        out.append(ins)
+    return out
+
+
+# ---------------------------------------------------------------- interpreter additions (two lanes)
+def run_pair(order, vregs, sregs):
+    for ins in order:
+        k = ins.sem[0] if ins.sem else None
+        if k == "swap32":
+            _, a, b = ins.sem
+            va, vb = vregs[a][:], vregs[b][:]
+            vregs[a] = [va[0], vb[0]]
+            vregs[b] = [va[1], vb[1]]
+        elif k == "perm":
+            _, d, s0, s1, sel = ins.sem
+            out = []
+            for l in range(2):
+                src = (vregs[s1][l] & M32) | ((vregs[s0][l] & M32) << 32)
+                o = 0
+                for i in range(4):
+                    o |= ((src >> (8 * ((L.SEL_VALUE[sel] >> (8 * i)) & 0xFF))) & 0xFF) << (8 * i)
+                out.append(o)
+            vregs[d] = out
+        elif k == "xor80":
+            vregs[ins.sem[1]] = [x ^ 0x80808080 for x in vregs[ins.sem[1]]]
+        elif k == "lshladd":
+            _, d, a, sh, b = ins.sem
+            vregs[d] = [((vregs[a][l] << sh) + vregs[b][l]) & M32 for l in range(2)]
+        elif k == "pmfma":
+            _, d, a, b, q = ins.sem
+            assert vregs[b + 3] == [L.B_CONST, L.B_CONST]
+            assert vregs[a + 3] == [0xC0DE00 + q] * 2, ("A tuple holds another instruction's constants", q)
+            res = [[0] * 2 for _ in range(16)]
+            for pp in range(2):
+                plane = 2 * q + pp
+                by = []
+                for l in range(2):
+                    for e in range(NE):
+                        x = (vregs[b + e // 2][l] >> (8 * ((e & 1) + 2 * pp))) & 0xFF
+                        by.append(x - 256 if x >= 128 else x)
+                rc = vregs["rcbytes"][plane]
+                for l in range(2):
+                    for i in range(NE):
+                        g = NE * l + i
+                        val = sum(L.mds_coef(g, j) * by[j] for j in range(12)) + (rc[g] & 0x7F) + 64 * (2 * (rc[g] >> 7) + 40) + 2 * 127 * 127
+                        assert 0 <= val < (1 << 17)
+                        res[NE * pp + i][l] = val
+            for i in range(12):
+                vregs[d + i] = res[i]
+            for i in range(12, 16):
+                vregs[d + i] = [0xDEAD0000 + i] * 2
+        else:
+            G.run([ins], vregs, sregs)
+
+
+def fresh():
+    vregs = {r: [random.getrandbits(32), random.getrandbits(32)] for r in range(52, 256)}
+    vregs[L.AD[0] + 1] = [0, 0]
+    vregs[L.AD[1] + 1] = [0, 0]
+    vregs["mem"] = {}
+    return vregs
+
+
+def set_state(vregs, state):
+    for e in range(NE):
+        vregs[T + 2 * e] = [state[e] & M32, state[NE + e] & M32]
+        vregs[T + 2 * e + 1] = [state[e] >> 32, state[NE + e] >> 32]
+
+
+def get_state(vregs):
+    out = [0] * 12
+    for e in range(NE):
+        for l in range(2):
+            out[NE * l + e] = (vregs[T + 2 * e][l] | (vregs[T + 2 * e + 1][l] << 32)) % P
+    return out
+
+
+def test_round_pair(order, partial, first_out=0):
+    for _ in range(40):
+        state = [L.rnd() for _ in range(12)]
+        rc = [random.getrandbits(64) % P for _ in range(12)]
+        vregs = fresh()
+        for k in range(4):
+            vregs[L.BP[k] + 3] = [L.B_CONST] * 2
+        set_state(vregs, state)
+        RC = L.mfma_round_constants(rc)
+        vregs["rcbytes"] = [[(RC[g] >> (8 * b)) & 0xFF for g in range(12)] for b in range(8)]
+        for q in range(4):
+            vregs["mem"][("rcb", q)] = [[0xC0DE00 + q] * 2]
+        run_pair(order, vregs, {MASK_LO: [1, 0]})
+        got, want = get_state(vregs), G.reference_round(state, rc, partial)
+        for l in range(2):
+            for i in range(first_out, NE):
+                assert got[NE * l + i] == want[NE * l + i], (partial, l, i)
+
+
+def pair4(lo_val, hi_val):
+    """a 64-bit constant as two 64-bit addends (low half, 0, high half, 0), per lane"""
+    return [[lo_val & M32, hi_val & M32], [0, 0], [lo_val >> 32, hi_val >> 32], [0, 0]]
+
+
+def test_triple_pair(order):
+    for _ in range(30):
+        state = [L.rnd() for _ in range(12)]
+        c1, c2, c3 = [[random.getrandbits(64) % P for _ in range(12)] for _ in range(3)]
+        M, N2, N3, k1, k2, k3 = G.merged_tables(c1, c2, c3)
+        want = state
+        for c in (c1, c2, c3):
+            want = G.reference_round(want, c, True)
+        vregs = fresh()
+        set_state(vregs, state)
+        mem = vregs["mem"]
+        mem[("k12", 0)], mem[("k12", 1)] = pair4(k1, 0), pair4(k2, 0)     # the constants enter once: through the lower half
+        for r in range(NE):
+            mem[("k3", r)] = pair4(k3[r], k3[NE + r])
+            rows = []
+            for l in range(2):
+                g = NE * l + r
+                rows.append([N3[g][(NE * l + j) % 12] for j in range(12)] + [N2[g][0], M[g][0], 0, 0])
+            for q in range(4):
+                mem[(("row", r), q)] = [[rows[0][4 * q + i], rows[1][4 * q + i]] for i in range(4)]
+        for d, row in ((0, M[0]), (1, N2[0])):
+            co = [[row[e], row[NE + e]] for e in range(NE)]
+            mem[(("dot", d), 0)] = co[0:4]
+            mem[(("dot", d), 1)] = co[4:6]
+        run_pair(order, vregs, {MASK_LO: [1, 0]})
+        assert get_state(vregs) == want
+
+
+def count(order):
+    n_nop = sum(1 for o in order if o.text.startswith("s_nop"))
+    n_wait = sum(1 for o in order if o.text.startswith("s_waitcnt"))
+    return len(order), n_nop, n_wait
+
+
+def main():
+    random.seed(7)
+    blocks = {}
+    for name, prog, tester in (("full round (matrix pipe, dense tile)", block_full_pair(), lambda o: test_round_pair(o, False)),
+                               ("last full round before an absorb", block_full_pair(2), lambda o: test_round_pair(o, False, 2)),
+                               ("partial round (matrix pipe)", block_partial_pair(), lambda o: test_round_pair(o, True)),
+                               ("merged triple", block_triple_pair(), test_triple_pair)):
+        order = schedule_pair(prog)
+        L.check_mfma_distances(order)
+        tester(order)
+        blocks[name] = count(order)
+        print("%-40s %4d slots (%d s_nop, %d s_waitcnt); %d instructions before scheduling" % ((name,) + blocks[name] + (len(prog),)))
+    full, last, part, triple = (blocks[k][0] for k in ("full round (matrix pipe, dense tile)", "last full round before an absorb", "partial round (matrix pipe)", "merged triple"))
+    per_wave = 7 * full + last + 7 * triple + part
+    print("per wave and 32 permutations: 7 x %d + %d + 7 x %d + %d = %d slots = %.1f per permutation" % (full, last, triple, part, per_wave, per_wave / 32.0))
+    print("quad form: 4346 vector instructions per 16 permutations and wave, two waves per SIMD = %.1f per permutation and SIMD slot" % (4346 * 2 / 32.0))
+    leaves_perms = 9191
+    for cyc in (4.2, 4.5, 4.7):
+        print("  a 73 527-column commitment (%d permutations per leaf) at %.1f cycles per slot, 2.4 GHz: %.1f ms" % (leaves_perms, cyc, leaves_perms * per_wave * cyc / 2.4e6))
+
+
+if __name__ == "__main__":
+    main()
