@@ -77,10 +77,10 @@ def poseidon_lane_slots():
         return None
 
 KERNELS = ("lde_columns", "leaf_hash", "quotient_eval")
-PMC_NAMES = {"lde_columns": ("lde_columns_wave_kernel", "lde_columns_v2_kernel"), "leaf_hash": ("leaf_hash_kernel",), "leaf_hash_lane": ("leaf_hash_lane_kernel",),
+PMC_NAMES = {"lde_columns": ("lde_columns_wave_kernel", "lde_columns_v2_kernel"), "leaf_hash": ("leaf_hash_pair_kernel", "leaf_hash_kernel"), "leaf_hash_lane": ("leaf_hash_lane_kernel",),
              "quotient_eval": ("quotient_tiles_kernel", "quotient_eval_kernel")}
 FORM_KERNEL = {"quad": "leaf_hash_kernel", "lane": "leaf_hash_lane_kernel", "row": "leaf_hash_row_kernel", "merged": "leaf_hash_multi_kernel",
-               "host": "host threads"}
+               "host": "host threads", "pair": "leaf_hash_pair_kernel"}
 
 
 def self_launch(argv, n_gpus, script=None):

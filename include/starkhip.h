@@ -145,9 +145,10 @@ int starkhip_prove_columns(void* ctx, starkhip_air_t air, const starkhip_config_
  * "quotient_waves", "quotient_slots", "lde_closed_forms" (1 = constant and unit-vector trace columns take their closed-form LDE
  * instead of five transforms, 0 = every column is transformed; same bytes either way), "host_commit_leaves" (default 64: trace commitments of at most this many leaves -- FP12Mul's 32 -- are hashed by host threads with the
  * challenger's permutation, 0.8 us against 5.6 us per permutation of a lone GPU wave; 0 = never; only with "leaf_hash_form" 0), "leaf_hash_form" (0 = a context on its own
- * hashes commitments of <= 4096 leaves in the row form -- 16 lanes per leaf, the shortest chain per leaf -- and larger ones in
- * the quad form; 1 = quad always; 2 = row always; 3 = lane form, one lane per leaf: what a pool with five or more big contexts uses for groups of big
- * commitments, slower than the quad form for one commitment alone; same digests; a pool's commitments always go through its scheduler).  Unknown
+ * hashes commitments of <= 4096 leaves in the row form -- 16 lanes per leaf, the shortest chain per leaf --, those of >= 32 768 leaves in
+ * the pair form -- two lanes per leaf, one 256-register wave per SIMD -- and the ones between in the quad form; 1 = quad always; 2 = row always;
+ * 3 = lane form, one lane per leaf: what a pool with five or more big contexts uses for groups of big commitments, slower than the pair form for
+ * one commitment alone; 4 = pair always; same digests; a pool's commitments always go through its scheduler).  Unknown
  * name or value out of range: STARKHIP_ERR_BAD_SHAPE. */
 int starkhip_set_option(void* ctx, const char* name, long value);
 
@@ -222,7 +223,7 @@ typedef struct {
     float host_ms[2];     /* as starkhip_last_host_timings */
     double t_submit, t_generate_start, t_generate_end, t_prove_start, t_done; /* seconds since the pool was created */
     int leaf_hash_form;       /* how the trace commitment went out: 0 quad form, 1 row form, 2 one grid merged with other proofs' commitments
-                                 (quad form), 3 lane form, 4 hashed by host threads (at most "host_commit_leaves" leaves); kernel_ms[1] is
+                                 (quad form), 3 lane form, 4 hashed by host threads (at most "host_commit_leaves" leaves), 5 pair form; kernel_ms[1] is
                                  that kernel's own duration on its launch stream (form 4: the host's time) */
     unsigned leaf_hash_group; /* commitments that were launched side by side with it (itself included) */
 } starkhip_ticket_info_t;

@@ -817,7 +817,7 @@ class ProofPool:
                        "kernel_ms": {"lde_columns": float(info.kernel_ms[0]), "leaf_hash": float(info.kernel_ms[1]), "quotient_eval": float(info.kernel_ms[2])},
                        "host_ms": {"fiat_shamir": float(info.host_ms[0]), "other": float(info.host_ms[1])},
                        "timeline_s": [info.t_submit, info.t_generate_start, info.t_generate_end, info.t_prove_start, info.t_done],
-                       "leaf_hash_form": ("quad", "row", "merged", "lane", "host")[min(info.leaf_hash_form, 4)], "leaf_hash_group": int(info.leaf_hash_group)}
+                       "leaf_hash_form": ("quad", "row", "merged", "lane", "host", "pair")[min(info.leaf_hash_form, 5)], "leaf_hash_group": int(info.leaf_hash_group)}
 
     def reservation(self):
         """starkhip_pool_reservation: what the pool's contexts hold (bytes; summed over the devices' pools, the per-context figures the largest)."""

@@ -71,6 +71,8 @@ hipError_t launch_leaf_hash(const gl_t* mat, size_t n_cols, unsigned log_n, unsi
 // the same digests from the row form (16 lanes per leaf): shorter chain per leaf, 4x the lane-instructions -- for a lone commitment of few leaves
 // the same digests from the lane form (one lane per leaf): fewest instructions per permutation, but 1/4 of the waves -- for big commitments when several are in flight
 hipError_t launch_leaf_hash_lane(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st);
+// the same digests from the pair form (two lanes per leaf, one 256-register wave per SIMD at 32 768 leaves): a LONE big commitment
+hipError_t launch_leaf_hash_pair(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st);
 hipError_t launch_leaf_hash_row(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st);
 hipError_t launch_leaf_hash_rows(const gl_t* rows, size_t width, size_t n_leaves, gl_t* digests, hipStream_t st);
 hipError_t launch_merkle_levels(gl_t* digests, unsigned log_leaves, unsigned cap_h, hipStream_t st);

@@ -542,6 +542,163 @@ static hipError_t ensure_lane_tables() {
     return e;
 }
 
+// ---- the pair form (poseidon_dev.h): two lanes per leaf, for a LONE commitment of >= 32 768 leaves (1 024 waves: one per SIMD).
+// Same digests as leaf_hash_kernel.  Lane l < 32 of a wave absorbs columns 8 b .. 8 b + 5 of block b at point 32 w + l, lane l + 32
+// columns 8 b + 6, 8 b + 7 of the same point and carries the capacity: every load is a 256-byte run.
+__constant__ PairTables PAIR_TABLES;
+__global__ __launch_bounds__(256, 2) void leaf_hash_pair_kernel(const gl_t* __restrict__ mat, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                                                              gl_t* __restrict__ digests) {
+    __shared__ PairTables T;
+    {
+        const uint32_t* src = (const uint32_t*)&PAIR_TABLES;
+        uint32_t* dst = (uint32_t*)&T;
+        for (unsigned idx = threadIdx.x; idx < sizeof(PairTables) / 4; idx += blockDim.x) dst[idx] = src[idx];
+    }
+    __syncthreads();
+    const unsigned log_N = log_n + rate_bits;
+    const size_t N = (size_t)1 << log_N;
+    const unsigned lane = threadIdx.x & 63u, half = lane >> 5;
+    // every lane stays active to the end (the matrix-pipe rounds read all 64 lanes' operand registers); pairs beyond the last leaf shadow it
+    const size_t q_raw = (blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6)) * 32u + (lane & 31u);
+    const bool live = q_raw < N;
+    const size_t q = live ? q_raw : N - 1;
+    const size_t sidx = q >> log_n, k = q & (((size_t)1 << log_n) - 1);
+    const size_t i = (k << rate_bits) + sidx;
+    const size_t j = gl_bitrev((uint32_t)i, log_N);
+    if (n_cols <= 4) {
+        if (live && half == 0)
+            for (unsigned e = 0; e < 4; e++) digests[4 * j + e] = e < n_cols ? mat[q + (size_t)e * N] : 0;
+        return;
+    }
+    const size_t n_full = n_cols / 8, rem = n_cols % 8;
+    const unsigned first = half ? 6u : 0u;            // this lane's columns inside a block of eight: first .. first + cnt - 1
+    const gl_t* col = mat + q + (size_t)first * N;
+    gl_t nx[6];
+    if (n_full) {
+        nx[0] = col[0];
+        nx[1] = col[N];
+        if (half == 0) {
+#pragma unroll
+            for (int e = 2; e < 6; e++) nx[e] = col[(size_t)e * N];
+        }
+    }
+    LaneZeros Z;
+    lane_zeros_init(Z);
+    PairMfma M;
+    pair_mfma_init(M, lane);
+    uint64_t mask_lo = 0xFFFFFFFFull;
+    asm volatile("" : "+s"(mask_lo));
+    PairState st;
+#pragma unroll
+    for (int w = 0; w < 4; w++) st.t0[w] = st.t1[w] = st.t2[w] = 0;
+    for (size_t b = 0; b < n_full; b++) {
+        pair_set(st.t0, 0, nx[0]);
+        pair_set(st.t0, 1, nx[1]);
+        if (half == 0) {   // the upper lane's elements 2 .. 5 are the capacity
+            pair_set(st.t1, 0, nx[2]);
+            pair_set(st.t1, 1, nx[3]);
+            pair_set(st.t2, 0, nx[4]);
+            pair_set(st.t2, 1, nx[5]);
+        }
+        if (b + 1 < n_full) {
+            const gl_t* nc = col + 8 * (b + 1) * N;   // requested one permutation ahead
+            nx[0] = nc[0];
+            nx[1] = nc[N];
+            if (half == 0) {
+#pragma unroll
+                for (int e = 2; e < 6; e++) nx[e] = nc[(size_t)e * N];
+            }
+            poseidon_permute_pair_asm<true>(st, &T, Z, M, lane, mask_lo);
+        } else {
+            poseidon_permute_pair_asm<false>(st, &T, Z, M, lane, mask_lo);
+        }
+    }
+    if (rem) {
+        const gl_t* nc = col + 8 * n_full * N;
+        const unsigned cnt = half ? 2u : 6u;
+#pragma unroll
+        for (unsigned e = 0; e < 6; e++) {
+            if (e < cnt && first + e < rem) {
+                const gl_t x = nc[(size_t)e * N];
+                if (e < 2) pair_set(st.t0, e, x);
+                else if (e < 4) pair_set(st.t1, e - 2, x);
+                else pair_set(st.t2, e - 4, x);
+            }
+        }
+        poseidon_permute_pair_asm<false>(st, &T, Z, M, lane, mask_lo);
+    }
+    if (live && half == 0) {
+        digests[4 * j + 0] = gl_canon(pair_get(st.t0, 0));
+        digests[4 * j + 1] = gl_canon(pair_get(st.t0, 1));
+        digests[4 * j + 2] = gl_canon(pair_get(st.t1, 0));
+        digests[4 * j + 3] = gl_canon(pair_get(st.t1, 1));
+    }
+}
+static void build_pair_tables(PairTables& T) {
+    static PoseidonMergedTables P;
+    build_poseidon_merged_tables(P);
+    auto split = [](gl_t v) { return RcPair{v & 0xFFFFFFFFull, v >> 32}; };
+    memset(&T, 0, sizeof T);
+    for (unsigned h = 0; h < 2; h++) {
+        for (unsigned e = 0; e < 6; e++) T.rc0[h][e] = POSEIDON_RC_HOST[6 * h + e];
+        for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++)
+            for (unsigned r = 0; r < 6; r++) T.k3[t][h][r] = split(P.k3[t][6 * h + r]);
+        uint32_t* c = T.coef[h];
+        for (unsigned e = 0; e < 6; e++) {
+            c[e] = (uint32_t)P.M[0][6 * h + e];
+            c[8 + e] = (uint32_t)P.N2[0][6 * h + e];
+        }
+        for (unsigned r = 0; r < 6; r++) {
+            const unsigned g = 6 * h + r;
+            uint32_t* row = c + 16 + 16 * r;
+            for (unsigned jj = 0; jj < 12; jj++) row[jj] = (uint32_t)P.N3[g][(6 * h + jj) % 12];   // own six, then the partner's
+            row[12] = (uint32_t)P.N2[g][0];
+            row[13] = (uint32_t)P.M[g][0];
+        }
+    }
+    for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++) {   // the constants of the two dot products enter once: through the lower half
+        T.k12[t][0][0] = split(P.k1[t]);
+        T.k12[t][0][1] = split(P.k2[t]);
+    }
+    // the matrix-pipe rounds' constants, as in build_lane_tables (the same offsets: a row still sums twelve signed bytes)
+    static const int CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    static const int NEXT_ROUND[PAIR_MFMA_ROUNDS] = {1, 2, 3, 4, 26, 27, 28, 29, 30};
+    for (int m = 0; m < PAIR_MFMA_ROUNDS; m++)
+        for (unsigned lane = 0; lane < 64; lane++) {
+            const unsigned row = lane & 31u, khalf = lane >> 5, i = (row & 3u) + 4u * (row >> 3), out_half = (row >> 2) & 1u;
+            if (khalf != 0 || i >= 12u) continue;
+            const unsigned g = 6u * out_half + i % 6u, pp = i / 6u;
+            uint64_t rowsum = 0;
+            for (int jj = 0; jj < 12; jj++) rowsum += (uint64_t)CIRC[(jj + 12 - (int)g) % 12] + ((g == 0 && jj == 0) ? 8u : 0u);
+            const gl_t off = gl_mul((gl_t)(STARKHIP_LANE_K_OFFSET - 128 * rowsum), 0x0101010101010101ull % GL_P);
+            const gl_t rc = NEXT_ROUND[m] < 30 ? POSEIDON_RC_HOST[12 * NEXT_ROUND[m] + g] : 0;
+            const gl_t RC = gl_sub(rc, off);
+            for (unsigned qq = 0; qq < 4; qq++) {
+                const uint32_t byte = (uint32_t)(RC >> (8 * (2 * qq + pp))) & 0xFFu;
+                T.rcb[m][qq][lane] = (byte & 0x7Fu) | ((2u * (byte >> 7) + 40u) << 8) | (127u << 16) | (127u << 24);
+            }
+        }
+}
+static hipError_t ensure_pair_tables() {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(mu);
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (done[dev]) return hipSuccess;
+    static PairTables T;
+    static bool built = false;
+    if (!built) {
+        build_pair_tables(T);
+        built = true;
+    }
+    e = hipMemcpyToSymbol(HIP_SYMBOL(PAIR_TABLES), &T, sizeof T);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}
+
 // Leaves stored row-major and already in tree order: leaf j = rows[j][0..width)
 __global__ __launch_bounds__(64) void leaf_hash_rows_kernel(const gl_t* __restrict__ rows, size_t width, size_t n_leaves,
                                                              gl_t* __restrict__ digests) { STARKHIP_PRIO_ENTRY
@@ -607,6 +764,12 @@ hipError_t launch_leaf_hash_lane(const gl_t* mat, size_t n_cols, unsigned log_n,
     size_t N = (size_t)1 << (log_n + rate_bits);
     if (hipError_t e = ensure_lane_tables(); e != hipSuccess) return e;
     hipLaunchKernelGGL(leaf_hash_lane_kernel, dim3(nblocks(N, 256)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
+    return hipGetLastError();
+}
+hipError_t launch_leaf_hash_pair(const gl_t* mat, size_t n_cols, unsigned log_n, unsigned rate_bits, gl_t* digests, hipStream_t st) {
+    size_t N = (size_t)1 << (log_n + rate_bits);
+    if (hipError_t e = ensure_pair_tables(); e != hipSuccess) return e;
+    hipLaunchKernelGGL(leaf_hash_pair_kernel, dim3(nblocks(N, 128)), dim3(256), 0, st, mat, n_cols, log_n, rate_bits, digests);
     return hipGetLastError();
 }
 hipError_t launch_leaf_hash_multi(const LeafHashBatch& B, unsigned count, size_t n_cols, unsigned log_n, unsigned rate_bits, hipStream_t st) {

@@ -884,4 +884,122 @@ __device__ __forceinline__ void poseidon_permute_lane_asm(LaneState& st, const L
     else lane_full_round_asm(st, rc_lds + 30 * RC_ROW, Z);
 }
 
+// ---- the PAIR form (tools/gen_pair_round_asm.py -> pair_round_asm.inc): lanes l and l + 32 of a wave share one permutation -- the lower
+// lane holds state elements 0 .. 5, the upper lane 6 .. 11 -- so a commitment of 32 768 leaves is 1 024 waves of 256 registers: one per SIMD,
+// the form a LONE FinalExp-class commitment takes (the lane form's 512 waves would leave half the chip idle, the quad form costs 272 issue
+// slots per permutation against 212 here).  Full rounds and the lone partial round: six S-boxes per lane, then the circulant layer on the
+// matrix pipe with a DENSE weight tile and two byte planes per instruction (four v_mfma_i32_32x32x32_i8 per round; the operand maps are
+// in the generator).  Merged triples: the two dot products are partial sums over a lane's own elements added across the pair with
+// v_permlane32_swap_b32; the dense layer reads the partner's six elements (one exchange per triple) and computes the lane's six outputs.
+#include "pair_round_asm.inc"
+constexpr int PAIR_MFMA_ROUNDS = 9;   // full rounds 0 .. 3, the lone partial round 25, full rounds 26 .. 29
+struct PairTables {
+    gl_t rc0[2][6];                 // [half]: the first round's constants of the half's elements
+    RcPair k12[7][2][2];            // [triple][half]: k1, k2 -- in the lower half only (the sums are added across the pair), zero in the upper
+    RcPair k3[7][2][6];             // [triple][half][local output]
+    // per half, 448 bytes: row 0 of M and of N2 against the half's own six elements (6 + 2 pad dwords each), then per local output r
+    // (g = 6 half + r) sixteen dwords: N3[g][own six], N3[g][the partner's six, neighbours crossed], N2[g][0], M[g][0], 0, 0
+    uint32_t coef[2][112];
+    uint32_t rcb[PAIR_MFMA_ROUNDS][4][64];   // per matrix-pipe round, instruction and LANE: dword 3 of the weight tile (the constants' bytes)
+};
+typedef uint32_t pair_u32x4 __attribute__((ext_vector_type(4)));
+struct PairState {
+    pair_u32x4 t0, t1, t2;          // the lane's six elements: (0, 1), (2, 3), (4, 5), low dword first
+};
+struct PairMfma {
+    uint32_t aw[2][4];
+    uint32_t bc[4];
+};
+// Weight tile: lane (row = lane & 31, khalf = lane >> 5) holds the 16 weights of `row` that meet the 16 K-values of lane half `khalf` of
+// the state operand: K-value (dword d < 3, byte i) = byte plane p + (i >> 1) of the half's element 2 d + (i & 1).  Row -> result register
+// i = (row & 3) + 4 (row >> 3) of the lane half (row >> 2) & 1: output g = 6 half + i % 6 against plane p + i / 6 (i < 12).
+__device__ __forceinline__ void pair_mfma_init(PairMfma& M, unsigned lane) {
+    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const unsigned row = lane & 31u, khalf = lane >> 5, i = (row & 3u) + 4u * (row >> 3), out_half = (row >> 2) & 1u;
+    const bool live = i < 12u;
+    const unsigned g = 6u * out_half + i % 6u, pp = i / 6u;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const unsigned j = 6u * khalf + 2u * d + (b & 1u);
+            uint32_t c = 0;
+#pragma unroll
+            for (unsigned gg = 0; gg < 12; gg++)
+#pragma unroll
+                for (unsigned jj = 0; jj < 12; jj++)
+                    if (gg == g && jj == j) c = CIRC[(jj + 12u - gg) % 12u] + ((gg == 0 && jj == 0) ? 8u : 0u);
+            if ((unsigned)(b >> 1) == pp) w |= c << (8 * b);
+        }
+        M.aw[0][d] = M.aw[1][d] = live ? w : 0u;
+    }
+    M.aw[0][3] = M.aw[1][3] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) M.bc[k] = STARKHIP_LANE_B_CONST;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int d = 0; d < 4; d++) asm volatile("" : "+v"(M.aw[k][d]));
+#pragma unroll
+    for (int k = 0; k < 4; k++) asm volatile("" : "+v"(M.bc[k]));
+}
+#define STARKHIP_PAIR_MFMA_BLOCK(NAME, TEXT)                                                                                               \
+    __device__ __forceinline__ void NAME(PairState& st, uint32_t rcb_lds, const LaneZeros& Z, PairMfma& M, uint64_t mask_lo) {             \
+        asm(TEXT                                                                                                                           \
+            : STARKHIP_PAIR_STATE0(st.t0), STARKHIP_PAIR_STATE1(st.t1), STARKHIP_PAIR_STATE2(st.t2), STARKHIP_PAIR_AW03(M.aw[0][3]),       \
+              STARKHIP_PAIR_AW13(M.aw[1][3])                                                                                               \
+            : STARKHIP_PAIR_A_RCB(rcb_lds), STARKHIP_PAIR_ZA(Z.za), STARKHIP_PAIR_ZB(Z.zb), STARKHIP_PAIR_AW00(M.aw[0][0]),                \
+              STARKHIP_PAIR_AW01(M.aw[0][1]), STARKHIP_PAIR_AW02(M.aw[0][2]), STARKHIP_PAIR_AW10(M.aw[1][0]), STARKHIP_PAIR_AW11(M.aw[1][1]), \
+              STARKHIP_PAIR_AW12(M.aw[1][2]), STARKHIP_PAIR_BC0(M.bc[0]), STARKHIP_PAIR_BC1(M.bc[1]), STARKHIP_PAIR_BC2(M.bc[2]),          \
+              STARKHIP_PAIR_BC3(M.bc[3]), STARKHIP_PAIR_S_SEL_A(STARKHIP_LANE_SEL_A_VALUE), STARKHIP_PAIR_S_SEL_B(STARKHIP_LANE_SEL_B_VALUE), \
+              STARKHIP_PAIR_S_X80(0x80808080u), STARKHIP_PAIR_S_K64K(65536u), STARKHIP_PAIR_MASK_LO(mask_lo)                               \
+            : STARKHIP_PAIR_CLOBBERS, STARKHIP_PAIR_MFMA_CLOBBERS);                                                                        \
+    }
+STARKHIP_PAIR_MFMA_BLOCK(pair_full_round_asm, STARKHIP_PAIR_FULL_ROUND_ASM)
+STARKHIP_PAIR_MFMA_BLOCK(pair_last_round_asm, STARKHIP_PAIR_LAST_ROUND_ASM)
+STARKHIP_PAIR_MFMA_BLOCK(pair_partial_round_asm, STARKHIP_PAIR_PARTIAL_ROUND_ASM)
+#undef STARKHIP_PAIR_MFMA_BLOCK
+__device__ __forceinline__ void pair_triple_asm(PairState& st, uint32_t k3_lds, uint32_t k12_lds, uint32_t coef_lds, const LaneZeros& Z, uint64_t mask_lo) {
+    asm(STARKHIP_PAIR_TRIPLE_ASM
+        : STARKHIP_PAIR_STATE0(st.t0), STARKHIP_PAIR_STATE1(st.t1), STARKHIP_PAIR_STATE2(st.t2)
+        : STARKHIP_PAIR_A_K3(k3_lds), STARKHIP_PAIR_A_K12(k12_lds), STARKHIP_PAIR_A_COEF(coef_lds), STARKHIP_PAIR_ZA(Z.za), STARKHIP_PAIR_ZB(Z.zb),
+          STARKHIP_PAIR_MASK_LO(mask_lo)
+        : STARKHIP_PAIR_CLOBBERS);
+}
+__device__ __forceinline__ gl_t pair_get(const pair_u32x4& t, int i) { return (gl_t)t[2 * i] | ((gl_t)t[2 * i + 1] << 32); }
+__device__ __forceinline__ void pair_set(pair_u32x4& t, int i, gl_t x) {
+    t[2 * i] = (uint32_t)x;
+    t[2 * i + 1] = (uint32_t)(x >> 32);
+}
+// One permutation of the pair's state.  CAP_ONLY: of the result only each lane's elements 2 .. 5 are computed (the capacity is the upper
+// lane's 2 .. 5; the caller overwrites the rest).  `half` = lane >> 5.
+template <bool CAP_ONLY>
+__device__ __forceinline__ void poseidon_permute_pair_asm(PairState& st, const PairTables* __restrict__ T, const LaneZeros& Z, PairMfma& M, unsigned lane,
+                                                          uint64_t mask_lo) {
+    const unsigned half = lane >> 5;
+    {
+        const gl_t* rc0 = T->rc0[half];
+        asm volatile("" : "+v"(rc0));
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            pair_set(st.t0, i, gl_add_nc(pair_get(st.t0, i), rc0[i]));
+            pair_set(st.t1, i, gl_add_nc(pair_get(st.t1, i), rc0[2 + i]));
+            pair_set(st.t2, i, gl_add_nc(pair_get(st.t2, i), rc0[4 + i]));
+        }
+    }
+    const uint32_t k3_lds = (uint32_t)(uintptr_t)&T->k3[0][half][0], k12_lds = (uint32_t)(uintptr_t)&T->k12[0][half][0],
+                   coef_lds = (uint32_t)(uintptr_t)&T->coef[half][0], rcb_lds = (uint32_t)(uintptr_t)&T->rcb[0][0][0] + lane * 4u;
+    constexpr uint32_t K3_TRIPLE = 2 * 6 * sizeof(RcPair), K12_TRIPLE = 2 * 2 * sizeof(RcPair), RCB_ROUND = 4 * 64 * 4;
+#pragma unroll 1
+    for (uint32_t m = 0; m < 4; m++) pair_full_round_asm(st, rcb_lds + m * RCB_ROUND, Z, M, mask_lo);
+#pragma unroll 1
+    for (uint32_t t = 0; t < 7; t++) pair_triple_asm(st, k3_lds + t * K3_TRIPLE, k12_lds + t * K12_TRIPLE, coef_lds, Z, mask_lo);
+    pair_partial_round_asm(st, rcb_lds + 4 * RCB_ROUND, Z, M, mask_lo);
+#pragma unroll 1
+    for (uint32_t m = 5; m < 8; m++) pair_full_round_asm(st, rcb_lds + m * RCB_ROUND, Z, M, mask_lo);
+    if (CAP_ONLY) pair_last_round_asm(st, rcb_lds + 8 * RCB_ROUND, Z, M, mask_lo);
+    else pair_full_round_asm(st, rcb_lds + 8 * RCB_ROUND, Z, M, mask_lo);
+}
+
 }  // namespace starkhip

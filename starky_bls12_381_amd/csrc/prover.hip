@@ -135,7 +135,7 @@ struct Ctx {
     std::vector<std::unique_ptr<PlanDev>> plan_cache;
     Tables* tab = nullptr;    // the current shape's (ensure_tables)
     PlanDev* plan = nullptr;  // the current AIR's (ensure_plan)
-    long opt_leaf_hash_form = 0;     // 0: row form for a lone context's commitments of <= 4096 leaves, quad form otherwise; 1: quad always; 2: row always
+    long opt_leaf_hash_form = 0;     // 0: a lone context's commitments: row form for <= 4096 leaves, pair form for >= 32 768, quad form between; 1: quad always; 2: row always; 3: lane always; 4: pair always
 #ifdef STARKHIP_LDE_V2_DEFAULT      // A/B builds (make variant NAME=ldev2 DEFS=-DSTARKHIP_LDE_V2_DEFAULT): pooled contexts cannot be given an option from outside
     long opt_lde_impl = 1;
 #else
@@ -386,8 +386,14 @@ static inline size_t digest_words(size_t n_leaves) { return 8 * n_leaves; }
 static bool use_row_form(const Ctx* c, size_t n_cols, unsigned log_N) {
     if (c->opt_leaf_hash_form == 1) return false;
     if (c->opt_leaf_hash_form == 2) return true;
-    if (c->opt_leaf_hash_form == 3) return false;
+    if (c->opt_leaf_hash_form == 3 || c->opt_leaf_hash_form == 4) return false;
     return log_N <= 12 && n_cols >= 64;
+}
+// The pair form (two lanes per leaf, 256 registers per wave) fills the chip from 32 768 leaves on: 1 024 waves, one per SIMD.
+static bool use_pair_form(const Ctx* c, size_t n_cols, unsigned log_N) {
+    if (c->opt_leaf_hash_form == 4) return true;
+    if (c->opt_leaf_hash_form != 0) return false;
+    return log_N >= 15 && n_cols >= 64;
 }
 
 int ctx_create(int device, Ctx** out, int priority) {
@@ -499,7 +505,7 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
     else if (k == "lde_closed_forms" && (value == 0 || value == 1)) c->opt_lde_closed_forms = value;
     else if (k == "lde_impl" && (value == 0 || value == 1)) c->opt_lde_impl = value;
     else if (k == "host_commit_leaves" && value >= 0 && value <= 4096) c->opt_host_commit_leaves = value;
-    else if (k == "leaf_hash_form" && value >= 0 && value <= 3) c->opt_leaf_hash_form = value;
+    else if (k == "leaf_hash_form" && value >= 0 && value <= 4) c->opt_leaf_hash_form = value;
     else if (k == "quotient_chunks" && value >= 0 && value <= 4096) c->opt_quotient_chunks = value;  // plans are cached by (AIR, chunks)
     else return STARKHIP_ERR_BAD_SHAPE;
     return STARKHIP_OK;
@@ -803,6 +809,9 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     } else if (c->opt_leaf_hash_form == 3) {
         c->hash_timing.form = 3; c->hash_timing.group = 1;
         HIPCHK(launch_leaf_hash_lane(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
+    } else if (use_pair_form(c, C, log_N)) {
+        c->hash_timing.form = 5; c->hash_timing.group = 1;
+        HIPCHK(launch_leaf_hash_pair(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
     } else if (use_row_form(c, C, log_N)) {
         c->hash_timing.form = 1; c->hash_timing.group = 1;
         HIPCHK(launch_leaf_hash_row(c->lde.as<gl_t>(), C, log_n, r, c->digests.as<gl_t>(), st));
@@ -1333,6 +1342,7 @@ int merkle_cap(Ctx* c, const uint64_t* lde_natural, size_t n_cols, unsigned log_
     HIPCHK(c->digests.ensure(digest_words(N) * 8));
     HIPCHK(hipMemcpyAsync(c->lde.p, lde_natural, n_cols * N * 8, hipMemcpyHostToDevice, c->st));
     if (c->opt_leaf_hash_form == 3) HIPCHK(launch_leaf_hash_lane(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
+    else if (use_pair_form(c, n_cols, log_N)) HIPCHK(launch_leaf_hash_pair(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
     else if (use_row_form(c, n_cols, log_N)) HIPCHK(launch_leaf_hash_row(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
     else HIPCHK(launch_leaf_hash(c->lde.as<gl_t>(), n_cols, log_N, 0, c->digests.as<gl_t>(), c->st));
     HIPCHK(launch_merkle_levels(c->digests.as<gl_t>(), log_N, cap_h, c->st));

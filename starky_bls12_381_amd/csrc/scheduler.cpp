@@ -157,12 +157,13 @@ void HashService::launch_big(Req* r, bool lane, unsigned group) {
     if (lane) s = pick_small_stream(&e);  // lane-form grids are a quarter of the chip each: they must overlap, not queue in one stream
     if (e == hipSuccess) e = hipStreamWaitEvent(s, r->ready, 0);
     if (r->timing) {
-        r->timing->form = lane ? 3 : 0;
+        r->timing->form = lane ? 3 : 5;
         r->timing->group = group;
         if (e == hipSuccess && r->timing->t0) e = hipEventRecord(r->timing->t0, s);
     }
+    // a big commitment on its own: the pair form (is_big() = 32 768 leaves or more: 1 024 waves of it fill the chip)
     if (e == hipSuccess) e = lane ? launch_leaf_hash_lane(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s)
-                                  : launch_leaf_hash(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s);
+                                  : launch_leaf_hash_pair(r->mat, r->n_cols, r->log_n, r->rate_bits, r->digests, s);
     if (e == hipSuccess && r->timing && r->timing->t1) e = hipEventRecord(r->timing->t1, s);
     if (e == hipSuccess) e = hipEventRecord(r->done, s);
     r->err = e;

@@ -114,11 +114,14 @@ def test_merkle_cap_matches_oracle(prover, log_N, ncols, cap_h):
 @pytest.mark.parametrize("log_N,ncols,cap_h", [(5, 60285 // 16, 4), (4, 3, 4), (8, 5, 2), (12, 200, 4), (6, 8, 0), (13, 21, 4), (2, 9, 0), (3, 100, 1),
                                                # tails of 0 .. 7 after one and after two full blocks
                                                (10, 16, 4), (10, 24, 4), (10, 12, 4), (10, 13, 4), (10, 9, 4), (10, 17, 4), (10, 20, 4), (10, 11, 4),
-                                               (10, 10, 4), (10, 14, 4), (10, 15, 4), (10, 23, 4)])
-@pytest.mark.parametrize("form", [2, 1, 3])
+                                               (10, 10, 4), (10, 14, 4), (10, 15, 4), (10, 23, 4),
+                                               # the pair form's own range (>= 32 768 leaves), and a last wave that is not full
+                                               (15, 19, 4), (16, 9, 4), (7, 40, 2)])
+@pytest.mark.parametrize("form", [2, 1, 3, 4])
 def test_merkle_cap_in_both_leaf_hash_forms(prover, log_N, ncols, cap_h, form):
-    """The row form (16 lanes per leaf, what a lone context uses for <= 4096 leaves) and the quad form (4 lanes per leaf) give the
-    oracle's cap for every shape, whichever the automatic choice would have been."""
+    """The row form (16 lanes per leaf, what a lone context uses for <= 4096 leaves), the quad form (4 lanes per leaf), the lane form
+    (one lane per leaf) and the pair form (two lanes per leaf, a lone commitment of >= 32 768 leaves) give the oracle's cap for every
+    shape, whichever the automatic choice would have been."""
     rng = np.random.default_rng(1000 + log_N + ncols)
     mat = _rand(rng, (ncols, 1 << log_N))
     mat[:, 0] = 0                      # an all-zero leaf

@@ -336,31 +336,59 @@ def test_triple_pair(order):
         assert get_state(vregs) == want
 
 
-def count(order):
-    n_nop = sum(1 for o in order if o.text.startswith("s_nop"))
-    n_wait = sum(1 for o in order if o.text.startswith("s_waitcnt"))
-    return len(order), n_nop, n_wait
+def check_swaps(order):
+    for i, ins in enumerate(order):
+        if getattr(ins, "dpp", False):
+            for back in (1, 2):
+                if i - back >= 0:
+                    assert not (ins.reads & order[i - back].writes), ("a swap's operand written fewer than three slots before it", i, ins.text)
 
 
 def main():
     random.seed(7)
-    blocks = {}
-    for name, prog, tester in (("full round (matrix pipe, dense tile)", block_full_pair(), lambda o: test_round_pair(o, False)),
-                               ("last full round before an absorb", block_full_pair(2), lambda o: test_round_pair(o, False, 2)),
-                               ("partial round (matrix pipe)", block_partial_pair(), lambda o: test_round_pair(o, True)),
-                               ("merged triple", block_triple_pair(), test_triple_pair)):
+    blocks = (("STARKHIP_PAIR_FULL_ROUND_ASM", block_full_pair(), lambda o: test_round_pair(o, False), "full round: six S-boxes per lane, circulant layer on the matrix pipe"),
+              ("STARKHIP_PAIR_LAST_ROUND_ASM", block_full_pair(2), lambda o: test_round_pair(o, False, 2), "last full round before an absorb: the lane's outputs 2 .. 5 only (the capacity is the upper lane's)"),
+              ("STARKHIP_PAIR_PARTIAL_ROUND_ASM", block_partial_pair(), lambda o: test_round_pair(o, True), "partial round"),
+              ("STARKHIP_PAIR_TRIPLE_ASM", block_triple_pair(), test_triple_pair, "three partial rounds at once (poseidon_merged.h)"))
+    done, slots = [], {}
+    for name, prog, tester, what in blocks:
         order = schedule_pair(prog)
-        L.check_mfma_distances(order)
+        L.check_hazards(order)
+        check_swaps(order)
         tester(order)
-        blocks[name] = count(order)
-        print("%-40s %4d slots (%d s_nop, %d s_waitcnt); %d instructions before scheduling" % ((name,) + blocks[name] + (len(prog),)))
-    full, last, part, triple = (blocks[k][0] for k in ("full round (matrix pipe, dense tile)", "last full round before an absorb", "partial round (matrix pipe)", "merged triple"))
-    per_wave = 7 * full + last + 7 * triple + part
-    print("per wave and 32 permutations: 7 x %d + %d + 7 x %d + %d = %d slots = %.1f per permutation" % (full, last, triple, part, per_wave, per_wave / 32.0))
-    print("quad form: 4346 vector instructions per 16 permutations and wave, two waves per SIMD = %.1f per permutation and SIMD slot" % (4346 * 2 / 32.0))
-    leaves_perms = 9191
-    for cyc in (4.2, 4.5, 4.7):
-        print("  a 73 527-column commitment (%d permutations per leaf) at %.1f cycles per slot, 2.4 GHz: %.1f ms" % (leaves_perms, cyc, leaves_perms * per_wave * cyc / 2.4e6))
+        done.append((name, order, what))
+        slots[name] = len(order)
+    per_wave = 7 * slots["STARKHIP_PAIR_FULL_ROUND_ASM"] + slots["STARKHIP_PAIR_LAST_ROUND_ASM"] + 7 * slots["STARKHIP_PAIR_TRIPLE_ASM"] + slots["STARKHIP_PAIR_PARTIAL_ROUND_ASM"]
+    print("// generated by tools/gen_pair_round_asm.py -- do not edit.  The PAIR form: lanes l and l + 32 share a permutation (elements 0 .. 5 / 6 .. 11).")
+    print("// Physical registers: state v[%d:%d] (in and out), LDS addresses v%d (k3) v%d (k12) v%d (coefficient rows) v%d (the matrix-pipe rounds' constants)," % (T, T + 11, L.A_K3, L.A_K12, L.A_COEF, L.A_RCB))
+    print("// zeros v%d v%d, s[%d:%d] = the lower half-wave's lane mask; v%d .. v255 and s%d .. s%d are clobbered." % (L.AD[0] + 1, L.AD[1] + 1, MASK_LO, MASK_LO + 1, 92, L.SINK, L.FCS[1] + 1))
+    print("// Per wave and 32 permutations: 7 x %d + %d + 7 x %d + %d = %d issue slots = %.1f per permutation (quad form: 271.6, lane form: 183.7)." %
+          (slots["STARKHIP_PAIR_FULL_ROUND_ASM"], slots["STARKHIP_PAIR_LAST_ROUND_ASM"], slots["STARKHIP_PAIR_TRIPLE_ASM"], slots["STARKHIP_PAIR_PARTIAL_ROUND_ASM"], per_wave, per_wave / 32.0))
+    for name, order, what in done:
+        L.emit(name, order, what)
+    for i in range(3):
+        print('#define STARKHIP_PAIR_STATE%d "+{v[%d:%d]}"' % (i, T + 4 * i, T + 4 * i + 3))
+    print('#define STARKHIP_PAIR_A_K3 "{v%d}"' % L.A_K3)
+    print('#define STARKHIP_PAIR_A_K12 "{v%d}"' % L.A_K12)
+    print('#define STARKHIP_PAIR_A_COEF "{v%d}"' % L.A_COEF)
+    print('#define STARKHIP_PAIR_A_RCB "{v%d}"' % L.A_RCB)
+    print('#define STARKHIP_PAIR_ZA "{v%d}"' % (L.AD[0] + 1))
+    print('#define STARKHIP_PAIR_ZB "{v%d}"' % (L.AD[1] + 1))
+    print('#define STARKHIP_PAIR_MASK_LO "{s[%d:%d]}"' % (MASK_LO, MASK_LO + 1))
+    bound = set(range(T, T + 12)) | {L.AD[0] + 1, L.AD[1] + 1}
+    vs = [r for r in range(T + 12, 256) if r not in bound]
+    ss = list(range(L.SINK, L.FCS[1] + 2))
+    print("#define STARKHIP_PAIR_CLOBBERS %s" % ", ".join(['"v%d"' % r for r in vs] + ['"s%d"' % r for r in ss]))
+    # the matrix-pipe blocks: weight tile (dword 3 is loaded inside: in / out), the B tuples' constant dwords (their other dwords: clobbered)
+    for k in range(2):
+        for d in range(3):
+            print('#define STARKHIP_PAIR_AW%d%d "{v%d}"' % (k, d, L.AW[k] + d))
+        print('#define STARKHIP_PAIR_AW%d3 "+{v%d}"' % (k, L.AW[k] + 3))
+    for k in range(4):
+        print('#define STARKHIP_PAIR_BC%d "{v%d}"' % (k, L.BP[k] + 3))
+    for name, reg in (("SEL_A", L.S_SEL["A"]), ("SEL_B", L.S_SEL["B"]), ("X80", L.S_X80), ("K64K", L.S_64K)):
+        print('#define STARKHIP_PAIR_S_%s "{s%d}"' % (name, reg))
+    print("#define STARKHIP_PAIR_MFMA_CLOBBERS %s" % ", ".join(['"v%d"' % (L.BP[k] + d) for k in range(4) for d in range(3)]))
 
 
 if __name__ == "__main__":
