@@ -60,6 +60,17 @@ VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
 POSEIDON_QUAD_INSTRS = 7 * 261 + 204 + 7 * 309 + 152
 
 
+def poseidon_pair_slots():
+    """issue slots per wave and 32 permutations of the pair form (two lanes per permutation), as tools/gen_pair_round_asm.py writes them
+    into the header of csrc/pair_round_asm.inc"""
+    import re
+    try:
+        text = open(os.path.join(ROOT, "starky_bls12_381_amd", "csrc", "pair_round_asm.inc")).read(2000)
+        return int(re.search(r"= (\d+) issue slots", text).group(1))
+    except (OSError, AttributeError):
+        return None
+
+
 def poseidon_lane_slots():
     """issue slots of one permutation in the lane form (one permutation per lane), from the block sizes tools/gen_lane_round_asm.py writes
     into csrc/lane_round_asm.inc: 7 full rounds with the circulant layer on the matrix pipe, the capacity-only last round, 7 merged triples
@@ -402,7 +413,7 @@ def main():
         dom_ms = sum(timed_kernel_ms[dom]) / len(timed_kernel_ms[dom])
         side = (sum(timed_groups) / len(timed_groups)) if (dom == "leaf_hash_lane_kernel" and timed_groups) else 1.0
         per_launch_gbs = alg_by_kernel[dom] / (dom_ms * 1e-3) / 1e9
-        pmc_key = {"leaf_hash_lane_kernel": "leaf_hash_lane", "leaf_hash_kernel": "leaf_hash", "lde_columns_wave_kernel": "lde_columns",
+        pmc_key = {"leaf_hash_lane_kernel": "leaf_hash_lane", "leaf_hash_kernel": "leaf_hash", "leaf_hash_pair_kernel": "leaf_hash", "lde_columns_wave_kernel": "lde_columns",
                    "quotient_tiles_kernel": "quotient_eval"}.get(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": per_launch_gbs * side, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": per_launch_gbs * side / HBM_PEAK_GBS, "traffic": pmc.get(pmc_key),
@@ -454,10 +465,14 @@ def main():
                 gbs = alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 kernels[k] = {"avg_ms": ms, "algorithmic_bytes": alg[k], "algorithmic_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
                               "traffic_bytes": pmc.get(k), "traffic_over_algorithmic": (pmc[k] / alg[k]) if k in pmc else None}
-            # the quad-form leaf hash alone: static instruction count of one quad permutation x permutations / 16 quads per wave
-            wave_instr = perms * POSEIDON_QUAD_INSTRS / 16.0
+            # the leaf hash alone: a lone FinalExp commitment goes out in the pair form (32 permutations per wave, the generator's slot count);
+            # a library that still sends it through the quad form: static instruction count of one quad permutation, 16 quads per wave
+            pair_slots = poseidon_pair_slots()
+            solo_form = info["leaf_hash_form"]
+            wave_instr = perms * pair_slots / 32.0 if (solo_form == "pair" and pair_slots) else perms * POSEIDON_QUAD_INSTRS / 16.0
             lh_ms = solo_ms["leaf_hash"]
-            kernels["leaf_hash"]["valu"] = {"kernel": "leaf_hash_kernel", "wave_instructions": wave_instr,
+            kernels["leaf_hash"]["valu"] = {"kernel": FORM_KERNEL.get(solo_form, solo_form), "wave_instructions": wave_instr,
+                                            "note": "one wave per SIMD: a lone wave issues a 64-bit-encoded instruction every 4.7 - 5.2 cycles (profiles/r03_k_valu_rates.txt), the peak counts 4",
                                             "achieved_Ginstr_per_s": wave_instr / (lh_ms * 1e-3) / 1e9 if lh_ms > 0 else 0.0, "peak_Ginstr_per_s": VALU_PEAK_GINSTR,
                                             "frac": (wave_instr / (lh_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR) if lh_ms > 0 else 0.0}
         if "leaf_hash_lane_kernel" in timed_kernel_ms:

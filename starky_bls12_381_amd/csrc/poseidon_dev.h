@@ -621,6 +621,7 @@ __device__ __forceinline__ gl_t poseidon_permute_row(gl_t s, const RcPair* __res
 // 4346 / 16 = 272 wave-instructions against ~ 195 with the whole state in one lane (full round 12 x 52 + 12 x 28, merged triple
 // 3 x 52 + 12 x 32 + 58).  Everything is uniform over the wave here -- round constants, the merged layers' coefficients -- so it comes
 // from one LDS image by broadcast reads (a scalar-register formulation would need 190 coefficients per triple in 100 SGPRs).
+typedef const __attribute__((address_space(3))) gl_t* lds_gl_ptr;
 struct LaneTables {
     RcPair rc[31][12];         // round constants in halves; rc[30] = 0 (the "next round" of the last one)
     RcPair k12[7][2];          // k1, k2 of the merged triples
@@ -847,8 +848,11 @@ __device__ __forceinline__ void poseidon_permute_lane_asm(LaneState& st, const L
     {
         // the first round's constants are read HERE, every permutation: hoisted out of the caller's loop they are 48 registers hipcc
         // spills to scratch and reloads one after the other (the pointer goes through an empty asm so that it cannot)
-        const gl_t* rc0 = T->rc0;
-        asm volatile("" : "+v"(rc0));
+        // (... as an LDS pointer: through a generic one they are flat loads, which count on vmcnt too -- the wait for them would also wait
+        // for the NEXT permutation's columns, requested from HBM a moment ago)
+        uint32_t rc0_lds = (uint32_t)(uintptr_t)&T->rc0[0];
+        asm volatile("" : "+v"(rc0_lds));
+        const lds_gl_ptr rc0 = (lds_gl_ptr)rc0_lds;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             lane_set(st.t0, i, gl_add_nc(lane_get(st.t0, i), rc0[i]));
@@ -891,7 +895,11 @@ __device__ __forceinline__ void poseidon_permute_lane_asm(LaneState& st, const L
 // matrix pipe with a DENSE weight tile and two byte planes per instruction (four v_mfma_i32_32x32x32_i8 per round; the operand maps are
 // in the generator).  Merged triples: the two dot products are partial sums over a lane's own elements added across the pair with
 // v_permlane32_swap_b32; the dense layer reads the partner's six elements (one exchange per triple) and computes the lane's six outputs.
+#ifdef STARKHIP_PAIR_INC   // experiment builds: another schedule of the same blocks (tools/experiments/pair_variants.sh)
+#include STARKHIP_PAIR_INC
+#else
 #include "pair_round_asm.inc"
+#endif
 constexpr int PAIR_MFMA_ROUNDS = 9;   // full rounds 0 .. 3, the lone partial round 25, full rounds 26 .. 29
 struct PairTables {
     gl_t rc0[2][6];                 // [half]: the first round's constants of the half's elements
@@ -979,8 +987,9 @@ __device__ __forceinline__ void poseidon_permute_pair_asm(PairState& st, const P
                                                           uint64_t mask_lo) {
     const unsigned half = lane >> 5;
     {
-        const gl_t* rc0 = T->rc0[half];
-        asm volatile("" : "+v"(rc0));
+        uint32_t rc0_lds = (uint32_t)(uintptr_t)&T->rc0[half][0];   // (an LDS pointer: see poseidon_permute_lane_asm)
+        asm volatile("" : "+v"(rc0_lds));
+        const lds_gl_ptr rc0 = (lds_gl_ptr)rc0_lds;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             pair_set(st.t0, i, gl_add_nc(pair_get(st.t0, i), rc0[i]));

@@ -147,7 +147,7 @@ def test_a_failing_job_reports_its_code_and_the_pool_goes_on():
 
 
 def test_final_exp_four_in_flight_match_the_oracle_digest():
-    """The regime bench.py times: FOUR FinalExp proofs in flight on one GPU.  All four prove the benchmark's first seeded
+    """FOUR FinalExp proofs in flight on one GPU, each commitment a launch of its own.  All four prove the benchmark's first seeded
     input (0x5EED0001); every proof's SHA-256 equals the CPU oracle's (tests/golden/final_exp_seed_5eed0001_proof.sha256, made by
     tests/make_final_exp_golden.py --seed 0x5EED0001 on the GPU box's host) -- contention changes nothing in the bytes."""
     air = S.AIR_FINAL_EXP
@@ -159,12 +159,15 @@ def test_final_exp_four_in_flight_match_the_oracle_digest():
     pool = S.ProofPool(0, big_contexts=4, small_contexts=1, generator_threads=1)
     try:
         tickets = [pool.submit(air, cfg, cols, pis, layout=1) for _ in range(4)]
-        digests = [hashlib.sha256(pool.wait(t)[0].tobytes()).hexdigest() for t in tickets]
+        got = [pool.wait(t) for t in tickets]
+        digests = [hashlib.sha256(pr.tobytes()).hexdigest() for pr, _ in got]
         stats = pool.stats()
     finally:
         pool.close()
     assert digests == [want] * 4
     assert stats["big_commit_launches"] == 4
+    # below five big contexts a big commitment goes out on its own, in the pair form (two lanes per leaf; kernels_hash.hip)
+    assert {info["leaf_hash_form"] for _, info in got} == {"pair"}
 
 
 def test_final_exp_in_lane_form_groups_match_the_oracle_digest(monkeypatch):

@@ -16,7 +16,8 @@ from bls_util import random_fp12  # noqa: E402
 pv = S.Prover(0)
 out = {"shapes": []}
 bad = 0
-for log_N, ncols, cap_h in [(5, 8, 2), (5, 16, 2), (6, 9, 2), (7, 40, 2), (10, 13, 4), (10, 24, 4), (12, 200, 4), (15, 19, 4), (5, 3767, 4)]:
+TIMING = "--timing" in sys.argv   # a variant build whose digests may be wrong (ablations): the pair form's duration only
+for log_N, ncols, cap_h in [] if TIMING else [(5, 8, 2), (5, 16, 2), (6, 9, 2), (7, 40, 2), (10, 13, 4), (10, 24, 4), (12, 200, 4), (15, 19, 4), (5, 3767, 4)]:
     rng = np.random.default_rng(log_N + ncols)
     mat = rng.integers(0, S.P, size=(ncols, 1 << log_N), dtype=np.uint64)
     mat[:, 0] = 0
@@ -34,14 +35,14 @@ if bad == 0 and "--no-proof" not in sys.argv:
     trace, pis = S.trace_final_exp(random_fp12(0x5EED0001), compact=True)
     res = {}
     proofs = {}
-    for form, name in ((1, "quad"), (4, "pair"), (0, "auto")):
+    for form, name in ((4, "pair"),) if TIMING else ((1, "quad"), (4, "pair"), (0, "auto")):
         pv.set_option("leaf_hash_form", form)
         ms = []
         for rep in range(3):
             proofs[name] = pv.prove(air, cfg, trace, pis)
             ms.append(round(pv.last_kernel_timings()["leaf_hash"], 2))
         res[name] = ms
-    res["same_bytes"] = bool(np.array_equal(proofs["quad"], proofs["pair"]) and np.array_equal(proofs["quad"], proofs["auto"]))
+    res["same_bytes"] = None if TIMING else bool(np.array_equal(proofs["quad"], proofs["pair"]) and np.array_equal(proofs["quad"], proofs["auto"]))
     print(json.dumps(res))
 pv.close()
 sys.exit(1 if bad else 0)

@@ -285,6 +285,7 @@ def block_partial_mfma():
 
 # ---------------------------------------------------------------- scheduling with load latency, counted waits
 LOAD_LATENCY = 16
+VALU_RAW, SGPR_RAW = 1, 3   # slots: VALU result -> VALU read; VALU-written SGPR (carry) -> VALU read (W1).  Experiments change them (gen_pair_round_asm.py)
 
 
 def schedule_lane(prog):
@@ -298,7 +299,7 @@ def schedule_lane(prog):
         for r in ins.reads:
             if r in last_w:
                 j = last_w[r]
-                d = 1
+                d = VALU_RAW
                 if is_load[j]:
                     d = LOAD_LATENCY
                 elif is_mfma[j]:
@@ -308,7 +309,7 @@ def schedule_lane(prog):
                 preds[i].append((j, d))
         for r in ins.sreads:
             if r in last_sw:
-                preds[i].append((last_sw[r], 3))                        # W1
+                preds[i].append((last_sw[r], SGPR_RAW))                 # W1
         for w in ins.writes:
             if w in last_w:
                 j = last_w[w]

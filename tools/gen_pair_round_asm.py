@@ -26,6 +26,12 @@ import gen_lane_round_asm as L  # noqa: E402
 
 Ins, v, vp, sp = G.Ins, G.v, G.vp, G.sp
 P, M32, M64 = G.P, G.M32, G.M64
+ABLATE = os.environ.get("PAIR_ABLATE", "")         # timing experiments only (wrong results): "seeds", "rows"
+# slots between an LDS load and its first use that the scheduler aims for (a wave alone on its SIMD has nobody to hide a longer wait)
+ROUND_LOAD_LATENCY = int(os.environ.get("PAIR_LOAD_LATENCY", 16))
+TRIPLE_LOAD_LATENCY = int(os.environ.get("PAIR_TRIPLE_LOAD_LATENCY", os.environ.get("PAIR_LOAD_LATENCY", 56)))   # measured: 16 -> 123.9 ms, 28 -> 122.0, 56 -> 121.6
+L.VALU_RAW = int(os.environ.get("PAIR_VALU_RAW", L.VALU_RAW))
+L.SGPR_RAW = int(os.environ.get("PAIR_SGPR_RAW", L.SGPR_RAW))
 G.NL = 2   # lane 0 = lower half-wave (elements 0 .. 5), lane 1 = upper half-wave (elements 6 .. 11)
 
 T, S = L.T, L.S                  # state: six pairs v[80:91]; S-box outputs / hi halves: six pairs v[104:115]
@@ -164,11 +170,13 @@ def block_triple_pair():
         partners(prog, PT + 2 * e, PT + 2 * e + 2, T + 2 * e, T + 2 * e + 2)
     for r in range(NE):
         sd = L.SEEDR + 8 + 4 * (r % 2)
-        L.load(prog, sd, 4, L.A_K3, 16 * r, ("k3", r))
+        if ABLATE != "seeds" or r == 0:
+            L.load(prog, sd, 4, L.A_K3, 16 * r, ("k3", r))
         A, B = L.ACC + 4 * (r % 2), L.ACC + 4 * (r % 2) + 2
         cr = L.COEFR + 16 * (r % 2)
         for q in range(4):
-            L.load(prog, cr + 4 * q, 4, L.A_COEF, ROW_OFF + 64 * r + 16 * q, (("row", r), q))
+            if ABLATE != "rows" or r < 2:
+                L.load(prog, cr + 4 * q, 4, L.A_COEF, ROW_OFF + 64 * r + 16 * q, (("row", r), q))
         for j in range(12):   # the row's columns in the LANE's order: its own six elements, then the partner's
             src = T + 2 * j if j < NE else PT + 2 * ((j - NE) ^ 1)
             L.madc(prog, A, src, ("v", cr + j), seed=sd if j == 0 else None)
@@ -352,10 +360,12 @@ def main():
               ("STARKHIP_PAIR_TRIPLE_ASM", block_triple_pair(), test_triple_pair, "three partial rounds at once (poseidon_merged.h)"))
     done, slots = [], {}
     for name, prog, tester, what in blocks:
+        L.LOAD_LATENCY = TRIPLE_LOAD_LATENCY if name == "STARKHIP_PAIR_TRIPLE_ASM" else ROUND_LOAD_LATENCY
         order = schedule_pair(prog)
         L.check_hazards(order)
         check_swaps(order)
-        tester(order)
+        if not ABLATE:
+            tester(order)
         done.append((name, order, what))
         slots[name] = len(order)
     per_wave = 7 * slots["STARKHIP_PAIR_FULL_ROUND_ASM"] + slots["STARKHIP_PAIR_LAST_ROUND_ASM"] + 7 * slots["STARKHIP_PAIR_TRIPLE_ASM"] + slots["STARKHIP_PAIR_PARTIAL_ROUND_ASM"]

@@ -17,7 +17,8 @@ import tempfile
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 KERNELS = [
     ("kernels_lde.hip", r"lde_columns_wave_kernelE", "LDE, 2^13 rows (wave-resident kernel): the column loop holds the inverse transform and the coset loop"),
-    ("kernels_hash.hip", r"leaf_hash_kernelE", "leaf hash: the blocks are the round loops of one permutation"),
+    ("kernels_hash.hip", r"leaf_hash_kernelE", "leaf hash, quad form: the blocks are the round loops of one permutation"),
+    ("kernels_hash.hip", r"leaf_hash_pair_kernelE", "leaf hash, pair form (a lone big commitment): the blocks are the generated rounds (csrc/pair_round_asm.inc) and the absorb loop around them"),
     ("kernels_quotient.hip", r"quotient_tiles_kernelILb0ELj0E", "tiled quotient evaluator: record steps (12 v_mad_u64_u32 each) and piece ends"),
 ]
 

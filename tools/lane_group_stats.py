@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """From a rocprofv3 --kernel-trace of the default bench run (several proofs in flight): how the trace commitments actually ran --
-launches of leaf_hash_lane_kernel (groups, one lane per leaf) and of leaf_hash_kernel (quad form), their durations and how many ran
+launches of leaf_hash_lane_kernel (groups, one lane per leaf) and of leaf_hash_pair_kernel (a big commitment on its own, two lanes per
+leaf; leaf_hash_kernel, the quad form, in libraries before it), their durations and how many ran
 side by side.  bench.py quotes the result next to its one-proof-in-flight roofline figures (profiles/lane_group_latest.json, with
 the SHA-256 of the kernel sources like pmc_traffic_latest.json).
 
@@ -20,7 +21,7 @@ def main():
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select name, start, end from kernels order by start"))
     res = {}
-    for key, pat in (("leaf_hash_lane_kernel", "leaf_hash_lane_kernel"), ("leaf_hash_kernel", "leaf_hash_kernel")):
+    for key, pat in (("leaf_hash_lane_kernel", "leaf_hash_lane_kernel"), ("leaf_hash_pair_kernel", "leaf_hash_pair_kernel"), ("leaf_hash_kernel", "leaf_hash_kernel")):
         ls = [(s, e) for n, s, e in rows if pat in n and "multi" not in n]
         if not ls:
             continue
@@ -31,7 +32,7 @@ def main():
         res[key] = {"trace_commitment_launches": len(big), "average_ms": sum(e - s for s, e in big) / len(big) / 1e6,
                     "side_by_side_average": sum(conc) / len(conc), "launches_in_groups_of_four": len(full),
                     "average_ms_in_groups_of_four": (sum(full) / len(full)) if full else None}
-    res["source_sha256"] = kernel_fingerprint("leaf_hash_kernel")
+    res["source_sha256"] = kernel_fingerprint("leaf_hash_lane_kernel")
     res["_source"] = "rocprofv3 --kernel-trace of `python3 bench.py --steps 24 --warmup 2 --no-cpu-baseline --no-boundary` (default proofs in flight)"
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))

@@ -20,7 +20,7 @@ def main():
         seen = {}
         for f, ctr in ((dbs[pair], "FETCH_SIZE"), (dbs[pair + 1], "WRITE_SIZE")):
             cur = sqlite3.connect(f).cursor()
-            for k in ("leaf_hash_lane_kernel", "leaf_hash_kernel", "quotient_tiles_kernel", "lde_columns_wave_kernel", "lde_columns_v2_kernel"):
+            for k in ("leaf_hash_lane_kernel", "leaf_hash_pair_kernel", "leaf_hash_kernel", "quotient_tiles_kernel", "lde_columns_wave_kernel", "lde_columns_v2_kernel"):
                 rows = list(cur.execute("select value, duration from counters_collection where kernel_name like ? and counter_name = ? order by duration desc",
                                         ("%" + k + "%", ctr)))
                 if not rows:
