@@ -73,8 +73,8 @@ def poseidon_pair_slots():
 
 def poseidon_lane_slots():
     """issue slots of one permutation in the lane form (one permutation per lane), from the block sizes tools/gen_lane_round_asm.py writes
-    into csrc/lane_round_asm.inc: 7 full rounds with the circulant layer on the matrix pipe, the capacity-only last round, 7 merged triples
-    of partial rounds, the lone partial round"""
+    into csrc/lane_round_asm.inc: 7 full rounds with the circulant layer on the matrix pipe, the capacity-only last round, 5 merges of four
+    partial rounds, the two plain partial rounds"""
     import re
     sizes = {}
     for line in open(os.path.join(ROOT, "starky_bls12_381_amd", "csrc", "lane_round_asm.inc")):
@@ -83,7 +83,7 @@ def poseidon_lane_slots():
             sizes[m.group(1)] = int(m.group(2))
     try:
         return (7 * sizes["full round, circulant layer on the matrix pipe"] + sizes["last full round before an absorb: the capacity outputs only"]
-                + 7 * sizes["three partial rounds at once (poseidon_merged.h)"] + sizes["partial round, circulant layer on the matrix pipe"])
+                + 5 * sizes["four partial rounds at once"] + 2 * sizes["partial round, circulant layer on the matrix pipe"])
     except KeyError:
         return None
 

@@ -420,30 +420,6 @@ __global__ __launch_bounds__(256, 2) void leaf_hash_lane_kernel(const gl_t* __re
 #pragma unroll
         for (int e = 0; e < 8; e++) nx[e] = col[(size_t)e * N];
     }
-#ifdef STARKHIP_LANE_CPP_ROUNDS  // what hipcc makes of the C++ rounds (poseidon_permute_lane_merged), kept for comparison
-    gl_t s[12];
-#pragma unroll
-    for (int e = 0; e < 12; e++) s[e] = 0;
-    for (size_t b = 0; b < n_full; b++) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) s[e] = nx[e];
-        if (b + 1 < n_full) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) nx[e] = col[(8 * (b + 1) + e) * N];  // requested one permutation ahead
-            poseidon_permute_lane_merged<true>(s, &T);
-        } else {
-            poseidon_permute_lane_merged<false>(s, &T);
-        }
-    }
-    if (rem) {
-        for (size_t e = 0; e < rem; e++) s[e] = col[(8 * n_full + e) * N];
-        poseidon_permute_lane_merged<false>(s, &T);
-    }
-    if (live) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) digests[4 * j + e] = gl_canon(s[e]);
-    }
-#else
     LaneZeros Z;
     lane_zeros_init(Z);
     LaneMfma M;
@@ -478,34 +454,38 @@ __global__ __launch_bounds__(256, 2) void leaf_hash_lane_kernel(const gl_t* __re
 #pragma unroll
         for (int e = 0; e < 4; e++) digests[4 * j + e] = gl_canon(lane_get(st.t0, e));
     }
-#endif
 }
 static void build_lane_tables(LaneTables& T) {
-    static PoseidonMergedTables P;
-    build_poseidon_merged_tables(P);
+    static PoseidonMergedFours P;
+    build_poseidon_merged_fours(P);
+    if (!P.sums_fit) abort();   // (a property of the MDS matrix, checked where the tables are made: the accumulators' 64 bits)
     auto split = [](gl_t v) { return RcPair{v & 0xFFFFFFFFull, v >> 32}; };
     memset(&T, 0, sizeof T);
     for (int r = 0; r < 30; r++)
         for (int e = 0; e < 12; e++) T.rc[r][e] = split(POSEIDON_RC_HOST[12 * r + e]);
     for (int e = 0; e < 12; e++) T.rc0[e] = POSEIDON_RC_HOST[e];
-    for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++) {
-        T.k12[t][0] = split(P.k1[t]);
-        T.k12[t][1] = split(P.k2[t]);
-        for (int e = 0; e < 12; e++) T.k3[t][e] = split(P.k3[t][e]);
+    for (int t = 0; t < POSEIDON_MERGED_FOURS; t++) {
+        T.kf[t][0] = split(P.k1[t]);
+        T.kf[t][1] = split(P.k2[t]);
+        T.kf[t][2] = split(P.k3[t]);
+        for (int e = 0; e < 12; e++) T.k4[t][e] = split(P.k4[t][e]);
     }
     for (int r = 0; r < 12; r++) {
-        for (int c = 0; c < 12; c++) T.row[r][c] = (uint32_t)P.N3[r][c];
-        T.row[r][12] = (uint32_t)P.N2[r][0];
-        T.row[r][13] = (uint32_t)P.M[r][0];
+        for (int c = 0; c < 12; c++) T.row[r][c] = (uint32_t)P.N4[r][c];
+        T.row[r][12] = (uint32_t)P.N3[r][0];
+        T.row[r][13] = (uint32_t)P.N2[r][0];
+        T.row[r][14] = (uint32_t)P.M[r][0];
         T.m0[r] = (uint32_t)P.M[0][r];
         T.n20[r] = (uint32_t)P.N2[0][r];
+        T.n30[r] = (uint32_t)P.N3[0][r];
     }
+    T.n30[12] = (uint32_t)P.N2[0][0];
     // The matrix-pipe rounds (poseidon_dev.h: poseidon_permute_lane_asm): table m serves the round whose layer is seeded with rc[next[m]].
     // The products see signed bytes (byte - 128) and the spare K-values add 34 818 = STARKHIP_LANE_K_OFFSET to every plane, so the 64-bit
     // constant whose bytes ride in the weight tile is  RC[g] = rc[g] - (34 818 - 128 rowsum[g]) * 0x0101010101010101  mod p.
     static const int CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    static const int NEXT_ROUND[8] = {1, 2, 3, 4, 26, 27, 28, 29};
-    for (int m = 0; m < 8; m++)
+    static const int NEXT_ROUND[9] = {1, 2, 3, 4, 25, 26, 27, 28, 29};
+    for (int m = 0; m < 9; m++)
         for (unsigned lane = 0; lane < 64; lane++) {
             const unsigned row = lane & 31u, half = lane >> 5, g = (row & 3u) + 4u * (row >> 3);
             const bool live = ((row >> 2) & 1u) == half && g < 12u;
@@ -635,34 +615,39 @@ __global__ __launch_bounds__(256, 2) void leaf_hash_pair_kernel(const gl_t* __re
     }
 }
 static void build_pair_tables(PairTables& T) {
-    static PoseidonMergedTables P;
-    build_poseidon_merged_tables(P);
+    static PoseidonMergedFours P;
+    build_poseidon_merged_fours(P);
+    if (!P.sums_fit) abort();
     auto split = [](gl_t v) { return RcPair{v & 0xFFFFFFFFull, v >> 32}; };
     memset(&T, 0, sizeof T);
     for (unsigned h = 0; h < 2; h++) {
         for (unsigned e = 0; e < 6; e++) T.rc0[h][e] = POSEIDON_RC_HOST[6 * h + e];
-        for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++)
-            for (unsigned r = 0; r < 6; r++) T.k3[t][h][r] = split(P.k3[t][6 * h + r]);
+        for (int t = 0; t < POSEIDON_MERGED_FOURS; t++)
+            for (unsigned r = 0; r < 6; r++) T.k4[t][h][r] = split(P.k4[t][6 * h + r]);
         uint32_t* c = T.coef[h];
         for (unsigned e = 0; e < 6; e++) {
             c[e] = (uint32_t)P.M[0][6 * h + e];
             c[8 + e] = (uint32_t)P.N2[0][6 * h + e];
+            c[16 + e] = (uint32_t)P.N3[0][6 * h + e];
         }
+        c[16 + 6] = (uint32_t)P.N2[0][0];
         for (unsigned r = 0; r < 6; r++) {
             const unsigned g = 6 * h + r;
-            uint32_t* row = c + 16 + 16 * r;
-            for (unsigned jj = 0; jj < 12; jj++) row[jj] = (uint32_t)P.N3[g][(6 * h + jj) % 12];   // own six, then the partner's
-            row[12] = (uint32_t)P.N2[g][0];
-            row[13] = (uint32_t)P.M[g][0];
+            uint32_t* row = c + 24 + 16 * r;
+            for (unsigned jj = 0; jj < 12; jj++) row[jj] = (uint32_t)P.N4[g][(6 * h + jj) % 12];   // own six, then the partner's
+            row[12] = (uint32_t)P.N3[g][0];
+            row[13] = (uint32_t)P.N2[g][0];
+            row[14] = (uint32_t)P.M[g][0];
         }
     }
-    for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++) {   // the constants of the two dot products enter once: through the lower half
-        T.k12[t][0][0] = split(P.k1[t]);
-        T.k12[t][0][1] = split(P.k2[t]);
+    for (int t = 0; t < POSEIDON_MERGED_FOURS; t++) {   // the constants of the three dot products enter once: through the lower half
+        T.kf[t][0][0] = split(P.k1[t]);
+        T.kf[t][0][1] = split(P.k2[t]);
+        T.kf[t][0][2] = split(P.k3[t]);
     }
     // the matrix-pipe rounds' constants, as in build_lane_tables (the same offsets: a row still sums twelve signed bytes)
     static const int CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    static const int NEXT_ROUND[PAIR_MFMA_ROUNDS] = {1, 2, 3, 4, 26, 27, 28, 29, 30};
+    static const int NEXT_ROUND[PAIR_MFMA_ROUNDS] = {1, 2, 3, 4, 25, 26, 27, 28, 29, 30};
     for (int m = 0; m < PAIR_MFMA_ROUNDS; m++)
         for (unsigned lane = 0; lane < 64; lane++) {
             const unsigned row = lane & 31u, khalf = lane >> 5, i = (row & 3u) + 4u * (row >> 3), out_half = (row >> 2) & 1u;

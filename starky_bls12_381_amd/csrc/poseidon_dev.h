@@ -624,133 +624,22 @@ __device__ __forceinline__ gl_t poseidon_permute_row(gl_t s, const RcPair* __res
 typedef const __attribute__((address_space(3))) gl_t* lds_gl_ptr;
 struct LaneTables {
     RcPair rc[31][12];         // round constants in halves; rc[30] = 0 (the "next round" of the last one)
-    RcPair k12[7][2];          // k1, k2 of the merged triples
-    RcPair k3[7][12];
-    uint32_t row[12][16];      // per output row of the dense layer: N3[r][0 .. 11], N2[r][0], M[r][0], -, -
-    uint32_t m0[12], n20[12];  // row 0 of M and of N2 (the two intermediate dot products)
-    // The rounds whose circulant layer runs on the matrix pipe (full rounds 0 .. 3 and 26 .. 28, the lone partial round 25; lane_round_asm.inc,
-    // tools/gen_lane_round_asm.py): per round, byte plane and LANE the fourth dword of the weight tile -- the constant bytes that ride in
-    // the spare K-values (kernels_hash.hip: build_lane_tables)
-    uint32_t rcb[8][8][64];
+    RcPair kf[5][3];           // k1, k2, k3 of the merged fours (poseidon_merged.h)
+    RcPair k4[5][12];
+    uint32_t row[12][16];      // per output row of the dense layer: N4[r][0 .. 11], N3[r][0], N2[r][0], M[r][0], -
+    uint32_t m0[12], n20[12];  // row 0 of M and of N2 (the first two intermediate dot products) ...
+    uint32_t n30[16];          // ... and of N3, then N2[0][0] (the third)
+    // The rounds whose circulant layer runs on the matrix pipe (full rounds 0 .. 3 and 26 .. 28, the plain partial rounds 24 and 25;
+    // lane_round_asm.inc, tools/gen_lane_round_asm.py): per round, byte plane and LANE the fourth dword of the weight tile -- the constant
+    // bytes that ride in the spare K-values (kernels_hash.hip: build_lane_tables)
+    uint32_t rcb[9][8][64];
     gl_t rc0[12];              // the first round's constants as whole words (added to the state at the start of every permutation)
 };
 
-// circulant layer; the accumulators start from `seed` (the next round's constants); outputs 0 .. N_OUT - 1 only
-template <int FIRST_OUT>
-__device__ __forceinline__ void mds_lane(gl_t (&s)[12], const RcPair* __restrict__ seed) {
-    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    uint32_t lo[12], hi[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        lo[i] = (uint32_t)s[i];
-        hi[i] = (uint32_t)(s[i] >> 32);
-    }
-#pragma unroll
-    for (int r = FIRST_OUT; r < 12; r++) {
-        const RcPair c = seed[r];
-        uint64_t A = c.lo, B = c.hi;
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const int j = (i + r) % 12;
-            const uint32_t k = CIRC[i] + ((r == 0 && i == 0) ? 8u : 0u);
-            A = mad32(lo[j], k, A);
-            B = mad32(hi[j], k, B);
-            asm("" : "+v"(A));
-            asm("" : "+v"(B));
-        }
-        s[r] = combine_lohi_nc(A, B);
-    }
-}
-
-__device__ __forceinline__ gl_t dot_lane(const uint32_t (&lo)[12], const uint32_t (&hi)[12], const uint32_t* __restrict__ coef, const RcPair& seed, uint64_t& A,
-                                         uint64_t& B) {
-    A = seed.lo;
-    B = seed.hi;
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-        const uint4 c = *(const uint4*)(coef + 4 * q);
-        const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            A = mad32(lo[4 * q + i], cc[i], A);
-            B = mad32(hi[4 * q + i], cc[i], B);
-            asm("" : "+v"(A));
-            asm("" : "+v"(B));
-        }
-    }
-    return 0;
-}
-
-// three partial rounds (poseidon_merged.h); s has this round's constants added on entry and the round's after the third on exit
-__device__ __forceinline__ void partial3_lane(gl_t (&s)[12], const LaneTables* __restrict__ T, int t) {
-    s[0] = sbox_nc(s[0]);  // x1
-    uint32_t lo[12], hi[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        lo[i] = (uint32_t)s[i];
-        hi[i] = (uint32_t)(s[i] >> 32);
-    }
-    uint64_t A, B;
-    uint32_t zoff = 0;
-    asm volatile("" : "+v"(zoff));
-    dot_lane(lo, hi, (const uint32_t*)((const char*)T->m0 + zoff), T->k12[t][0], A, B);
-    const gl_t x2 = sbox_nc(combine_lohi_nc(A, B));
-    const uint32_t x2l = (uint32_t)x2, x2h = (uint32_t)(x2 >> 32);
-    dot_lane(lo, hi, (const uint32_t*)((const char*)T->n20 + zoff), T->k12[t][1], A, B);
-    A = mad32(x2l, 25u, A);  // M[0][0] x2
-    B = mad32(x2h, 25u, B);
-    const gl_t x3 = sbox_nc(combine_lohi_nc(A, B));
-    const uint32_t x3l = (uint32_t)x3, x3h = (uint32_t)(x3 >> 32);
-#pragma unroll
-    for (int r = 0; r < 12; r++) {
-        // The rows are the same for every triple: left alone, hipcc keeps all 190 coefficients in registers (474 of them, one wave per
-        // SIMD).  The OFFSET is made opaque, not the pointer: the loads stay LDS loads.
-        uint32_t off = (uint32_t)r * (uint32_t)sizeof(T->row[0]);
-        asm volatile("" : "+v"(off));
-        const uint32_t* rowp = (const uint32_t*)((const char*)&T->row[0][0] + off);
-        dot_lane(lo, hi, rowp, T->k3[t][r], A, B);
-        const uint32_t b2 = rowp[12], b3 = rowp[13];
-        A = mad32(x2l, b2, A);
-        B = mad32(x2h, b2, B);
-        A = mad32(x3l, b3, A);
-        B = mad32(x3h, b3, B);
-        s[r] = combine_lohi_nc(A, B);  // A, B < 2^57
-    }
-}
-
-// One permutation, the whole state in this lane.  CAP_ONLY: only elements 8 .. 11 of the result are computed (the caller overwrites
-// the rate).  In: any representatives; out: any representatives.
-template <bool CAP_ONLY>
-__device__ __forceinline__ void poseidon_permute_lane_merged(gl_t (&s)[12], const LaneTables* __restrict__ T) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add_nc(s[i], T->rc[0][i].lo | (T->rc[0][i].hi << 32));
-    int r = 0;
-#pragma unroll 1
-    for (; r < 4; r++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox_nc(s[i]);
-        mds_lane<0>(s, T->rc[r + 1]);
-    }
-#pragma unroll 1
-    for (int t = 0; t < QUAD_MERGED_TRIPLES; t++) partial3_lane(s, T, t);
-    r = 4 + 3 * QUAD_MERGED_TRIPLES;  // 25
-    s[0] = sbox_nc(s[0]);
-    mds_lane<0>(s, T->rc[r + 1]);
-    r++;
-#pragma unroll 1
-    for (; r < 29; r++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox_nc(s[i]);
-        mds_lane<0>(s, T->rc[r + 1]);
-    }
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = sbox_nc(s[i]);
-    mds_lane<CAP_ONLY ? 8 : 0>(s, T->rc[30]);
-}
-
-// ---- the lane form's rounds as scheduled asm blocks (tools/gen_lane_round_asm.py -> lane_round_asm.inc): 989 slots per full round,
-// 732 per merged triple, LDS loads a row ahead with counted waits -- against 1337 and 1464 (a third of them wait states) from the C++
-// above.  The state lives in three 8-register tuples bound to v[80:103]: the rate is the first two, the capacity the third.
+// ---- the lane form's rounds as scheduled asm blocks (tools/gen_lane_round_asm.py -> lane_round_asm.inc; the block sizes are in its
+// header), LDS loads a row ahead with counted waits -- hipcc made 1337 slots of a full round and 1464 of three merged partial rounds, a
+// third of them wait states (history section 5).  The state lives in three 8-register tuples bound to v[80:103]: the rate is the first
+// two, the capacity the third.  Partial rounds 4 .. 23 run FOUR at a time (poseidon_merged.h), 24 and 25 as plain rounds.
 #include "lane_round_asm.inc"
 typedef uint32_t lane_u32x8 __attribute__((ext_vector_type(8)));
 struct LaneState {
@@ -774,10 +663,10 @@ STARKHIP_LANE_ROUND_BLOCK(lane_full_round_asm, STARKHIP_LANE_FULL_ROUND_ASM)
 STARKHIP_LANE_ROUND_BLOCK(lane_last_round_asm, STARKHIP_LANE_LAST_ROUND_ASM)
 STARKHIP_LANE_ROUND_BLOCK(lane_partial_round_asm, STARKHIP_LANE_PARTIAL_ROUND_ASM)
 #undef STARKHIP_LANE_ROUND_BLOCK
-__device__ __forceinline__ void lane_triple_asm(LaneState& st, uint32_t k3_lds, uint32_t k12_lds, uint32_t coef_lds, const LaneZeros& Z) {
-    asm(STARKHIP_LANE_TRIPLE_ASM
+__device__ __forceinline__ void lane_four_asm(LaneState& st, uint32_t k4_lds, uint32_t kf_lds, uint32_t coef_lds, const LaneZeros& Z) {
+    asm(STARKHIP_LANE_FOUR_ASM
         : STARKHIP_LANE_STATE0(st.t0), STARKHIP_LANE_STATE1(st.t1), STARKHIP_LANE_STATE2(st.t2)
-        : STARKHIP_LANE_A_K3(k3_lds), STARKHIP_LANE_A_K12(k12_lds), STARKHIP_LANE_A_COEF(coef_lds), STARKHIP_LANE_ZA(Z.za), STARKHIP_LANE_ZB(Z.zb)
+        : STARKHIP_LANE_A_K3(k4_lds), STARKHIP_LANE_A_K12(kf_lds), STARKHIP_LANE_A_COEF(coef_lds), STARKHIP_LANE_ZA(Z.za), STARKHIP_LANE_ZB(Z.zb)
         : STARKHIP_LANE_CLOBBERS);
 }
 // The operands of the matrix-pipe rounds that live across the whole kernel: the weight tile of v_mfma_i32_32x32x32_i8 for THIS lane
@@ -840,8 +729,8 @@ __device__ __forceinline__ void lane_set(lane_u32x8& t, int i, gl_t x) {
     t[2 * i + 1] = (uint32_t)(x >> 32);
 }
 // One permutation.  CAP_ONLY: only the capacity (st.t2) of the result is computed -- the caller overwrites the rate.
-// Rounds 0 .. 3, 25 (the lone partial round) and 26 .. 28 run their circulant layer on the matrix pipe (866 and 292 slots against 980 and
-// 418); the merged triples (21-bit coefficients: three weight planes, no gain) and the capacity-only last round stay multiply-add chains.
+// Rounds 0 .. 3, 24, 25 (the plain partial rounds) and 26 .. 28 run their circulant layer on the matrix pipe (844 and 268 slots against 980
+// and 418); the merged fours (29-bit coefficients: four weight planes, no gain) and the capacity-only last round stay multiply-add chains.
 // -DSTARKHIP_LANE_NO_MFMA: the round-3 form throughout (A/B measurements).
 template <bool CAP_ONLY>
 __device__ __forceinline__ void poseidon_permute_lane_asm(LaneState& st, const LaneTables* __restrict__ T, const LaneZeros& Z, LaneMfma& M, unsigned lane) {
@@ -860,16 +749,17 @@ __device__ __forceinline__ void poseidon_permute_lane_asm(LaneState& st, const L
             lane_set(st.t2, i, gl_add_nc(lane_get(st.t2, i), rc0[8 + i]));
         }
     }
-    const uint32_t rc_lds = (uint32_t)(uintptr_t)&T->rc[0][0], k3_lds = (uint32_t)(uintptr_t)&T->k3[0][0], k12_lds = (uint32_t)(uintptr_t)&T->k12[0][0],
+    const uint32_t rc_lds = (uint32_t)(uintptr_t)&T->rc[0][0], k4_lds = (uint32_t)(uintptr_t)&T->k4[0][0], kf_lds = (uint32_t)(uintptr_t)&T->kf[0][0],
                    coef_lds = (uint32_t)(uintptr_t)&T->row[0][0];
-    constexpr uint32_t RC_ROW = 12 * sizeof(RcPair);
+    constexpr uint32_t RC_ROW = 12 * sizeof(RcPair), KF_ROW = 3 * sizeof(RcPair);
 #ifdef STARKHIP_LANE_NO_MFMA
     (void)M;
     (void)lane;
 #pragma unroll 1
     for (uint32_t r = 0; r < 4; r++) lane_full_round_asm(st, rc_lds + (r + 1) * RC_ROW, Z);
 #pragma unroll 1
-    for (uint32_t t = 0; t < 7; t++) lane_triple_asm(st, k3_lds + t * RC_ROW, k12_lds + t * 2 * (uint32_t)sizeof(RcPair), coef_lds, Z);
+    for (uint32_t t = 0; t < 5; t++) lane_four_asm(st, k4_lds + t * RC_ROW, kf_lds + t * KF_ROW, coef_lds, Z);
+    lane_partial_round_asm(st, rc_lds + 25 * RC_ROW, Z);
     lane_partial_round_asm(st, rc_lds + 26 * RC_ROW, Z);
 #pragma unroll 1
     for (uint32_t r = 26; r < 29; r++) lane_full_round_asm(st, rc_lds + (r + 1) * RC_ROW, Z);
@@ -879,10 +769,11 @@ __device__ __forceinline__ void poseidon_permute_lane_asm(LaneState& st, const L
 #pragma unroll 1
     for (uint32_t m = 0; m < 4; m++) lane_full_round_mfma_asm(st, rcb_lds + m * RCB_ROUND, Z, M);
 #pragma unroll 1
-    for (uint32_t t = 0; t < 7; t++) lane_triple_asm(st, k3_lds + t * RC_ROW, k12_lds + t * 2 * (uint32_t)sizeof(RcPair), coef_lds, Z);
-    lane_partial_round_mfma_asm(st, rcb_lds + 4 * RCB_ROUND, Z, M);
+    for (uint32_t t = 0; t < 5; t++) lane_four_asm(st, k4_lds + t * RC_ROW, kf_lds + t * KF_ROW, coef_lds, Z);
 #pragma unroll 1
-    for (uint32_t m = 5; m < 8; m++) lane_full_round_mfma_asm(st, rcb_lds + m * RCB_ROUND, Z, M);
+    for (uint32_t m = 4; m < 6; m++) lane_partial_round_mfma_asm(st, rcb_lds + m * RCB_ROUND, Z, M);
+#pragma unroll 1
+    for (uint32_t m = 6; m < 9; m++) lane_full_round_mfma_asm(st, rcb_lds + m * RCB_ROUND, Z, M);
 #endif
     if (CAP_ONLY) lane_last_round_asm(st, rc_lds + 30 * RC_ROW, Z);
     else lane_full_round_asm(st, rc_lds + 30 * RC_ROW, Z);
@@ -893,21 +784,23 @@ __device__ __forceinline__ void poseidon_permute_lane_asm(LaneState& st, const L
 // the form a LONE FinalExp-class commitment takes (the lane form's 512 waves would leave half the chip idle, the quad form costs 272 issue
 // slots per permutation against 212 here).  Full rounds and the lone partial round: six S-boxes per lane, then the circulant layer on the
 // matrix pipe with a DENSE weight tile and two byte planes per instruction (four v_mfma_i32_32x32x32_i8 per round; the operand maps are
-// in the generator).  Merged triples: the two dot products are partial sums over a lane's own elements added across the pair with
-// v_permlane32_swap_b32; the dense layer reads the partner's six elements (one exchange per triple) and computes the lane's six outputs.
+// in the generator).  Partial rounds 4 .. 23 four at a time (poseidon_merged.h): the three dot products are partial sums over a lane's own
+// elements added across the pair with v_permlane32_swap_b32; the dense layer reads the partner's six elements (one exchange per merge) and
+// computes the lane's six outputs.
 #ifdef STARKHIP_PAIR_INC   // experiment builds: another schedule of the same blocks (tools/experiments/pair_variants.sh)
 #include STARKHIP_PAIR_INC
 #else
 #include "pair_round_asm.inc"
 #endif
-constexpr int PAIR_MFMA_ROUNDS = 9;   // full rounds 0 .. 3, the lone partial round 25, full rounds 26 .. 29
+constexpr int PAIR_MFMA_ROUNDS = 10;   // full rounds 0 .. 3, the plain partial rounds 24 and 25, full rounds 26 .. 29
 struct PairTables {
     gl_t rc0[2][6];                 // [half]: the first round's constants of the half's elements
-    RcPair k12[7][2][2];            // [triple][half]: k1, k2 -- in the lower half only (the sums are added across the pair), zero in the upper
-    RcPair k3[7][2][6];             // [triple][half][local output]
-    // per half, 448 bytes: row 0 of M and of N2 against the half's own six elements (6 + 2 pad dwords each), then per local output r
-    // (g = 6 half + r) sixteen dwords: N3[g][own six], N3[g][the partner's six, neighbours crossed], N2[g][0], M[g][0], 0, 0
-    uint32_t coef[2][112];
+    RcPair kf[5][2][3];             // [merged four][half]: k1, k2, k3 -- in the lower half only (the sums are added across the pair), zero in the upper
+    RcPair k4[5][2][6];             // [merged four][half][local output]
+    // per half, 480 bytes: rows 0 of M, N2 and N3 against the half's own six elements (8 dwords each; N2[0][0] in dword 6 of the third),
+    // then per local output r (g = 6 half + r) sixteen dwords: N4[g][own six], N4[g][the partner's six, neighbours crossed], N3[g][0],
+    // N2[g][0], M[g][0], 0
+    uint32_t coef[2][120];
     uint32_t rcb[PAIR_MFMA_ROUNDS][4][64];   // per matrix-pipe round, instruction and LANE: dword 3 of the weight tile (the constants' bytes)
 };
 typedef uint32_t pair_u32x4 __attribute__((ext_vector_type(4)));
@@ -968,10 +861,10 @@ STARKHIP_PAIR_MFMA_BLOCK(pair_full_round_asm, STARKHIP_PAIR_FULL_ROUND_ASM)
 STARKHIP_PAIR_MFMA_BLOCK(pair_last_round_asm, STARKHIP_PAIR_LAST_ROUND_ASM)
 STARKHIP_PAIR_MFMA_BLOCK(pair_partial_round_asm, STARKHIP_PAIR_PARTIAL_ROUND_ASM)
 #undef STARKHIP_PAIR_MFMA_BLOCK
-__device__ __forceinline__ void pair_triple_asm(PairState& st, uint32_t k3_lds, uint32_t k12_lds, uint32_t coef_lds, const LaneZeros& Z, uint64_t mask_lo) {
-    asm(STARKHIP_PAIR_TRIPLE_ASM
+__device__ __forceinline__ void pair_four_asm(PairState& st, uint32_t k4_lds, uint32_t kf_lds, uint32_t coef_lds, const LaneZeros& Z, uint64_t mask_lo) {
+    asm(STARKHIP_PAIR_FOUR_ASM
         : STARKHIP_PAIR_STATE0(st.t0), STARKHIP_PAIR_STATE1(st.t1), STARKHIP_PAIR_STATE2(st.t2)
-        : STARKHIP_PAIR_A_K3(k3_lds), STARKHIP_PAIR_A_K12(k12_lds), STARKHIP_PAIR_A_COEF(coef_lds), STARKHIP_PAIR_ZA(Z.za), STARKHIP_PAIR_ZB(Z.zb),
+        : STARKHIP_PAIR_A_K3(k4_lds), STARKHIP_PAIR_A_K12(kf_lds), STARKHIP_PAIR_A_COEF(coef_lds), STARKHIP_PAIR_ZA(Z.za), STARKHIP_PAIR_ZB(Z.zb),
           STARKHIP_PAIR_MASK_LO(mask_lo)
         : STARKHIP_PAIR_CLOBBERS);
 }
@@ -997,18 +890,19 @@ __device__ __forceinline__ void poseidon_permute_pair_asm(PairState& st, const P
             pair_set(st.t2, i, gl_add_nc(pair_get(st.t2, i), rc0[4 + i]));
         }
     }
-    const uint32_t k3_lds = (uint32_t)(uintptr_t)&T->k3[0][half][0], k12_lds = (uint32_t)(uintptr_t)&T->k12[0][half][0],
+    const uint32_t k4_lds = (uint32_t)(uintptr_t)&T->k4[0][half][0], kf_lds = (uint32_t)(uintptr_t)&T->kf[0][half][0],
                    coef_lds = (uint32_t)(uintptr_t)&T->coef[half][0], rcb_lds = (uint32_t)(uintptr_t)&T->rcb[0][0][0] + lane * 4u;
-    constexpr uint32_t K3_TRIPLE = 2 * 6 * sizeof(RcPair), K12_TRIPLE = 2 * 2 * sizeof(RcPair), RCB_ROUND = 4 * 64 * 4;
+    constexpr uint32_t K4_FOUR = 2 * 6 * sizeof(RcPair), KF_FOUR = 2 * 3 * sizeof(RcPair), RCB_ROUND = 4 * 64 * 4;
 #pragma unroll 1
     for (uint32_t m = 0; m < 4; m++) pair_full_round_asm(st, rcb_lds + m * RCB_ROUND, Z, M, mask_lo);
 #pragma unroll 1
-    for (uint32_t t = 0; t < 7; t++) pair_triple_asm(st, k3_lds + t * K3_TRIPLE, k12_lds + t * K12_TRIPLE, coef_lds, Z, mask_lo);
-    pair_partial_round_asm(st, rcb_lds + 4 * RCB_ROUND, Z, M, mask_lo);
+    for (uint32_t t = 0; t < 5; t++) pair_four_asm(st, k4_lds + t * K4_FOUR, kf_lds + t * KF_FOUR, coef_lds, Z, mask_lo);
 #pragma unroll 1
-    for (uint32_t m = 5; m < 8; m++) pair_full_round_asm(st, rcb_lds + m * RCB_ROUND, Z, M, mask_lo);
-    if (CAP_ONLY) pair_last_round_asm(st, rcb_lds + 8 * RCB_ROUND, Z, M, mask_lo);
-    else pair_full_round_asm(st, rcb_lds + 8 * RCB_ROUND, Z, M, mask_lo);
+    for (uint32_t m = 4; m < 6; m++) pair_partial_round_asm(st, rcb_lds + m * RCB_ROUND, Z, M, mask_lo);
+#pragma unroll 1
+    for (uint32_t m = 6; m < 9; m++) pair_full_round_asm(st, rcb_lds + m * RCB_ROUND, Z, M, mask_lo);
+    if (CAP_ONLY) pair_last_round_asm(st, rcb_lds + 9 * RCB_ROUND, Z, M, mask_lo);
+    else pair_full_round_asm(st, rcb_lds + 9 * RCB_ROUND, Z, M, mask_lo);
 }
 
 }  // namespace starkhip

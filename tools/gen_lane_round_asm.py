@@ -119,7 +119,7 @@ def block_partial():
 
 def dot(prog, A, B, coef_off, seed_regs, key):
     """A / B = seed + sum_j coef[j] * halves of T[j]; coefficient row (12 words) from LDS at A_COEF + coef_off"""
-    cr = COEFR + 16 * (key[1] % 2) if key[0] == "row" else COEFR + 16 * key[1]
+    cr = COEFR + 16 * (key[1] % 2)
     for q in range(3):
         load(prog, cr + 4 * q, 4, A_COEF, coef_off + 16 * q, (key, q))
     if key[0] == "row":
@@ -156,6 +156,92 @@ def block_triple():
         madc(prog, A, YY + 4, ("v", cr + 13))
         madc(prog, B, YY + 5, ("v", cr + 13))
         fold_to(prog, O + 2 * r, A, B, r % 2)
+    for e in range(12):
+        prog.append(Ins("v_mov_b64 %s, %s" % (vp(T + 2 * e), vp(O + 2 * e)), [O + 2 * e, O + 2 * e + 1], [T + 2 * e, T + 2 * e + 1], sem=("mov64", T + 2 * e, O + 2 * e)))
+    return prog
+
+
+# ---------------------------------------------------------------- FOUR partial rounds at once
+# With M the MDS matrix, Mz = M with row 0 zeroed, N_k = M Mz^(k-1), u the state at the start of partial round r (constants added),
+# x1 = u0^7, ut = (x1, u1 .. u11), c1 .. c4 the constants of rounds r + 1 .. r + 4 (c?z: element 0 zeroed):
+#     y1  = (M ut)[0] + k1                                          x2 = y1^7      k1 = c1[0]
+#     y2  = (N2 ut)[0] + M[0][0] x2 + k2                             x3 = y2^7      k2 = (M c1z)[0] + c2[0]
+#     y3  = (N3 ut)[0] + N2[0][0] x2 + M[0][0] x3 + k3               x4 = y3^7      k3 = (N2 c1z)[0] + (M c2z)[0] + c3[0]
+#     out = N4 ut + N3[:,0] x2 + N2[:,0] x3 + M[:,0] x4 + k4                        k4 = N3 c1z + N2 c2z + M c3z + c4
+# N4's entries are below 2^29 and a row of it, with its three x-coefficients, sums to less than 0.83 * 2^32: the two accumulators of
+# an output (products with the 32-bit halves of the inputs) stay below 2^64 -- but no longer below 2^57, so their fold takes the
+# multiply-add's carry (fold_big).  Five merges would need 37-bit coefficients.  Per round 825 / 4 slots against 732 / 3.
+FC2 = [72, 74]    # scalar pairs: carry out of fold_big's first multiply-add
+N30_OFF = N20_OFF + 48     # LaneTables: n30[16] = row 0 of N3, then N2[0][0]
+KQ = S                     # the third scalar seed's registers (the S-box output area is idle in this block): v[104:107]
+
+
+def merged_tables4(c1, c2, c3, c4):
+    M = [[CIRC[(j - i) % 12] + (8 if i == 0 and j == 0 else 0) for j in range(12)] for i in range(12)]
+    Mz = [[0] * 12 if i == 0 else M[i][:] for i in range(12)]
+
+    def mm(a, b):
+        return [[sum(a[i][k] * b[k][j] for k in range(12)) for j in range(12)] for i in range(12)]
+
+    def mv(a, x):
+        return [sum(a[i][j] * x[j] for j in range(12)) % P for i in range(12)]
+    N2 = mm(M, Mz)
+    N3 = mm(N2, Mz)
+    N4 = mm(N3, Mz)
+    c1z, c2z, c3z = [0] + c1[1:], [0] + c2[1:], [0] + c3[1:]
+    k1 = c1[0]
+    k2 = (mv(M, c1z)[0] + c2[0]) % P
+    k3 = (mv(N2, c1z)[0] + mv(M, c2z)[0] + c3[0]) % P
+    a, b, c = mv(N3, c1z), mv(N2, c2z), mv(M, c3z)
+    k4 = [(a[i] + b[i] + c[i] + c4[i]) % P for i in range(12)]
+    for g in range(12):
+        assert (sum(N4[g]) + N3[g][0] + N2[g][0] + M[g][0]) * M32 + M32 < 1 << 64
+    return M, N2, N3, N4, k1, k2, k3, k4
+
+
+def fold_big(prog, dst, A, B, k):
+    """dst = A + B 2^32 mod p (some representative) for ANY 64-bit A and B: as fold_to, with the first multiply-add's carry folded in
+    before the second addition (then neither correction can overflow: after a carry the sum is below 2^64 - 2^32)."""
+    FT, CV, FC, C2 = FOLD + 4 * k, FOLD + 4 * k + 2, FCS[k], FC2[k]
+    prog.append(Ins("v_mad_u64_u32 %s, %s, %s, -1, %s" % (vp(FT), sp(C2), v(B + 1), vp(A)), [B + 1, A, A + 1], [FT, FT + 1], swrites=[C2], sem=("mad", FT, C2, B + 1, "eps", A)))
+    prog.append(Ins("v_addc_co_u32 %s, %s, 0, 0, %s" % (v(CV), sp(SINK), sp(C2)), [], [CV], sreads=[C2], sem=("addc", CV, None, None, None, C2)))
+    prog.append(Ins("v_mad_u64_u32 %s, %s, %s, -1, %s" % (vp(FT), sp(SINK), v(CV), vp(FT)), [CV, FT, FT + 1], [FT, FT + 1], sem=("mad", FT, None, CV, "eps", FT)))
+    prog.append(Ins("v_add_co_u32 %s, %s, %s, %s" % (v(FT + 1), sp(FC), v(FT + 1), v(B)), [FT + 1, B], [FT + 1], swrites=[FC], sem=("addco", FT + 1, FC, FT + 1, B)))
+    prog.append(Ins("v_addc_co_u32 %s, %s, 0, 0, %s" % (v(CV), sp(SINK), sp(FC)), [], [CV], sreads=[FC], sem=("addc", CV, None, None, None, FC)))
+    prog.append(Ins("v_mad_u64_u32 %s, %s, %s, -1, %s" % (vp(dst), sp(SINK), v(CV), vp(FT)), [CV, FT, FT + 1], [dst, dst + 1], sem=("mad", dst, None, CV, "eps", FT)))
+
+
+def block_four():
+    prog = []
+    sbox(prog, T, T, 0)                                       # x1 replaces element 0: T is ut
+    load(prog, SEEDR, 4, A_K12, 0, ("kf", 0))
+    load(prog, SEEDR + 4, 4, A_K12, 16, ("kf", 1))
+    load(prog, KQ, 4, A_K12, 32, ("kf", 2))
+    dot(prog, ACC, ACC + 2, M0_OFF, SEEDR, ("dot", 0))
+    fold_to(prog, YY, ACC, ACC + 2, 0)
+    sbox(prog, YY + 2, YY, 1)                                  # x2
+    dot(prog, ACC + 4, ACC + 6, N20_OFF, SEEDR + 4, ("dot", 1))
+    madc(prog, ACC + 4, YY + 2, 25)                            # M[0][0] x2
+    madc(prog, ACC + 6, YY + 3, 25)
+    fold_to(prog, YY, ACC + 4, ACC + 6, 1)
+    sbox(prog, YY + 4, YY, 0)                                  # x3
+    cr = dot(prog, ACC, ACC + 2, N30_OFF, KQ, ("dot", 2))
+    load(prog, cr + 12, 1, A_COEF, N30_OFF + 48, (("dot", 2), 3))
+    madc(prog, ACC, YY + 2, ("v", cr + 12))                    # N2[0][0] x2
+    madc(prog, ACC + 2, YY + 3, ("v", cr + 12))
+    madc(prog, ACC, YY + 4, 25)                                # M[0][0] x3
+    madc(prog, ACC + 2, YY + 5, 25)
+    fold_to(prog, YY, ACC, ACC + 2, 0)
+    sbox(prog, YY + 6, YY, 1)                                  # x4
+    for r in range(12):
+        sd = SEEDR + 8 + 4 * (r % 2)
+        load(prog, sd, 4, A_K3, 16 * r, ("k4", r))
+        A, B = ACC + 4 * (r % 2), ACC + 4 * (r % 2) + 2
+        cr = dot(prog, A, B, ROW_OFF + 64 * r, sd, ("row", r))
+        for q in range(3):                                     # N3[r][0] x2 + N2[r][0] x3 + M[r][0] x4
+            madc(prog, A, YY + 2 + 2 * q, ("v", cr + 12 + q))
+            madc(prog, B, YY + 3 + 2 * q, ("v", cr + 12 + q))
+        fold_big(prog, O + 2 * r, A, B, r % 2)
     for e in range(12):
         prog.append(Ins("v_mov_b64 %s, %s" % (vp(T + 2 * e), vp(O + 2 * e)), [O + 2 * e, O + 2 * e + 1], [T + 2 * e, T + 2 * e + 1], sem=("mov64", T + 2 * e, O + 2 * e)))
     return prog
@@ -561,6 +647,32 @@ def test_triple(order):
         assert get_state(vregs) == want
 
 
+def test_four(order):
+    for _ in range(30):
+        state = [rnd() for _ in range(12)]
+        c1, c2, c3, c4 = [[random.getrandbits(64) % P for _ in range(12)] for _ in range(4)]
+        M, N2, N3, N4, k1, k2, k3, k4 = merged_tables4(c1, c2, c3, c4)
+        want = state
+        for c in (c1, c2, c3, c4):
+            want = G.reference_round(want, c, True)
+        vregs = fresh()
+        set_state(vregs, state)
+        mem = vregs["mem"]
+        mem[("kf", 0)], mem[("kf", 1)], mem[("kf", 2)] = pair4(k1), pair4(k2), pair4(k3)
+        for r in range(12):
+            mem[("k4", r)] = pair4(k4[r])
+            row = [N4[r][j] for j in range(12)] + [N3[r][0], N2[r][0], M[r][0], 0]
+            for q in range(4):
+                mem[(("row", r), q)] = [[x] for x in row[4 * q:4 * q + 4]]
+        for q in range(3):
+            mem[(("dot", 0), q)] = [[M[0][j]] for j in range(4 * q, 4 * q + 4)]
+            mem[(("dot", 1), q)] = [[N2[0][j]] for j in range(4 * q, 4 * q + 4)]
+            mem[(("dot", 2), q)] = [[N3[0][j]] for j in range(4 * q, 4 * q + 4)]
+        mem[(("dot", 2), 3)] = [[N2[0][0]]]
+        G.run(order, vregs, {})
+        assert get_state(vregs) == want
+
+
 def emit(name, order, what):
     n_wait = sum(1 for o in order if o.text.startswith("s_waitcnt"))
     n_nop = sum(1 for o in order if o.text.startswith("s_nop"))
@@ -583,6 +695,7 @@ def main():
             ("STARKHIP_LANE_LAST_ROUND_ASM", block_full(8), lambda o: test_round(o, False, 8), "last full round before an absorb: the capacity outputs only"),
             ("STARKHIP_LANE_PARTIAL_ROUND_ASM", block_partial(), lambda o: test_round(o, True), "partial round"),
             ("STARKHIP_LANE_TRIPLE_ASM", block_triple(), test_triple, "three partial rounds at once (poseidon_merged.h)"),
+            ("STARKHIP_LANE_FOUR_ASM", block_four(), test_four, "four partial rounds at once"),
             ("STARKHIP_LANE_FULL_ROUND_MFMA_ASM", block_full_mfma(), lambda o: test_round_mfma(o, False), "full round, circulant layer on the matrix pipe"),
             ("STARKHIP_LANE_PARTIAL_ROUND_MFMA_ASM", block_partial_mfma(), lambda o: test_round_mfma(o, True), "partial round, circulant layer on the matrix pipe")):
         order = schedule(prog)
@@ -599,7 +712,7 @@ def main():
     print('#define STARKHIP_LANE_ZB "{v%d}"' % (AD[1] + 1))
     bound = set(range(T, T + 24)) | {AD[0] + 1, AD[1] + 1}
     vs = [r for r in range(S, 256) if r not in bound]
-    ss = list(range(SINK, FCS[1] + 2))
+    ss = list(range(SINK, FCS[1] + 2)) + list(range(FC2[0], FC2[1] + 2))
     print("#define STARKHIP_LANE_CLOBBERS %s" % ", ".join(['"v%d"' % r for r in vs] + ['"s%d"' % r for r in ss]))
     # the matrix-pipe blocks: weight tiles (dword 3 of each is loaded inside: in / out), the B tuples' constant dwords, the constant
     # table's address, the selectors and constants in scalar registers; the B tuples' other dwords are clobbered on top of the rest

@@ -128,13 +128,15 @@ def block_partial_pair():
 # ---------------------------------------------------------------- merged triple
 # LDS rows per lane half (the kernel gives the two halves different base addresses): dot rows of six coefficients (own elements),
 # dense rows of 16 dwords: [own six, partner six, b2, b3, 0, 0].
-def dot6(prog, A, B, coef_off, seed_regs, key):
-    cr = L.COEFR + 16 * key[1]
+def dot6(prog, A, B, coef_off, seed_regs, key, wide=False):
+    """A / B = seed + sum over the lane's own six elements; `wide`: eight dwords of the row are loaded (the caller uses dword 6)"""
+    cr = L.COEFR + 16 * (key[1] % 2)
     L.load(prog, cr, 4, L.A_COEF, coef_off, (key, 0))
-    L.load(prog, cr + 4, 2, L.A_COEF, coef_off + 16, (key, 1))
+    L.load(prog, cr + 4, 4 if wide else 2, L.A_COEF, coef_off + 16, (key, 1))
     for j in range(NE):
         L.madc(prog, A, T + 2 * j, ("v", cr + j), seed=seed_regs if j == 0 else None)
         L.madc(prog, B, T + 2 * j + 1, ("v", cr + j), seed=seed_regs + 2 if j == 0 else None)
+    return cr
 
 
 def pair_sums(prog, A, B, k):
@@ -189,6 +191,89 @@ def block_triple_pair():
     for e in range(NE):
         prog.append(Ins("v_mov_b64 %s, %s" % (vp(T + 2 * e), vp(O + 2 * e)), [O + 2 * e, O + 2 * e + 1], [T + 2 * e, T + 2 * e + 1], sem=("mov64", T + 2 * e, O + 2 * e)))
     return prog
+
+
+# ---------------------------------------------------------------- FOUR partial rounds at once (gen_lane_round_asm.py: block_four)
+# per lane half, 480 bytes: rows 0 of M, N2, N3 against the half's own six elements (8 dwords each; N2[0][0] in dword 6 of the third), then
+# per local output r (g = 6 half + r) sixteen dwords: N4[g][own six], N4[g][the partner's six, neighbours crossed], N3[g][0], N2[g][0], M[g][0], 0
+F_DOT0, F_DOT1, F_DOT2, F_ROW = 0, 32, 64, 96
+KQ = S + 4          # the third scalar seed: v[108:111] (x1 is in v[104:105], the rest of the S-box output area is idle here)
+
+
+def block_four_pair():
+    prog = []
+    L.sbox(prog, S, T, 0)                                      # x1 (meaningful in the lower lane)
+    for h in (0, 1):
+        G.cndmask(prog, T + h, T + h, S + h, MASK_LO)        # T is ut now
+    L.load(prog, L.SEEDR, 4, L.A_K12, 0, ("kf", 0))           # k1, k2, k3: in the lower half's table, zero in the upper half's
+    L.load(prog, L.SEEDR + 4, 4, L.A_K12, 16, ("kf", 1))
+    L.load(prog, KQ, 4, L.A_K12, 32, ("kf", 2))
+    dot6(prog, L.ACC, L.ACC + 2, F_DOT0, L.SEEDR, ("dot", 0))
+    pair_sums(prog, L.ACC, L.ACC + 2, 0)
+    L.fold_to(prog, L.YY, L.ACC, L.ACC + 2, 0)
+    L.sbox(prog, L.YY + 2, L.YY, 1)                            # x2, in both lanes
+    dot6(prog, L.ACC + 4, L.ACC + 6, F_DOT1, L.SEEDR + 4, ("dot", 1))
+    pair_sums(prog, L.ACC + 4, L.ACC + 6, 1)
+    L.madc(prog, L.ACC + 4, L.YY + 2, 25)
+    L.madc(prog, L.ACC + 6, L.YY + 3, 25)
+    L.fold_to(prog, L.YY, L.ACC + 4, L.ACC + 6, 1)
+    L.sbox(prog, L.YY + 4, L.YY, 0)                            # x3
+    cr = dot6(prog, L.ACC, L.ACC + 2, F_DOT2, KQ, ("dot", 2), wide=True)
+    pair_sums(prog, L.ACC, L.ACC + 2, 0)
+    L.madc(prog, L.ACC, L.YY + 2, ("v", cr + 6))               # N2[0][0] x2
+    L.madc(prog, L.ACC + 2, L.YY + 3, ("v", cr + 6))
+    L.madc(prog, L.ACC, L.YY + 4, 25)                          # M[0][0] x3
+    L.madc(prog, L.ACC + 2, L.YY + 5, 25)
+    L.fold_to(prog, L.YY, L.ACC, L.ACC + 2, 0)
+    L.sbox(prog, L.YY + 6, L.YY, 1)                            # x4
+    for e in range(0, NE, 2):                                  # the partner's six elements: PT + 2 e = its element e ^ 1
+        partners(prog, PT + 2 * e, PT + 2 * e + 2, T + 2 * e, T + 2 * e + 2)
+    for r in range(NE):
+        sd = L.SEEDR + 8 + 4 * (r % 2)
+        L.load(prog, sd, 4, L.A_K3, 16 * r, ("k4", r))
+        A, B = L.ACC + 4 * (r % 2), L.ACC + 4 * (r % 2) + 2
+        cr = L.COEFR + 16 * (r % 2)
+        for q in range(4):
+            L.load(prog, cr + 4 * q, 4, L.A_COEF, F_ROW + 64 * r + 16 * q, (("row", r), q))
+        for j in range(12):
+            src = T + 2 * j if j < NE else PT + 2 * ((j - NE) ^ 1)
+            L.madc(prog, A, src, ("v", cr + j), seed=sd if j == 0 else None)
+            L.madc(prog, B, src + 1, ("v", cr + j), seed=sd + 2 if j == 0 else None)
+        for q in range(3):                                     # N3[g][0] x2 + N2[g][0] x3 + M[g][0] x4
+            L.madc(prog, A, L.YY + 2 + 2 * q, ("v", cr + 12 + q))
+            L.madc(prog, B, L.YY + 3 + 2 * q, ("v", cr + 12 + q))
+        L.fold_big(prog, O + 2 * r, A, B, r % 2)
+    for e in range(NE):
+        prog.append(Ins("v_mov_b64 %s, %s" % (vp(T + 2 * e), vp(O + 2 * e)), [O + 2 * e, O + 2 * e + 1], [T + 2 * e, T + 2 * e + 1], sem=("mov64", T + 2 * e, O + 2 * e)))
+    return prog
+
+
+def test_four_pair(order):
+    for _ in range(30):
+        state = [L.rnd() for _ in range(12)]
+        c1, c2, c3, c4 = [[random.getrandbits(64) % P for _ in range(12)] for _ in range(4)]
+        M, N2, N3, N4, k1, k2, k3, k4 = L.merged_tables4(c1, c2, c3, c4)
+        want = state
+        for c in (c1, c2, c3, c4):
+            want = G.reference_round(want, c, True)
+        vregs = fresh()
+        set_state(vregs, state)
+        mem = vregs["mem"]
+        mem[("kf", 0)], mem[("kf", 1)], mem[("kf", 2)] = pair4(k1, 0), pair4(k2, 0), pair4(k3, 0)
+        for r in range(NE):
+            mem[("k4", r)] = pair4(k4[r], k4[NE + r])
+            rows = []
+            for l in range(2):
+                g = NE * l + r
+                rows.append([N4[g][(NE * l + j) % 12] for j in range(12)] + [N3[g][0], N2[g][0], M[g][0], 0])
+            for q in range(4):
+                mem[(("row", r), q)] = [[rows[0][4 * q + i], rows[1][4 * q + i]] for i in range(4)]
+        for d, row, extra in ((0, M[0], 0), (1, N2[0], 0), (2, N3[0], N2[0][0])):
+            co = [[row[e], row[NE + e]] for e in range(NE)] + [[extra, extra], [0, 0]]
+            mem[(("dot", d), 0)] = co[0:4]
+            mem[(("dot", d), 1)] = co[4:8] if d == 2 else co[4:6]
+        run_pair(order, vregs, {MASK_LO: [1, 0]})
+        assert get_state(vregs) == want
 
 
 # ---------------------------------------------------------------- scheduling: the lane generator's, plus the swap's two wait states
@@ -357,10 +442,10 @@ def main():
     blocks = (("STARKHIP_PAIR_FULL_ROUND_ASM", block_full_pair(), lambda o: test_round_pair(o, False), "full round: six S-boxes per lane, circulant layer on the matrix pipe"),
               ("STARKHIP_PAIR_LAST_ROUND_ASM", block_full_pair(2), lambda o: test_round_pair(o, False, 2), "last full round before an absorb: the lane's outputs 2 .. 5 only (the capacity is the upper lane's)"),
               ("STARKHIP_PAIR_PARTIAL_ROUND_ASM", block_partial_pair(), lambda o: test_round_pair(o, True), "partial round"),
-              ("STARKHIP_PAIR_TRIPLE_ASM", block_triple_pair(), test_triple_pair, "three partial rounds at once (poseidon_merged.h)"))
+              ("STARKHIP_PAIR_FOUR_ASM", block_four_pair(), test_four_pair, "four partial rounds at once (poseidon_merged.h)"))
     done, slots = [], {}
     for name, prog, tester, what in blocks:
-        L.LOAD_LATENCY = TRIPLE_LOAD_LATENCY if name == "STARKHIP_PAIR_TRIPLE_ASM" else ROUND_LOAD_LATENCY
+        L.LOAD_LATENCY = TRIPLE_LOAD_LATENCY if name == "STARKHIP_PAIR_FOUR_ASM" else ROUND_LOAD_LATENCY
         order = schedule_pair(prog)
         L.check_hazards(order)
         check_swaps(order)
@@ -368,12 +453,12 @@ def main():
             tester(order)
         done.append((name, order, what))
         slots[name] = len(order)
-    per_wave = 7 * slots["STARKHIP_PAIR_FULL_ROUND_ASM"] + slots["STARKHIP_PAIR_LAST_ROUND_ASM"] + 7 * slots["STARKHIP_PAIR_TRIPLE_ASM"] + slots["STARKHIP_PAIR_PARTIAL_ROUND_ASM"]
+    per_wave = 7 * slots["STARKHIP_PAIR_FULL_ROUND_ASM"] + slots["STARKHIP_PAIR_LAST_ROUND_ASM"] + 5 * slots["STARKHIP_PAIR_FOUR_ASM"] + 2 * slots["STARKHIP_PAIR_PARTIAL_ROUND_ASM"]
     print("// generated by tools/gen_pair_round_asm.py -- do not edit.  The PAIR form: lanes l and l + 32 share a permutation (elements 0 .. 5 / 6 .. 11).")
     print("// Physical registers: state v[%d:%d] (in and out), LDS addresses v%d (k3) v%d (k12) v%d (coefficient rows) v%d (the matrix-pipe rounds' constants)," % (T, T + 11, L.A_K3, L.A_K12, L.A_COEF, L.A_RCB))
     print("// zeros v%d v%d, s[%d:%d] = the lower half-wave's lane mask; v%d .. v255 and s%d .. s%d are clobbered." % (L.AD[0] + 1, L.AD[1] + 1, MASK_LO, MASK_LO + 1, 92, L.SINK, L.FCS[1] + 1))
-    print("// Per wave and 32 permutations: 7 x %d + %d + 7 x %d + %d = %d issue slots = %.1f per permutation (quad form: 271.6, lane form: 183.7)." %
-          (slots["STARKHIP_PAIR_FULL_ROUND_ASM"], slots["STARKHIP_PAIR_LAST_ROUND_ASM"], slots["STARKHIP_PAIR_TRIPLE_ASM"], slots["STARKHIP_PAIR_PARTIAL_ROUND_ASM"], per_wave, per_wave / 32.0))
+    print("// Per wave and 32 permutations: 7 x %d + %d + 5 x %d + 2 x %d = %d issue slots = %.1f per permutation (quad form: 271.6, lane form: 177.1)." %
+          (slots["STARKHIP_PAIR_FULL_ROUND_ASM"], slots["STARKHIP_PAIR_LAST_ROUND_ASM"], slots["STARKHIP_PAIR_FOUR_ASM"], slots["STARKHIP_PAIR_PARTIAL_ROUND_ASM"], per_wave, per_wave / 32.0))
     for name, order, what in done:
         L.emit(name, order, what)
     for i in range(3):
@@ -387,7 +472,7 @@ def main():
     print('#define STARKHIP_PAIR_MASK_LO "{s[%d:%d]}"' % (MASK_LO, MASK_LO + 1))
     bound = set(range(T, T + 12)) | {L.AD[0] + 1, L.AD[1] + 1}
     vs = [r for r in range(T + 12, 256) if r not in bound]
-    ss = list(range(L.SINK, L.FCS[1] + 2))
+    ss = list(range(L.SINK, L.FCS[1] + 2)) + list(range(L.FC2[0], L.FC2[1] + 2))
     print("#define STARKHIP_PAIR_CLOBBERS %s" % ", ".join(['"v%d"' % r for r in vs] + ['"s%d"' % r for r in ss]))
     # the matrix-pipe blocks: weight tile (dword 3 is loaded inside: in / out), the B tuples' constant dwords (their other dwords: clobbered)
     for k in range(2):
