@@ -109,6 +109,7 @@ static std::atomic<unsigned long> g_fake_launches(0), g_fake_merged(0);
 hipError_t launch_leaf_hash(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t) { g_fake_launches++; return hipSuccess; }
 hipError_t launch_leaf_hash_row(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t) { g_fake_launches++; return hipSuccess; }
 hipError_t launch_leaf_hash_lane(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t) { g_fake_launches++; return hipSuccess; }
+hipError_t launch_leaf_hash_pair(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t) { g_fake_launches++; return hipSuccess; }
 hipError_t launch_leaf_hash_multi(const LeafHashBatch&, unsigned count, size_t, unsigned, unsigned, hipStream_t) {
     g_fake_launches++;
     g_fake_merged += count;

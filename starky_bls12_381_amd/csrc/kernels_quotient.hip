@@ -470,7 +470,6 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
         r.a = q[0];
         r.b = q[1];
     };
-    auto ring_read_ctl = [&](uint32_t base, unsigned i) -> uint32_t { return *(const uint32_t*)((const char*)ring + base + i * 32u); };
     uint64_t pc_addr = (uint64_t)(P.pieces + stream.piece_off);
     asm volatile("" : "+v"(pc_addr));  // formally divergent: the descriptor is fetched with a vector load (VM counter)
 
