@@ -455,10 +455,10 @@ __global__ __launch_bounds__(256, 2) void leaf_hash_lane_kernel(const gl_t* __re
         for (int e = 0; e < 4; e++) digests[4 * j + e] = gl_canon(lane_get(st.t0, e));
     }
 }
-static void build_lane_tables(LaneTables& T) {
+static bool build_lane_tables(LaneTables& T) {
     static PoseidonMergedFours P;
     build_poseidon_merged_fours(P);
-    if (!P.sums_fit) abort();   // (a property of the MDS matrix, checked where the tables are made: the accumulators' 64 bits)
+    if (!P.sums_fit) return false;   // (a property of the MDS matrix, checked where the tables are made: the accumulators' 64 bits)
     auto split = [](gl_t v) { return RcPair{v & 0xFFFFFFFFull, v >> 32}; };
     memset(&T, 0, sizeof T);
     for (int r = 0; r < 30; r++)
@@ -501,6 +501,7 @@ static void build_lane_tables(LaneTables& T) {
                 T.rcb[m][b][lane] = live ? ((byte & 0x7Fu) | ((2u * (byte >> 7) + 40u) << 8) | (127u << 16) | (127u << 24)) : 0u;
             }
         }
+    return true;
 }
 static hipError_t ensure_lane_tables() {
     static std::mutex mu;
@@ -514,7 +515,7 @@ static hipError_t ensure_lane_tables() {
     static LaneTables T;
     static bool built = false;
     if (!built) {
-        build_lane_tables(T);
+        if (!build_lane_tables(T)) return hipErrorInvalidValue;
         built = true;
     }
     e = hipMemcpyToSymbol(HIP_SYMBOL(LANE_TABLES), &T, sizeof T);
@@ -614,10 +615,10 @@ __global__ __launch_bounds__(256, 2) void leaf_hash_pair_kernel(const gl_t* __re
         digests[4 * j + 3] = gl_canon(pair_get(st.t1, 1));
     }
 }
-static void build_pair_tables(PairTables& T) {
+static bool build_pair_tables(PairTables& T) {
     static PoseidonMergedFours P;
     build_poseidon_merged_fours(P);
-    if (!P.sums_fit) abort();
+    if (!P.sums_fit) return false;
     auto split = [](gl_t v) { return RcPair{v & 0xFFFFFFFFull, v >> 32}; };
     memset(&T, 0, sizeof T);
     for (unsigned h = 0; h < 2; h++) {
@@ -663,6 +664,7 @@ static void build_pair_tables(PairTables& T) {
                 T.rcb[m][qq][lane] = (byte & 0x7Fu) | ((2u * (byte >> 7) + 40u) << 8) | (127u << 16) | (127u << 24);
             }
         }
+    return true;
 }
 static hipError_t ensure_pair_tables() {
     static std::mutex mu;
@@ -676,7 +678,7 @@ static hipError_t ensure_pair_tables() {
     static PairTables T;
     static bool built = false;
     if (!built) {
-        build_pair_tables(T);
+        if (!build_pair_tables(T)) return hipErrorInvalidValue;
         built = true;
     }
     e = hipMemcpyToSymbol(HIP_SYMBOL(PAIR_TABLES), &T, sizeof T);

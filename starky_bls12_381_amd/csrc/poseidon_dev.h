@@ -741,7 +741,7 @@ __device__ __forceinline__ void poseidon_permute_lane_asm(LaneState& st, const L
         // for the NEXT permutation's columns, requested from HBM a moment ago)
         uint32_t rc0_lds = (uint32_t)(uintptr_t)&T->rc0[0];
         asm volatile("" : "+v"(rc0_lds));
-        const lds_gl_ptr rc0 = (lds_gl_ptr)rc0_lds;
+        const lds_gl_ptr rc0 = (lds_gl_ptr)(uintptr_t)rc0_lds;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             lane_set(st.t0, i, gl_add_nc(lane_get(st.t0, i), rc0[i]));
@@ -882,7 +882,7 @@ __device__ __forceinline__ void poseidon_permute_pair_asm(PairState& st, const P
     {
         uint32_t rc0_lds = (uint32_t)(uintptr_t)&T->rc0[half][0];   // (an LDS pointer: see poseidon_permute_lane_asm)
         asm volatile("" : "+v"(rc0_lds));
-        const lds_gl_ptr rc0 = (lds_gl_ptr)rc0_lds;
+        const lds_gl_ptr rc0 = (lds_gl_ptr)(uintptr_t)rc0_lds;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             pair_set(st.t0, i, gl_add_nc(pair_get(st.t0, i), rc0[i]));

@@ -103,7 +103,7 @@ inline void build_poseidon_merged_fours(PoseidonMergedFours& T) {
     for (int g = 0; g < 12; g++) {
         unsigned __int128 tot = T.N3[g][0] + T.N2[g][0] + T.M[g][0];
         for (int j = 0; j < 12; j++) tot += T.N4[g][j];
-        if (tot * 0xFFFFFFFFull + 0xFFFFFFFFull >> 64) T.sums_fit = false;
+        if ((tot * 0xFFFFFFFFull + 0xFFFFFFFFull) >> 64) T.sums_fit = false;
     }
     auto matvec_mod = [](const uint64_t (&a)[12][12], const gl_t* v, gl_t* o) {
         for (int i = 0; i < 12; i++) {

@@ -133,34 +133,6 @@ def dot(prog, A, B, coef_off, seed_regs, key):
 ROW_OFF, M0_OFF, N20_OFF = 0, 12 * 64, 12 * 64 + 48   # LaneTables: row[12][16], m0[12], n20[12] contiguous
 
 
-def block_triple():
-    prog = []
-    sbox(prog, T, T, 0)                                       # x1 replaces element 0: T is u'
-    load(prog, SEEDR, 4, A_K12, 0, ("k12", 0))
-    load(prog, SEEDR + 4, 4, A_K12, 16, ("k12", 1))
-    dot(prog, ACC, ACC + 2, M0_OFF, SEEDR, ("dot", 0))
-    fold_to(prog, YY, ACC, ACC + 2, 0)
-    sbox(prog, YY + 2, YY, 1)                                  # x2
-    dot(prog, ACC + 4, ACC + 6, N20_OFF, SEEDR + 4, ("dot", 1))
-    madc(prog, ACC + 4, YY + 2, 25)
-    madc(prog, ACC + 6, YY + 3, 25)
-    fold_to(prog, YY, ACC + 4, ACC + 6, 1)
-    sbox(prog, YY + 4, YY, 0)                                  # x3
-    for r in range(12):
-        sd = SEEDR + 8 + 4 * (r % 2)
-        load(prog, sd, 4, A_K3, 16 * r, ("k3", r))
-        A, B = ACC + 4 * (r % 2), ACC + 4 * (r % 2) + 2
-        cr = dot(prog, A, B, ROW_OFF + 64 * r, sd, ("row", r))
-        madc(prog, A, YY + 2, ("v", cr + 12))
-        madc(prog, B, YY + 3, ("v", cr + 12))
-        madc(prog, A, YY + 4, ("v", cr + 13))
-        madc(prog, B, YY + 5, ("v", cr + 13))
-        fold_to(prog, O + 2 * r, A, B, r % 2)
-    for e in range(12):
-        prog.append(Ins("v_mov_b64 %s, %s" % (vp(T + 2 * e), vp(O + 2 * e)), [O + 2 * e, O + 2 * e + 1], [T + 2 * e, T + 2 * e + 1], sem=("mov64", T + 2 * e, O + 2 * e)))
-    return prog
-
-
 # ---------------------------------------------------------------- FOUR partial rounds at once
 # With M the MDS matrix, Mz = M with row 0 zeroed, N_k = M Mz^(k-1), u the state at the start of partial round r (constants added),
 # x1 = u0^7, ut = (x1, u1 .. u11), c1 .. c4 the constants of rounds r + 1 .. r + 4 (c?z: element 0 zeroed):
@@ -623,30 +595,6 @@ def test_round(order, partial, first_out=0):
             assert got[e] == want[e], (partial, e)
 
 
-def test_triple(order):
-    for _ in range(30):
-        state = [rnd() for _ in range(12)]
-        c1, c2, c3 = [[random.getrandbits(64) % P for _ in range(12)] for _ in range(3)]
-        M, N2, N3, k1, k2, k3 = G.merged_tables(c1, c2, c3)
-        want = state
-        for c in (c1, c2, c3):
-            want = G.reference_round(want, c, True)
-        vregs = fresh()
-        set_state(vregs, state)
-        mem = vregs["mem"]
-        mem[("k12", 0)], mem[("k12", 1)] = pair4(k1), pair4(k2)
-        for r in range(12):
-            mem[("k3", r)] = pair4(k3[r])
-            row = [N3[r][j] for j in range(12)] + [N2[r][0], M[r][0], 0, 0]
-            for q in range(4):
-                mem[(("row", r), q)] = [[x] for x in row[4 * q:4 * q + 4]]
-        for q in range(3):
-            mem[(("dot", 0), q)] = [[M[0][j]] for j in range(4 * q, 4 * q + 4)]
-            mem[(("dot", 1), q)] = [[N2[0][j]] for j in range(4 * q, 4 * q + 4)]
-        G.run(order, vregs, {})
-        assert get_state(vregs) == want
-
-
 def test_four(order):
     for _ in range(30):
         state = [rnd() for _ in range(12)]
@@ -694,7 +642,6 @@ def main():
             ("STARKHIP_LANE_FULL_ROUND_ASM", block_full(), lambda o: test_round(o, False), "full round: twelve S-boxes, circulant layer"),
             ("STARKHIP_LANE_LAST_ROUND_ASM", block_full(8), lambda o: test_round(o, False, 8), "last full round before an absorb: the capacity outputs only"),
             ("STARKHIP_LANE_PARTIAL_ROUND_ASM", block_partial(), lambda o: test_round(o, True), "partial round"),
-            ("STARKHIP_LANE_TRIPLE_ASM", block_triple(), test_triple, "three partial rounds at once (poseidon_merged.h)"),
             ("STARKHIP_LANE_FOUR_ASM", block_four(), test_four, "four partial rounds at once"),
             ("STARKHIP_LANE_FULL_ROUND_MFMA_ASM", block_full_mfma(), lambda o: test_round_mfma(o, False), "full round, circulant layer on the matrix pipe"),
             ("STARKHIP_LANE_PARTIAL_ROUND_MFMA_ASM", block_partial_mfma(), lambda o: test_round_mfma(o, True), "partial round, circulant layer on the matrix pipe")):

@@ -1,20 +1,20 @@
 #!/usr/bin/env python3
-"""The PAIR form of the Poseidon permutation, costed: lanes l and l + 32 of a wave share one permutation (lane l holds state elements
-0 .. 5, lane l + 32 elements 6 .. 11), one 256-register wave per SIMD -- the form a LONE FinalExp-class commitment would take instead
-of the quad form.  This script builds the rounds with the instruction model, list scheduler and interpreter of
-tools/gen_lane_round_asm.py / gen_row_round_asm.py, checks them on two lanes against the rounds in Python integers, and prints the
-issue slots per permutation -- the number the decision to build the kernel rests on.  It emits no include file: nothing in the
-product uses this form (yet).
+"""Generates csrc/pair_round_asm.inc: the rounds of the PAIR form of the Poseidon permutation -- lanes l and l + 32 of a wave share one
+permutation (lane l holds state elements 0 .. 5, lane l + 32 elements 6 .. 11), one 256-register wave per SIMD: what a LONE commitment of
+>= 32 768 leaves takes (poseidon_dev.h, kernels_hash.hip: leaf_hash_pair_kernel).  Built with the instruction
+model, list scheduler and interpreter of tools/gen_lane_round_asm.py / gen_row_round_asm.py; every block is executed on two lanes
+against the rounds in Python integers before it is printed.
 
   full round      six S-boxes per lane; the circulant layer on the matrix pipe as in the lane form, but with a DENSE weight tile: the
                   two lane halves supply the two K halves of v_mfma_i32_32x32x32_i8 (elements 0 .. 5 and 6 .. 11 of the same column),
-                  and the result rows are chosen so that outputs 0 .. 5 land in the lower half-wave and 6 .. 11 in the upper one
-  merged triple   three partial rounds at once (poseidon_merged.h): the two dot products are partial sums over a lane's own six
+                  TWO byte planes per instruction, and the result rows chosen so that outputs 0 .. 5 land in the lower half-wave and
+                  6 .. 11 in the upper one
+  merged four     four partial rounds at once (poseidon_merged.h): the three dot products are partial sums over a lane's own six
                   elements added across the pair with v_permlane32_swap_b32; the dense 12 x 12 layer needs the partner's six elements
                   (12 swaps) and computes six outputs per lane
-  partial round   the lone one: S-box on element 0 (lower half only), layer on the matrix pipe
+  partial round   the two plain ones: S-box on element 0 (lower half only), layer on the matrix pipe
 
-    python tools/gen_pair_round_asm.py
+    python tools/gen_pair_round_asm.py > starky_bls12_381_amd/csrc/pair_round_asm.inc
 """
 import os
 import random
@@ -29,13 +29,13 @@ P, M32, M64 = G.P, G.M32, G.M64
 ABLATE = os.environ.get("PAIR_ABLATE", "")         # timing experiments only (wrong results): "seeds", "rows"
 # slots between an LDS load and its first use that the scheduler aims for (a wave alone on its SIMD has nobody to hide a longer wait)
 ROUND_LOAD_LATENCY = int(os.environ.get("PAIR_LOAD_LATENCY", 16))
-TRIPLE_LOAD_LATENCY = int(os.environ.get("PAIR_TRIPLE_LOAD_LATENCY", os.environ.get("PAIR_LOAD_LATENCY", 56)))   # measured: 16 -> 123.9 ms, 28 -> 122.0, 56 -> 121.6
+TRIPLE_LOAD_LATENCY = int(os.environ.get("PAIR_TRIPLE_LOAD_LATENCY", os.environ.get("PAIR_LOAD_LATENCY", 56)))   # the merged rounds; measured with triples: 16 -> 123.9 ms, 28 -> 122.0, 56 -> 121.6
 L.VALU_RAW = int(os.environ.get("PAIR_VALU_RAW", L.VALU_RAW))
 L.SGPR_RAW = int(os.environ.get("PAIR_SGPR_RAW", L.SGPR_RAW))
 G.NL = 2   # lane 0 = lower half-wave (elements 0 .. 5), lane 1 = upper half-wave (elements 6 .. 11)
 
 T, S = L.T, L.S                  # state: six pairs v[80:91]; S-box outputs / hi halves: six pairs v[104:115]
-PT = 116                         # the partner's six elements (pairs v[116:127]) -- merged triple
+PT = 116                         # the partner's six elements (pairs v[116:127]) -- merged fours
 O = L.O                          # dense layer outputs: six pairs v[176:187]
 TMP = 188                        # copies for the swaps (four pairs)
 MASK_LO = 70                     # SGPR pair in: lanes 0 .. 31
@@ -125,9 +125,9 @@ def block_partial_pair():
     return prog
 
 
-# ---------------------------------------------------------------- merged triple
-# LDS rows per lane half (the kernel gives the two halves different base addresses): dot rows of six coefficients (own elements),
-# dense rows of 16 dwords: [own six, partner six, b2, b3, 0, 0].
+# ---------------------------------------------------------------- pieces of the merged partial rounds
+# LDS rows per lane half (the kernel gives the two halves different base addresses): dot rows of the half's own six elements, dense rows
+# of 16 dwords (own six, partner's six, the x-coefficients)
 def dot6(prog, A, B, coef_off, seed_regs, key, wide=False):
     """A / B = seed + sum over the lane's own six elements; `wide`: eight dwords of the row are loaded (the caller uses dword 6)"""
     cr = L.COEFR + 16 * (key[1] % 2)
@@ -145,52 +145,6 @@ def pair_sums(prog, A, B, k):
     partners(prog, ca, cb, A, B)       # ca = partner's B, cb = partner's A
     G.add64(prog, A, A, cb)
     G.add64(prog, B, B, ca)
-
-
-DOT_OFF0, DOT_OFF1, ROW_OFF = 0, 32, 64     # bytes in the half's coefficient table
-
-
-def block_triple_pair():
-    prog = []
-    L.sbox(prog, S, T, 0)                                      # x1 (meaningful in the lower lane)
-    for h in (0, 1):
-        G.cndmask(prog, T + h, T + h, S + h, MASK_LO)        # T is u' now
-    L.load(prog, L.SEEDR, 4, L.A_K12, 0, ("k12", 0))          # k1 (lower half; zero in the upper half's table)
-    L.load(prog, L.SEEDR + 4, 4, L.A_K12, 16, ("k12", 1))
-    dot6(prog, L.ACC, L.ACC + 2, DOT_OFF0, L.SEEDR, ("dot", 0))
-    pair_sums(prog, L.ACC, L.ACC + 2, 0)
-    L.fold_to(prog, L.YY, L.ACC, L.ACC + 2, 0)
-    L.sbox(prog, L.YY + 2, L.YY, 1)                            # x2, in both lanes
-    dot6(prog, L.ACC + 4, L.ACC + 6, DOT_OFF1, L.SEEDR + 4, ("dot", 1))
-    pair_sums(prog, L.ACC + 4, L.ACC + 6, 1)
-    L.madc(prog, L.ACC + 4, L.YY + 2, 25)
-    L.madc(prog, L.ACC + 6, L.YY + 3, 25)
-    L.fold_to(prog, L.YY, L.ACC + 4, L.ACC + 6, 1)
-    L.sbox(prog, L.YY + 4, L.YY, 0)                            # x3
-    # the partner's six elements, neighbours crossed (partners()): PT + 2 e = the partner's element e ^ 1
-    for e in range(0, NE, 2):
-        partners(prog, PT + 2 * e, PT + 2 * e + 2, T + 2 * e, T + 2 * e + 2)
-    for r in range(NE):
-        sd = L.SEEDR + 8 + 4 * (r % 2)
-        if ABLATE != "seeds" or r == 0:
-            L.load(prog, sd, 4, L.A_K3, 16 * r, ("k3", r))
-        A, B = L.ACC + 4 * (r % 2), L.ACC + 4 * (r % 2) + 2
-        cr = L.COEFR + 16 * (r % 2)
-        for q in range(4):
-            if ABLATE != "rows" or r < 2:
-                L.load(prog, cr + 4 * q, 4, L.A_COEF, ROW_OFF + 64 * r + 16 * q, (("row", r), q))
-        for j in range(12):   # the row's columns in the LANE's order: its own six elements, then the partner's
-            src = T + 2 * j if j < NE else PT + 2 * ((j - NE) ^ 1)
-            L.madc(prog, A, src, ("v", cr + j), seed=sd if j == 0 else None)
-            L.madc(prog, B, src + 1, ("v", cr + j), seed=sd + 2 if j == 0 else None)
-        L.madc(prog, A, L.YY + 2, ("v", cr + 12))
-        L.madc(prog, B, L.YY + 3, ("v", cr + 12))
-        L.madc(prog, A, L.YY + 4, ("v", cr + 13))
-        L.madc(prog, B, L.YY + 5, ("v", cr + 13))
-        L.fold_to(prog, O + 2 * r, A, B, r % 2)
-    for e in range(NE):
-        prog.append(Ins("v_mov_b64 %s, %s" % (vp(T + 2 * e), vp(O + 2 * e)), [O + 2 * e, O + 2 * e + 1], [T + 2 * e, T + 2 * e + 1], sem=("mov64", T + 2 * e, O + 2 * e)))
-    return prog
 
 
 # ---------------------------------------------------------------- FOUR partial rounds at once (gen_lane_round_asm.py: block_four)
@@ -399,34 +353,6 @@ def test_round_pair(order, partial, first_out=0):
 def pair4(lo_val, hi_val):
     """a 64-bit constant as two 64-bit addends (low half, 0, high half, 0), per lane"""
     return [[lo_val & M32, hi_val & M32], [0, 0], [lo_val >> 32, hi_val >> 32], [0, 0]]
-
-
-def test_triple_pair(order):
-    for _ in range(30):
-        state = [L.rnd() for _ in range(12)]
-        c1, c2, c3 = [[random.getrandbits(64) % P for _ in range(12)] for _ in range(3)]
-        M, N2, N3, k1, k2, k3 = G.merged_tables(c1, c2, c3)
-        want = state
-        for c in (c1, c2, c3):
-            want = G.reference_round(want, c, True)
-        vregs = fresh()
-        set_state(vregs, state)
-        mem = vregs["mem"]
-        mem[("k12", 0)], mem[("k12", 1)] = pair4(k1, 0), pair4(k2, 0)     # the constants enter once: through the lower half
-        for r in range(NE):
-            mem[("k3", r)] = pair4(k3[r], k3[NE + r])
-            rows = []
-            for l in range(2):
-                g = NE * l + r
-                rows.append([N3[g][(NE * l + j) % 12] for j in range(12)] + [N2[g][0], M[g][0], 0, 0])
-            for q in range(4):
-                mem[(("row", r), q)] = [[rows[0][4 * q + i], rows[1][4 * q + i]] for i in range(4)]
-        for d, row in ((0, M[0]), (1, N2[0])):
-            co = [[row[e], row[NE + e]] for e in range(NE)]
-            mem[(("dot", d), 0)] = co[0:4]
-            mem[(("dot", d), 1)] = co[4:6]
-        run_pair(order, vregs, {MASK_LO: [1, 0]})
-        assert get_state(vregs) == want
 
 
 def check_swaps(order):
