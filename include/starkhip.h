@@ -366,8 +366,9 @@ int starkhip_trace_log_expand_device(void* ctx, const void* log, uint64_t* trace
 /* device field arithmetic under test: out[i] = canonical(op(a[i], b[i])) with the lazy-reduction helpers the kernels use
  * (op codes: starky_bls12_381_amd/csrc/kernels_selftest.hip); lets the tests feed boundary operands */
 int starkhip_field_ops_batch(void* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
-/* CPU check (no GPU needed) of the constant tables the leaf-hash kernel uses for its merged partial rounds: replays the
- * merged formulation on n_states inputs against the plain permutation; returns the number of mismatches (0 = good) */
+/* CPU check (no GPU needed) of the constant tables the leaf-hash kernels use for their merged partial rounds -- three at a time in the
+ * quad form, four at a time in the lane and pair forms: replays both formulations on n_states inputs against the plain permutation;
+ * returns the number of mismatches (0 = good), -1 if a sum of the four-round merge would not fit its 64-bit accumulator */
 int starkhip_selfcheck_hash_tables(unsigned n_states);
 /* The launch plan of a trace's LDE (no GPU needed).  The trace columns wait for the LDE inside the buffer the LDE is written to, as
  * its last n_cols * n words, so the LDE goes out in several launches, each overwriting only parked columns that an earlier launch

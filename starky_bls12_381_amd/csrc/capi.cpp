@@ -547,7 +547,11 @@ int starkhip_field_ops_batch(void* ctx, int op, const uint64_t* a, const uint64_
     if (!ctx) return STARKHIP_ERR_NO_DEVICE;
     return field_ops((Ctx*)ctx, op, a, b, out, n);
 }
-int starkhip_selfcheck_hash_tables(unsigned n_states) { return quad_merged_tables_selfcheck(n_states); }
+int starkhip_selfcheck_hash_tables(unsigned n_states) {
+    const int fours = merged_fours_selfcheck(n_states);   // the lane and pair forms' tables (poseidon_host.cpp)
+    if (fours < 0) return -1;
+    return quad_merged_tables_selfcheck(n_states) + fours;
+}
 size_t starkhip_lde_launch_ranges(size_t n_cols, unsigned rate_bits, uint64_t* triples, size_t cap) {
     const std::vector<LdeLaunch> plan = lde_launch_plan(n_cols, rate_bits);
     for (size_t i = 0; i < plan.size() && i < cap; i++) {

@@ -80,6 +80,7 @@ hipError_t launch_permute_batch(gl_t* states, size_t n, hipStream_t st);
 // kernels_selftest.hip
 // CPU replay of the leaf-hash kernel's merged-partial-round tables against the plain permutation; mismatching states out of n
 int quad_merged_tables_selfcheck(unsigned n);
+int merged_fours_selfcheck(unsigned n);   // poseidon_host.cpp: the same for the four-round merges of the lane and pair forms
 hipError_t launch_field_ops(int op, const gl_t* a, const gl_t* b, gl_t* out, size_t n, hipStream_t st);
 hipError_t launch_pow_grind(const gl_t* base_state, int pos, unsigned pow_bits, uint64_t start, uint64_t count, unsigned long long* best,
                             hipStream_t st);

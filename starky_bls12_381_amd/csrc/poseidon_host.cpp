@@ -400,4 +400,82 @@ void poseidon_permute_host(gl_t* s) {
     else poseidon_permute(s);
 }
 
+// Host replay of the permutation with its partial rounds 4 .. 23 taken FOUR at a time from build_poseidon_merged_fours' tables, in the
+// arithmetic the lane and pair forms of the leaf hash use (sums of products with the 32-bit halves of the state in 64-bit accumulators,
+// folded mod p), against the plain permutation on `n` pseudo-random states and the all-(p - 1) state: a CPU-side check of the tables and
+// of the claim that the accumulators fit (tests/test_field_hash_cpu.py).  Returns the number of mismatching states, -1 if a sum overflowed.
+int merged_fours_selfcheck(unsigned n) {
+    static PoseidonMergedFours T;
+    build_poseidon_merged_fours(T);
+    if (!T.sums_fit) return -1;
+    const uint64_t* RC = POSEIDON_RC_HOST;
+    bool overflow = false;
+    auto acc2 = [&](const uint64_t* coef, unsigned cnt, const gl_t* v, gl_t seed) {  // seed + sum coef[j] v[j] mod p, through the two accumulators
+        unsigned __int128 A = seed & EPS, B = seed >> 32;
+        for (unsigned j = 0; j < cnt; j++) {
+            A += (unsigned __int128)(v[j] & EPS) * coef[j];
+            B += (unsigned __int128)(v[j] >> 32) * coef[j];
+        }
+        if ((A >> 64) || (B >> 64)) overflow = true;
+        return (gl_t)((A + (B << 32)) % GL_P);
+    };
+    auto full = [&](gl_t* s, int next_round) {  // S-box layer, MDS layer, the next round's constants
+        gl_t t[12];
+        for (int i = 0; i < 12; i++) t[i] = sbox_nc(s[i]);
+        for (int g = 0; g < 12; g++) s[g] = acc2(T.M[g], 12, t, next_round < 30 ? RC[12 * next_round + g] : 0);
+    };
+    auto partial = [&](gl_t* s, int next_round) {
+        s[0] = sbox_nc(s[0]);
+        gl_t t[12];
+        for (int i = 0; i < 12; i++) t[i] = s[i];
+        for (int g = 0; g < 12; g++) s[g] = acc2(T.M[g], 12, t, RC[12 * next_round + g]);
+    };
+    int bad = 0;
+    uint64_t seed = 0x9E3779B97F4A7C15ull;
+    for (unsigned it = 0; it <= n; it++) {
+        gl_t s[12], want[12];
+        for (int i = 0; i < 12; i++) {
+            seed = seed * 6364136223846793005ull + 1442695040888963407ull;
+            s[i] = it == n ? GL_P - 1 : (seed ^ (seed >> 29)) % GL_P;
+            want[i] = s[i];
+        }
+        poseidon_permute(want);
+        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], RC[i]);
+        for (int r = 0; r < 4; r++) full(s, r + 1);
+        for (int t = 0; t < POSEIDON_MERGED_FOURS; t++) {
+            gl_t u[15];  // ut, x2, x3, x4
+            u[0] = sbox_nc(s[0]);
+            for (int i = 1; i < 12; i++) u[i] = s[i];
+            uint64_t row[15];
+            const gl_t y1 = acc2(T.M[0], 12, u, T.k1[t]);
+            u[12] = sbox_nc(y1);
+            for (int j = 0; j < 12; j++) row[j] = T.N2[0][j];
+            row[12] = T.M[0][0];
+            const gl_t y2 = acc2(row, 13, u, T.k2[t]);
+            u[13] = sbox_nc(y2);
+            for (int j = 0; j < 12; j++) row[j] = T.N3[0][j];
+            row[12] = T.N2[0][0];
+            row[13] = T.M[0][0];
+            const gl_t y3 = acc2(row, 14, u, T.k3[t]);
+            u[14] = sbox_nc(y3);
+            for (int g = 0; g < 12; g++) {
+                for (int j = 0; j < 12; j++) row[j] = T.N4[g][j];
+                row[12] = T.N3[g][0];
+                row[13] = T.N2[g][0];
+                row[14] = T.M[g][0];
+                s[g] = acc2(row, 15, u, T.k4[t][g]);
+            }
+        }
+        partial(s, 25);
+        partial(s, 26);
+        for (int r = 26; r < 30; r++) full(s, r + 1);
+        for (int i = 0; i < 12; i++)
+            if (s[i] % GL_P != want[i]) {
+                bad++;
+                break;
+            }
+    }
+    return overflow ? -1 : bad;
+}
+
 }  // namespace starkhip

@@ -157,9 +157,10 @@ def test_config_mirrors_standard_fast_config():
 
 
 def test_merged_partial_round_tables_reproduce_the_permutation():
-    """The leaf-hash kernel takes the 22 partial rounds three at a time from host-built tables (integer matrices M Mz Mz,
-    per-lane coefficient views, folded constants).  The library replays that formulation on the CPU, with exactly those
-    tables, against the plain permutation."""
+    """The leaf-hash kernels take the 22 partial rounds three at a time (quad form: integer matrices M Mz Mz, per-lane coefficient
+    views, folded constants) or four at a time (lane and pair forms: M Mz Mz Mz, whose rows must still sum to less than 2^32 for the
+    64-bit accumulators) from host-built tables.  The library replays both formulations on the CPU, with exactly those tables, against
+    the plain permutation."""
     import starky_bls12_381_amd as S
     assert S.lib.starkhip_selfcheck_hash_tables(200) == 0
 
