@@ -128,6 +128,17 @@ int starkhip_quotient_plan_check(starkhip_air_t air, unsigned want_chunks, uint6
             stats[4] = Q.n_cell_records; stats[5] = Q.n_direct_loads; stats[6] = Q.tile_list.size(); stats[7] = Q.contribs.size();
             if (seed == 0xBA1A) { stats[6] = Q.cost_sum_max; stats[7] = Q.cost_sum_mean; }  // balance figures (tools)
             if (seed == 0xBA1B) { stats[4] = Q.n_piece_ends; stats[5] = Q.tile_phases; stats[6] = Q.rec_sum_max; stats[7] = Q.rec_sum_total; }
+            if (seed == 0xBA1C) {  // the announcements (tools): fast pairs, direct pairs, and the direct second factors there are
+                uint64_t fast = 0, dpairs = 0, direct_b = 0, direct_b_end = 0;
+                for (const QTRec& r : Q.recs) {
+                    if ((r.ctl & QT_SPECIAL) != 0 && !(r.ctl & QT_SRC_GLOBAL) && !(r.ctl & QT_STOP)) {
+                        fast += r.aux & QT_AUX_PAIRS_MASK;
+                        dpairs += (r.aux >> QT_AUX_DPAIRS_SHIFT) & QT_AUX_DPAIRS_MASK;
+                    }
+                    if ((r.ctl & (QT_SRC_GLOBAL | QT_MULV | QT_SETV)) == (QT_SRC_GLOBAL | QT_MULV) && !(r.aux & QT_AUX_SLOT)) (r.ctl & QT_END ? direct_b_end : direct_b)++;
+                }
+                stats[4] = fast; stats[5] = dpairs; stats[6] = direct_b; stats[7] = direct_b_end;
+            }
         }
         if (!ok) return STARKHIP_ERR_BAD_SHAPE;
         return (want[0] == got[0] && want[1] == got[1]) ? STARKHIP_OK : STARKHIP_ERR_VERIFY;

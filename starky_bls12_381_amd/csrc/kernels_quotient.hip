@@ -515,6 +515,7 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
     unsigned next_block = 2, next_slot = 2;
     uint32_t n_plain = 0;                 // plain records known to follow (wave-uniform)
     uint32_t n_pairs = 0;                 // fast pairs known to follow them (degree-2 monomials inside the tile: two records each)
+    uint32_t n_dpairs = 0;                // direct pairs known to follow those (second factor outside the tile: a direct load)
     ring_read(0, 0, W0);
     ring_read(0, 1, W1);
     ring_read(0, 2, W2);
@@ -580,6 +581,16 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
         QT_MADS(W, xp_)                                                                                               \
         QT_ADVANCE(U, W)                                                                                              \
     }
+    // a direct pair: record g = the first factor (a cell of the tile), record g + 1 = the second factor, column aux, with the weights;
+    // both second factors of a turn's two pairs are requested when the turn starts
+#define QT_DIRECT_OF(W) direct(__builtin_amdgcn_readfirstlane(W.a.y), __builtin_amdgcn_readfirstlane(W.a.x) & QT_NEXT)
+#define QT_DPAIR_B(U, W, D, XA, WC2, X2)                                                                              \
+    {                                                                                                                 \
+        lds_read(WC2.a.x, X2);                                                                                        \
+        const gl_t xp_ = gl_mul_nc(XA, D);                                                                            \
+        QT_MADS(W, xp_)                                                                                               \
+        QT_ADVANCE(U, W)                                                                                              \
+    }
     // any record: (W1c, X1) of record g + 1 as well (re-read when the tile changes)
 #define QT_GENERIC(U, W, X, WC1, X1, WC2, X2)                                                                         \
     {                                                                                                                 \
@@ -592,6 +603,7 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
             const uint32_t aux = __builtin_amdgcn_readfirstlane(W.a.y);                                               \
             n_plain = ctl >> QT_RUN_SHIFT;                                                                            \
             n_pairs = (ctl & QT_SRC_GLOBAL) ? 0u : (aux & QT_AUX_PAIRS_MASK);                                         \
+            n_dpairs = (ctl & QT_SRC_GLOBAL) ? 0u : ((aux >> QT_AUX_DPAIRS_SHIFT) & QT_AUX_DPAIRS_MASK);              \
             gl_t x = X;                                                                                               \
             if ((ctl & QT_ODD_SOURCE) != 0) {                                                                         \
                 if (ctl & (QT_TILE | QT_STOP)) {                                                                      \
@@ -655,6 +667,15 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                     QT_PAIR_B(3, W3, x3, x2, W1, x1)
                     n_pairs -= 2u;
                 }
+            if (n_plain == 0u && n_pairs == 0u)
+                while (n_dpairs >= 2u) {
+                    const gl_t d0_ = QT_DIRECT_OF(W1), d1_ = QT_DIRECT_OF(W3);
+                    QT_PAIR_A(0, W0, W2, x2)
+                    QT_DPAIR_B(1, W1, d0_, x0, W3, x3)
+                    QT_PAIR_A(2, W2, W0, x0)
+                    QT_DPAIR_B(3, W3, d1_, x2, W1, x1)
+                    n_dpairs -= 2u;
+                }
             QT_GENERIC(0, W0, x0, W1, x1, W2, x2)
             while (n_plain >= 4u) {
                 QT_PLAIN(1, W1, x1, W3, x3)
@@ -670,6 +691,15 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                     QT_PAIR_A(3, W3, W1, x1)
                     QT_PAIR_B(0, W0, x0, x3, W2, x2)
                     n_pairs -= 2u;
+                }
+            if (n_plain == 0u && n_pairs == 0u)
+                while (n_dpairs >= 2u) {
+                    const gl_t d0_ = QT_DIRECT_OF(W2), d1_ = QT_DIRECT_OF(W0);
+                    QT_PAIR_A(1, W1, W3, x3)
+                    QT_DPAIR_B(2, W2, d0_, x1, W0, x0)
+                    QT_PAIR_A(3, W3, W1, x1)
+                    QT_DPAIR_B(0, W0, d1_, x3, W2, x2)
+                    n_dpairs -= 2u;
                 }
             QT_GENERIC(1, W1, x1, W2, x2, W3, x3)
             while (n_plain >= 4u) {
@@ -687,6 +717,15 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                     QT_PAIR_B(1, W1, x1, x0, W3, x3)
                     n_pairs -= 2u;
                 }
+            if (n_plain == 0u && n_pairs == 0u)
+                while (n_dpairs >= 2u) {
+                    const gl_t d0_ = QT_DIRECT_OF(W3), d1_ = QT_DIRECT_OF(W1);
+                    QT_PAIR_A(2, W2, W0, x0)
+                    QT_DPAIR_B(3, W3, d0_, x2, W1, x1)
+                    QT_PAIR_A(0, W0, W2, x2)
+                    QT_DPAIR_B(1, W1, d1_, x0, W3, x3)
+                    n_dpairs -= 2u;
+                }
             QT_GENERIC(2, W2, x2, W3, x3, W0, x0)
             while (n_plain >= 4u) {
                 QT_PLAIN(3, W3, x3, W1, x1)
@@ -703,6 +742,15 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                     QT_PAIR_B(2, W2, x2, x1, W0, x0)
                     n_pairs -= 2u;
                 }
+            if (n_plain == 0u && n_pairs == 0u)
+                while (n_dpairs >= 2u) {
+                    const gl_t d0_ = QT_DIRECT_OF(W0), d1_ = QT_DIRECT_OF(W2);
+                    QT_PAIR_A(3, W3, W1, x1)
+                    QT_DPAIR_B(0, W0, d0_, x3, W2, x2)
+                    QT_PAIR_A(1, W1, W3, x3)
+                    QT_DPAIR_B(2, W2, d1_, x1, W0, x0)
+                    n_dpairs -= 2u;
+                }
             QT_GENERIC(3, W3, x3, W0, x0, W1, x1)
         }
 stream_done:
@@ -711,6 +759,8 @@ stream_done:
 #undef QT_PLAIN
 #undef QT_PAIR_A
 #undef QT_PAIR_B
+#undef QT_DPAIR_B
+#undef QT_DIRECT_OF
 #undef QT_GENERIC
     // waves whose stream ended before the chunk's last tile (never by construction) would desynchronise the barrier count
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

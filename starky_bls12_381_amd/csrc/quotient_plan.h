@@ -93,6 +93,10 @@ struct QTPiece {
 // and the kernel evaluates a run of them two pairs at a time without looking at their control words' flags (generic steps cost ~ 80 issue
 // slots per record, a pair in the fast path ~ 40).  Records inside a fast run carry no run length and no announcement.
 static const uint32_t QT_AUX_PAIRS_MASK = 0xFFFFu;
+// ... and in bits 30:16 how many DIRECT PAIRS follow the fast pairs: (QT_SETV, cell a of the tile) then (QT_SRC_GLOBAL | QT_MULV, column b, weights),
+// no other flag, not a descriptor slot -- the kernel requests both factors b of two such pairs at once and multiplies without looking at a
+// flag.  Always an even number, and only announced behind an even number of fast pairs (the kernel's loops take two pairs per turn).
+static const uint32_t QT_AUX_DPAIRS_SHIFT = 16, QT_AUX_DPAIRS_MASK = 0x7FFFu;
 static const uint32_t QT_AUX_SLOT = 0x80000000u;   // aux of a QT_SRC_GLOBAL record: the cell is descriptor slot (aux & 3), not column aux
 static const unsigned QT_FOREIGN_SHIFT = 9;
 static_assert(sizeof(QTPiece) == 32, "piece descriptors are fetched as 8 dwords");
@@ -598,6 +602,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                 auto is_plain = [&](size_t i) { return (in(i).ctl & QT_SPECIAL) == 0; };
                 auto is_pair_a = [&](size_t i) { return (in(i).ctl & QT_SPECIAL) == QT_SETV; };   // first factor, a cell of the tile
                 auto is_pair_b = [&](size_t i) { return (in(i).ctl & QT_SPECIAL) == QT_MULV; };   // second factor, a cell of the tile, not the piece's last record
+                auto is_dpair_b = [&](size_t i) { return (in(i).ctl & QT_SPECIAL) == (QT_SRC_GLOBAL | QT_MULV) && !(in(i).aux & QT_AUX_SLOT); };   // second factor: a direct load
                 std::vector<QTRec> out;
                 std::vector<uint32_t> ocb, oce;
                 out.reserve(n_in + 8);
@@ -618,9 +623,17 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                     uint32_t plains = (uint32_t)(p_end - i - 1), pairs = (uint32_t)((q_end - p_end) / 2);
                     const bool can_announce_pairs = !(rec.ctl & QT_SRC_GLOBAL);   // its aux is a column (or a descriptor slot)
                     if (!can_announce_pairs || pairs > QT_AUX_PAIRS_MASK) pairs = 0;
+                    // direct pairs behind the fast pairs (two per turn of the kernel's loop, and its fast-pair loop leaves an odd pair to the
+                    // generic step, which would forget the announcement)
+                    uint32_t dpairs = 0;
+                    if (can_announce_pairs && pairs % 2 == 0 && p_end + 2 * (size_t)pairs == q_end) {
+                        size_t d_end = q_end;
+                        while (d_end + 1 < n_in && is_pair_a(d_end) && is_dpair_b(d_end + 1)) d_end += 2;
+                        dpairs = std::min<uint32_t>((uint32_t)((d_end - q_end) / 2) & ~1u, QT_AUX_DPAIRS_MASK & ~1u);
+                    }
                     uint32_t first = std::min<uint32_t>(plains, QT_MAX_RUN);
                     rec.ctl |= first << QT_RUN_SHIFT;
-                    if (plains <= QT_MAX_RUN && can_announce_pairs) rec.aux = pairs;
+                    if (plains <= QT_MAX_RUN && can_announce_pairs) rec.aux = pairs | (dpairs << QT_AUX_DPAIRS_SHIFT);
                     emit(rec, rec_c_begin[stream_first + i], rec_c_end[stream_first + i]);
                     size_t at = i + 1;
                     uint32_t left = plains - first;
@@ -628,7 +641,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                         if (done == QT_MAX_RUN) {
                             const uint32_t more = std::min<uint32_t>(left, QT_MAX_RUN);
                             left -= more;
-                            emit({QT_SRC_ONE | QT_SETV | (more << QT_RUN_SHIFT), left == 0 ? pairs : 0u, {0, 0, 0, 0, 0, 0}}, 0, 0);
+                            emit({QT_SRC_ONE | QT_SETV | (more << QT_RUN_SHIFT), left == 0 ? (pairs | (dpairs << QT_AUX_DPAIRS_SHIFT)) : 0u, {0, 0, 0, 0, 0, 0}}, 0, 0);
                             done = 0;
                         }
                         emit(in(at), rec_c_begin[stream_first + at], rec_c_end[stream_first + at]);
@@ -636,7 +649,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                     }
                     // the announced pairs go out as they are (their own control words announce nothing); unannounced ones are
                     // ordinary special records and get their turn in this loop
-                    const size_t fast_end = p_end + 2 * (size_t)pairs;
+                    const size_t fast_end = p_end + 2 * (size_t)pairs + 2 * (size_t)dpairs;   // (the direct pairs likewise)
                     for (; at < fast_end; at++) emit(in(at), rec_c_begin[stream_first + at], rec_c_end[stream_first + at]);
                     i = at;
                 }
@@ -716,6 +729,7 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
             gl_t v = 1;
             uint32_t announced = 0;  // plain records the last special record said would follow
             uint32_t fast = 0;       // records of announced fast pairs still to come (two per pair): evaluated without a look at their flags
+            uint32_t dfast = 0;      // the same for the announced direct pairs behind them
             if ((rec->ctl & QT_SPECIAL) == 0) return false;  // a stream opens with a special record (the kernel knows no run length before it)
             for (;; rec++) {
                 const uint32_t ctl = rec->ctl;
@@ -727,13 +741,22 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
                     const uint32_t want = (fast & 1u) ? QT_MULV : QT_SETV;
                     if ((ctl & QT_SPECIAL) != want || (ctl >> QT_RUN_SHIFT) != 0 || rec->aux != 0) return false;
                     fast--;
+                } else if (announced == 0 && dfast != 0) {
+                    // inside a direct run: (SETV, cell in the tile) then (SRC_GLOBAL | MULV, a column), nothing announced, not a piece's end
+                    if ((ctl >> QT_RUN_SHIFT) != 0) return false;
+                    if (dfast & 1u) {
+                        if ((ctl & QT_SPECIAL) != (QT_SRC_GLOBAL | QT_MULV) || (rec->aux & QT_AUX_SLOT)) return false;
+                    } else if ((ctl & QT_SPECIAL) != QT_SETV || rec->aux != 0) return false;
+                    dfast--;
                 } else {
                     if (announced != 0) return false;  // a special record inside an announced run: the kernel would not look at its flags
                     announced = ctl >> QT_RUN_SHIFT;
                     if (announced > QT_MAX_RUN) return false;
                     if (!(ctl & QT_SRC_GLOBAL)) {
-                        if (rec->aux & ~QT_AUX_PAIRS_MASK) return false;
-                        fast = 2 * rec->aux;
+                        const uint32_t pairs = rec->aux & QT_AUX_PAIRS_MASK, dpairs = (rec->aux >> QT_AUX_DPAIRS_SHIFT) & QT_AUX_DPAIRS_MASK;
+                        if ((rec->aux >> 31) || (dpairs & 1u) || (dpairs && (pairs & 1u))) return false;
+                        fast = 2 * pairs;
+                        dfast = 2 * dpairs;
                     }
                 }
                 if (ctl & QT_STOP) break;
