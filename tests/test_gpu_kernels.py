@@ -134,6 +134,16 @@ def test_merkle_cap_in_both_leaf_hash_forms(prover, log_N, ncols, cap_h, form):
     assert np.array_equal(cap, O.merkle_cap(np.ascontiguousarray(mat.T), cap_h))
 
 
+def test_leaf_hash_form_option_knows_its_five_values(prover):
+    """0 = automatic, 1 quad, 2 row, 3 lane, 4 pair; anything else is refused and the setting stays."""
+    for bad in (5, -1):
+        with pytest.raises(S.StarkhipError):
+            prover.set_option("leaf_hash_form", bad)
+    rng = np.random.default_rng(5)
+    mat = _rand(rng, (9, 1 << 15))   # 32 768 leaves: the automatic choice is the pair form
+    assert np.array_equal(prover.merkle_cap(mat, 4), O.merkle_cap(np.ascontiguousarray(mat.T), 4))
+
+
 @pytest.mark.parametrize("n,rate_bits", [(16, 1), (64, 1), (64, 2), (1024, 2), (1024, 1), (8192, 2)])
 def test_toy_air_proof_is_bit_identical_to_oracle(prover, n, rate_bits):
     air = S.AIR_TEST_FIBONACCI
