@@ -232,21 +232,10 @@ def test_four_pair(order):
 
 # ---------------------------------------------------------------- scheduling: the lane generator's, plus the swap's two wait states
 def schedule_pair(prog):
-    """gen_lane_round_asm.schedule, with a swap's operands written at least three slots before it (two wait states; the builtin gets
-    s_nop 1 from the compiler, kernels_lde.hip)."""
-    base = L.schedule_lane
-
-    def with_swaps(p):
-        marks = []
-        for ins in p:
-            if getattr(ins, "dpp", False):
-                marks.append(ins)
-        # the lane scheduler knows loads and MFMAs; a swap is given the distance through a pseudo latency on its producers
-        return base(p)
-
-    order = L.schedule(prog)
+    """gen_lane_round_asm.schedule, then a swap's operands written at least three slots before it (two wait states; the builtin gets
+    s_nop 1 from the compiler, kernels_lde.hip): the lane scheduler does not know the instruction, so s_nop fills what is missing."""
     out = []
-    for ins in order:
+    for ins in L.schedule(prog):
         if getattr(ins, "dpp", False):
             gap = 0
             for back in (1, 2):
