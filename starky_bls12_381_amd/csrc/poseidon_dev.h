@@ -618,9 +618,10 @@ __device__ __forceinline__ gl_t poseidon_permute_row(gl_t s, const RcPair* __res
 // The quad form spends 4 lanes on a permutation because one big commitment alone has too few leaves for the chip (32 768 for
 // FinalExp: 512 waves).  With SEVERAL big commitments in flight that reason is gone, and the quad form's price shows: in the 22
 // partial rounds all four lanes execute the single S-box (three multiplies per round and quad), so a permutation costs
-// 4346 / 16 = 272 wave-instructions against ~ 195 with the whole state in one lane (full round 12 x 52 + 12 x 28, merged triple
-// 3 x 52 + 12 x 32 + 58).  Everything is uniform over the wave here -- round constants, the merged layers' coefficients -- so it comes
-// from one LDS image by broadcast reads (a scalar-register formulation would need 190 coefficients per triple in 100 SGPRs).
+// 4346 / 16 = 272 wave-instructions against 177 with the whole state in one lane (11 335 issue slots per 64 permutations: full
+// rounds with their circulant layer on the matrix pipe, partial rounds four at a time; the block sizes are in lane_round_asm.inc).
+// Everything is uniform over the wave here -- round constants, the merged layers' coefficients -- so it comes from one LDS image by
+// broadcast reads (a scalar-register formulation would need some 230 coefficients per merge in 100 SGPRs).
 typedef const __attribute__((address_space(3))) gl_t* lds_gl_ptr;
 struct LaneTables {
     RcPair rc[31][12];         // round constants in halves; rc[30] = 0 (the "next round" of the last one)

@@ -172,14 +172,16 @@ def merged_tables4(c1, c2, c3, c4):
 
 
 def fold_big(prog, dst, A, B, k):
-    """dst = A + B 2^32 mod p (some representative) for ANY 64-bit A and B: as fold_to, with the first multiply-add's carry folded in
-    before the second addition (then neither correction can overflow: after a carry the sum is below 2^64 - 2^32)."""
+    """dst = A + B 2^32 mod p (some representative) for 64-bit A and B with B < 2^64 - 2^32 (here both are below 0.83 * 2^64):
+        A + B 2^32 = A_lo + (A_hi + B_lo) 2^32 + B_hi 2^64 = (s : A_lo) + (B_hi + c) eps   mod p,   s + c 2^32 = A_hi + B_lo
+    -- one addition with carry-out in place, the carry into B_hi (which cannot wrap), one multiply-add whose own carry-out is worth eps
+    once more (after it the sum is below (B_hi + c) eps < 2^64 - 2^32, so that last correction cannot overflow).  Five instructions; A is
+    consumed."""
     FT, CV, FC, C2 = FOLD + 4 * k, FOLD + 4 * k + 2, FCS[k], FC2[k]
-    prog.append(Ins("v_mad_u64_u32 %s, %s, %s, -1, %s" % (vp(FT), sp(C2), v(B + 1), vp(A)), [B + 1, A, A + 1], [FT, FT + 1], swrites=[C2], sem=("mad", FT, C2, B + 1, "eps", A)))
+    prog.append(Ins("v_add_co_u32 %s, %s, %s, %s" % (v(A + 1), sp(FC), v(A + 1), v(B)), [A + 1, B], [A + 1], swrites=[FC], sem=("addco", A + 1, FC, A + 1, B)))
+    prog.append(Ins("v_addc_co_u32 %s, %s, %s, 0, %s" % (v(CV), sp(SINK), v(B + 1), sp(FC)), [B + 1], [CV], sreads=[FC], sem=("addc", CV, None, B + 1, None, FC)))
+    prog.append(Ins("v_mad_u64_u32 %s, %s, %s, -1, %s" % (vp(FT), sp(C2), v(CV), vp(A)), [CV, A, A + 1], [FT, FT + 1], swrites=[C2], sem=("mad", FT, C2, CV, "eps", A)))
     prog.append(Ins("v_addc_co_u32 %s, %s, 0, 0, %s" % (v(CV), sp(SINK), sp(C2)), [], [CV], sreads=[C2], sem=("addc", CV, None, None, None, C2)))
-    prog.append(Ins("v_mad_u64_u32 %s, %s, %s, -1, %s" % (vp(FT), sp(SINK), v(CV), vp(FT)), [CV, FT, FT + 1], [FT, FT + 1], sem=("mad", FT, None, CV, "eps", FT)))
-    prog.append(Ins("v_add_co_u32 %s, %s, %s, %s" % (v(FT + 1), sp(FC), v(FT + 1), v(B)), [FT + 1, B], [FT + 1], swrites=[FC], sem=("addco", FT + 1, FC, FT + 1, B)))
-    prog.append(Ins("v_addc_co_u32 %s, %s, 0, 0, %s" % (v(CV), sp(SINK), sp(FC)), [], [CV], sreads=[FC], sem=("addc", CV, None, None, None, FC)))
     prog.append(Ins("v_mad_u64_u32 %s, %s, %s, -1, %s" % (vp(dst), sp(SINK), v(CV), vp(FT)), [CV, FT, FT + 1], [dst, dst + 1], sem=("mad", dst, None, CV, "eps", FT)))
 
 

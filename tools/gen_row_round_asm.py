@@ -476,6 +476,8 @@ def run(order, vregs, sregs):
             vregs[d], vregs[d + 1] = lo, hi
             if cout is not None:
                 sregs[cout] = co
+            else:
+                assert not any(co), ("a multiply-add whose carry-out nobody reads overflowed", ins.text)
         elif k == "mov":
             vregs[ins.sem[1]] = V(ins.sem[2])[:]
         elif k == "mov64":
