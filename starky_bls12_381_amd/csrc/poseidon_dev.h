@@ -618,7 +618,7 @@ __device__ __forceinline__ gl_t poseidon_permute_row(gl_t s, const RcPair* __res
 // The quad form spends 4 lanes on a permutation because one big commitment alone has too few leaves for the chip (32 768 for
 // FinalExp: 512 waves).  With SEVERAL big commitments in flight that reason is gone, and the quad form's price shows: in the 22
 // partial rounds all four lanes execute the single S-box (three multiplies per round and quad), so a permutation costs
-// 4346 / 16 = 272 wave-instructions against 177 with the whole state in one lane (11 335 issue slots per 64 permutations: full
+// 4346 / 16 = 272 wave-instructions against 176 with the whole state in one lane (11.3 K issue slots per 64 permutations: full
 // rounds with their circulant layer on the matrix pipe, partial rounds four at a time; the block sizes are in lane_round_asm.inc).
 // Everything is uniform over the wave here -- round constants, the merged layers' coefficients -- so it comes from one LDS image by
 // broadcast reads (a scalar-register formulation would need some 230 coefficients per merge in 100 SGPRs).
