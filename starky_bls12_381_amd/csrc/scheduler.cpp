@@ -277,7 +277,7 @@ void HashService::run() {
             const double waited = (now_s() - small_.front()->t_arrive) * 1e3;
             small_ready = announced_ <= 0 || waited >= gather_ms || stop_;
         }
-        // Lane form (one lane per leaf: 177 issue slots per permutation against the pair form's 206 and the quad form's 272, but 512 waves
+        // Lane form (one lane per leaf: 176 issue slots per permutation against the pair form's 205 and the quad form's 272, but 512 waves
         // of 256 registers per commitment -- a quarter of the chip): FOUR side by side run at the issue limit, 344 ms for four against
         // 118 ms each in the pair form.  Launched one by one as they arrive they leave the chip half empty and fall into step behind each
         // other, so they go out in GROUPS: a group waits (bounded) while big proofs that have started have not reached their commitment;
