@@ -23,7 +23,6 @@
 namespace starkhip {
 struct QOp;  // quotient_ops.h
 struct QTRec;  // quotient_plan.h
-struct QTPiece;
 struct QTStream;
 struct QTContrib;
 }
@@ -96,7 +95,7 @@ hipError_t launch_quotient_combine(const gl_t* partial, const gl_t* chunk_scale,
 // tiled evaluator (quotient_plan.h): per-proof record weights, the LDS-tiled pass, the sum over chunks / Z_H
 hipError_t launch_quotient_weights(QTRec* recs, const uint32_t* contrib_off, const QTContrib* contribs, uint32_t n_recs, gl_t* apow, uint32_t K,
                                    const gl_t* consts, const gl_t* pis, gl_t alpha0, gl_t alpha1, hipStream_t st);
-hipError_t launch_quotient_tiles(const QTRec* recs, const QTPiece* pieces, const QTStream* streams, const uint32_t* chunk_tile_off,
+hipError_t launch_quotient_tiles(const QTRec* recs, const QTStream* streams, const uint32_t* chunk_tile_off,
                                  const uint32_t* tile_list, unsigned n_chunks, const gl_t* lde, const gl_t* tab, gl_t* partial, unsigned log_n,
                                  unsigned rate_bits, unsigned qdb, unsigned n_cols, unsigned dbg, hipStream_t st);
 hipError_t launch_quotient_tiles_combine(const gl_t* partial, unsigned n_chunks, const gl_t* tab, unsigned log_n, unsigned qdb, gl_t* out,

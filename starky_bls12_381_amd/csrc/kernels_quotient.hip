@@ -281,7 +281,6 @@ __global__ void quotient_combine_kernel(const gl_t* __restrict__ partial, const 
 // Gate cells and factors outside the tile are direct loads; a piece's gate cells are requested when the previous piece ends.
 struct QTParams {
     const QTRec* recs;
-    const QTPiece* pieces;
     const QTStream* streams;          // [n_chunks][QT_WAVES]
     const uint32_t* chunk_tile_off;   // [n_chunks + 1]
     const uint32_t* tile_list;
@@ -353,6 +352,15 @@ __device__ __forceinline__ gl_t qt_fold_sums(const uint64_t (&S)[6]) {
     return r + ((uint64_t)t << 32);
 }
 
+#ifdef STARKHIP_QT_PROF  // `make variant NAME=qprof DEFS=-DSTARKHIP_QT_PROF`: per-wave clocks of the tiled evaluator (tools/quotient_wave_prof.py)
+// [workgroup][wave][4]: cycles from the wave's start to its end, cycles between arriving at a tile barrier and leaving it, barriers,
+// (producer wave only) cycles waiting for its tile loads
+__device__ unsigned long long qt_prof[16384 * (QT_WAVES + 1) * 4];
+// [chunk][wave][tile < 192]: cycles an evaluator wave of the workgroups with blockIdx.x == 0 worked on each tile (barrier to barrier)
+__device__ unsigned long long qt_tile_prof[64 * QT_WAVES * 192];
+#define QT_PROF_CLOCK() __builtin_amdgcn_s_memtime()
+#endif
+
 template <bool SMALL_N, unsigned DBG>
 __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(QTParams P) { STARKHIP_PRIO_ENTRY
     __shared__ gl_t tile[2][(QT_TILE_COLS + 1) * QT_TILE_ROWS];  // + the column of ones (QT_ONES_SLOT: constant terms are plain records)
@@ -382,6 +390,10 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
             tile[buf][QT_ONES_SLOT * QT_TILE_ROWS + lane] = 1;
             if (lane < QT_TILE_ROWS - 64) tile[buf][QT_ONES_SLOT * QT_TILE_ROWS + 64 + lane] = 1;
         }
+#ifdef STARKHIP_QT_PROF
+        const unsigned long long pt_start = QT_PROF_CLOCK();
+        unsigned long long pt_bar = 0, pt_load = 0;
+#endif
         const uint32_t boff_next_last = __builtin_amdgcn_readlane(boff_next, 63);  // successor of the block's last point: row 64
         const uint32_t boff_block = __builtin_amdgcn_readfirstlane(boff_local);    // !SMALL_N: the 64 points are 512 contiguous bytes
         for (unsigned ti = 0; ti <= n_tiles; ti++) {
@@ -416,12 +428,36 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                 }
                 dst[lane * QT_TILE_ROWS + 64] = ext;
             }
+#ifdef STARKHIP_QT_PROF
+            const unsigned long long pa = QT_PROF_CLOCK();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long pb = QT_PROF_CLOCK();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const unsigned long long pc = QT_PROF_CLOCK();
+            pt_load += pb - pa;
+            pt_bar += pc - pb;
+#else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         }
+#ifdef STARKHIP_QT_PROF
+        if (lane == 0) {
+            unsigned long long* o = qt_prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (QT_WAVES + 1) + wave) * 4;
+            o[0] = QT_PROF_CLOCK() - pt_start;
+            o[1] = pt_bar;
+            o[2] = n_tiles + 1;
+            o[3] = pt_load;
+        }
+#endif
         asm volatile("s_barrier" ::: "memory");  // the evaluators' reduction barrier
         return;
     }
 
+#ifdef STARKHIP_QT_PROF
+    const unsigned long long pt_start = QT_PROF_CLOCK();
+    unsigned long long pt_bar = 0, pt_last = pt_start;
+    unsigned pt_n = 0;
+#endif
     const gl_t mask_tr = P.tab[t], mask_first = P.tab[size + t], mask_last = P.tab[2 * size + t];
     // LDS addressing: a record's offset already holds slot * 520 (+ 8 for the next row); the lane adds its row.  Blocks that
     // lie inside one coset with n >= 64 have "next row = lane + 1" (row 64 = successor of the last point).  Otherwise (SMALL_N:
@@ -442,7 +478,6 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
     // direct-to-LDS load issued 16 .. 32 records ahead of use, and reads a record with two broadcast ds_read_b128.
     const QTStream stream = P.streams[chunk * QT_WAVES + wave];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(1))) u32x4* GlobalQuad;  // global address space: plain global_load, not flat
     u32x4* const ring = (u32x4*)&rec_ring[wave][0][0][0];
     const char* const rec_base = (const char*)(P.recs + stream.rec_off);
     // The refill is issued from inline asm: once hipcc sees an LDS-DMA builtin in the loop it waits lgkmcnt(0) / vmcnt(0) at
@@ -470,9 +505,6 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
         r.a = q[0];
         r.b = q[1];
     };
-    uint64_t pc_addr = (uint64_t)(P.pieces + stream.piece_off);
-    asm volatile("" : "+v"(pc_addr));  // formally divergent: the descriptor is fetched with a vector load (VM counter)
-
     auto direct = [&](uint32_t col, bool next) -> gl_t {
         const char* base = lde + ((uint64_t)col << col_shift);
         return *(const gl_t*)(base + (next ? boff_next : boff_local));
@@ -482,11 +514,12 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
     uint64_t S0[6] = {0, 0, 0, 0, 0, 0}, S1[6] = {0, 0, 0, 0, 0, 0};
     uint32_t piece_ctl = 0;
     gl_t gate[4] = {0, 0, 0, 0};
-    auto gates_request = [&]() {  // descriptor of the piece that starts now + its gate cells (used when the piece ends)
-        const u32x4 d0 = ((GlobalQuad)pc_addr)[0];
-        const uint32_t d4 = ((const __attribute__((address_space(1))) uint32_t*)pc_addr)[4];
-        const uint32_t dgate[4] = {d0.y, d0.z, d0.w, d4};
-        piece_ctl = __builtin_amdgcn_readfirstlane(d0.x);
+    // The descriptor of the piece that starts (a QT_DESC record: QTPiece in the weight words, quotient_plan.h): its gate cells -- and
+    // the cells absorbed from other tiles -- are requested now and used when the piece ends.  The record has been in registers for
+    // four steps, so nothing here waits (round 5 fetched descriptors from an array of their own: a dependent L2 round trip per piece).
+    auto gates_request = [&](const Rec& d) {
+        const uint32_t dgate[4] = {d.a.z, d.a.w, d.b.x, d.b.y};
+        piece_ctl = __builtin_amdgcn_readfirstlane(d.b.z);
         const uint32_t ng = ((piece_ctl >> 2) & 7u) + ((piece_ctl >> QT_FOREIGN_SHIFT) & 7u);  // gates, then the absorbed pieces' cells (quotient_plan.h)
 #pragma unroll
         for (unsigned g = 0; g < 4; g++)
@@ -497,7 +530,6 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
     };
     ring_fill(0, 0);
     ring_fill(1, 1);
-    gates_request();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // Record pipeline (round 4).  A record is read WHOLE from the ring (two broadcast ds_read_b128: control word, weights) four steps
     // before it is evaluated, into the register set the step that has just finished frees; its cell is requested two steps ahead, the
@@ -591,6 +623,20 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
         QT_MADS(W, xp_)                                                                                               \
         QT_ADVANCE(U, W)                                                                                              \
     }
+#ifdef STARKHIP_QT_PROF
+#define QT_TILE_BARRIER()                                                                                             \
+    {                                                                                                                 \
+        const unsigned long long pa_ = QT_PROF_CLOCK();                                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                               \
+        const unsigned long long pb_ = QT_PROF_CLOCK();                                                               \
+        if (blockIdx.x == 0 && chunk < 64 && pt_n < 192 && lane == 0) qt_tile_prof[(chunk * QT_WAVES + wave) * 192 + pt_n] = pa_ - pt_last; \
+        pt_bar += pb_ - pa_;                                                                                          \
+        pt_last = pb_;                                                                                                \
+        pt_n++;                                                                                                       \
+    }
+#else
+#define QT_TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     // any record: (W1c, X1) of record g + 1 as well (re-read when the tile changes)
 #define QT_GENERIC(U, W, X, WC1, X1, WC2, X2)                                                                         \
     {                                                                                                                 \
@@ -608,7 +654,7 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
             if ((ctl & QT_ODD_SOURCE) != 0) {                                                                         \
                 if (ctl & (QT_TILE | QT_STOP)) {                                                                      \
                     /* every LDS read of this tile has returned; the gate loads of the next piece stay in flight */   \
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                 \
+                    QT_TILE_BARRIER()                                                                                 \
                     ti++;                                                                                             \
                     if ((ctl & QT_STOP) != 0 || ti >= n_tiles) goto stream_done;                                      \
                     lds_cur = lds_local + (ti & 1u) * (uint32_t)((QT_TILE_COLS + 1) * QT_TILE_ROWS * sizeof(gl_t));         \
@@ -616,7 +662,10 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                     lds_read(WC2.a.x, X2);                                                                            \
                     goto advance_##U;                                                                                 \
                 }                                                                                                     \
-                if (ctl & QT_SRC_ONE) x = 1;                                                                          \
+                if (ctl & QT_SRC_ONE) {                                                                               \
+                    x = 1;                                                                                            \
+                    if ((ctl & QT_NEXT) && !(DBG & 4u)) gates_request(W); /* QT_DESC: a piece starts */              \
+                }                                                                                                     \
                 if ((ctl & QT_SRC_GLOBAL) && !(DBG & 8u)) {                                                           \
                     if (aux & QT_AUX_SLOT) { /* a cell requested with the piece's gates */                            \
                         const uint32_t sl = aux & 3u;                                                                 \
@@ -643,8 +692,6 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                 acc0 = gl_mad_nc(G, qt_fold_sums(S0), acc0);                                                          \
                 acc1 = gl_mad_nc(G, qt_fold_sums(S1), acc1);                                                          \
                 _Pragma("unroll") for (int l = 0; l < 6; l++) S0[l] = S1[l] = 0;                                      \
-                pc_addr += sizeof(QTPiece);                                                                           \
-                gates_request();                                                                                      \
             }                                                                                                         \
         }                                                                                                             \
     advance_##U:                                                                                                      \
@@ -762,8 +809,18 @@ stream_done:
 #undef QT_DPAIR_B
 #undef QT_DIRECT_OF
 #undef QT_GENERIC
+#undef QT_TILE_BARRIER
     // waves whose stream ended before the chunk's last tile (never by construction) would desynchronise the barrier count
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef STARKHIP_QT_PROF
+    if (lane == 0) {
+        unsigned long long* o = qt_prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (QT_WAVES + 1) + wave) * 4;
+        o[0] = QT_PROF_CLOCK() - pt_start;
+        o[1] = pt_bar;
+        o[2] = pt_n;
+        o[3] = 0;
+    }
+#endif
 
     // acc of the eight waves -> partial[chunk]
     gl_t* red = tile[0];
@@ -791,6 +848,7 @@ __global__ void quotient_weights_kernel(QTRec* recs, const uint32_t* contrib_off
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_recs) return;
     const uint32_t c0 = contrib_off[r], c1 = contrib_off[r + 1];
+    if (c0 == c1) return;  // markers and no-ops keep their zeros, descriptors (QT_DESC) the gate cells their weight words hold
     gl_t w[2] = {0, 0};
     for (uint32_t c = c0; c < c1; c++) {
         const QTContrib t = contribs[c];
@@ -837,12 +895,12 @@ hipError_t launch_quotient_weights(QTRec* recs, const uint32_t* contrib_off, con
     return hipGetLastError();
 }
 
-hipError_t launch_quotient_tiles(const QTRec* recs, const QTPiece* pieces, const QTStream* streams, const uint32_t* chunk_tile_off,
+hipError_t launch_quotient_tiles(const QTRec* recs, const QTStream* streams, const uint32_t* chunk_tile_off,
                                  const uint32_t* tile_list, unsigned n_chunks, const gl_t* lde, const gl_t* tab, gl_t* partial, unsigned log_n,
                                  unsigned rate_bits, unsigned qdb, unsigned n_cols, unsigned dbg, hipStream_t st) {
     QTParams P;
     P.dbg = dbg;
-    P.recs = recs; P.pieces = pieces; P.streams = streams; P.chunk_tile_off = chunk_tile_off; P.tile_list = tile_list;
+    P.recs = recs; P.streams = streams; P.chunk_tile_off = chunk_tile_off; P.tile_list = tile_list;
     P.lde = lde; P.tab = tab; P.partial = partial; P.log_n = log_n; P.rate_bits = rate_bits; P.qdb = qdb; P.n_cols = n_cols;
     const size_t size = (size_t)1 << (log_n + qdb);
     const dim3 grid((unsigned)((size + 63) / 64), n_chunks), block(64 * (QT_WAVES + 1));
@@ -902,3 +960,12 @@ hipError_t launch_quotient_combine(const gl_t* partial, const gl_t* chunk_scale,
 }
 
 }  // namespace starkhip
+
+#ifdef STARKHIP_QT_PROF
+extern "C" __attribute__((visibility("default"))) int starkhip_debug_qt_prof(unsigned long long* out, size_t n_words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(starkhip::qt_prof), n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+extern "C" __attribute__((visibility("default"))) int starkhip_debug_qt_tile_prof(unsigned long long* out, size_t n_words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(starkhip::qt_tile_prof), n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -129,7 +129,7 @@ struct Ctx {
         int air = -1;
         unsigned chunks = 0, want = 0;
         uint32_t recs = 0;
-        DevBuf q_recs, q_pieces, q_streams, q_chunk_tile_off, q_tile_list, q_contrib_off, q_contribs, q_consts, q_apow;
+        DevBuf q_recs, q_streams, q_chunk_tile_off, q_tile_list, q_contrib_off, q_contribs, q_consts, q_apow;
     };
     std::vector<std::unique_ptr<Tables>> table_cache;
     std::vector<std::unique_ptr<PlanDev>> plan_cache;
@@ -346,14 +346,13 @@ static int ensure_plan(Ctx* c, const AirInfo& air, size_t quotient_points) {
         Ctx::PlanDev* d;
         ~Release() {
             if (!d) return;
-            for (DevBuf* b : {&d->q_recs, &d->q_pieces, &d->q_streams, &d->q_chunk_tile_off, &d->q_tile_list, &d->q_contrib_off, &d->q_contribs, &d->q_consts, &d->q_apow}) b->release();
+            for (DevBuf* b : {&d->q_recs, &d->q_streams, &d->q_chunk_tile_off, &d->q_tile_list, &d->q_contrib_off, &d->q_contribs, &d->q_consts, &d->q_apow}) b->release();
         }
     } guard{D};
     struct Up { DevBuf* b; const void* src; size_t bytes; };
     const std::vector<gl_t>& consts = air.prog.consts;
     const gl_t zero = 0;
     const Up ups[] = {{&D->q_recs, Q.recs.data(), Q.recs.size() * sizeof(QTRec)},
-                      {&D->q_pieces, Q.pieces.data(), Q.pieces.size() * sizeof(QTPiece)},
                       {&D->q_streams, Q.streams.data(), Q.streams.size() * sizeof(QTStream)},
                       {&D->q_chunk_tile_off, Q.chunk_tile_off.data(), Q.chunk_tile_off.size() * 4},
                       {&D->q_tile_list, Q.tile_list.empty() ? (const void*)&zero : (const void*)Q.tile_list.data(), std::max<size_t>(1, Q.tile_list.size()) * 4},
@@ -448,7 +447,7 @@ void ctx_destroy(Ctx* c) {
     for (auto& t : c->table_cache)
         for (DevBuf* b : {&t->tw_fwd, &t->tw_inv, &t->coset_scale, &t->qtab, &t->qshift_inv, &t->lde2_fwd, &t->lde2_inv, &t->lde2_cs, &t->lde2_oh, &t->lde_wave}) b->release();
     for (auto& d : c->plan_cache)
-        for (DevBuf* b : {&d->q_recs, &d->q_pieces, &d->q_streams, &d->q_chunk_tile_off, &d->q_tile_list, &d->q_contrib_off, &d->q_contribs, &d->q_consts, &d->q_apow}) b->release();
+        for (DevBuf* b : {&d->q_recs, &d->q_streams, &d->q_chunk_tile_off, &d->q_tile_list, &d->q_contrib_off, &d->q_contribs, &d->q_consts, &d->q_apow}) b->release();
     DevBuf* bufs[] = {&c->d_ops, &c->d_loads, &c->d_chunk_off, &c->staging,
                       &c->values, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial, &c->qvals, &c->qcoef,
                       &c->qlde, &c->qdigests, &c->zpow, &c->gzpow, &c->open_local, &c->open_next, &c->open_q, &c->ext_apow, &c->comb_partial,
@@ -515,7 +514,7 @@ size_t ctx_device_bytes(Ctx* c) {
     for (auto& t : c->table_cache)
         for (DevBuf* b : {&t->tw_fwd, &t->tw_inv, &t->coset_scale, &t->qtab, &t->qshift_inv, &t->lde2_fwd, &t->lde2_inv, &t->lde2_cs, &t->lde2_oh, &t->lde_wave}) total += b->cap;
     for (auto& d : c->plan_cache)
-        for (DevBuf* b : {&d->q_recs, &d->q_pieces, &d->q_streams, &d->q_chunk_tile_off, &d->q_tile_list, &d->q_contrib_off, &d->q_contribs, &d->q_consts, &d->q_apow}) total += b->cap;
+        for (DevBuf* b : {&d->q_recs, &d->q_streams, &d->q_chunk_tile_off, &d->q_tile_list, &d->q_contrib_off, &d->q_contribs, &d->q_consts, &d->q_apow}) total += b->cap;
     DevBuf* bufs[] = {&c->d_ops, &c->d_loads, &c->d_chunk_off, &c->staging, &c->values, &c->lde, &c->digests, &c->pis, &c->apow, &c->chunk_scale, &c->partial,
                       &c->qvals, &c->qcoef, &c->qlde, &c->qdigests, &c->zpow, &c->gzpow, &c->open_local, &c->open_next, &c->open_q, &c->ext_apow,
                       &c->comb_partial, &c->comb_out, &c->fri_coef, &c->fri_vals, &c->scale_tab, &c->pow_state, &c->pow_best, &c->qidx, &c->gather_t,
@@ -842,7 +841,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             HIPCHK(launch_quotient_weights(c->plan->q_recs.as<QTRec>(), c->plan->q_contrib_off.as<uint32_t>(), c->plan->q_contribs.as<QTContrib>(), c->plan->recs,
                                            c->plan->q_apow.as<gl_t>(), P.n_constraints, c->plan->q_consts.as<gl_t>(), c->pis.as<gl_t>(), alphas[0], alphas[1], st));
             HIPCHK(hipEventRecord(c->kev[2], st));
-            HIPCHK(launch_quotient_tiles(c->plan->q_recs.as<QTRec>(), c->plan->q_pieces.as<QTPiece>(), c->plan->q_streams.as<QTStream>(),
+            HIPCHK(launch_quotient_tiles(c->plan->q_recs.as<QTRec>(), c->plan->q_streams.as<QTStream>(),
                                          c->plan->q_chunk_tile_off.as<uint32_t>(), c->plan->q_tile_list.as<uint32_t>(), n_chunks, c->lde.as<gl_t>(),
                                          c->tab->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, (unsigned)((c->opt_quotient_debug <= 4 || c->opt_quotient_debug == 8) ? c->opt_quotient_debug : 0), st));
             HIPCHK(hipEventRecord(c->kev[3], st));
@@ -874,7 +873,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
             HIPCHK(c->partial.ensure((size_t)std::max(n_chunks, c->plan->chunks) * 2 * size * 8));
             HIPCHK(launch_quotient_weights(c->plan->q_recs.as<QTRec>(), c->plan->q_contrib_off.as<uint32_t>(), c->plan->q_contribs.as<QTContrib>(), c->plan->recs,
                                            c->plan->q_apow.as<gl_t>(), P.n_constraints, c->plan->q_consts.as<gl_t>(), c->pis.as<gl_t>(), alphas[0], alphas[1], st));
-            HIPCHK(launch_quotient_tiles(c->plan->q_recs.as<QTRec>(), c->plan->q_pieces.as<QTPiece>(), c->plan->q_streams.as<QTStream>(),
+            HIPCHK(launch_quotient_tiles(c->plan->q_recs.as<QTRec>(), c->plan->q_streams.as<QTStream>(),
                                          c->plan->q_chunk_tile_off.as<uint32_t>(), c->plan->q_tile_list.as<uint32_t>(), c->plan->chunks, c->lde.as<gl_t>(),
                                          c->tab->qtab.as<gl_t>(), c->partial.as<gl_t>(), log_n, r, qdb, (unsigned)C, 0, st));
             HIPCHK(launch_quotient_tiles_combine(c->partial.as<gl_t>(), c->plan->chunks, c->tab->qtab.as<gl_t>(), log_n, qdb, c->comb_partial.as<gl_t>(), st));

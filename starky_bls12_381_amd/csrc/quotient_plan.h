@@ -49,6 +49,7 @@ static const unsigned QT_MAX_PIECE = 192;   // records per piece after splitting
 // Y = S3 + hi(S1) 2^22 + lo(S2) 2^12 + lo(S4) 2^22 + hi(X)), i.e. < (0.9375 + 2^-9) * 2^64: no wrap.  At 1024 records the sums
 // themselves still fit but X and Y can wrap -- planner, host replay and kernel all use THIS bound.
 static const unsigned QT_MAX_CHAIN = 960;
+static const unsigned QT_FOLD_MAX_MONOS = 8;  // supergroups of at most this many monomials, all of them single cells, give one gate to their monomials (pass 1b)
 static const unsigned QT_MAX_RUN = 252;     // longest plain run one special record announces (a multiple of four that fits eight bits)
 static const unsigned QT_LIMB_BITS = 22;    // weights are split into three limbs of 22 bits
 
@@ -67,6 +68,8 @@ enum : uint32_t {
     QT_RUN_SHIFT = 24,         // [31:24] of a SPECIAL record (any flag below set): the number of plain records (no flag at all) that
                                // follow it before the next special one, at most QT_MAX_RUN -- the kernel evaluates such a run four
                                // records at a time without looking at their control words' flags; plain records carry 0 here
+    QT_DESC = QT_SRC_ONE | QT_SETV | QT_NEXT,  // the descriptor of the piece that starts here (QTPiece in the weight words: w[0 .. 3] = gate, w[4] = ctl);
+                               // a no-op as a record (QT_NEXT means nothing for x = 1, so the combination is free)
     QT_SPECIAL = QT_SRC_ONE | QT_SRC_GLOBAL | QT_SETV | QT_MULV | QT_END | QT_TILE | QT_STOP,
     QT_ODD_SOURCE = QT_SRC_ONE | QT_SRC_GLOBAL | QT_SETV | QT_MULV | QT_TILE | QT_STOP
 };
@@ -187,6 +190,83 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         }
     }
     if (k != K) throw std::runtime_error("quotient_plan: constraint count mismatch");
+
+    // ---- pass 1b: fold ONE gate of the tiny supergroups into their monomials.  mask * g * G' * sum_m w(m) m  =  mask * G' * sum_m w(m) (g m):
+    // the same constraint powers, regrouped under the supergroup without g.  A piece end (two folds, the gate product, the next
+    // descriptor) costs as much as twenty-three plain records (measured per tile: profiles/r06_quotient_cost_fit.txt), and FinalExp has
+    // 4 409 supergroups "selector_i * (k_i + sum of five cells)" and 2 384 "g0 * a * b * (cell + k)" of six and two records each: 28 % of
+    // its piece ends for 4 % of its records, all of them in one tile (that of the shared cells).  Folded, the first family is 4 409 x
+    // (one plain record + five pairs) in the SELECTORS' tiles -- which otherwise keep three of seven waves busy -- and the second merges
+    // four to one.  Only supergroups whose monomials are all single cells or constants are folded (the products stay pairs), and only
+    // uncomplemented gates ((1 - c) m would be two monomials).
+    {
+        const size_t n_sg0 = sg_gates.size();
+        std::vector<std::vector<uint32_t>> sg_monos(n_sg0);  // distinct first cells (NONE = the constant) -- enough for "tiny and linear"
+        std::vector<uint8_t> linear(n_sg0, 1);
+        for (const Term& t : terms) {
+            if (t.cells[1] != NONE) linear[t.sg] = 0;
+            std::vector<uint32_t>& mm = sg_monos[t.sg];
+            if (mm.size() <= QT_FOLD_MAX_MONOS && std::find(mm.begin(), mm.end(), t.cells[0]) == mm.end()) mm.push_back(t.cells[0]);
+        }
+        auto key_without = [&](uint32_t sg, size_t drop) {
+            std::string key((const char*)&sg_kind[sg], 4);
+            for (size_t g = 0; g < sg_gates[sg].size(); g++)
+                if (g != drop) key.append((const char*)&sg_gates[sg][g], 4);
+            return key;
+        };
+        // candidates: (supergroup, gate index) -> key of the target; a target is the better the more tiny supergroups reach it
+        std::unordered_map<std::string, uint32_t> reach;
+        std::vector<uint32_t> tiny;
+        for (uint32_t sg = 0; sg < n_sg0; sg++) {
+            if (!linear[sg] || sg_gates[sg].empty() || sg_monos[sg].empty() || sg_monos[sg].size() > QT_FOLD_MAX_MONOS) continue;
+            bool any = false;
+            for (size_t g = 0; g < sg_gates[sg].size(); g++)
+                if (!(sg_gates[sg][g] & REF_COMPL)) {
+                    reach[key_without(sg, g)]++;
+                    any = true;
+                }
+            if (any) tiny.push_back(sg);
+        }
+        std::vector<uint32_t> fold_gate(n_sg0, NONE), fold_to(n_sg0, NONE);
+        for (uint32_t sg : tiny) {
+            size_t best = NONE;
+            uint32_t best_reach = 0;
+            for (size_t g = 0; g < sg_gates[sg].size(); g++) {
+                if (sg_gates[sg][g] & REF_COMPL) continue;
+                const uint32_t r = reach[key_without(sg, g)];
+                if (r > best_reach) {
+                    best_reach = r;
+                    best = g;
+                }
+            }
+            // alone in its target the supergroup would only trade its gate for a longer monomial: fold when at least two meet, or when
+            // the target is an existing supergroup (then this one's piece end disappears)
+            std::string key = key_without(sg, best);
+            const bool target_exists = sg_index.find(key) != sg_index.end();
+            if (best_reach < 2 && !target_exists) continue;
+            uint32_t to;
+            auto it = sg_index.find(key);
+            if (it == sg_index.end()) {
+                to = (uint32_t)sg_gates.size();
+                std::vector<uint32_t> gs;
+                for (size_t g = 0; g < sg_gates[sg].size(); g++)
+                    if (g != best) gs.push_back(sg_gates[sg][g]);
+                sg_index.emplace(std::move(key), to);
+                sg_gates.push_back(std::move(gs));
+                sg_kind.push_back(sg_kind[sg]);
+            } else {
+                to = it->second;
+            }
+            fold_gate[sg] = sg_gates[sg][best] & (REF_COL_MASK | REF_NEXT);
+            fold_to[sg] = to;
+        }
+        for (Term& t : terms) {
+            if (t.sg >= n_sg0 || fold_to[t.sg] == NONE) continue;
+            t.cells[t.cells[0] == NONE ? 0 : 1] = fold_gate[t.sg];  // linear: at most one cell so far
+            if (t.cells[1] != NONE && t.cells[1] < t.cells[0]) std::swap(t.cells[0], t.cells[1]);
+            t.sg = fold_to[t.sg];
+        }
+    }
 #ifdef STARKHIP_DEBUG
     if (getenv("STARKHIP_PLAN_STATS")) {  // development aid: supergroups by (terms, gates)
         std::vector<uint32_t> n_terms(sg_gates.size(), 0), max_deg(sg_gates.size(), 0);
@@ -267,12 +347,13 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
     }
     auto mono_records = [&](const Mono& m) -> uint32_t { return m.cells[0] == NONE ? 1u : m.cells[1] == NONE ? 1u : m.cells[2] == NONE ? 2u : 3u; };
     // Inside a piece the order of the monomials is free (a sum): single cells first (they form the plain runs), then the degree-2
-    // monomials with both cells in the piece's tile (the fast pairs), then everything else (constants, factors in other tiles, degree 3).
+    // monomials with both cells in the piece's tile (the fast pairs), then those with one cell in it (the direct pairs), then the rest.
     {
         auto klass = [&](const Mono& m, uint32_t tile) -> int {
             if (m.cells[1] == NONE) return 0;   // one cell of the tile, or the constant (the tile's column of ones)
             if (m.cells[1] != NONE && m.cells[2] == NONE && tile_of(m.cells[0]) == tile && tile_of(m.cells[1]) == tile) return 1;
-            return 2;
+            if (m.cells[1] != NONE && m.cells[2] == NONE && (tile_of(m.cells[0]) == tile || tile_of(m.cells[1]) == tile)) return 2;  // direct pairs
+            return 3;
         };
         for (const Piece& p : pieces)
             std::stable_sort(monos.begin() + p.m_begin, monos.begin() + p.m_end,
@@ -316,16 +397,54 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
             if (!dead[j]) kept.push_back(std::move(pieces[j]));
         pieces.swap(kept);
     }
-    // split big pieces (the contribution is linear in T, so a piece may be cut anywhere)
+    // Costs by kind of record, in cycles of an evaluator wave's clock between two tile barriers, fitted to the per-tile clocks of
+    // the profiling variant over FinalExp's 8 043 (tile, wave) phases (tools/quotient_wave_prof.py + tools/plan_streams.cpp ->
+    // tools/fit_plan_costs.py, R^2 = 0.99; profiles/r06_quotient_cost_fit.txt): four plain records in the straight-line block 690,
+    // a plain record through the generic step 356, two fast pairs 830, two direct pairs 1 058, any other special record ~ 1 350, a
+    // piece end 4 010 (2 600 once the descriptor rides in the record stream), a tile change 2 500.  (The round-4 figures -- 18 issue
+    // slots per record, 240 per piece end -- had a piece end at thirteen records; it costs twenty-three, so tiles were dealt unevenly:
+    // the busiest wave of a tile worked 1.31 x the mean.)
+    const uint32_t PIECE_COST = 2600, REC_COST = 172, PAIR_COST = 415, DPAIR_COST = 530, GENERIC_COST = 1350, TILE_COST = 2500;
+    auto measure = [&](Piece& p) {
+        uint32_t recs = 0, cost = 0;
+        for (uint32_t b = p.m_begin; b < p.m_end; b++) {
+            const Mono& m = monos[b];
+            const uint32_t r = mono_records(m);
+            recs += r;
+            if (m.cells[1] == NONE) cost += REC_COST;
+            else if (m.cells[2] == NONE && tile_of(m.cells[0]) == p.tile && tile_of(m.cells[1]) == p.tile) cost += PAIR_COST;
+            else if (m.cells[2] == NONE && (tile_of(m.cells[0]) == p.tile || tile_of(m.cells[1]) == p.tile)) cost += DPAIR_COST;
+            else cost += GENERIC_COST * r;
+        }
+        recs += (uint32_t)p.foreign.size();
+        cost += GENERIC_COST * (uint32_t)p.foreign.size();
+        p.n_recs = recs;
+        p.cost = PIECE_COST + cost;
+    };
+    for (Piece& p : pieces) measure(p);
+    // Split pieces (the contribution is linear in T, so a piece may be cut anywhere): into parts of at most QT_MAX_PIECE records, and
+    // so that no part is longer than a wave's share of its tile -- a tile with three pieces (the 128 tiles of FinalExp's selector
+    // columns: one transition piece of 128 records, a first-row and a last-row piece of 64) otherwise keeps three waves busy and four
+    // waiting at the barrier.  A part that goes on from the previous tile in the same wave has no end of its own (pass 4), so in such
+    // runs of tiles the split costs nothing; elsewhere it costs a piece end, hence no part below half of one.
     {
+        std::vector<uint64_t> tile_total(pieces.empty() ? 0 : pieces.back().tile + 1, 0);
+        for (const Piece& p : pieces) tile_total[p.tile] += p.cost;
         std::vector<Piece> cut;
         cut.reserve(pieces.size() + pieces.size() / 4);
         for (const Piece& p : pieces) {
-            uint32_t b = p.m_begin, recs = 0, start = p.m_begin;
+            const uint64_t share = std::max<uint64_t>(tile_total[p.tile] / QT_WAVES, 2 * PIECE_COST);
+            const uint32_t body = p.cost - PIECE_COST, own = p.n_recs - (uint32_t)p.foreign.size();
+            uint32_t parts = std::max<uint32_t>(1, (own + QT_MAX_PIECE - 1) / QT_MAX_PIECE);
+            if (body > share) parts = std::max<uint32_t>(parts, std::min<uint32_t>((uint32_t)((body + share - 1) / share), std::max<uint32_t>(1, body / (PIECE_COST / 2))));
+            // cut at monomial boundaries into `parts` runs of about equal record count
+            uint32_t b = p.m_begin, start = p.m_begin, recs = 0, made = 0;
+            const uint32_t per = (own + parts - 1) / parts;
             for (; b < p.m_end; b++) {
                 const uint32_t r = mono_records(monos[b]);
-                if (recs + r > QT_MAX_PIECE && recs) {
+                if (recs && (recs + r > QT_MAX_PIECE || (recs + r > per && made + 1 < parts))) {
                     cut.push_back({p.sg, p.tile, start, b, 0, 0, {}});
+                    made++;
                     start = b;
                     recs = 0;
                 }
@@ -335,24 +454,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         }
         pieces.swap(cut);
     }
-    // Issue slots by kind of record (round-4 counters): a plain record 18, a degree-2 monomial inside the tile 40 for its two records, anything
-    // that goes through the generic step ~ 90 per record; a piece end ~ 150 on top of its last record's generic step.
-    const uint32_t PIECE_COST = 240, REC_COST = 18, PAIR_COST = 40, GENERIC_COST = 90, TILE_COST = 150;
-    for (Piece& p : pieces) {
-        uint32_t recs = 0, cost = 0;
-        for (uint32_t b = p.m_begin; b < p.m_end; b++) {
-            const Mono& m = monos[b];
-            const uint32_t r = mono_records(m);
-            recs += r;
-            if (m.cells[1] == NONE) cost += REC_COST;
-            else if (m.cells[2] == NONE && tile_of(m.cells[0]) == p.tile && tile_of(m.cells[1]) == p.tile) cost += PAIR_COST;
-            else cost += GENERIC_COST * r;
-        }
-        recs += (uint32_t)p.foreign.size();
-        cost += GENERIC_COST * (uint32_t)p.foreign.size();
-        p.n_recs = recs;
-        p.cost = PIECE_COST + cost;
-    }
+    for (Piece& p : pieces) measure(p);
 
     // ---- pass 3: tiles in walking order, cut into chunks of about equal cost
     std::vector<uint32_t> tile_first_piece;  // index into pieces of each non-empty tile (+ sentinel)
@@ -373,7 +475,11 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
     QTPlan Q;
     Q.n_cols = P.n_cols;
     Q.n_constraints = K;
-    Q.n_supergroups = sg_gates.size();
+    {  // supergroups in use (pass 1b empties the tiny ones it folds and may open new targets)
+        std::vector<uint8_t> used(sg_gates.size(), 0);
+        for (const Term& t : terms) used[t.sg] = 1;
+        Q.n_supergroups = (size_t)std::count(used.begin(), used.end(), 1);
+    }
     Q.n_pieces = pieces.size();
     Q.n_absorbed = Q_absorbed;
     if (tiles.empty()) {  // a program without terms: one empty chunk
@@ -491,9 +597,13 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
         for (unsigned w = 0; w < QT_WAVES; w++) {
             Q.streams.push_back({(uint32_t)Q.recs.size(), (uint32_t)Q.pieces.size()});
             const size_t stream_first = Q.recs.size();
-            // a run of plain records needs a special record in front of it that announces its length; nothing precedes the first record
-            // of a stream, so every stream opens with a no-op (v = 1, no accumulation)
-            push_rec(QT_SRC_ONE | QT_SETV, 0, 0, 0);
+            // A piece's DESCRIPTOR rides in the record stream, as a no-op record (QT_DESC: x = 1, v = x, no accumulation) in front of the
+            // piece: its weight words hold the gate cells and the piece control word.  The kernel has it in registers four steps before
+            // its turn like any record, so the piece's gate cells are requested without a dependent global load in between (a descriptor
+            // array of its own cost one L2 round trip per piece end, waited for on the spot: the fit had a piece end at 4 010 cycles).  A run
+            // of plain records needs a special record in front of it that announces its length anyway, and nothing precedes the first
+            // record of a stream.
+            bool descriptor_due = true;  // the next piece that does not go on from the previous tile opens with its descriptor
             for (uint32_t t = t_lo; t < t_hi; t++) {
                 const uint32_t tile = tiles[t];
                 const std::vector<uint32_t>& mine = assign[t - t_lo][w];
@@ -507,6 +617,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                     size_t foreign_cells = 0;
                     for (uint32_t b : pc.foreign) foreign_cells += monos[b].cells[0] != NONE;
                     const bool slots = !continues && gates.size() + foreign_cells <= 4;
+                    if (continues && descriptor_due) throw std::runtime_error("quotient_plan: a stream's first piece cannot continue another");
                     if (!continues) {
                         QTPiece d = {0, {0, 0, 0, 0}, {0, 0, 0}};
                         uint32_t compl_mask = 0;
@@ -519,6 +630,10 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                             for (uint32_t b : pc.foreign)
                                 if (monos[b].cells[0] != NONE) d.gate[gates.size() + n_foreign++] = monos[b].cells[0] & (REF_COL_MASK | REF_NEXT);
                         d.ctl = sg_kind[pc.sg] | ((uint32_t)gates.size() << 2) | (compl_mask << 5) | (n_foreign << QT_FOREIGN_SHIFT);
+                        Q.recs.push_back({QT_DESC, 0, {d.gate[0], d.gate[1], d.gate[2], d.gate[3], d.ctl, 0}});
+                        rec_c_begin.push_back(0);
+                        rec_c_end.push_back(0);
+                        descriptor_due = false;
                         Q.pieces.push_back(d);
                         Q.n_direct_loads += gates.size() + n_foreign;
                         Q.n_piece_ends++;
@@ -591,6 +706,7 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                         }
                     }
                 }
+                if (descriptor_due && Q.recs.size() == stream_first) push_rec(QT_SRC_ONE | QT_SETV, 0, 0, 0);  // an empty first tile: the stream still opens with a special record
                 push_rec(QT_TILE, 0, 0, 0);
             }
             push_rec(QT_STOP, 0, 0, 0);
@@ -688,6 +804,7 @@ inline void quotient_plan_weights_host(const AirProgram& P, QTPlan& Q, const gl_
         for (uint32_t e = 1; e < P.n_constraints; e++) apow[j][e] = gl_mul(apow[j][e - 1], alphas[j]);
     }
     for (size_t r = 0; r < Q.recs.size(); r++) {
+        if (Q.contrib_off[r] == Q.contrib_off[r + 1]) continue;  // no weights: markers, no-ops, and the descriptors, whose words hold the gate cells
         for (int j = 0; j < 2; j++) {
             gl_t w = 0;
             for (uint32_t c = Q.contrib_off[r]; c < Q.contrib_off[r + 1]; c++) {
@@ -721,7 +838,9 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
         for (unsigned w = 0; w < QT_WAVES; w++) {
             const QTStream& st = Q.streams[c * QT_WAVES + w];
             const QTRec* rec = &Q.recs[st.rec_off];
-            const QTPiece* pc = &Q.pieces[st.piece_off];
+            QTPiece cur = {0, {0, 0, 0, 0}, {0, 0, 0}};  // the descriptor of the piece under way, from the stream
+            const QTPiece* pc = &cur;
+            bool have_desc = false;
             uint32_t ti = Q.chunk_tile_off[c];
             uint64_t S[2][6] = {{0}};
             unsigned n_in_piece = 0;
@@ -765,6 +884,15 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
                     ti++;
                     continue;
                 }
+                if ((ctl & (QT_DESC | QT_SRC_GLOBAL | QT_MULV | QT_END)) == QT_DESC) {  // the next piece's descriptor
+                    if (n_in_piece || in_product || have_desc) return false;
+                    cur.gate[0] = rec->w[0], cur.gate[1] = rec->w[1], cur.gate[2] = rec->w[2], cur.gate[3] = rec->w[3];
+                    cur.ctl = rec->w[4];
+                    if (rec->w[5]) return false;
+                    have_desc = true;
+                    v = 1;
+                    continue;
+                }
                 if (ti >= Q.chunk_tile_off[c + 1]) return false;
                 const uint32_t tile = Q.tile_list[ti];
                 gl_t x;
@@ -805,6 +933,7 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
                         S[j][3 + l] += (uint64_t)x1 * rec->w[3 * j + l];
                     }
                 if (++n_in_piece > QT_MAX_CHAIN) return false;  // the device fold's chains would wrap (see QT_MAX_CHAIN)
+                if (!have_desc) return false;  // a record that accumulates belongs to a piece, and a piece opens with its descriptor
                 if (ctl & QT_END) {
                     const uint32_t kind = pc->ctl & 3u, ng = (pc->ctl >> 2) & 7u, cm = (pc->ctl >> 5) & 15u;
                     gl_t G = masks[kind];
@@ -818,7 +947,7 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
                         for (int l = 0; l < 6; l++) S[j][l] = 0;
                     }
                     n_in_piece = 0;
-                    pc++;
+                    have_desc = false;
                 }
             }
             if (n_in_piece || announced || fast) return false;

@@ -44,7 +44,8 @@ def main():
         pv.set_option("quotient_impl", impl)
         if impl == 0:
             pv.set_option("quotient_chunks", chunks)
-            pv.set_option("quotient_debug", args.debug)
+            if args.debug:  # the option exists in `make DEBUG_KNOBS=1` builds only
+                pv.set_option("quotient_debug", args.debug)
         ts = []
         for r in range(args.reps):
             try:
