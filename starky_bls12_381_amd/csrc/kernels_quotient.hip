@@ -365,7 +365,7 @@ template <bool SMALL_N, unsigned DBG>
 __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(QTParams P) { STARKHIP_PRIO_ENTRY
     __shared__ gl_t tile[2][(QT_TILE_COLS + 1) * QT_TILE_ROWS];  // + the column of ones (QT_ONES_SLOT: constant terms are plain records)
     __shared__ uint32_t rec_ring[QT_WAVES][3][32][4];  // per evaluating wave: three blocks of 16 records (32 x 16 bytes each)
-    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 .. QT_WAVES - 1 evaluate, QT_WAVES stages the tiles
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 .. QT_WAVES - 1 evaluate; SMALL_N: wave QT_WAVES stages the tiles
     const unsigned lane = threadIdx.x & 63u;
     const size_t n = (size_t)1 << P.log_n, size = n << P.qdb;
     const unsigned t_raw = blockIdx.x * 64u + lane;
@@ -382,20 +382,14 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
     const uint32_t* tiles = P.tile_list + P.chunk_tile_off[chunk];
     const unsigned n_tiles = P.chunk_tile_off[chunk + 1] - P.chunk_tile_off[chunk];
 
-    if (wave == QT_WAVES) {
-        // ---- producer: tile ti + 1 goes from HBM straight into the other LDS buffer (global_load_lds_dwordx4: no vector
-        // registers, all 64 column loads of a tile in flight at once) while the eight evaluating waves work on tile ti.  Its
-        // loads are the only ones it waits for, and nobody else waits for them: the evaluators meet it at the barrier.
+    if (SMALL_N && wave == QT_WAVES) {
+        // ---- producer wave of the SMALL_N kernels (n < 64: FP12Mul's 16 rows; a wave's lanes span several cosets, so a column is not
+        // one contiguous run and goes through registers): tile ti + 1 is staged while the evaluating waves work on tile ti
         for (unsigned buf = 0; buf < 2; buf++) {  // the column of ones of both buffers, once (visible after the first barrier)
             tile[buf][QT_ONES_SLOT * QT_TILE_ROWS + lane] = 1;
             if (lane < QT_TILE_ROWS - 64) tile[buf][QT_ONES_SLOT * QT_TILE_ROWS + 64 + lane] = 1;
         }
-#ifdef STARKHIP_QT_PROF
-        const unsigned long long pt_start = QT_PROF_CLOCK();
-        unsigned long long pt_bar = 0, pt_load = 0;
-#endif
         const uint32_t boff_next_last = __builtin_amdgcn_readlane(boff_next, 63);  // successor of the block's last point: row 64
-        const uint32_t boff_block = __builtin_amdgcn_readfirstlane(boff_local);    // !SMALL_N: the 64 points are 512 contiguous bytes
         for (unsigned ti = 0; ti <= n_tiles; ti++) {
             if (ti < n_tiles && !(DBG & 1u)) {
                 const uint32_t c0 = tiles[ti] * QT_TILE_COLS;
@@ -403,54 +397,63 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                 const uint32_t ecol = c0 + lane;  // row 64: one lane per column
                 gl_t ext = 0;
                 if (ecol < P.n_cols) ext = *(const gl_t*)(lde + ((uint64_t)ecol << col_shift) + boff_next_last);
-                if (SMALL_N) {
 #pragma unroll 1
-                    for (unsigned b = 0; b < QT_TILE_COLS; b += 16) {
-                        gl_t v[16];
+                for (unsigned b = 0; b < QT_TILE_COLS; b += 16) {
+                    gl_t v[16];
 #pragma unroll
-                        for (unsigned i = 0; i < 16; i++) {
-                            const uint32_t col = c0 + b + i;
-                            v[i] = 0;
-                            if (col < P.n_cols) v[i] = *(const gl_t*)(lde + ((uint64_t)col << col_shift) + boff_local);
-                        }
+                    for (unsigned i = 0; i < 16; i++) {
+                        const uint32_t col = c0 + b + i;
+                        v[i] = 0;
+                        if (col < P.n_cols) v[i] = *(const gl_t*)(lde + ((uint64_t)col << col_shift) + boff_local);
+                    }
 #pragma unroll
-                        for (unsigned i = 0; i < 16; i++) dst[(b + i) * QT_TILE_ROWS + lane] = v[i];
-                    }
-                } else if (lane < 32) {  // 32 lanes x 16 bytes = the 64 rows of one column per instruction
-                    const unsigned ncol = min((unsigned)QT_TILE_COLS, P.n_cols - c0);
-                    const char* src = lde + ((uint64_t)c0 << col_shift) + boff_block + lane * 16u;
-#pragma unroll 4
-                    for (unsigned col = 0; col < ncol; col++) {
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                         (__attribute__((address_space(3))) void*)(dst + col * QT_TILE_ROWS), 16, 0, 0);
-                        src += (size_t)1 << col_shift;
-                    }
+                    for (unsigned i = 0; i < 16; i++) dst[(b + i) * QT_TILE_ROWS + lane] = v[i];
                 }
                 dst[lane * QT_TILE_ROWS + 64] = ext;
             }
-#ifdef STARKHIP_QT_PROF
-            const unsigned long long pa = QT_PROF_CLOCK();
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            const unsigned long long pb = QT_PROF_CLOCK();
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const unsigned long long pc = QT_PROF_CLOCK();
-            pt_load += pb - pa;
-            pt_bar += pc - pb;
-#else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
         }
-#ifdef STARKHIP_QT_PROF
-        if (lane == 0) {
-            unsigned long long* o = qt_prof + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (QT_WAVES + 1) + wave) * 4;
-            o[0] = QT_PROF_CLOCK() - pt_start;
-            o[1] = pt_bar;
-            o[2] = n_tiles + 1;
-            o[3] = pt_load;
-        }
-#endif
         asm volatile("s_barrier" ::: "memory");  // the evaluators' reduction barrier
         return;
+    }
+    // ---- n >= 64 (every AIR but FP12Mul): no producer wave.  Round 5 had seven evaluating waves and a producer per workgroup; with
+    // two workgroups on a CU that is 4 + 4 + 4 + 2 evaluating waves on the four SIMDs, the fourth SIMD half idle while the others
+    // run at the vector pipe's rate (per-wave clocks: tools/quotient_wave_prof.py; the evaluators of the crowded SIMDs reached every
+    // barrier last).  Now EIGHT waves evaluate -- four per SIMD -- and each stages an eighth of the next tile itself: eight
+    // global_load_lds_dwordx4 per tile, 33 lanes each -- lanes 0 .. 31 the 64 points of the column (512 contiguous bytes), lane 32
+    // the successor of the last point (row 64, the first half of its 16 bytes; contiguous too except in a coset's last block) --
+    // issued when the wave enters tile ti, for tile ti + 1, into the other buffer; the wave waits for them before the barrier
+    // that ends tile ti.  No vector registers are held; the tile's first column rides in the QT_TILE record.
+    const uint32_t boff_next_last = __builtin_amdgcn_readlane(boff_next, 63);
+    const uint32_t boff_block = __builtin_amdgcn_readfirstlane(boff_local);  // the 64 points are 512 contiguous bytes
+    const uint32_t tile_lds = (uint32_t)(uintptr_t)&tile[0][0];
+    auto tile_fill = [&](uint32_t c0, unsigned buf) {  // both wave-uniform
+        if (SMALL_N || (DBG & 1u)) return;
+        if (lane < 33) {
+            const uint32_t off = lane < 32 ? boff_block + lane * 16u : boff_next_last;
+#pragma unroll
+            for (unsigned i = 0; i < QT_TILE_COLS / QT_WAVES; i++) {
+                const uint32_t slot = wave * (QT_TILE_COLS / QT_WAVES) + i, col = c0 + slot;
+                if (col < P.n_cols) {
+                    const char* base = lde + ((uint64_t)col << col_shift);
+                    const uint32_t dst = tile_lds + (buf * (QT_TILE_COLS + 1) + slot) * (uint32_t)(QT_TILE_ROWS * sizeof(gl_t));
+                    uint32_t keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(off), "s"(base), "s"(dst)
+                                 : "memory");
+                }
+            }
+        }
+    };
+    static_assert(QT_TILE_COLS % QT_WAVES == 0, "every wave stages the same number of columns");
+    if (!SMALL_N) {
+        if (wave == 0)
+            for (unsigned buf = 0; buf < 2; buf++) {  // the column of ones of both buffers, once (visible after the first barrier)
+                tile[buf][QT_ONES_SLOT * QT_TILE_ROWS + lane] = 1;
+                if (lane < QT_TILE_ROWS - 64) tile[buf][QT_ONES_SLOT * QT_TILE_ROWS + 64 + lane] = 1;
+            }
+        if (n_tiles) tile_fill(tiles[0] * QT_TILE_COLS, 0);
     }
 
 #ifdef STARKHIP_QT_PROF
@@ -527,6 +530,8 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                 const uint32_t ref = __builtin_amdgcn_readfirstlane(dgate[g]);
                 gate[g] = direct(ref & REF_COL_MASK, ref & REF_NEXT);
             }
+        // (all four slots loaded from vector addresses, without the scalar chains and the branches, was slower: 20.45 against 20.15 ms --
+        // the unused slots' loads cost more than the chains; profiles/r06_ab_experiments.txt 3)
     };
     ring_fill(0, 0);
     ring_fill(1, 1);
@@ -552,7 +557,8 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
     ring_read(0, 1, W1);
     ring_read(0, 2, W2);
     ring_read(0, 3, W3);
-    asm volatile("s_barrier" ::: "memory");  // tile 0 is staged
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile 0 is staged
+    if (!SMALL_N && n_tiles > 1) tile_fill(tiles[1] * QT_TILE_COLS, 1);
 
     uint32_t lds_cur = lds_local;  // this lane's row in the tile buffer in use (byte offset from tile[0])
     // `c`: the control word as it came from the ring (a vector register): offset = low half, one add
@@ -627,7 +633,7 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
 #define QT_TILE_BARRIER()                                                                                             \
     {                                                                                                                 \
         const unsigned long long pa_ = QT_PROF_CLOCK();                                                               \
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \
         const unsigned long long pb_ = QT_PROF_CLOCK();                                                               \
         if (blockIdx.x == 0 && chunk < 64 && pt_n < 192 && lane == 0) qt_tile_prof[(chunk * QT_WAVES + wave) * 192 + pt_n] = pa_ - pt_last; \
         pt_bar += pb_ - pa_;                                                                                          \
@@ -635,7 +641,7 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
         pt_n++;                                                                                                       \
     }
 #else
-#define QT_TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#define QT_TILE_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  /* vmcnt: this wave's share of the next tile */
 #endif
     // any record: (W1c, X1) of record g + 1 as well (re-read when the tile changes)
 #define QT_GENERIC(U, W, X, WC1, X1, WC2, X2)                                                                         \
@@ -658,6 +664,10 @@ __global__ __launch_bounds__(64 * (QT_WAVES + 1), 4) void quotient_tiles_kernel(
                     ti++;                                                                                             \
                     if ((ctl & QT_STOP) != 0 || ti >= n_tiles) goto stream_done;                                      \
                     lds_cur = lds_local + (ti & 1u) * (uint32_t)((QT_TILE_COLS + 1) * QT_TILE_ROWS * sizeof(gl_t));         \
+                    if (!SMALL_N) { /* the tile after this one, into the buffer everybody has just left */         \
+                        const uint32_t c0n_ = __builtin_amdgcn_readfirstlane(W.a.z);                                  \
+                        if (c0n_ != 0xFFFFFFFFu) tile_fill(c0n_, (ti + 1u) & 1u);                                     \
+                    }                                                                                                 \
                     lds_read(WC1.a.x, X1); /* the cells of the next two records live in the new tile */               \
                     lds_read(WC2.a.x, X2);                                                                            \
                     goto advance_##U;                                                                                 \
@@ -903,8 +913,8 @@ hipError_t launch_quotient_tiles(const QTRec* recs, const QTStream* streams, con
     P.recs = recs; P.streams = streams; P.chunk_tile_off = chunk_tile_off; P.tile_list = tile_list;
     P.lde = lde; P.tab = tab; P.partial = partial; P.log_n = log_n; P.rate_bits = rate_bits; P.qdb = qdb; P.n_cols = n_cols;
     const size_t size = (size_t)1 << (log_n + qdb);
-    const dim3 grid((unsigned)((size + 63) / 64), n_chunks), block(64 * (QT_WAVES + 1));
     const bool small = log_n < 6 || size < 64;
+    const dim3 grid((unsigned)((size + 63) / 64), n_chunks), block(64 * (QT_WAVES + (small ? 1 : 0)));  // SMALL_N: + the producer wave
 #ifdef STARKHIP_DEBUG  // make DEBUG_KNOBS=1: profiling variants with parts switched off (results are garbage); not in the release library
     switch (dbg) {  // 1 tile loads, 2 arithmetic, 3 both, 4 piece ends, 8 factors outside the tile not loaded
         case 0: break;

@@ -41,7 +41,7 @@ static const unsigned QT_ONES_SLOT = 64;     // = QT_TILE_COLS: one more "column
                                             // term is a PLAIN record (a cell read like any other) instead of a special one
 static const unsigned QT_TILE_ROWS = 66;    // 64 points + the successor of the last one (next-row reads are "lane + 1") + 8 bytes so
                                             // that every column starts on a 16-byte boundary (direct-to-LDS loads write 16 bytes per lane)
-static const unsigned QT_WAVES = 7;         // evaluating waves per workgroup (an eighth wave stages the tiles)
+static const unsigned QT_WAVES = 8;         // evaluating waves per workgroup: four per SIMD with two workgroups on a CU (for n >= 64 they stage the tiles themselves)
 static const unsigned QT_MAX_PIECE = 192;   // records per piece after splitting
 // Records one accumulation chain may hold before its fold: a piece, or the pieces of one supergroup a wave carries across tile
 // boundaries.  Each record adds a (32-bit half) x (22-bit limb) product < 2^54 to six 64-bit sums, so S < 960 * 2^54 =
@@ -708,6 +708,8 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                 }
                 if (descriptor_due && Q.recs.size() == stream_first) push_rec(QT_SRC_ONE | QT_SETV, 0, 0, 0);  // an empty first tile: the stream still opens with a special record
                 push_rec(QT_TILE, 0, 0, 0);
+                // the wave enters tile t + 1 behind this record and stages its share of tile t + 2 then: that tile's first column
+                Q.recs.back().w[0] = t + 2 < t_hi ? tiles[t + 2] * QT_TILE_COLS : 0xFFFFFFFFu;
             }
             push_rec(QT_STOP, 0, 0, 0);
             // announcements: every special record says how many plain records follow it (QT_RUN_SHIFT) and, in aux, how many fast pairs
@@ -882,6 +884,7 @@ inline bool quotient_plan_eval_host(const QTPlan& Q, const gl_t* local, const gl
                 if (ctl & QT_TILE) {
                     if (in_product) return false;  // a piece may go on in the next tile (same supergroup), a monomial may not
                     ti++;
+                    if (rec->w[0] != (ti + 1 < Q.chunk_tile_off[c + 1] ? Q.tile_list[ti + 1] * QT_TILE_COLS : 0xFFFFFFFFu)) return false;  // the tile to stage next
                     continue;
                 }
                 if ((ctl & (QT_DESC | QT_SRC_GLOBAL | QT_MULV | QT_END)) == QT_DESC) {  // the next piece's descriptor

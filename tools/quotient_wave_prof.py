@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wave clocks of the tiled quotient evaluator (round 6): how long the seven evaluator waves and the producer wave of a workgroup
-sit at the tile barrier, from s_memtime stamps in the profiling variant of the kernel.
+"""Per-wave clocks of the tiled quotient evaluator (round 6): how long the eight evaluating waves of a workgroup sit at the tile barrier, from s_memtime stamps in the profiling variant of the kernel.
 
     make variant NAME=qprof DEFS=-DSTARKHIP_QT_PROF
     STARKHIP_LIBRARY=build/qprof/libstarkhip_qprof.so python3 tools/quotient_wave_prof.py > gpurun_out/quotient_wave_prof.json
@@ -32,7 +31,7 @@ def main():
     for r in range(2):
         pv.prove_device(air, cfg, d.data_ptr(), n, pis, layout=1)
     ms = pv.last_kernel_timings()["quotient_eval"]
-    waves = 8
+    waves = 9  # the profile's row per workgroup: eight evaluating waves (+ an unused row; the SMALL_N kernels' producer)
     chunks = 16
     blocks = (n << 2) // 64
     wgs = chunks * blocks
@@ -42,8 +41,7 @@ def main():
     rc = fn(buf.ctypes.data, buf.size)
     assert rc == 0, rc
     p = buf.reshape(wgs, waves, 4).astype(np.float64)
-    ev = p[:, :7, :]
-    pr = p[:, 7, :]
+    ev = p[:, :8, :]
     tot = ev[:, :, 0]
     bar = ev[:, :, 1]
     out = {
@@ -55,20 +53,17 @@ def main():
         "evaluator_barrier_fraction_best_wave_per_wg": (bar / tot).min(1).mean(),
         "evaluator_barrier_fraction_worst_wave_per_wg": (bar / tot).max(1).mean(),
         "barriers_per_wave": ev[:, :, 2].mean(),
-        "producer_total_cycles_mean": pr[:, 0].mean(),
-        "producer_barrier_fraction": pr[:, 1].sum() / pr[:, 0].sum(),
-        "producer_load_wait_fraction": pr[:, 3].sum() / pr[:, 0].sum(),
-        "by_chunk_barrier_fraction": (bar.reshape(chunks, blocks, 7).sum((1, 2)) / tot.reshape(chunks, blocks, 7).sum((1, 2))).round(4).tolist(),
-        "by_chunk_total_cycles": tot.reshape(chunks, blocks, 7).mean((1, 2)).round(0).tolist(),
+        "by_chunk_barrier_fraction": (bar.reshape(chunks, blocks, 8).sum((1, 2)) / tot.reshape(chunks, blocks, 8).sum((1, 2))).round(4).tolist(),
+        "by_chunk_total_cycles": tot.reshape(chunks, blocks, 8).mean((1, 2)).round(0).tolist(),
     }
     print(json.dumps(out, indent=1))
-    # per-tile busy cycles of the workgroups with blockIdx.x == 0 (one per chunk): gpurun_out/quotient_tile_prof.npy [64][7][192]
-    tb = np.zeros(64 * 7 * 192, dtype=np.uint64)
+    # per-tile busy cycles of the workgroups with blockIdx.x == 0 (one per chunk): gpurun_out/quotient_tile_prof.npy [64][8][192]
+    tb = np.zeros(64 * 8 * 192, dtype=np.uint64)
     fn2 = api.lib.starkhip_debug_qt_tile_prof
     fn2.argtypes = [C.c_void_p, C.c_size_t]
     assert fn2(tb.ctypes.data, tb.size) == 0
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    np.save(os.path.join(ROOT, "gpurun_out", "quotient_tile_prof.npy"), tb.reshape(64, 7, 192))
+    np.save(os.path.join(ROOT, "gpurun_out", "quotient_tile_prof.npy"), tb.reshape(64, 8, 192))
 
 
 if __name__ == "__main__":
