@@ -188,6 +188,28 @@ def cpu_baseline_sample(S, blob, n_cols, log_n, rate_bits, budget_cols=4096, bud
     return out
 
 
+def thread_cpu_by_name():
+    """CPU seconds of this process's LIVE threads by thread name (/proc/self/task/*/schedstat): which threads the host time of the timed
+    region went to -- the pool's own (starkhip-gen / -rec / -ctx / -hash), this script's, or the HIP runtime's.  Threads that have exited
+    (the helpers of a recording) are missing; their time is in `recording`."""
+    out = {}
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                name = open(f"/proc/self/task/{tid}/comm").read().strip()
+                if int(tid) == os.getpid():
+                    name = "main thread (this script)"
+                elif not name.startswith("starkhip"):
+                    name += f" (unnamed: HIP runtime, torch) tid {tid}" if os.environ.get("STARKHIP_BENCH_THREAD_IDS") else " (unnamed: HIP runtime, torch)"
+                ns = int(open(f"/proc/self/task/{tid}/schedstat").read().split()[0])
+            except (OSError, ValueError, IndexError):
+                continue
+            out[name] = out.get(name, 0.0) + ns * 1e-9
+    except OSError:
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -314,6 +336,7 @@ def main():
         dist.barrier()
     cpu0 = time.process_time()
     host_cpu0 = S.api.host_cpu_seconds()
+    threads0 = thread_cpu_by_name()
     t0 = time.perf_counter()
     tickets = [submit(k) for k in range(total_steps)]
     timed_last = {}
@@ -346,6 +369,9 @@ def main():
     host_cpu1 = S.api.host_cpu_seconds()
     cpu_split = {k: (host_cpu1[k] - host_cpu0[k]) / max(1, total_steps) for k in host_cpu1}
     cpu_split["runtime_and_caller"] = cpu_s_per_proof - cpu_split["recording"] - cpu_split["proving"]
+    threads1 = thread_cpu_by_name()
+    cpu_by_thread = {k: round((v - threads0.get(k, 0.0)) / max(1, total_steps), 4) for k, v in threads1.items()}
+    cpu_by_thread = dict(sorted(((k, v) for k, v in cpu_by_thread.items() if v >= 0.0005), key=lambda kv: -kv[1])[:10])
     elapsed = parallel.max_over_ranks(dist, elapsed_own, device=reduce_device)
     # every rank's own rate and CPU budget, for rank 0's line (N > 1: a bent curve must be attributable to a rank and to host or device)
     host_info = pool.host_info()
@@ -496,7 +522,7 @@ def main():
                                       f"{inflight} (start-up and tail of the pool dropped), summed over pools and ranks; null when a pool made fewer than "
                                       f"{3 * inflight} proofs in the timed region"),
             "host": {"cpus_granted": cpu_quota(), "cpu_budget_process": int(S.lib.starkhip_cpu_budget()), "pools": host_info,
-                     "cpu_seconds_per_proof": cpu_s_per_proof, "cpu_seconds_per_proof_by_role": cpu_split, "hw_queues_late": S.api.hw_queues_late(),
+                     "cpu_seconds_per_proof": cpu_s_per_proof, "cpu_seconds_per_proof_by_role": cpu_split, "cpu_seconds_per_proof_by_thread_name": cpu_by_thread, "hw_queues_late": S.api.hw_queues_late(),
                      "note": ("cpus_granted: cgroup quota / affinity mask of this process; cpu_budget_process: the library's figure (the same, divided by "
                               "LOCAL_WORLD_SIZE under torch.distributed.run); pools[].cpu_budget: what each pool plans with (divided again by the pools of an "
                               "in-process multi-device handle), its generator threads and the threads one FinalExp recording may use; cpu_seconds_per_proof: "

@@ -96,13 +96,14 @@ static void fill_trace_g1_addition(Trace& t, const Fp pt1[2], const Fp pt2[2], s
     const size_t end_row = start_row + 11;
     const L12 &x1 = pt1[0].l, &y1 = pt1[1].l, &x2 = pt2[0].l, &y2 = pt2[1].l, &x3 = x3_fp.l, &y3 = y3_fp.l;
     const L12& p = modulus_limbs();
-    for (size_t row = start_row; row <= end_row; row++) {
-        t.put(row, col + X1, x1);
-        t.put(row, col + Y1, y1);
-        t.put(row, col + X2, x2);
-        t.put(row, col + Y2, y2);
-        t.put(row, col + X3, x3);
-        t.put(row, col + Y3, y3);
+    {
+        RowSpan rows_(t, end_row - start_row + 1);
+        t.put(start_row, col + X1, x1);
+        t.put(start_row, col + Y1, y1);
+        t.put(start_row, col + X2, x2);
+        t.put(start_row, col + Y2, y2);
+        t.put(start_row, col + X3, x3);
+        t.put(start_row, col + Y3, y3);
     }
     auto mul_block = [&](const L12& a, const L12& b, size_t c) {  // multiplication + reduction + range check of the remainder
         fill_multiplication_trace_no_mod_reduction(t, a, b, start_row, end_row, c);
@@ -112,26 +113,29 @@ static void fill_trace_g1_addition(Trace& t, const Fp pt1[2], const Fp pt2[2], s
     };
     const L12 x2_mod = add12(x2, p), y2_mod = add12(y2, p), x1_mod = add12(x1, p);
     const L12 x2_x1 = sub12(x2_mod, x1), y2_y1 = sub12(y2_mod, y1);
-    for (size_t row = start_row; row <= end_row; row++) {
-        fill_trace_addition_fp(t, x2, p, row, col + X2_X1_DIFF);
-        fill_trace_subtraction_fp(t, x2_mod, x1, row, col + X2_X1_DIFF + FP_ADDITION_TOTAL);
-        fill_trace_addition_fp(t, y2, p, row, col + Y2_Y1_DIFF);
-        fill_trace_subtraction_fp(t, y2_mod, y1, row, col + Y2_Y1_DIFF + FP_ADDITION_TOTAL);
+    {
+        RowSpan rows_(t, end_row - start_row + 1);
+        fill_trace_addition_fp(t, x2, p, start_row, col + X2_X1_DIFF);
+        fill_trace_subtraction_fp(t, x2_mod, x1, start_row, col + X2_X1_DIFF + FP_ADDITION_TOTAL);
+        fill_trace_addition_fp(t, y2, p, start_row, col + Y2_Y1_DIFF);
+        fill_trace_subtraction_fp(t, y2_mod, y1, start_row, col + Y2_Y1_DIFF + FP_ADDITION_TOTAL);
     }
     const L12 x2_x1_sq = mul_block(x2_x1, x2_x1, col + X2_X1_SQ);
     const L12 y2_y1_sq = mul_block(y2_y1, y2_y1, col + Y2_Y1_SQ);
     const L12 x1_x2 = add12(x1, x2), x1_x2_x3 = add12(x1_x2, x3);
-    for (size_t row = start_row; row <= end_row; row++) {
-        fill_trace_addition_fp(t, x1, x2, row, col + X1_X2_X3_SUM);
-        fill_trace_addition_fp(t, x1_x2, x3, row, col + X1_X2_X3_SUM + FP_ADDITION_TOTAL);
+    {
+        RowSpan rows_(t, end_row - start_row + 1);
+        fill_trace_addition_fp(t, x1, x2, start_row, col + X1_X2_X3_SUM);
+        fill_trace_addition_fp(t, x1_x2, x3, start_row, col + X1_X2_X3_SUM + FP_ADDITION_TOTAL);
     }
     const L12 lhs1 = mul_block(x1_x2_x3, x2_x1_sq, col + X1_X2_X3_X2_X1_SQ);
     if (lhs1 != y2_y1_sq) throw std::runtime_error("g1 addition: slope identity does not hold");
     const L12 y1_y3 = add12(y1, y3), x1_x3 = sub12(x1_mod, x3);
-    for (size_t row = start_row; row <= end_row; row++) {
-        fill_trace_addition_fp(t, y1, y3, row, col + Y1_Y3);
-        fill_trace_addition_fp(t, x1, p, row, col + X1_X3);
-        fill_trace_subtraction_fp(t, x1_mod, x3, row, col + X1_X3 + FP_ADDITION_TOTAL);
+    {
+        RowSpan rows_(t, end_row - start_row + 1);
+        fill_trace_addition_fp(t, y1, y3, start_row, col + Y1_Y3);
+        fill_trace_addition_fp(t, x1, p, start_row, col + X1_X3);
+        fill_trace_subtraction_fp(t, x1_mod, x3, start_row, col + X1_X3 + FP_ADDITION_TOTAL);
     }
     const L12 lhs2 = mul_block(y1_y3, x2_x1, col + Y1_Y3_X2_X1);
     const L12 rhs2 = mul_block(y2_y1, x1_x3, col + Y2_Y1_X1_X3);

@@ -189,19 +189,16 @@ struct FillTask {
 void fill_task(Trace& t, const FillTask& task, const Fp12& X, const Fp12 (&T)[32], size_t n_rows) {
     auto val = [&](int s) -> const Fp12& { return s < 0 ? X : T[s]; };
     if (task.op < 0) {
-        for (size_t row = 0; row < n_rows; row++) {
-            t.at(row, FINAL_EXP_ROW_SELECTORS + row) = 1;
-            t.put(row, FINAL_EXP_INPUT_OFFSET, X);
-        }
-        for (const Op& op : OPS)
-            for (size_t row = 0; row < n_rows; row++) t.put(row, T_OFF[op.out], T[op.out]);
+        for (size_t row = 0; row < n_rows; row++) t.at(row, FINAL_EXP_ROW_SELECTORS + row) = 1;
+        t.put_rows(0, n_rows, FINAL_EXP_INPUT_OFFSET, X);  // constant over the rows (final_exponentiate.rs:958-1033)
+        for (const Op& op : OPS) t.put_rows(0, n_rows, T_OFF[op.out], T[op.out]);
         return;
     }
     const Op& op = OPS[task.op];
     const size_t r0 = op.row, r1 = op.row + op_rows(op.kind) - 1;
     const Fp12& a = val(op.a);
     if (task.j0 == 0)
-        for (size_t row = r0; row <= r1; row++) t.at(row, op_selector(op.kind)) = 1;
+        { RowSpan rows_(t, r1 - r0 + 1); t.at(r0, op_selector(op.kind)) = 1; }
     switch (op.kind) {
         case OP_FROB: fill_trace_fp12_forbenius_map(t, a, op.pow, r0, r1, OPW); break;
         case OP_MUL: fill_trace_fp12_multiplication(t, a, val(op.b), r0, r1, OPW); break;

@@ -98,13 +98,15 @@ void fill_range_check_trace(Trace& t, const L12& x, size_t row, size_t col) {  /
 void fill_multiplication_trace_no_mod_reduction(Trace& t, const L12& x, const L12& y, size_t start_row, size_t end_row, size_t col) {
     uint32_t selector = 1;
     t.at(start_row, col + MULTIPLICATION_FIRST_ROW_OFFSET) = 1;
-    for (size_t i = start_row; i < start_row + 11; i++) t.at(i, col + MULTIPLICATION_SELECTOR_OFFSET) = 1;
-    for (size_t row = start_row; row <= end_row; row++) {
-        t.put(row, col + X_INPUT_OFFSET, x);
-        t.put(row, col + Y_INPUT_OFFSET, y);
-        for (int i = 0; i < 12; i++) t.at(row, col + SELECTOR_OFFSET + i) = (selector >> i) & 1;
-        selector *= 2;
+    { RowSpan rows_(t, 11); t.at(start_row, col + MULTIPLICATION_SELECTOR_OFFSET) = 1; }
+    {
+        RowSpan rows_(t, end_row - start_row + 1);
+        t.put(start_row, col + X_INPUT_OFFSET, x);
+        t.put(start_row, col + Y_INPUT_OFFSET, y);
     }
+    // the one-hot step selector (fp.rs:216-222 writes all twelve bits of `selector` on every row; the eleven zeros land on zeros)
+    for (size_t row = start_row; row <= end_row && row < start_row + 12; row++) t.at(row, col + SELECTOR_OFFSET + (row - start_row)) = 1;
+    (void)selector;
     L24 prev;
     prev.fill(0);
     for (size_t i = 0; i < 12; i++) {
@@ -127,9 +129,9 @@ L12 fill_reduction_trace(Trace& t, const L24& x, size_t start_row, size_t end_ro
     L12 div, rem;
     div_rem_modulus(x, div, rem);
     fill_multiplication_trace_no_mod_reduction(t, div, MODULUS, start_row, end_row, col + REDUCE_MULTIPLICATION_OFFSET);
-    for (size_t row = start_row; row <= end_row; row++) t.put(row, col + REDUCE_X_OFFSET, x);
+    { RowSpan rows_(t, end_row - start_row + 1); t.put(start_row, col + REDUCE_X_OFFSET, x); }
     L24 div_x_mod = mul_wide(div, MODULUS);
-    for (size_t row = start_row; row <= end_row; row++) t.put(row, col + REDUCED_OFFSET, rem);
+    { RowSpan rows_(t, end_row - start_row + 1); t.put(start_row, col + REDUCED_OFFSET, rem); }
     fill_addition_trace(t, div_x_mod, widen(rem), start_row + 11, col + REDUCTION_ADDITION_OFFSET);
     return rem;
 }

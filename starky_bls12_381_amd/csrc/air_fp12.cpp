@@ -9,29 +9,30 @@ using namespace bls;
 using namespace wire;
 
 static void rows_addred6(Trace& t, const Fp6& a, const Fp6& b, size_t r0, size_t r1, size_t col) {
-    for (size_t r = r0; r <= r1; r++) fill_trace_addition_with_reduction_fp6(t, a, b, r, col);
+    { RowSpan rows_(t, r1 - r0 + 1); fill_trace_addition_with_reduction_fp6(t, a, b, r0, col); }
 }
 static void rows_subred6(Trace& t, const Fp6& a, const Fp6& b, size_t r0, size_t r1, size_t col) {
-    for (size_t r = r0; r <= r1; r++) fill_trace_subtraction_with_reduction_fp6(t, a, b, r, col);
+    { RowSpan rows_(t, r1 - r0 + 1); fill_trace_subtraction_with_reduction_fp6(t, a, b, r0, col); }
 }
 static void rows_nr6(Trace& t, const Fp6& a, size_t r0, size_t r1, size_t col) {
-    for (size_t r = r0; r <= r1; r++) fill_trace_non_residue_multiplication_fp6(t, a, r, col);
+    { RowSpan rows_(t, r1 - r0 + 1); fill_trace_non_residue_multiplication_fp6(t, a, r0, col); }
 }
 static void rows_addred(Trace& t, const Fp2& a, const Fp2& b, size_t r0, size_t r1, size_t col) {
-    for (size_t r = r0; r <= r1; r++) fill_trace_addition_with_reduction(t, a, b, r, col);
+    { RowSpan rows_(t, r1 - r0 + 1); fill_trace_addition_with_reduction(t, a, b, r0, col); }
 }
 static void rows_subred(Trace& t, const Fp2& a, const Fp2& b, size_t r0, size_t r1, size_t col) {
-    for (size_t r = r0; r <= r1; r++) fill_trace_subtraction_with_reduction(t, a, b, r, col);
+    { RowSpan rows_(t, r1 - r0 + 1); fill_trace_subtraction_with_reduction(t, a, b, r0, col); }
 }
 
 // ------------------------------------------------------------------ fillers
 void fill_trace_multiply_by_014(Trace& t, const Fp12& x, const Fp2& o0, const Fp2& o1, const Fp2& o4, size_t r0, size_t r1, size_t col) {  // fp12.rs:132-183
-    for (size_t row = r0; row <= r1; row++) {
-        t.put(row, col + MULTIPLY_BY_014_INPUT_OFFSET, x);
-        t.put(row, col + MULTIPLY_BY_014_O0_OFFSET, o0);
-        t.put(row, col + MULTIPLY_BY_014_O1_OFFSET, o1);
-        t.put(row, col + MULTIPLY_BY_014_O4_OFFSET, o4);
-        t.at(row, col + MULTIPLY_BY_014_SELECTOR_OFFSET) = 1;
+    {
+        RowSpan rows_(t, r1 - r0 + 1);
+        t.put(r0, col + MULTIPLY_BY_014_INPUT_OFFSET, x);
+        t.put(r0, col + MULTIPLY_BY_014_O0_OFFSET, o0);
+        t.put(r0, col + MULTIPLY_BY_014_O1_OFFSET, o1);
+        t.put(r0, col + MULTIPLY_BY_014_O4_OFFSET, o4);
+        t.at(r0, col + MULTIPLY_BY_014_SELECTOR_OFFSET) = 1;
     }
     t.at(r1, col + MULTIPLY_BY_014_SELECTOR_OFFSET) = 0;
     const Fp6 c0 = x.c6(0), c1 = x.c6(1);
@@ -53,10 +54,11 @@ void fill_trace_multiply_by_014(Trace& t, const Fp12& x, const Fp2& o0, const Fp
     rows_subred6(t, t6, t1, r0, r1, col + MULTIPLY_BY_014_Y_CALC_OFFSET);
 }
 void fill_trace_fp12_multiplication(Trace& t, const Fp12& x, const Fp12& y, size_t r0_, size_t r1_, size_t col) {  // fp12.rs:186-231
-    for (size_t row = r0_; row <= r1_; row++) {
-        t.put(row, col + FP12_MUL_X_INPUT_OFFSET, x);
-        t.put(row, col + FP12_MUL_Y_INPUT_OFFSET, y);
-        t.at(row, col + FP12_MUL_SELECTOR_OFFSET) = 1;
+    {
+        RowSpan rows_(t, r1_ - r0_ + 1);
+        t.put(r0_, col + FP12_MUL_X_INPUT_OFFSET, x);
+        t.put(r0_, col + FP12_MUL_Y_INPUT_OFFSET, y);
+        t.at(r0_, col + FP12_MUL_SELECTOR_OFFSET) = 1;
     }
     t.at(r1_, col + FP12_MUL_SELECTOR_OFFSET) = 0;
     const Fp6 c0 = x.c6(0), c1 = x.c6(1), r0 = y.c6(0), r1 = y.c6(1);
@@ -78,9 +80,10 @@ void fill_trace_fp12_multiplication(Trace& t, const Fp12& x, const Fp12& y, size
     rows_subred6(t, t6, t1, r0_, r1_, col + FP12_MUL_Y_CALC_OFFSET);
 }
 void fill_trace_cyclotomic_sq(Trace& t, const Fp12& x, size_t r0, size_t r1, size_t col) {  // fp12.rs:234-330
-    for (size_t row = r0; row <= r1; row++) {
-        t.put(row, col + CYCLOTOMIC_SQ_INPUT_OFFSET, x);
-        t.at(row, col + CYCLOTOMIC_SQ_SELECTOR_OFFSET) = 1;
+    {
+        RowSpan rows_(t, r1 - r0 + 1);
+        t.put(r0, col + CYCLOTOMIC_SQ_INPUT_OFFSET, x);
+        t.at(r0, col + CYCLOTOMIC_SQ_SELECTOR_OFFSET) = 1;
     }
     t.at(r1, col + CYCLOTOMIC_SQ_SELECTOR_OFFSET) = 0;
     const Fp2 c0c0 = x.c2(0), c0c1 = x.c2(1), c0c2 = x.c2(2), c1c0 = x.c2(3), c1c1 = x.c2(4), c1c2 = x.c2(5);
@@ -93,7 +96,7 @@ void fill_trace_cyclotomic_sq(Trace& t, const Fp12& x, size_t r0, size_t r1, siz
     fp4_square(c0c1, c1c2, t20, t21);
     fill_trace_fp4_sq(t, c0c1, c1c2, r0, r1, col + CYCLOTOMIC_SQ_T2_CALC_OFFSET);
     Fp2 t3 = t21.mul_by_nonresidue();
-    for (size_t row = r0; row <= r1; row++) fill_trace_non_residue_multiplication(t, t21, row, col + CYCLOTOMIC_SQ_T3_CALC_OFFSET);
+    { RowSpan rows_(t, r1 - r0 + 1); fill_trace_non_residue_multiplication(t, t21, r0, col + CYCLOTOMIC_SQ_T3_CALC_OFFSET); }
     // three "(t - c) * 2 + t" legs, then three "(t + c) * 2 + t" legs
     auto sub_leg = [&](const Fp2& tv, const Fp2& cv, size_t o_sub, size_t o_mul, size_t o_out) {
         Fp2 d = tv - cv;
@@ -124,9 +127,10 @@ void fill_trace_cyclotomic_sq(Trace& t, const Fp12& x, size_t r0, size_t r1, siz
 void fill_trace_cyclotomic_exp_steps(Trace& t, const Fp12& x, size_t start_row, size_t end_row, size_t col, size_t j0, size_t j1) {
     if (end_row + 1 - start_row != 70 * 12 + 1) throw std::runtime_error("fill_trace_cyclotomic_exp: needs 841 rows");
     if (j0 == 0) {
-        for (size_t row = start_row; row <= end_row; row++) {
-            t.put(row, col + INPUT_OFFSET, x);
-            t.at(row, col + CYCLOTOMIC_EXP_SELECTOR_OFFSET) = 1;
+        {
+            RowSpan rows_(t, end_row - start_row + 1);
+            t.put(start_row, col + INPUT_OFFSET, x);
+            t.at(start_row, col + CYCLOTOMIC_EXP_SELECTOR_OFFSET) = 1;
         }
         t.at(end_row, col + CYCLOTOMIC_EXP_SELECTOR_OFFSET) = 0;
         t.at(start_row, col + CYCLOTOMIC_EXP_START_ROW) = 1;
@@ -137,9 +141,10 @@ void fill_trace_cyclotomic_exp_steps(Trace& t, const Fp12& x, size_t start_row, 
     for (size_t j = 0; j < j1; j++) {
         const size_t s_row = start_row + j * 12, e_row = s_row + 11;
         if (j >= j0) {
-            for (size_t row = s_row; row <= e_row; row++) {
-                if (bitone) t.at(row, col + BIT1_SELECTOR_OFFSET) = 1;
-                t.put(row, col + Z_OFFSET, z);
+            {
+                RowSpan rows_(t, e_row - s_row + 1);
+                if (bitone) t.at(s_row, col + BIT1_SELECTOR_OFFSET) = 1;
+                t.put(s_row, col + Z_OFFSET, z);
             }
             t.at(s_row, col + FIRST_ROW_SELECTOR_OFFSET) = 1;
         }
@@ -167,16 +172,17 @@ void fill_trace_cyclotomic_exp(Trace& t, const Fp12& x, size_t start_row, size_t
 }
 void fill_trace_fp12_forbenius_map(Trace& t, const Fp12& x, size_t pow, size_t r0, size_t r1, size_t col) {  // fp12.rs:377-409
     const size_t div = pow / 12, rem = pow % 12;
-    for (size_t row = r0; row <= r1; row++) {
-        t.put(row, col + FP12_FORBENIUS_MAP_INPUT_OFFSET, x);
-        t.at(row, col + FP12_FORBENIUS_MAP_SELECTOR_OFFSET) = 1;
-        t.at(row, col + FP12_FORBENIUS_MAP_POW_OFFSET) = pow;
-        t.at(row, col + FP12_FORBENIUS_MAP_DIV_OFFSET) = div;
-        t.at(row, col + FP12_FORBENIUS_MAP_REM_OFFSET) = rem;
-        t.at(row, col + FP12_FORBENIUS_MAP_BIT0_OFFSET) = rem & 1;
-        t.at(row, col + FP12_FORBENIUS_MAP_BIT1_OFFSET) = (rem >> 1) & 1;
-        t.at(row, col + FP12_FORBENIUS_MAP_BIT2_OFFSET) = (rem >> 2) & 1;
-        t.at(row, col + FP12_FORBENIUS_MAP_BIT3_OFFSET) = rem >> 3;
+    {
+        RowSpan rows_(t, r1 - r0 + 1);
+        t.put(r0, col + FP12_FORBENIUS_MAP_INPUT_OFFSET, x);
+        t.at(r0, col + FP12_FORBENIUS_MAP_SELECTOR_OFFSET) = 1;
+        t.at(r0, col + FP12_FORBENIUS_MAP_POW_OFFSET) = pow;
+        t.at(r0, col + FP12_FORBENIUS_MAP_DIV_OFFSET) = div;
+        t.at(r0, col + FP12_FORBENIUS_MAP_REM_OFFSET) = rem;
+        t.at(r0, col + FP12_FORBENIUS_MAP_BIT0_OFFSET) = rem & 1;
+        t.at(r0, col + FP12_FORBENIUS_MAP_BIT1_OFFSET) = (rem >> 1) & 1;
+        t.at(r0, col + FP12_FORBENIUS_MAP_BIT2_OFFSET) = (rem >> 2) & 1;
+        t.at(r0, col + FP12_FORBENIUS_MAP_BIT3_OFFSET) = rem >> 3;
     }
     t.at(r1, col + FP12_FORBENIUS_MAP_SELECTOR_OFFSET) = 0;
     const Fp6 r0v = x.c6(0), r1v = x.c6(1);

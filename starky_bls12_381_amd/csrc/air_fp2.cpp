@@ -132,10 +132,11 @@ void fill_trace_non_residue_multiplication(Trace& t, const Fp2& x, size_t row, s
     fill_range_check_trace(t, rem, row, col + FP2_NON_RESIDUE_MUL_Z1_RANGECHECK_OFFSET);
 }
 void fill_trace_fp4_sq(Trace& t, const Fp2& x, const Fp2& y, size_t start_row, size_t end_row, size_t col) {  // fp2.rs:450-494
-    for (size_t row = start_row; row <= end_row; row++) {
-        t.put(row, col + FP4_SQ_INPUT_X_OFFSET, x);
-        t.put(row, col + FP4_SQ_INPUT_Y_OFFSET, y);
-        t.at(row, col + FP4_SQ_SELECTOR_OFFSET) = 1;
+    {
+        RowSpan rows_(t, end_row - start_row + 1);
+        t.put(start_row, col + FP4_SQ_INPUT_X_OFFSET, x);
+        t.put(start_row, col + FP4_SQ_INPUT_Y_OFFSET, y);
+        t.at(start_row, col + FP4_SQ_SELECTOR_OFFSET) = 1;
     }
     t.at(end_row, col + FP4_SQ_SELECTOR_OFFSET) = 0;
     Fp2 t0 = x * x;
@@ -143,24 +144,25 @@ void fill_trace_fp4_sq(Trace& t, const Fp2& x, const Fp2& y, size_t start_row, s
     Fp2 t1 = y * y;
     generate_trace_fp2_mul(t, y, y, start_row, end_row, col + FP4_SQ_T1_CALC_OFFSET);
     Fp2 t2 = t1.mul_by_nonresidue();
-    for (size_t row = start_row; row <= end_row; row++) fill_trace_non_residue_multiplication(t, t1, row, col + FP4_SQ_T2_CALC_OFFSET);
-    for (size_t row = start_row; row <= end_row; row++) fill_trace_addition_with_reduction(t, t2, t0, row, col + FP4_SQ_X_CALC_OFFSET);
+    { RowSpan rows_(t, end_row - start_row + 1); fill_trace_non_residue_multiplication(t, t1, start_row, col + FP4_SQ_T2_CALC_OFFSET); }
+    { RowSpan rows_(t, end_row - start_row + 1); fill_trace_addition_with_reduction(t, t2, t0, start_row, col + FP4_SQ_X_CALC_OFFSET); }
     Fp2 t3 = x + y;
-    for (size_t row = start_row; row <= end_row; row++) fill_trace_addition_with_reduction(t, x, y, row, col + FP4_SQ_T3_CALC_OFFSET);
+    { RowSpan rows_(t, end_row - start_row + 1); fill_trace_addition_with_reduction(t, x, y, start_row, col + FP4_SQ_T3_CALC_OFFSET); }
     Fp2 t4 = t3 * t3;
     generate_trace_fp2_mul(t, t3, t3, start_row, end_row, col + FP4_SQ_T4_CALC_OFFSET);
     Fp2 t5 = t4 - t0;
-    for (size_t row = start_row; row <= end_row; row++) fill_trace_subtraction_with_reduction(t, t4, t0, row, col + FP4_SQ_T5_CALC_OFFSET);
-    for (size_t row = start_row; row <= end_row; row++) fill_trace_subtraction_with_reduction(t, t5, t1, row, col + FP4_SQ_Y_CALC_OFFSET);
+    { RowSpan rows_(t, end_row - start_row + 1); fill_trace_subtraction_with_reduction(t, t4, t0, start_row, col + FP4_SQ_T5_CALC_OFFSET); }
+    { RowSpan rows_(t, end_row - start_row + 1); fill_trace_subtraction_with_reduction(t, t5, t1, start_row, col + FP4_SQ_Y_CALC_OFFSET); }
 }
 void fill_trace_fp2_forbenius_map(Trace& t, const Fp2& x, size_t pow, size_t start_row, size_t end_row, size_t col) {  // fp2.rs:497-521
     const size_t div = pow / 2, rem = pow % 2;
-    for (size_t row = start_row; row <= end_row; row++) {
-        t.put(row, col + FP2_FORBENIUS_MAP_INPUT_OFFSET, x);
-        t.at(row, col + FP2_FORBENIUS_MAP_SELECTOR_OFFSET) = 1;
-        t.at(row, col + FP2_FORBENIUS_MAP_POW_OFFSET) = pow;
-        t.at(row, col + FP2_FORBENIUS_MAP_DIV_OFFSET) = div;
-        t.at(row, col + FP2_FORBENIUS_MAP_REM_OFFSET) = rem;
+    {
+        RowSpan rows_(t, end_row - start_row + 1);
+        t.put(start_row, col + FP2_FORBENIUS_MAP_INPUT_OFFSET, x);
+        t.at(start_row, col + FP2_FORBENIUS_MAP_SELECTOR_OFFSET) = 1;
+        t.at(start_row, col + FP2_FORBENIUS_MAP_POW_OFFSET) = pow;
+        t.at(start_row, col + FP2_FORBENIUS_MAP_DIV_OFFSET) = div;
+        t.at(start_row, col + FP2_FORBENIUS_MAP_REM_OFFSET) = rem;
     }
     t.at(end_row, col + FP2_FORBENIUS_MAP_SELECTOR_OFFSET) = 0;
     const Fp& coef = FP2_FROBENIUS_COEFF[rem];

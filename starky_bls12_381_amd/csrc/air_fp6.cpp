@@ -60,20 +60,21 @@ void fill_trace_non_residue_multiplication_fp6(Trace& t, const Fp6& x, size_t ro
 
 // per-row replicated single-row gadgets
 static void rows_addred(Trace& t, const Fp2& a, const Fp2& b, size_t r0, size_t r1, size_t col) {
-    for (size_t r = r0; r <= r1; r++) fill_trace_addition_with_reduction(t, a, b, r, col);
+    { RowSpan rows_(t, r1 - r0 + 1); fill_trace_addition_with_reduction(t, a, b, r0, col); }
 }
 static void rows_subred(Trace& t, const Fp2& a, const Fp2& b, size_t r0, size_t r1, size_t col) {
-    for (size_t r = r0; r <= r1; r++) fill_trace_subtraction_with_reduction(t, a, b, r, col);
+    { RowSpan rows_(t, r1 - r0 + 1); fill_trace_subtraction_with_reduction(t, a, b, r0, col); }
 }
 static void rows_nr(Trace& t, const Fp2& a, size_t r0, size_t r1, size_t col) {
-    for (size_t r = r0; r <= r1; r++) fill_trace_non_residue_multiplication(t, a, r, col);
+    { RowSpan rows_(t, r1 - r0 + 1); fill_trace_non_residue_multiplication(t, a, r0, col); }
 }
 
 void fill_trace_fp6_multiplication(Trace& t, const Fp6& x, const Fp6& y, size_t r0_, size_t r1_, size_t col) {  // fp6.rs:211-309
-    for (size_t row = r0_; row <= r1_; row++) {
-        t.put(row, col + FP6_MUL_X_INPUT_OFFSET, x);
-        t.put(row, col + FP6_MUL_Y_INPUT_OFFSET, y);
-        t.at(row, col + FP6_MUL_SELECTOR_OFFSET) = 1;
+    {
+        RowSpan rows_(t, r1_ - r0_ + 1);
+        t.put(r0_, col + FP6_MUL_X_INPUT_OFFSET, x);
+        t.put(r0_, col + FP6_MUL_Y_INPUT_OFFSET, y);
+        t.at(r0_, col + FP6_MUL_SELECTOR_OFFSET) = 1;
     }
     t.at(r1_, col + FP6_MUL_SELECTOR_OFFSET) = 0;
     const Fp2 c0 = x.c2(0), c1 = x.c2(1), c2 = x.c2(2), r0 = y.c2(0), r1 = y.c2(1), r2 = y.c2(2);
@@ -122,10 +123,11 @@ void fill_trace_fp6_multiplication(Trace& t, const Fp6& x, const Fp6& y, size_t 
     rows_addred(t, t19, t1, r0_, r1_, col + FP6_MUL_Z_CALC_OFFSET);
 }
 void fill_trace_multiply_by_1(Trace& t, const Fp6& x, const Fp2& b1, size_t r0, size_t r1, size_t col) {  // fp6.rs:312-340
-    for (size_t row = r0; row <= r1; row++) {
-        t.put(row, col + MULTIPLY_BY_1_INPUT_OFFSET, x);
-        t.put(row, col + MULTIPLY_BY_1_B1_OFFSET, b1);
-        t.at(row, col + MULTIPLY_BY_1_SELECTOR_OFFSET) = 1;
+    {
+        RowSpan rows_(t, r1 - r0 + 1);
+        t.put(r0, col + MULTIPLY_BY_1_INPUT_OFFSET, x);
+        t.put(r0, col + MULTIPLY_BY_1_B1_OFFSET, b1);
+        t.at(r0, col + MULTIPLY_BY_1_SELECTOR_OFFSET) = 1;
     }
     t.at(r1, col + MULTIPLY_BY_1_SELECTOR_OFFSET) = 0;
     const Fp2 c0 = x.c2(0), c1 = x.c2(1), c2 = x.c2(2);
@@ -136,11 +138,12 @@ void fill_trace_multiply_by_1(Trace& t, const Fp6& x, const Fp2& b1, size_t r0, 
     generate_trace_fp2_mul(t, c1, b1, r0, r1, col + MULTIPLY_BY_1_Z_CALC_OFFSET);
 }
 void fill_trace_multiply_by_01(Trace& t, const Fp6& x, const Fp2& b0, const Fp2& b1, size_t r0, size_t r1, size_t col) {  // fp6.rs:343-406
-    for (size_t row = r0; row <= r1; row++) {
-        t.put(row, col + MULTIPLY_BY_01_INPUT_OFFSET, x);
-        t.put(row, col + MULTIPLY_BY_01_B0_OFFSET, b0);
-        t.put(row, col + MULTIPLY_BY_01_B1_OFFSET, b1);
-        t.at(row, col + MULTIPLY_BY_01_SELECTOR_OFFSET) = 1;
+    {
+        RowSpan rows_(t, r1 - r0 + 1);
+        t.put(r0, col + MULTIPLY_BY_01_INPUT_OFFSET, x);
+        t.put(r0, col + MULTIPLY_BY_01_B0_OFFSET, b0);
+        t.put(r0, col + MULTIPLY_BY_01_B1_OFFSET, b1);
+        t.at(r0, col + MULTIPLY_BY_01_SELECTOR_OFFSET) = 1;
     }
     t.at(r1, col + MULTIPLY_BY_01_SELECTOR_OFFSET) = 0;
     const Fp2 c0 = x.c2(0), c1 = x.c2(1), c2 = x.c2(2);
@@ -168,15 +171,16 @@ void fill_trace_multiply_by_01(Trace& t, const Fp6& x, const Fp2& b0, const Fp2&
 }
 void fill_trace_fp6_forbenius_map(Trace& t, const Fp6& x, size_t pow, size_t r0, size_t r1, size_t col) {  // fp6.rs:409-441
     const size_t div = pow / 6, rem = pow % 6;
-    for (size_t row = r0; row <= r1; row++) {
-        t.put(row, col + FP6_FORBENIUS_MAP_INPUT_OFFSET, x);
-        t.at(row, col + FP6_FORBENIUS_MAP_SELECTOR_OFFSET) = 1;
-        t.at(row, col + FP6_FORBENIUS_MAP_POW_OFFSET) = pow;
-        t.at(row, col + FP6_FORBENIUS_MAP_DIV_OFFSET) = div;
-        t.at(row, col + FP6_FORBENIUS_MAP_REM_OFFSET) = rem;
-        t.at(row, col + FP6_FORBENIUS_MAP_BIT0_OFFSET) = rem & 1;
-        t.at(row, col + FP6_FORBENIUS_MAP_BIT1_OFFSET) = (rem >> 1) & 1;
-        t.at(row, col + FP6_FORBENIUS_MAP_BIT2_OFFSET) = rem >> 2;
+    {
+        RowSpan rows_(t, r1 - r0 + 1);
+        t.put(r0, col + FP6_FORBENIUS_MAP_INPUT_OFFSET, x);
+        t.at(r0, col + FP6_FORBENIUS_MAP_SELECTOR_OFFSET) = 1;
+        t.at(r0, col + FP6_FORBENIUS_MAP_POW_OFFSET) = pow;
+        t.at(r0, col + FP6_FORBENIUS_MAP_DIV_OFFSET) = div;
+        t.at(r0, col + FP6_FORBENIUS_MAP_REM_OFFSET) = rem;
+        t.at(r0, col + FP6_FORBENIUS_MAP_BIT0_OFFSET) = rem & 1;
+        t.at(r0, col + FP6_FORBENIUS_MAP_BIT1_OFFSET) = (rem >> 1) & 1;
+        t.at(r0, col + FP6_FORBENIUS_MAP_BIT2_OFFSET) = rem >> 2;
     }
     t.at(r1, col + FP6_FORBENIUS_MAP_SELECTOR_OFFSET) = 0;
     const Fp2 c0 = x.c2(0), c1 = x.c2(1), c2 = x.c2(2);

@@ -167,13 +167,14 @@ extern "C" int starkhip_trace_miller_loop(const uint32_t px[12], const uint32_t 
             for (size_t j = k * per_task; j < std::min(blocks, (k + 1) * per_task); j++) {
                 const size_t s_row = j * 12, e_row = (j + 1) * 12 - 1;
                 const Block& b = at[j];
-                for (size_t row = s_row; row <= e_row; row++) {
-                    if (j == 0) part.at(row, M::FIRST_BIT_SELECTOR_OFFSET) = 1;
-                    if (b.i == 0) part.at(row, M::LAST_BIT_SELECTOR_OFFSET) = 1;
-                    if (b.bitone) part.at(row, M::BIT1_SELECTOR_OFFSET) = 1;
-                    part.at(row, M::ELL_COEFFS_INDEX_OFFEST + j) = 1;
-                    for (size_t c = 0; c < 3; c++) part.put(row, M::ELL_COEFFS_OFFSET + c * 24, ell[j][c]);
-                    part.put(row, M::F12_OFFSET, b.f12);
+                {
+                    RowSpan rows_(part, e_row - s_row + 1);
+                    if (j == 0) part.at(s_row, M::FIRST_BIT_SELECTOR_OFFSET) = 1;
+                    if (b.i == 0) part.at(s_row, M::LAST_BIT_SELECTOR_OFFSET) = 1;
+                    if (b.bitone) part.at(s_row, M::BIT1_SELECTOR_OFFSET) = 1;
+                    part.at(s_row, M::ELL_COEFFS_INDEX_OFFEST + j) = 1;
+                    for (size_t c = 0; c < 3; c++) part.put(s_row, M::ELL_COEFFS_OFFSET + c * 24, ell[j][c]);
+                    part.put(s_row, M::F12_OFFSET, b.f12);
                 }
                 if (j != 0) part.at(s_row, M::FIRST_ROW_SELECTOR_OFFSET) = 1;
                 const bls::EllCoeff& e = ell[j];

@@ -28,29 +28,60 @@ struct Trace {
     uint64_t* d;
     size_t rows, cols;
     TraceLog* log;
+    // Row span (RowSpan below): every write at row r stands for the same write on rows r .. r + span - 1.  The reference fills a
+    // gadget that is constant over a 12-row block with `for row in start..=end { fill_*(row) }` (e.g. src/fp12.rs:96, src/fp2.rs:146-154):
+    // twelve times the same natives and the same cells.  The fillers here run the body ONCE under a span of twelve -- one record
+    // with a run of twelve rows when recording (what twelve consecutive put()s leave), twelve rows written when filling a matrix.
+    size_t span = 1;
     Trace(uint64_t* dense, size_t r, size_t c, TraceLog* l = nullptr) : d(dense), rows(r), cols(c), log(l) {}
     struct Cell {  // `t.at(row, col) = v`
         Trace& t;
         size_t row, col;
         void operator=(uint64_t v) {
-            if (t.log) t.log->set(row, col, v);
-            else t.d[row * t.cols + col] = v;
+            for (size_t r = row; r < row + t.span; r++) {
+                if (t.log) {
+                    if (v != 0 && t.span > 1) {  // a run of the same non-zero value
+                        if (v >> 32) throw std::runtime_error("trace_log: cell value does not fit 32 bits");
+                        const uint32_t w = (uint32_t)v;
+                        t.log->put_rows(row, t.span, col, &w, 1);
+                        return;
+                    }
+                    t.log->set(r, col, v);
+                } else {
+                    t.d[r * t.cols + col] = v;
+                }
+            }
         }
     };
     Cell at(size_t row, size_t col) { return Cell{*this, row, col}; }
-    void put(size_t row, size_t col, const uint32_t* v, size_t n) {
+    void put(size_t row, size_t col, const uint32_t* v, size_t n) { put_rows(row, span, col, v, n); }
+    // the same vector on n_rows consecutive rows (one record when recording)
+    void put_rows(size_t row, size_t n_rows, size_t col, const uint32_t* v, size_t n) {
         if (log) {
-            log->put(row, col, v, n);
+            log->put_rows(row, n_rows, col, v, n);
             return;
         }
-        uint64_t* p = d + row * cols + col;
-        for (size_t i = 0; i < n; i++) p[i] = v[i];
+        for (size_t r = row; r < row + n_rows; r++) {
+            uint64_t* p = d + r * cols + col;
+            for (size_t i = 0; i < n; i++) p[i] = v[i];
+        }
     }
+    void put_rows(size_t row, size_t n_rows, size_t col, const Fp12& v) { for (int i = 0; i < 12; i++) put_rows(row, n_rows, col + 12 * i, v.c[i].l.data(), 12); }
     void put(size_t row, size_t col, const L12& v) { put(row, col, v.data(), 12); }
     void put(size_t row, size_t col, const L24& v) { put(row, col, v.data(), 24); }
     void put(size_t row, size_t col, const Fp2& v) { put(row, col, v.c[0].l); put(row, col + 12, v.c[1].l); }
     void put(size_t row, size_t col, const Fp6& v) { for (int i = 0; i < 6; i++) put(row, col + 12 * i, v.c[i].l); }
     void put(size_t row, size_t col, const Fp12& v) { for (int i = 0; i < 12; i++) put(row, col + 12 * i, v.c[i].l); }
+};
+
+struct RowSpan {  // `{ RowSpan rows(t, n); fill_x(t, ..., first_row, col); }` == `for row in first_row .. first_row + n { fill_x(t, ..., row, col) }`
+    Trace& t;
+    size_t old;
+    RowSpan(Trace& tr, size_t n) : t(tr), old(tr.span) {
+        if (old != 1) throw std::runtime_error("trace: nested row spans");
+        t.span = n;
+    }
+    ~RowSpan() { t.span = old; }
 };
 
 // What a generator calls first: a zeroed dense matrix over the caller's buffer, or -- when the calling thread is armed by

@@ -104,6 +104,8 @@ int host_alloc(Ctx*, size_t, void**) { return STARKHIP_ERR_NO_DEVICE; }
 void host_free(void*) {}
 int quad_merged_tables_selfcheck(unsigned) { return 0; }  // the real one is compiled with the HIP sources
 
+hipError_t event_wait_sleeping(hipEvent_t) { return hipSuccess; }  // prover.hip's sleeping wait: the fake device is always done
+
 // the two launches the commitment scheduler makes
 static std::atomic<unsigned long> g_fake_launches(0), g_fake_merged(0);
 hipError_t launch_leaf_hash(const gl_t*, size_t, unsigned, unsigned, gl_t*, hipStream_t) { g_fake_launches++; return hipSuccess; }

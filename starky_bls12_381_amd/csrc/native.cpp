@@ -106,52 +106,78 @@ L24 mul_wide(const L12& x, const L12& y) {  // mul_fp_without_reduction, native.
     return r;
 }
 
-// Knuth algorithm D, base 2^32, fixed 12-limb divisor p.  x / p must fit 12 limbs
-// (get_div_rem_modulus_from_biguint_12, native.rs:277-281).
+// floor(x / p) and x mod p for the fixed 12-limb divisor p; x / p must fit 12 limbs (get_div_rem_modulus_from_biguint_12,
+// native.rs:277-281 -- BigUint division there; any exact long division gives the same two numbers).  Knuth's algorithm D on 64-bit
+// limbs -- six divisor limbs, one hardware 128 / 64 division per quotient limb -- and only as many quotient limbs as x has above p's
+// length: the reduce gadget's operands (twelve or thirteen 32-bit limbs: quotient below 16) and the subtraction's p + a - b take one
+// step, a product of two field elements seven.  Round 5 ran the 32-bit form over all thirteen positions whatever x was: a third of a
+// FinalExp recording (tools: build/prof, gprof).
 void div_rem_modulus(const L24& x, L12& div, L12& rem) {
-    const int n = 12, m = 24;
-    const int s = __builtin_clz(MODULUS[11]);
-    uint32_t v[12], u[25];
-    for (int i = n - 1; i > 0; i--) v[i] = (MODULUS[i] << s) | (s ? (MODULUS[i - 1] >> (32 - s)) : 0);
-    v[0] = MODULUS[0] << s;
-    u[m] = s ? (x[m - 1] >> (32 - s)) : 0;
-    for (int i = m - 1; i > 0; i--) u[i] = (x[i] << s) | (s ? (x[i - 1] >> (32 - s)) : 0);
-    u[0] = x[0] << s;
-    uint32_t q[13];
+    constexpr int n = 6, s = 3;  // p's top 64-bit limb 0x1a0111ea397fe69a has three leading zeros
+    static const uint64_t V[n] = {  // p << 3
+        (0xb9feffffffffaaabull << s),
+        (0x1eabfffeb153ffffull << s) | (0xb9feffffffffaaabull >> (64 - s)),
+        (0x6730d2a0f6b0f624ull << s) | (0x1eabfffeb153ffffull >> (64 - s)),
+        (0x64774b84f38512bfull << s) | (0x6730d2a0f6b0f624ull >> (64 - s)),
+        (0x4b1ba7b6434bacd7ull << s) | (0x64774b84f38512bfull >> (64 - s)),
+        (0x1a0111ea397fe69aull << s) | (0x4b1ba7b6434bacd7ull >> (64 - s))};
+    uint64_t X[12];
+    for (int i = 0; i < 12; i++) X[i] = (uint64_t)x[2 * i] | ((uint64_t)x[2 * i + 1] << 32);
+    int m = 12;
+    while (m > n && X[m - 1] == 0) m--;
+    uint64_t u[13], q[7] = {0, 0, 0, 0, 0, 0, 0};
+    u[m] = X[m - 1] >> (64 - s);
+    for (int i = m - 1; i > 0; i--) u[i] = (X[i] << s) | (X[i - 1] >> (64 - s));
+    u[0] = X[0] << s;
+    typedef unsigned __int128 u128;
     for (int j = m - n; j >= 0; j--) {
-        uint64_t num = ((uint64_t)u[j + n] << 32) | u[j + n - 1];
-        uint64_t qhat = num / v[n - 1], rhat = num % v[n - 1];
-        while (qhat >= (1ULL << 32) || qhat * v[n - 2] > ((rhat << 32) | u[j + n - 2])) {
+        uint64_t qhat, rhat;
+        bool check = true;
+        if (u[j + n] >= V[n - 1]) {  // == V[n - 1] (the running remainder is below the divisor): the quotient limb is 2^64 - 1 or 2^64 - 2
+            qhat = ~0ull;
+            const u128 r = (u128)u[j + n - 1] + V[n - 1];
+            rhat = (uint64_t)r;
+            check = (r >> 64) == 0;
+        } else {
+            asm("divq %4" : "=a"(qhat), "=d"(rhat) : "a"(u[j + n - 1]), "d"(u[j + n]), "r"(V[n - 1]) : "cc");
+        }
+        while (check && (u128)qhat * V[n - 2] > (((u128)rhat << 64) | u[j + n - 2])) {
             qhat--;
-            rhat += v[n - 1];
-            if (rhat >= (1ULL << 32)) break;
+            const u128 r = (u128)rhat + V[n - 1];
+            rhat = (uint64_t)r;
+            check = (r >> 64) == 0;
         }
-        int64_t borrow = 0;
-        uint64_t carry = 0;
+        uint64_t carry = 0, borrow = 0;
         for (int i = 0; i < n; i++) {
-            uint64_t p = qhat * v[i] + carry;
-            carry = p >> 32;
-            int64_t t = (int64_t)u[i + j] - (int64_t)(uint32_t)p + borrow;
-            u[i + j] = (uint32_t)t;
-            borrow = t >> 32;  // 0 or -1
+            const u128 pr = (u128)qhat * V[i] + carry;
+            carry = (uint64_t)(pr >> 64);
+            const uint64_t lo = (uint64_t)pr, t = u[i + j] - lo, t2 = t - borrow;
+            borrow = (u[i + j] < lo) | (t < borrow);
+            u[i + j] = t2;
         }
-        int64_t t = (int64_t)u[j + n] - (int64_t)carry + borrow;
-        u[j + n] = (uint32_t)t;
-        q[j] = (uint32_t)qhat;
-        if (t < 0) {
-            q[j]--;
+        const uint64_t t = u[j + n] - carry, t2 = t - borrow;
+        const bool negative = (u[j + n] < carry) | (t < borrow);
+        u[j + n] = t2;
+        if (negative) {  // qhat was one too large (probability ~ 2^-63): add the divisor back
+            qhat--;
             uint64_t c = 0;
             for (int i = 0; i < n; i++) {
-                uint64_t a = (uint64_t)u[i + j] + v[i] + c;
-                u[i + j] = (uint32_t)a;
-                c = a >> 32;
+                const u128 a = (u128)u[i + j] + V[i] + c;
+                u[i + j] = (uint64_t)a;
+                c = (uint64_t)(a >> 64);
             }
-            u[j + n] += (uint32_t)c;
+            u[j + n] += c;
         }
+        q[j] = qhat;
     }
-    if (q[12] != 0) throw std::runtime_error("div_rem_modulus: quotient does not fit 12 limbs");
-    for (int i = 0; i < 12; i++) div[i] = q[i];
-    for (int i = 0; i < n; i++) rem[i] = (u[i] >> s) | (s && i + 1 <= n ? (uint32_t)((uint64_t)u[i + 1] << (32 - s)) : 0);
+    if (q[6] != 0) throw std::runtime_error("div_rem_modulus: quotient does not fit 12 limbs");
+    for (int i = 0; i < 6; i++) {
+        div[2 * i] = (uint32_t)q[i];
+        div[2 * i + 1] = (uint32_t)(q[i] >> 32);
+        const uint64_t r = (u[i] >> s) | (u[i + 1] << (64 - s));
+        rem[2 * i] = (uint32_t)r;
+        rem[2 * i + 1] = (uint32_t)(r >> 32);
+    }
 }
 
 static bool less_than(const uint32_t* a, const uint32_t* b, int len) {  // big_arithmetic.rs big_less_than

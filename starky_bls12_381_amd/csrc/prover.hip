@@ -172,7 +172,7 @@ struct Ctx {
 // eight proofs in flight, 0.80 of the 0.84 CPU-seconds a context thread spends per FinalExp proof were inside that call (it yields, so it
 // only shows where CPUs are idle; where they are not, it takes them from the recordings, which run at nice 10).  The device phases it
 // waits for are milliseconds long, so: look a few times, then sleep in steps that grow from 20 to 200 microseconds.
-static hipError_t event_wait_sleeping(hipEvent_t ev) {
+hipError_t event_wait_sleeping(hipEvent_t ev) {
 #ifdef STARKHIP_RUNTIME_WAIT  // A/B builds: the runtime's own wait (rounds 3-4)
     return hipEventSynchronize(ev);
 #endif

@@ -7,6 +7,7 @@
 
 #include "blob_arena.h"
 
+#include <pthread.h>
 #include <sched.h>
 #include <sys/resource.h>
 #include <sys/syscall.h>
@@ -140,10 +141,28 @@ hipError_t HashService::hash(const gl_t* mat, size_t n_cols, unsigned log_n, uns
     }
     (r.big ? big_ : small_).push_back(&r);
     cv_.notify_all();
+    // Both hand-overs between the caller's stream and the service's go through the HOST: the caller sleeps until its own work has
+    // reached `ready` and says so; the service launches then; the caller sleeps until `done` and goes on enqueueing.  Round 5 used
+    // hipStreamWaitEvent both ways -- and a thread of the HIP runtime then polls for as long as a cross-stream dependence is pending:
+    // 0.92 of a core during the benchmark, 0.12 of its 0.33 CPU-seconds per proof (tools/experiments/runtime_spin_probe.hip: 65 % of a
+    // core with such waits, none without; no runtime setting changed it).  The request has JOINED its window already (groups form while
+    // the LDEs still run); what the host round trips cost is a few hundred microseconds of idle stream per commitment.
+    lk.unlock();
+    const hipError_t er = event_wait_sleeping(ready);
+    lk.lock();
+    r.ready_state = er == hipSuccess ? 1 : 2;
+    if (er != hipSuccess) r.err = er;
+    cv_done_.notify_all();
     cv_done_.wait(lk, [&] { return r.state != 0; });
     lk.unlock();
     if (r.state == 2) return r.err;
-    return hipStreamWaitEvent(st, done, 0);
+    return event_wait_sleeping(done);
+}
+
+hipError_t HashService::wait_ready(Req* r) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return r->ready_state != 0; });
+    return r->ready_state == 1 ? hipSuccess : r->err;
 }
 
 void HashService::drain(std::vector<hipEvent_t>& evs) {
@@ -155,7 +174,7 @@ void HashService::launch_big(Req* r, bool lane, unsigned group) {
     hipStream_t s = (r->urgent && st_high_) ? st_high_ : st_;
     hipError_t e = hipSuccess;
     if (lane) s = pick_small_stream(&e);  // lane-form grids are a quarter of the chip each: they must overlap, not queue in one stream
-    if (e == hipSuccess) e = hipStreamWaitEvent(s, r->ready, 0);
+    if (e == hipSuccess) e = wait_ready(r);
     if (r->timing) {
         r->timing->form = lane ? 3 : 5;
         r->timing->group = group;
@@ -224,7 +243,7 @@ void HashService::launch_small(std::vector<Req*>& reqs) {
             for (size_t i = 0; i < cnt && e == hipSuccess; i++) {
                 B.mat[i] = g[at + i]->mat;
                 B.digests[i] = g[at + i]->digests;
-                e = hipStreamWaitEvent(s, g[at + i]->ready, 0);
+                e = wait_ready(g[at + i]);
             }
             const bool row_form = row_leaves_ && (((size_t)1 << (g[0]->log_n + g[0]->rate_bits)) <= row_leaves_);
             for (size_t i = 0; i < cnt; i++)
@@ -261,6 +280,7 @@ void HashService::launch_small(std::vector<Req*>& reqs) {
 double HashService::big_wait_bound() const { return big_expected_ > 0 ? big_gather_ms_ : std::min(big_gather_ms_, big_queued_wait_ms_); }
 
 void HashService::run() {
+    pthread_setname_np(pthread_self(), "starkhip-hash");  // thread names: bench.py attributes host CPU time by them
     (void)hipSetDevice(device_);
     int least = 0, greatest = 0;
     if (hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) != hipSuccess) st_ = nullptr;
@@ -499,6 +519,7 @@ struct Pool {
     }
 
     void generator_loop() {
+        pthread_setname_np(pthread_self(), "starkhip-gen");
         // Recording is the work that can wait: whenever the process is short of CPUs (16 per GPU on the measured boxes, and a batch
         // starts with four FinalExp recordings' worth of threads), the threads that feed the GPU -- the contexts' own: gathering a
         // recording for its upload, the challenger's hashing between two kernels -- must run first.  Per-thread nice value, inherited
@@ -598,6 +619,7 @@ struct Pool {
     }
 
     void prover_loop(Ctx* c, bool big) {
+        pthread_setname_np(pthread_self(), big ? "starkhip-ctx" : "starkhip-ctxs");
         std::deque<Job*>& q = big ? q_big : q_small;
         std::condition_variable& cv = big ? cv_big : cv_small;
         std::map<int, int>& idle = big ? idle_big : idle_small;

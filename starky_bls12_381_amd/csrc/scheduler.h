@@ -25,6 +25,7 @@
 namespace starkhip {
 
 unsigned cpu_budget();  // CPUs this process may really use (cgroup quota, affinity mask; scheduler.cpp)
+hipError_t event_wait_sleeping(hipEvent_t ev);  // prover.hip: a few queries, then sleeps of 20 .. 200 microseconds between them
 
 class HashService {
   public:
@@ -94,12 +95,14 @@ class HashService {
         hipEvent_t ready, done;
         bool big, urgent = false;
         int state = 0;  // 0 queued, 1 launched, 2 failed
+        int ready_state = 0;  // 0: the work that produces `mat` is still running (`ready` not reached), 1: it has run, 2: it failed (under mu_)
         hipError_t err = hipSuccess;
         double t_arrive = 0;
         Timing* timing = nullptr;
     };
     void run();
     double big_wait_bound() const;  // under mu_: how long the oldest queued big commitment waits at most for its group to fill
+    hipError_t wait_ready(Req* r);  // the service thread, before it launches r's kernel: sleeps until r's caller has seen `ready`
     void launch_big(Req* r, bool lane, unsigned group);
     void launch_small(std::vector<Req*>& reqs);
     void drain(std::vector<hipEvent_t>& evs);

@@ -38,16 +38,19 @@ struct TraceLog {
         open.assign(c, 0);
     }
 
-    void put(size_t row, size_t col, const uint32_t* v, size_t n) {
+    void put(size_t row, size_t col, const uint32_t* v, size_t n) { put_rows(row, 1, col, v, n); }
+    // the same vector on rows row .. row + n_rows - 1: exactly the record n_rows consecutive put()s leave (a generator that knows a
+    // block is constant over the rows -- FinalExp's input and its 32 intermediate Fp12, on all 8192 rows -- says so in one call)
+    void put_rows(size_t row, size_t n_rows, size_t col, const uint32_t* v, size_t n) {
         while (n && v[n - 1] == 0) n--;
         while (n && v[0] == 0) { v++; col++; n--; }
-        if (!n) return;
-        if (row >= rows || col + n > cols) throw std::runtime_error("trace_log: write outside the trace");
+        if (!n || !n_rows) return;
+        if (row + n_rows > rows || col + n > cols) throw std::runtime_error("trace_log: write outside the trace");
         const uint32_t o = open[col];
         if (o) {
             uint32_t* r = &words[o - 1];
             if (r[3] == n && r[1] + r[2] == row && memcmp(r + 4, v, n * sizeof(uint32_t)) == 0) {
-                r[2]++;
+                r[2] += (uint32_t)n_rows;
                 return;
             }
         }
@@ -56,7 +59,7 @@ struct TraceLog {
         open[col] = (uint32_t)words.size() + 1;
         words.push_back((uint32_t)col);
         words.push_back((uint32_t)row);
-        words.push_back(1);
+        words.push_back((uint32_t)n_rows);
         words.push_back((uint32_t)n);
         words.insert(words.end(), v, v + n);
     }

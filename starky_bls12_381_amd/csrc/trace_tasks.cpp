@@ -4,6 +4,7 @@
 // chain (milliseconds), each block's rows depend only on its operands.  A generator therefore describes its work as tasks
 // over disjoint cells; when it records and more than one thread is allowed, the tasks are filled into logs of their own and
 // taken over in task order (nothing copied), so the result is the same for any thread count > 1 and any timing.
+#include <pthread.h>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -50,6 +51,7 @@ void fill_tasks(Trace& t, size_t n_tasks, const std::function<void(Trace&, size_
     };
     std::vector<std::thread> pool;
     auto helper = [&] {
+        pthread_setname_np(pthread_self(), "starkhip-rec");
         worker();
         g_trace_worker_cpu_ns.fetch_add(thread_cpu_ns());  // a fresh thread: its clock started at zero
     };

@@ -232,7 +232,10 @@ def test_failures_of_final_exp_class_jobs_inside_lane_groups():
         assert e.value.code == S.ERR_BAD_SHAPE
         got = [pool.wait(t) for t in t_good]
         assert [sha(p) for p, _ in got] == [want] * 3
-        assert {i["leaf_hash_form"] for _, i in got} == {"lane"} and {i["leaf_hash_group"] for _, i in got} == {3}
+        # the three go out together -- unless the first had reached its commitment before this thread had submitted the others (seen once
+        # in the full suite, never alone: the submissions are four Python calls): then it goes out alone in the pair form and the two others as a group
+        forms = sorted((i["leaf_hash_form"], i["leaf_hash_group"]) for _, i in got)
+        assert forms in ([("lane", 3)] * 3, [("lane", 2), ("lane", 2), ("pair", 1)]), forms
         assert all(i["timeline_s"][4] - i["timeline_s"][3] < 1.0 for _, i in got), [i["timeline_s"] for _, i in got]   # nobody waited 1 s for the one that withdrew
         # 3.
         t_ecc = pool.submit(S.AIR_ECC_AGGREGATE, ecc_cfg, ecc_bad, ecc_pis)
