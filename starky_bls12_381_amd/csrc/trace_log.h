@@ -14,10 +14,49 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <stdexcept>
 #include <vector>
 
 namespace starkhip {
+
+// The word vectors of finished logs, kept for the next recording.  A FinalExp recording writes 142 MB of records into vectors that grow
+// by doubling -- 100 000 page faults and as many pages unmapped again when the log is freed: 0.25 s of kernel time beside 0.41 s of
+// recording (build/prof, getrusage), every time, because the allocator hands blocks of this size straight back to the system.  A log
+// returns its vectors here instead (capacity kept, at most TRACE_LOG_POOL_BYTES in all) and a new log takes the largest one.
+struct TraceLogWordPool {
+    static constexpr size_t TRACE_LOG_POOL_BYTES = (size_t)3 << 30;
+    enum Kind { WORDS = 0, OFFSETS = 1, OPEN = 2 };  // a list per use: the three differ by an order of magnitude in size
+    std::mutex mu;
+    std::vector<std::vector<uint32_t>> free_list[3];
+    size_t bytes = 0;
+    static TraceLogWordPool& instance() {
+        static TraceLogWordPool* p = new TraceLogWordPool();  // never destroyed: logs may be freed during process exit
+        return *p;
+    }
+    std::vector<uint32_t> take(Kind k) {
+        std::lock_guard<std::mutex> g(mu);
+        std::vector<std::vector<uint32_t>>& fl = free_list[k];
+        if (fl.empty()) return {};
+        size_t best = 0;
+        for (size_t i = 1; i < fl.size(); i++)
+            if (fl[i].capacity() > fl[best].capacity()) best = i;
+        std::vector<uint32_t> v = std::move(fl[best]);
+        fl[best] = std::move(fl.back());
+        fl.pop_back();
+        bytes -= v.capacity() * sizeof(uint32_t);
+        v.clear();
+        return v;
+    }
+    void give(Kind k, std::vector<uint32_t>&& v) {
+        const size_t b = v.capacity() * sizeof(uint32_t);
+        if (b < ((size_t)64 << 10)) return;  // small blocks stay with the allocator
+        std::lock_guard<std::mutex> g(mu);
+        if (bytes + b > TRACE_LOG_POOL_BYTES || free_list[k].size() >= 4096) return;  // over the limit: freed as before
+        bytes += b;
+        free_list[k].push_back(std::move(v));
+    }
+};
 
 struct TraceLog {
     size_t rows, cols;
@@ -27,9 +66,23 @@ struct TraceLog {
     std::vector<uint32_t> late_zeros;  // (col, row) pairs zeroed after everything else (see set())
 
     TraceLog() : rows(0), cols(0) {}
+    TraceLog(TraceLog&&) = default;
+    TraceLog& operator=(TraceLog&&) = default;
+    TraceLog(const TraceLog&) = default;
+    TraceLog& operator=(const TraceLog&) = default;
+    ~TraceLog() {
+        TraceLogWordPool& pool = TraceLogWordPool::instance();
+        pool.give(TraceLogWordPool::WORDS, std::move(words));
+        pool.give(TraceLogWordPool::OFFSETS, std::move(offsets));
+        pool.give(TraceLogWordPool::OPEN, std::move(open));
+    }
     void reset(size_t r, size_t c) {
         rows = r;
         cols = c;
+        TraceLogWordPool& pool = TraceLogWordPool::instance();
+        if (words.capacity() == 0) words = pool.take(TraceLogWordPool::WORDS);
+        if (offsets.capacity() == 0) offsets = pool.take(TraceLogWordPool::OFFSETS);
+        if (open.capacity() == 0) open = pool.take(TraceLogWordPool::OPEN);
         words.clear();
         offsets.clear();
         late_zeros.clear();
@@ -95,6 +148,7 @@ struct TraceLog {
         if (at + part.words.size() > 0xFFFFFFF0u) throw std::runtime_error("trace_log: log too large");
         part.base = (uint32_t)at;
         for (uint32_t& o : part.offsets) o += part.base;
+        TraceLogWordPool::instance().give(TraceLogWordPool::OPEN, std::move(part.open));
         part.open = std::vector<uint32_t>();
         parts.push_back(std::move(part));
         std::fill(open.begin(), open.end(), 0);  // no run of this log may be extended past records that came later

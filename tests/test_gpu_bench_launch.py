@@ -56,15 +56,18 @@ def test_bench_devices_in_process_prints_the_same_line_from_one_process():
 
 def test_bench_under_a_two_cpu_mask_reports_the_budget_and_still_verifies():
     """A host with two CPUs for the process (plain `taskset` on the command -- NOT under rocprofv3): the line must say so (cpus_granted, the
-    pool's budget and threads, CPU-seconds per proof) and the proofs must still verify and match; the rate is whatever two CPUs feed."""
+    pool's budget and threads, CPU-seconds per proof) and the proofs must still verify and match.  Two CPUs now feed the GPU: round 6 brought
+    the host cost from 0.45 to 0.16 - 0.20 CPU-seconds per proof (recordings 0.27 -> 0.12, the runtime thread that polled during cross-stream
+    waits gone), and the pool keeps 7.4 proofs/s on two CPUs where round 5 kept 5.4 (profiles/r06_cpu_sensitivity.txt; 24 steps).  The
+    bounds below leave room for a slower box and for the ramp of a 24-proof run."""
     cpus = sorted(os.sched_getaffinity(0))
     if len(cpus) < 2:
         pytest.skip("fewer than two CPUs")
     mask = ",".join(str(c) for c in cpus[:2])
-    d = _bench(["--steps", 16, "--warmup", 1, "--no-cpu-baseline", "--no-boundary", "--no-solo"], prefix=("taskset", "-c", mask))
+    d = _bench(["--steps", 24, "--warmup", 1, "--no-cpu-baseline", "--no-boundary", "--no-solo"], prefix=("taskset", "-c", mask))
     h = d["host"]
     assert h["cpus_granted"] == 2 and h["cpu_budget_process"] == 2 and h["pools"][0]["cpu_budget"] == 2
     assert h["pools"][0]["generator_threads"] >= 1 and h["pools"][0]["trace_threads_big"] == 1     # 3/4 of two CPUs: one thread per FinalExp recording
-    assert 0.05 < h["cpu_seconds_per_proof"] < 2.0
+    assert 0.05 < h["cpu_seconds_per_proof"] < 0.30
     assert d["timed_proofs_verified"] == 8 and d["oracle_digest_match"] is True
-    assert d["value"] > 0.5 and d["value_steady_state"] is None    # 16 proofs are two waves of the eight-context pool: no middle to speak of
+    assert d["value"] >= 6.5, d["value"]    # measured 7.0 - 7.4 with two CPUs (round 5: 5.4)
