@@ -32,7 +32,9 @@ Prints ONE JSON line on rank 0.  What is measured where (DESIGN.md section 6 has
                           per pool (the pool's start and tail dropped); null when the run is shorter than three waves
   host                    what the host side had: CPUs granted, the pool's CPU budget and threads, process CPU-seconds per proof in the
                           timed region -- so that a scaling curve that bends can be attributed to host or device
-  per_rank                --gpus N > 1: every rank's own proofs/s and CPU budget (value stays all ranks' proofs / the slowest rank's time)
+  per_rank                --gpus N > 1: every rank's own proofs/s, CPU budget, device ordinal and PCI address (value stays all ranks' proofs /
+                          the slowest rank's time); process_group / rccl_ranks: the backend and the ranks torch.distributed counts;
+                          devices_distinct: N ranks on N devices (false in a rehearsal on one card)
 """
 import argparse
 import json
@@ -260,6 +262,9 @@ def main():
     air = S.AIR_FINAL_EXP
     cfg = S.StarkConfig.for_air(air)
     C, n = S.air_columns(air), S.air_default_rows(air)
+    # the LDE kernel these options and this shape take (csrc/prover.hip run_lde_trace): 8192 rows go through the wave-resident kernel
+    # unless "lde_impl" = 1 is set (bench.py never sets it); every other power of two from 2^8 on through lde_columns_v2_kernel
+    LDE_KERNEL = "lde_columns_wave_kernel" if n == 8192 else "lde_columns_v2_kernel"
     log_n = n.bit_length() - 1
     N = n << cfg.rate_bits
 
@@ -355,7 +360,7 @@ def main():
             phase_ms[name] += v
         hk = FORM_KERNEL[info["leaf_hash_form"]]
         timed_kernel_ms.setdefault(hk, []).append(info["kernel_ms"]["leaf_hash"])
-        timed_kernel_ms.setdefault("lde_columns_wave_kernel", []).append(info["kernel_ms"]["lde_columns"])
+        timed_kernel_ms.setdefault(LDE_KERNEL, []).append(info["kernel_ms"]["lde_columns"])
         timed_kernel_ms.setdefault("quotient_tiles_kernel", []).append(info["kernel_ms"]["quotient_eval"])
         if info["leaf_hash_form"] == "lane":
             timed_groups.append(info["leaf_hash_group"])
@@ -375,7 +380,14 @@ def main():
     elapsed = parallel.max_over_ranks(dist, elapsed_own, device=reduce_device)
     # every rank's own rate and CPU budget, for rank 0's line (N > 1: a bent curve must be attributable to a rank and to host or device)
     host_info = pool.host_info()
-    per_rank = parallel.gather_over_ranks(dist, [total_steps / elapsed_own, float(host_info[0]["cpu_budget"]), cpu_s_per_proof], device=reduce_device)
+    # ... and the device it ran on: ordinal and PCI address (domain << 16 | bus << 8 | device), so that the line shows N ranks on N devices
+    dev_ordinal = torch.cuda.current_device()
+    props = torch.cuda.get_device_properties(dev_ordinal)
+    pci = (int(getattr(props, "pci_domain_id", 0)) << 16) | (int(getattr(props, "pci_bus_id", 0)) << 8) | int(getattr(props, "pci_device_id", 0))
+    per_rank = parallel.gather_over_ranks(dist, [total_steps / elapsed_own, float(host_info[0]["cpu_budget"]), cpu_s_per_proof, float(dev_ordinal), float(pci)],
+                                          device=reduce_device)
+    group = ({"backend": str(dist.get_backend()), "ranks": int(dist.get_world_size()),
+              "collectives_in_timed_region": "the two barriers that bracket it; no data-path collective (proof-parallel)"} if dist is not None else None)
     # steady state: per pool, the completions after its first `inflight` and up to its last `inflight` -- start-up and tail dropped
     steady, steady_n = 0.0, 0
     for times in done_by_slot.values():
@@ -411,7 +423,7 @@ def main():
         alg = {"lde_columns": 8.0 * C * (n + N),  # read values, write the LDE (IFFT and LDE fused in one kernel; round 4: no coefficients kept)
                "leaf_hash": 8.0 * C * N,              # read the LDE once
                "quotient_eval": 8.0 * C * N}          # read the LDE on the quotient coset once
-        alg_by_kernel = {"lde_columns_wave_kernel": alg["lde_columns"], "quotient_tiles_kernel": alg["quotient_eval"]}
+        alg_by_kernel = {LDE_KERNEL: alg["lde_columns"], "quotient_tiles_kernel": alg["quotient_eval"]}
         for kname in FORM_KERNEL.values():
             alg_by_kernel[kname] = alg["leaf_hash"]
         perms = (C + 7) // 8 * N
@@ -439,9 +451,12 @@ def main():
         dom_ms = sum(timed_kernel_ms[dom]) / len(timed_kernel_ms[dom])
         side = (sum(timed_groups) / len(timed_groups)) if (dom == "leaf_hash_lane_kernel" and timed_groups) else 1.0
         per_launch_gbs = alg_by_kernel[dom] / (dom_ms * 1e-3) / 1e9
-        pmc_key = {"leaf_hash_lane_kernel": "leaf_hash_lane", "leaf_hash_kernel": "leaf_hash", "leaf_hash_pair_kernel": "leaf_hash", "lde_columns_wave_kernel": "lde_columns",
+        pmc_key = {"leaf_hash_lane_kernel": "leaf_hash_lane", "leaf_hash_kernel": "leaf_hash", "leaf_hash_pair_kernel": "leaf_hash", LDE_KERNEL: "lde_columns",
                    "quotient_tiles_kernel": "quotient_eval"}.get(dom)
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": per_launch_gbs * side, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # `bound`: what limits the kernel.  Every heavy kernel of this prover is limited by the SIMDs' vector instruction issue (64-bit modular
+        # arithmetic out of 32-bit multiply-adds), not by HBM or the matrix pipe; achieved / peak / frac / traffic stay on the HBM axis, as the
+        # benchmark contract prescribes for a byte-moving path, and the `valu` block gives the fraction of the issue peak
+        roofline = {"bound": "valu-issue", "bound_axis_of_achieved_peak_frac": "hbm", "kernel": dom, "achieved": per_launch_gbs * side, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": per_launch_gbs * side / HBM_PEAK_GBS, "traffic": pmc.get(pmc_key),
                     "traffic_source": pmc_src, "traffic_stale_for": pmc_stale or None,
                     "algorithmic_bytes_per_launch": alg_by_kernel[dom], "avg_launch_ms": dom_ms, "launches_timed": len(timed_kernel_ms[dom]),
@@ -451,12 +466,11 @@ def main():
                                     "launch holds a quarter of the chip's registers; `achieved_per_launch` is the plain quotient)"
                                     if side > 1 else "algorithmic bytes per launch / average launch duration"),
                     "durations": (f"HIP events on the launch stream, the {len(timed_kernel_ms[dom])} launches of the timed region ({inflight} proofs in flight per device); "
-                                  "the other proofs' kernels run beside these launches at a raised issue priority (csrc/kernels.h), so a launch is "
-                                  "longer than the same launches with the chip to themselves while the proofs/s are higher"),
-                    "bound_note": ("`bound` names the contract's memory roofline; the limiter of this kernel is the SIMDs' instruction issue -- the `valu` block "
-                                   "is its fraction of that peak" if dom.startswith("leaf_hash") else None),
+                                  "the other proofs' kernels run beside these launches, so a launch is longer than the same launches with the chip to "
+                                  "themselves while the proofs/s are higher"),
+                    "bound_note": "achieved / peak / frac are algorithmic bytes against the 8 TB/s of HBM (the contract's axis); the kernel's limiter is `bound`",
                     "share_of_timed_kernel_time": {k: sum(v) for k, v in timed_kernel_ms.items()},
-                    "limiter": "integer VALU issue" if dom.startswith("leaf_hash") else "see kernels"}
+                    "limiter": "integer VALU issue"}
         POSEIDON_LANE_SLOTS = poseidon_lane_slots()
         if dom == "leaf_hash_lane_kernel" and POSEIDON_LANE_SLOTS:
             slots = perms / 64.0 * POSEIDON_LANE_SLOTS
@@ -529,7 +543,11 @@ def main():
                               "process CPU time over the timed region / proofs; by_role: recording = inside starkhip_trace_* on the generator threads and their helpers, "
                               "proving = the context threads inside prove() (launches, Fiat-Shamir sponge, upload gather), runtime_and_caller = the rest (the HIP "
                               "runtime's own threads, this script)")},
-            "per_rank": ([{"rank": r, "proofs_per_s": v[0], "cpu_budget": int(v[1]), "cpu_seconds_per_proof": v[2]} for r, v in enumerate(per_rank)]
+            "process_group": group,  # --gpus N > 1: the backend torch.distributed runs on ("nccl" = RCCL) and the ranks IT counts
+            "rccl_ranks": (group["ranks"] if group and group["backend"] == "nccl" else None),
+            "devices_distinct": (len({int(v[4]) for v in per_rank}) == len(per_rank) if world > 1 else None),  # False in a rehearsal on one card
+            "per_rank": ([{"rank": r, "proofs_per_s": v[0], "cpu_budget": int(v[1]), "cpu_seconds_per_proof": v[2], "device_ordinal": int(v[3]),
+                           "pci": "%04x:%02x:%02x" % (int(v[4]) >> 16, (int(v[4]) >> 8) & 0xFF, int(v[4]) & 0xFF)} for r, v in enumerate(per_rank)]
                          if world > 1 else None),
             "per_rank_min_max": ([min(v[0] for v in per_rank), max(v[0] for v in per_rank)] if world > 1 else None),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

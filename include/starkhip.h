@@ -269,6 +269,9 @@ int starkhip_pool_reservation(void* pool, starkhip_pool_reservation_t* out);
 typedef struct {
     unsigned cpu_budget, generator_threads, trace_threads_big, trace_threads_small, prover_threads;
     int device;
+    unsigned pools_on_device; /* pools of the same multi-device handle on this pool's device: 1, unless the handle was given one ordinal
+                               * several times -- the rehearsal of N devices on one card (the tests do it); such a handle's figures are not a
+                               * measurement of N devices, and starkhip_multipool_create says so once on stderr */
 } starkhip_pool_host_info_t;
 int starkhip_pool_host_info(void* pool, starkhip_pool_host_info_t* out);
 unsigned starkhip_cpu_budget(void);
@@ -332,8 +335,9 @@ double starkhip_air_cost(starkhip_air_t air);
 #define STARKHIP_N_PHASES 11
 int starkhip_last_timings(void* ctx, float ms[STARKHIP_N_PHASES]);
 /* durations (ms, HIP events on the launch stream) of the three heavy kernels of the last prove:
- * [0] lde_columns_v2_kernel (trace: the sum of its launches) [1] the trace commitment's leaf hash in the form it went out in
- * (leaf_hash_kernel / _row_kernel / _lane_kernel / merged) [2] quotient_tiles_kernel */
+ * [0] the trace's LDE kernel, the sum of its launches (lde_columns_wave_kernel for 8192 rows, lde_columns_v2_kernel for the other sizes
+ * from 2^8 on and with "lde_impl" = 1) [1] the trace commitment's leaf hash in the form it went out in (leaf_hash_kernel / _row_kernel /
+ * _lane_kernel / _pair_kernel / merged) [2] quotient_tiles_kernel */
 int starkhip_last_kernel_timings(void* ctx, float ms[3]);
 /* host time (ms, wall) inside the last prove: [0] Fiat-Shamir hashing -- the challenger's sequential Poseidon sponge over the
  * caps, the 2 (2 C + Q) opening words and the FRI data, on the proof's critical path (it falls inside the device phases

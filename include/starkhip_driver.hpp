@@ -244,8 +244,17 @@ class Pool {
         std::vector<const uint32_t*> ptr;
         std::vector<size_t> len;
         for (const auto& o : operands) { ptr.push_back(o.data()); len.push_back(o.size()); }
-        check("starkhip_multipool_submit_witness_batch",
-              starkhip_multipool_submit_witness_batch(pool_, airs.size(), airs.data(), ptr.data(), len.data(), STARKHIP_POW_SEARCH, t.data(), nullptr));
+        const int rc = starkhip_multipool_submit_witness_batch(pool_, airs.size(), airs.data(), ptr.data(), len.data(), STARKHIP_POW_SEARCH, t.data(), nullptr);
+        if (rc != STARKHIP_OK) {  // not all-or-nothing: the jobs that were accepted run -- wait for them and drop their proofs before the error goes up
+            for (uint64_t id : t) {
+                if (!id) continue;
+                uint64_t* blob = nullptr;
+                size_t words = 0;
+                starkhip_ticket_info_t info;
+                if (starkhip_multipool_wait(pool_, id, &blob, &words, &info) == STARKHIP_OK) starkhip_free(blob);
+            }
+        }
+        check("starkhip_multipool_submit_witness_batch", rc);
         return t;
     }
     // the finished proof of `ticket`; verify = the reference's verify_stark_proof(..).unwrap() right after prove

@@ -638,7 +638,7 @@ def hw_queues_late():
 
 
 class PoolHostInfo(C.Structure):
-    _fields_ = [(n, C.c_uint) for n in ("cpu_budget", "generator_threads", "trace_threads_big", "trace_threads_small", "prover_threads")] + [("device", C.c_int)]
+    _fields_ = [(n, C.c_uint) for n in ("cpu_budget", "generator_threads", "trace_threads_big", "trace_threads_small", "prover_threads")] + [("device", C.c_int), ("pools_on_device", C.c_uint)]
 
 
 lib.starkhip_pool_host_info.argtypes = [C.c_void_p, C.POINTER(PoolHostInfo)]
@@ -799,7 +799,16 @@ class ProofPool:
         lens = (C.c_size_t * n)(*[o.size for o in ops])
         tickets = (C.c_uint64 * n)()
         rcs = (C.c_int * n)()
-        _chk(lib.starkhip_multipool_submit_witness_batch(self._h, n, airs, ptrs, lens, pow_witness, tickets, rcs))
+        rc = lib.starkhip_multipool_submit_witness_batch(self._h, n, airs, ptrs, lens, pow_witness, tickets, rcs)
+        if rc != 0:
+            # the call is not all-or-nothing: the jobs it accepted are running.  Wait for them and drop their proofs before the error
+            # goes up (the Rust binding does the same by building its tickets first) -- a ticket nobody holds could never be freed
+            for t in tickets:
+                if int(t):
+                    out, words, info = _u64p(), C.c_size_t(), TicketInfo()
+                    if lib.starkhip_multipool_wait(self._h, int(t), C.byref(out), C.byref(words), C.byref(info)) == 0:
+                        lib.starkhip_free(out)
+            _chk(rc)
         return [int(t) for t in tickets]
 
     def wait(self, ticket, keep=True):

@@ -1,4 +1,6 @@
 // extern "C" surface of libstarkhip.so (declared in include/starkhip.h).
+#include <dirent.h>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -343,28 +345,37 @@ int starkhip_prove_compact(void* ctx, starkhip_air_t air, const starkhip_config_
 // itself, earlier (bench.py does).
 static std::atomic<int> g_hw_queues_late(-1);
 static bool hip_runtime_is_up() {
-    char link[64], target[256];
-    for (int fd = 0; fd < 1024; fd++) {
-        snprintf(link, sizeof link, "/proc/self/fd/%d", fd);
+    DIR* d = opendir("/proc/self/fd");  // every descriptor, whatever its number (a server may hold thousands)
+    if (!d) return false;
+    bool up = false;
+    char link[300], target[256];
+    while (const dirent* e = readdir(d)) {
+        if (e->d_name[0] == '.') continue;
+        snprintf(link, sizeof link, "/proc/self/fd/%s", e->d_name);
         const ssize_t n = readlink(link, target, sizeof target - 1);
         if (n <= 0) continue;
         target[n] = 0;
-        if (strcmp(target, "/dev/kfd") == 0) return true;
+        if (strcmp(target, "/dev/kfd") == 0) {
+            up = true;
+            break;
+        }
     }
-    return false;
+    closedir(d);
+    return up;
 }
 static void ask_for_hw_queues() {
-    if (g_hw_queues_late.load() >= 0) return;  // decided with the first pool
-    int late = 0;
-    if (!getenv("GPU_MAX_HW_QUEUES")) {
-        late = hip_runtime_is_up() ? 1 : 0;
-        setenv("GPU_MAX_HW_QUEUES", "16", 0);
-        if (late)
-            fprintf(stderr, "starkhip: the HIP runtime was initialised before the first pool could set GPU_MAX_HW_QUEUES=16; pools run on HIP's "
-                            "default of 4 hardware queues (about 6 %% slower). Export GPU_MAX_HW_QUEUES=16 before the process first uses HIP.\n");
-    }
-    int expected = -1;
-    g_hw_queues_late.compare_exchange_strong(expected, late);
+    static std::once_flag once;  // decided with the first pool, by one thread (setenv beside another thread's getenv is a race)
+    std::call_once(once, [] {
+        int late = 0;
+        if (!getenv("GPU_MAX_HW_QUEUES")) {
+            late = hip_runtime_is_up() ? 1 : 0;
+            setenv("GPU_MAX_HW_QUEUES", "16", 0);
+            if (late)
+                fprintf(stderr, "starkhip: the HIP runtime was initialised before the first pool could set GPU_MAX_HW_QUEUES=16; pools run on HIP's "
+                                "default of 4 hardware queues (about 6 %% slower). Export GPU_MAX_HW_QUEUES=16 before the process first uses HIP.\n");
+        }
+        g_hw_queues_late.store(late);
+    });
 }
 int starkhip_hw_queues_status(void) { return std::max(0, g_hw_queues_late.load()); }
 

@@ -103,7 +103,10 @@ inline void build_poseidon_merged_fours(PoseidonMergedFours& T) {
     for (int g = 0; g < 12; g++) {
         unsigned __int128 tot = T.N3[g][0] + T.N2[g][0] + T.M[g][0];
         for (int j = 0; j < 12; j++) tot += T.N4[g][j];
-        if ((tot * 0xFFFFFFFFull + 0xFFFFFFFFull) >> 64) T.sums_fit = false;
+        // the bound the FOLD needs, not only "the accumulators fit 64 bits": fold_big (tools/gen_lane_round_asm.py, gen_pair_round_asm.py)
+        // adds B_hi + carry with the carry-out dropped, which is right for B < 2^64 - 2^32 (today's constants give 0.83 * 2^64)
+        const unsigned __int128 limit = ((unsigned __int128)1 << 64) - ((unsigned __int128)1 << 32);
+        if (tot * 0xFFFFFFFFull + 0xFFFFFFFFull >= limit) T.sums_fit = false;
     }
     auto matvec_mod = [](const uint64_t (&a)[12][12], const gl_t* v, gl_t* o) {
         for (int i = 0; i < 12; i++) {

@@ -458,6 +458,7 @@ int run_generator(int air, const uint32_t* w, size_t n_rows, uint64_t* pis, uint
 
 struct Pool {
     int device = 0;
+    unsigned pools_on_device = 1;  // > 1: a multi-device handle was given this ordinal several times (starkhip_pool_host_info)
     double t0 = 0;
     std::unique_ptr<HashService> hs;
     std::vector<Ctx*> big_ctx, small_ctx;
@@ -748,7 +749,9 @@ int pool_create(const starkhip_pool_config_t& cfg_in, Pool** out, unsigned cpu_s
     // recording is host work the GPU waits for, but the CPU budget is shared with the prover threads (Fiat-Shamir hashing, kernel
     // launches): a quarter of the budget in recordings at once (at least 3), each on a few threads (trace_threads_for_call)
     p->cpus = std::max(1u, cpu_budget() / std::max(1u, cpu_share));  // cpu_share: pools of one multi-device handle share the process's CPUs
-    p->gen_threads = cfg.generator_threads ? cfg.generator_threads : std::min(12u, std::max(3u, p->cpus / 4));
+    // (the floor of three is capped by the budget itself: eight pools of a multi-device handle on sixteen CPUs plan with two each, and
+    // three generator threads apiece would be 24 recording threads on those sixteen)
+    p->gen_threads = cfg.generator_threads ? cfg.generator_threads : std::min(12u, std::max(std::min(3u, p->cpus), p->cpus / 4));
     p->trace_threads_cfg = cfg.trace_threads;
     int rc = STARKHIP_OK;
     for (unsigned i = 0; i < n_big + n_small && rc == STARKHIP_OK; i++) {
@@ -986,6 +989,7 @@ int pool_host_info(Pool* p, starkhip_pool_host_info_t* out) {
     out->trace_threads_small = (unsigned)p->trace_threads_for_call(false);
     out->prover_threads = (unsigned)(p->big_ctx.size() + p->small_ctx.size());
     out->device = p->device;
+    out->pools_on_device = p->pools_on_device;
     return STARKHIP_OK;
 }
 
@@ -1042,6 +1046,19 @@ int multipool_create(const int* devices, size_t n, const starkhip_pool_config_t&
     }
     mp->pools = made;
     mp->devices.assign(devices, devices + n);
+    // one ordinal given several times: a rehearsal of the multi-device control flow on one card.  Legitimate (the tests do it), but its
+    // figures must never pass for N devices: every pool reports how many share its device, and the process says so once.
+    bool shared = false;
+    for (size_t i = 0; i < n; i++) {
+        unsigned same = 0;
+        for (size_t k = 0; k < n; k++) same += devices[k] == devices[i];
+        made[i]->pools_on_device = same;
+        shared = shared || same > 1;
+    }
+    static std::atomic<bool> said(false);
+    if (shared && !said.exchange(true))
+        fprintf(stderr, "starkhip: starkhip_multipool_create was given the same device ordinal more than once -- the pools share that GPU "
+                        "(a rehearsal, not a measurement of %zu devices)\n", n);
     *out = mp.release();
     return STARKHIP_OK;
 }

@@ -13,21 +13,27 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_gpus_2_starts_itself_and_prints_one_line_for_two_ranks():
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_gpus_n_starts_itself_and_prints_one_line_for_n_ranks(ranks):
+    """Four ranks is what one card allows beside the test process (the box admits six GPU processes); the eight-rank control flow -- launcher
+    environment, process group, the line's reductions, teardown -- runs on the CPU in tests/test_bench_launch_cpu.py."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["STARKHIP_BENCH_REHEARSE"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--inflight", "2",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--inflight", "2",
                         "--no-cpu-baseline", "--no-boundary", "--no-solo"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    assert d["n_gpus"] == ranks and d["steps"] == 2 and d["value"] > 0
     assert d["timed_proofs_verified"] == 2 and "REHEARSAL" in d["data"]
-    assert d["config"]["parallelism"] == "proof-parallel x2"
-    assert d["per_rank"] and len(d["per_rank"]) == 2 and all(r["proofs_per_s"] > 0 and r["cpu_budget"] >= 1 for r in d["per_rank"])
+    assert d["config"]["parallelism"] == f"proof-parallel x{ranks}"
+    assert d["per_rank"] and len(d["per_rank"]) == ranks and all(r["proofs_per_s"] > 0 and r["cpu_budget"] >= 1 for r in d["per_rank"])
     lo, hi = d["per_rank_min_max"]
     assert lo <= hi and lo > 0
+    # what the driver reads to see that the process group saw N ranks on N devices: here gloo, every rank on the one card -- and the line says so
+    assert d["process_group"]["backend"] == "gloo" and d["process_group"]["ranks"] == ranks and d["rccl_ranks"] is None
+    assert d["devices_distinct"] is False and {r["device_ordinal"] for r in d["per_rank"]} == {0} and len({r["pci"] for r in d["per_rank"]}) == 1
 
 
 def _bench(args, env_extra=None, prefix=()):
@@ -50,6 +56,7 @@ def test_bench_devices_in_process_prints_the_same_line_from_one_process():
     assert "ONE process" in d["config"]["parallelism"] and "starkhip_multipool" in d["config"]["driver"]
     assert d["timed_proofs_verified"] == 4                      # 2 in flight x 2 pools: the last proof of each of the four inputs
     assert len(d["host"]["pools"]) == 2 and all(p["cpu_budget"] >= 1 for p in d["host"]["pools"])
+    assert all(p["pools_on_device"] == 2 for p in d["host"]["pools"])   # both pools on the one card: a handle that says so (and once on stderr)
     assert d["host"]["pools"][0]["cpu_budget"] <= max(1, d["host"]["cpu_budget_process"] // 2)   # the process's CPUs are split between its pools
     assert d["roofline"]["frac"] > 0 and d["per_rank"] is None
 

@@ -167,7 +167,7 @@ def merged_tables4(c1, c2, c3, c4):
     a, b, c = mv(N3, c1z), mv(N2, c2z), mv(M, c3z)
     k4 = [(a[i] + b[i] + c[i] + c4[i]) % P for i in range(12)]
     for g in range(12):
-        assert (sum(N4[g]) + N3[g][0] + N2[g][0] + M[g][0]) * M32 + M32 < 1 << 64
+        assert (sum(N4[g]) + N3[g][0] + N2[g][0] + M[g][0]) * M32 + M32 < (1 << 64) - (1 << 32)  # what fold_big needs: B < 2^64 - 2^32 (B_hi + carry must not wrap)
     return M, N2, N3, N4, k1, k2, k3, k4
 
 
