@@ -60,10 +60,9 @@ typedef enum {
 enum {
     STARKHIP_OK = 0,
     STARKHIP_ERR_QUOTIENT_NOT_DIVISIBLE = -1, /* "Quotient has failed, the vanishing polynomial is not divisible by Z_H" */
-    STARKHIP_ERR_ZETA_IN_SUBGROUP = -2, /* the challenge zeta lies in the trace subgroup H (starky fails there too: division by zeta - x) OR on the
-                                          coset 7 H (zeta^n == 7^n): the trace polynomials are opened from their values on that coset
-                                          (barycentric weights), which divides by zeta - 7 w^k.  The reference proves the
-                                          second case fine; probability 2^-115 per proof for either, deterministic for the input it hits */
+    STARKHIP_ERR_ZETA_IN_SUBGROUP = -2, /* the challenge zeta lies in the trace subgroup H: starky's "Opening point is in the subgroup" (probability
+                                          2^-115 per proof, deterministic for the input it hits).  zeta on the coset 7 H, where the trace polynomials'
+                                          values are kept, is proven as the reference proves it (the opening is then the value itself) */
     STARKHIP_ERR_BAD_SHAPE = -3,
     STARKHIP_ERR_HIP = -4,
     STARKHIP_ERR_OOM = -5,

@@ -407,6 +407,10 @@ static void wb_push1(wbuf* b, uint64_t x) { wb_push(b, &x, 1); }
 
 /* error codes shared with include/starkhip.h */
 #define ERR_QUOTIENT_NOT_DIVISIBLE (-1)
+/* Test hook (tests/test_gpu_airs.py): substitute zeta = 7 w_n^(k - 1), a point of the coset the product keeps its trace values on, so that
+ * the product's branch for that case (probability 2^-115 in a real transcript) can be compared byte for byte.  0 = off. */
+static long g_zeta_on_coset = 0;
+EXPORT void oracle_set_zeta_on_coset(long k_plus_1) { g_zeta_on_coset = k_plus_1; }
 #define ERR_ZETA_IN_SUBGROUP (-2)
 #define ERR_BAD_SHAPE (-3)
 
@@ -489,6 +493,7 @@ EXPORT int oracle_prove(const uint64_t* air_blob, size_t air_words, const oracle
     mtree qtree; mtree_build(&qtree, qlde, Q, logN, capH, 1);
     ch_observe_cap(&ch, mtree_cap(&qtree), (int)ncap);
     fe2 zeta = ch_get_ext(&ch);
+    if (g_zeta_on_coset > 0) zeta = e_make(f_mul(7, f_pow(f_root(logn), (uint64_t)(g_zeta_on_coset - 1) & (n - 1))), 0);  /* test hook, below */
     if (e_eq(e_pow(zeta, n), e_make(1, 0))) rc = ERR_ZETA_IN_SUBGROUP;
 
     /* ---- A.7 openings */

@@ -58,7 +58,9 @@ __global__ void coset_weights_kernel(gl2_t* __restrict__ wz, gl2_t* __restrict__
     if (k >= n) return;
     const gl_t x = gl_mul(GL_GENERATOR, gl_pow(gl_root_of_unity(log_n), k));
     const gl2_t d = gl2_sub(z, gl2_make(x, 0));
-    const gl2_t w = gl2_mul(gl2_mul_base(scale, x), gl2_inv(d));
+    // z ON the coset (z = x_k for one k; then scale = 0): L_j(x_k) is 1 for j = k and 0 elsewhere -- the opening is the value itself.  The
+    // reference evaluates coefficients and never notices (only z in the subgroup H fails there: src of "Opening point is in the subgroup")
+    const gl2_t w = (d.a0 == 0 && d.a1 == 0) ? gl2_one() : gl2_mul(gl2_mul_base(scale, x), gl2_inv(d));
     wz[k] = w;
     wgz[(k + 1) & (n - 1)] = w;
 }

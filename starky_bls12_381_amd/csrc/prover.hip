@@ -115,7 +115,7 @@ struct Ctx {
     bool urgent = false;  // ctx_set_urgent
     // tuning (starkhip_set_option; defaults are the measured best)
     long opt_quotient_impl = 0;   // 0: tiled evaluator (quotient_plan.h), 1: op-stream interpreter (quotient_ops.h)
-    long opt_quotient_waves = 65536, opt_quotient_slots = 0, opt_quotient_chunks = 0, opt_quotient_debug = 0;
+    long opt_quotient_waves = 65536, opt_quotient_slots = 0, opt_quotient_chunks = 0, opt_quotient_debug = 0, opt_zeta_on_coset = 0;
     // Shape-dependent tables and the per-AIR constraint plan are CACHED per context: a pooled context that alternates between
     // AIRs (a PairingPrecomp proof, then an FP12Mul one) finds both again instead of rebuilding the plan on the host and
     // re-allocating device buffers -- hipFree synchronises the whole device, i.e. waits for every other proof's kernels.
@@ -501,6 +501,7 @@ int ctx_set_option(Ctx* c, const char* name, long value) {
                        // prove() refuses to return it), 9 compares the two evaluators point by point on stderr
     else if (k == "quotient_debug" && value >= 0 && value <= 9) c->opt_quotient_debug = value;
 #endif
+    else if (k == "zeta_on_coset" && value >= 0) c->opt_zeta_on_coset = value;  // tests: substitute zeta = 7 w_n^(value - 1); the proof is not a transcript any more
     else if (k == "lde_closed_forms" && (value == 0 || value == 1)) c->opt_lde_closed_forms = value;
     else if (k == "lde_impl" && (value == 0 || value == 1)) c->opt_lde_impl = value;
     else if (k == "host_commit_leaves" && value >= 0 && value <= 4096) c->opt_host_commit_leaves = value;
@@ -923,6 +924,8 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     ch.observe_many(quot_cap.data(), quot_cap.size());
     gl2_t zeta = ch.get_ext();
     fs.stop();
+    if (c->opt_zeta_on_coset > 0)  // test hook ("zeta_on_coset" = k + 1): zeta = 7 w_n^k, a point of coset 0 itself (probability 2^-115 in a real transcript)
+        zeta = gl2_make(gl_mul(GL_GENERATOR, gl_pow(gl_root_of_unity(log_n), (uint64_t)(c->opt_zeta_on_coset - 1) & (n - 1))), 0);
     if (gl2_eq(gl2_pow(zeta, n), gl2_one())) return STARKHIP_ERR_ZETA_IN_SUBGROUP;
     gl2_t gzeta = gl2_mul_base(zeta, gl_root_of_unity(log_n));
 
@@ -932,7 +935,7 @@ int prove(Ctx* c, const AirInfo& air, const starkhip_config_t& cfg, const uint64
     // quotient polynomials from their coefficients
     const gl_t shift_n = gl_pow(GL_GENERATOR, n);  // 7^n
     const gl2_t zh = gl2_sub(gl2_pow(zeta, n), gl2_make(shift_n, 0));
-    if (gl2_eq(zh, gl2_zero())) return STARKHIP_ERR_ZETA_IN_SUBGROUP;  // zeta on the coset itself (as likely as the case above: 2^-115)
+    // (zh = 0: zeta lies on the coset 7 H itself -- the weights are then an indicator vector, coset_weights_kernel; starky proves there too)
     const gl2_t w_scale = gl2_mul_base(zh, gl_inv(gl_mul((gl_t)n, shift_n)));
     HIPCHK(launch_ext_powers(c->zpow.as<gl2_t>(), zeta, n, st));
     HIPCHK(launch_coset_weights(c->zpow.as<gl2_t>() + n, c->gzpow.as<gl2_t>(), zeta, w_scale, log_n, st));

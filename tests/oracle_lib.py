@@ -41,6 +41,8 @@ lib.oracle_check_trace.restype = C.c_long
 lib.oracle_prove.argtypes = [_u64p, C.c_size_t, C.POINTER(OracleConfig), _u64p, C.c_uint32, _u64p, C.c_uint64, C.POINTER(_u64p),
                              C.POINTER(C.c_size_t)]
 lib.oracle_free.argtypes = [C.c_void_p]
+lib.oracle_set_zeta_on_coset.argtypes = [C.c_long]
+lib.oracle_set_zeta_on_coset.restype = None
 lib.oracle_mul.argtypes = [C.c_uint64, C.c_uint64]
 lib.oracle_mul.restype = C.c_uint64
 lib.oracle_mul_slow.argtypes = [C.c_uint64, C.c_uint64]

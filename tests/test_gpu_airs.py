@@ -361,3 +361,46 @@ def test_handoff_round_trip_of_gpu_proofs(prover, air_name):
     back = H.loads(H.dumps(proof), degree_bits=lay.degree_bits, rate_bits=cfg.rate_bits, arity_bits=cfg.arity_bits, num_challenges=cfg.num_challenges)
     assert np.array_equal(back, proof)
     S.verify_stark_proof(air, cfg, back)
+
+
+@pytest.mark.parametrize("k", [0, 5, 255])
+def test_zeta_on_the_coset_of_the_kept_values_is_proven_like_the_reference(k):
+    """The product opens the trace polynomials from their values on the coset 7 H (it keeps no coefficients); the reference evaluates
+    coefficients.  For zeta ON that coset the interpolation weights degenerate -- the opening is the value itself -- and rounds 4-5 returned
+    ERR_ZETA_IN_SUBGROUP there, which starky reserves for zeta in H.  The case has probability 2^-115 in a transcript, so it is forced: the
+    "zeta_on_coset" option of the context and the oracle's hook substitute zeta = 7 w_n^k in both, and the proof bytes must agree (the
+    openings at zeta and at g zeta are then entries k and k + 1 of coset 0 of the LDE).  Such a proof is not a transcript, so the verifier is
+    not asked."""
+    cfg = S.StarkConfig.standard_fast_config()
+    pv = S.Prover(0)
+    try:
+        for air, (t, pis) in ((S.AIR_TEST_FIBONACCI, S.trace_fibonacci(3, 5, 256)),
+                              (S.AIR_FP12_MUL, S.trace_fp12_mul(random_fp12(0x5EED2300), random_fp12(0x5EED2301)))):
+            c = cfg if air == S.AIR_TEST_FIBONACCI else S.StarkConfig.for_air(air)
+            n = t.shape[0]
+            usual = pv.prove(air, c, t, pis)
+            pv.set_option("zeta_on_coset", (k % n) + 1)
+            O.lib.oracle_set_zeta_on_coset((k % n) + 1)
+            try:
+                forced = pv.prove(air, c, t, pis)
+                ref = O.prove(S.air_program(air), c, S.trace_rows_to_poly_values(t), pis)
+            finally:
+                pv.set_option("zeta_on_coset", 0)
+                O.lib.oracle_set_zeta_on_coset(0)
+            assert forced.size == ref.size and np.array_equal(forced, ref)
+            assert not np.array_equal(forced, usual)
+            # zeta is a base-field point: so are the openings (a zero second word), and the next-row openings of k are the local ones of k + 1
+            lay = S.proof_layout(forced)
+            cols = S.air_columns(air)
+            local = forced[lay.off_local_values:lay.off_local_values + 2 * cols].reshape(cols, 2)
+            nxt = forced[lay.off_next_values:lay.off_next_values + 2 * cols].reshape(cols, 2)
+            assert not local[:, 1].any() and not nxt[:, 1].any()
+            pv.set_option("zeta_on_coset", ((k + 1) % n) + 1)
+            try:
+                shifted = pv.prove(air, c, t, pis)
+            finally:
+                pv.set_option("zeta_on_coset", 0)
+            assert np.array_equal(shifted[lay.off_local_values:lay.off_local_values + 2 * cols].reshape(cols, 2), nxt)
+            assert np.array_equal(pv.prove(air, c, t, pis), usual)   # the option is off again
+    finally:
+        pv.close()
