@@ -39,9 +39,9 @@ python3 tools/pmc_traffic.py $OUT/${TAG}_pmc_traffic.json $(db prof_fetch) $(db 
 python3 tools/kernel_overlap.py $(db prof_ov) > $OUT/${TAG}_kernel_overlap.txt
 python3 tools/rocprof_export.py bygrid $(db prof_ov) $OUT/${TAG}_kernel_stats_by_grid_in_flight.csv
 python3 tools/rocprof_export.py stats $(db prof_ov) $OUT/${TAG}_kernel_stats_in_flight.csv
-tail -1 $OUT/prof_ov.log > $OUT/${TAG}_bench_in_flight_under_rocprof.json
+grep '^{"metric"' $OUT/prof_ov.log | tail -1 > $OUT/${TAG}_bench_in_flight_under_rocprof.json  # the bench line, not the profiler's last log line
 python3 tools/lane_group_stats.py $(db prof_ov) $OUT/${TAG}_lane_groups.json > /dev/null
-tail -1 $OUT/prof_kt.log > $OUT/${TAG}_bench_under_rocprof.json
+grep '^{"metric"' $OUT/prof_kt.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
 rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq $OUT/prof_ov $OUT/prof_lfetch $OUT/prof_lwrite $OUT/prof_lsq
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rate_bench tools/valu_rate_bench.hip && /tmp/valu_rate_bench > $OUT/${TAG}_valu_rates.txt 2>&1 || true
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
