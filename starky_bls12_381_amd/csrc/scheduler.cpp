@@ -376,16 +376,19 @@ void HashService::run() {
 // ------------------------------------------------------------------------------------------------ pool
 extern void set_thread_trace_threads(int n);  // capi.cpp: trace_threads() of the calling thread (0 = the process-wide setting)
 
-// Relative single-GPU proving cost per AIR, for placing jobs on the pools of a multi-device handle (longest processing time first):
-// FinalExp dominates (the reference's README.md:36-39 has the same ordering on its CPU; here 135 ms per proof in a full pool against
-// 20 / 7 ms per MillerLoop / PairingPrecomp proof).  The same table as the Python plan (parallel.AIR_COST).
+// What one proof of each AIR costs a pool, for placing jobs on the pools of a multi-device handle (longest processing time first):
+// milliseconds per proof with the pool FULL of that AIR on one MI355X (tools/air_pool_cost.py, profiles/r06_air_pool_cost.json) -- a job's
+// share of its device's time, not its latency.  One signature's six proofs add up to 214 ms, which is what a batch takes per signature
+// (4.9 signatures/s).  Rounds 1-5 used the reference's CPU seconds (92 : 12.5 : 4.5 : 0.22, README.md:36-39; ECCAgg a guess of 3): the same
+// order, but FP12Mul -- 32 leaves hashed on the host and a 24 ms sponge over 60 285 columns -- weighs more here than its 16 rows suggest.
+// The same table as the Python plan (parallel.AIR_COST).
 double air_cost(int air) {
     switch (air) {
-        case STARKHIP_AIR_FINAL_EXP: return 92.0;
-        case STARKHIP_AIR_MILLER_LOOP: return 12.5;
-        case STARKHIP_AIR_PAIRING_PRECOMP: return 4.5;
-        case STARKHIP_AIR_ECC_AGGREGATE: return 3.0;
-        case STARKHIP_AIR_FP12_MUL: return 0.22;
+        case STARKHIP_AIR_FINAL_EXP: return 128.0;
+        case STARKHIP_AIR_MILLER_LOOP: return 24.0;
+        case STARKHIP_AIR_PAIRING_PRECOMP: return 10.8;
+        case STARKHIP_AIR_ECC_AGGREGATE: return 12.6;
+        case STARKHIP_AIR_FP12_MUL: return 15.4;
         default: return 0.01;
     }
 }

@@ -9,8 +9,9 @@ import os
 
 import numpy as np
 
-# relative single-GPU proving cost per AIR (FinalExp dominates; README.md:36-39 of the reference has the same ordering)
-AIR_COST = {3: 92.0, 2: 12.5, 1: 4.5, 0: 0.22, 4: 3.0}
+# what one proof of each AIR costs a pool: ms per proof with the pool full of that AIR on one MI355X (tools/air_pool_cost.py,
+# profiles/r06_air_pool_cost.json; the same table as csrc/scheduler.cpp air_cost -- FinalExp dominates, as on the reference's CPU, README.md:36-39)
+AIR_COST = {3: 128.0, 2: 24.0, 1: 10.8, 0: 15.4, 4: 12.6}
 
 
 def rank_info():

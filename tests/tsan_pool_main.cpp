@@ -52,7 +52,7 @@ static int multi_device_pass() {
     std::vector<std::vector<uint32_t>> ops = {limbs(72, 1), limbs(96, 2), limbs(72, 3), limbs(96, 4), limbs(288, 5), limbs(144, 6)};
     std::vector<int> plan(airs.size());
     CHECK(starkhip_plan_lpt(airs.size(), airs.data(), 4, plan.data()) == STARKHIP_OK);
-    CHECK(plan[5] == 0 && plan[1] == 1 && plan[3] == 2 && plan[0] == 3 && plan[2] == 3 && plan[4] == 3);  // 92 | 12.5 | 12.5 | 4.5 + 4.5 + 0.22
+    CHECK(plan[5] == 0 && plan[1] == 1 && plan[3] == 2 && plan[4] == 3 && plan[0] == 3 && plan[2] == 1);  // 128 | 24 + 10.8 | 24 | 15.4 + 10.8
     std::vector<const uint32_t*> op_ptr;
     std::vector<size_t> op_len;
     for (auto& o : ops) { op_ptr.push_back(o.data()); op_len.push_back(o.size()); }
