@@ -771,6 +771,52 @@ inline QTPlan build_quotient_plan(const AirProgram& P, unsigned want_chunks) {
                     for (; at < fast_end; at++) emit(in(at), rec_c_begin[stream_first + at], rec_c_end[stream_first + at]);
                     i = at;
                 }
+                // Factors outside the tile that no announced pair run covers (odd pairs, pairs that end a piece, degree-3 monomials) were
+                // loaded where they are used: one exposed HBM / L2 round trip per record (the fit has such a record at ~ 8 000 cycles, 7 % of
+                // the evaluators' time for 2 619 records).  Where the piece's descriptor has a free slot -- gates + absorbed cells < 4 -- the
+                // cell goes there instead: requested with the gates when the piece starts, in a register long before its record's turn.
+                {
+                    const size_t NO_DESC = (size_t)-1;
+                    size_t desc = NO_DESC;
+                    uint32_t a_plain = 0, a_fast = 0, a_dfast = 0;  // what the kernel's straight-line loops will take without looking
+                    for (size_t k = 0; k < out.size(); k++) {
+                        QTRec& r = out[k];
+                        const uint32_t ctl = r.ctl;
+                        if ((ctl & QT_SPECIAL) == 0) {
+                            if (a_plain) a_plain--;
+                            continue;
+                        }
+                        if (a_plain == 0 && a_fast) { a_fast--; continue; }
+                        if (a_plain == 0 && a_dfast) { a_dfast--; continue; }
+                        a_plain = ctl >> QT_RUN_SHIFT;
+                        a_fast = (ctl & QT_SRC_GLOBAL) ? 0u : 2u * (r.aux & QT_AUX_PAIRS_MASK);
+                        a_dfast = (ctl & QT_SRC_GLOBAL) ? 0u : 2u * ((r.aux >> QT_AUX_DPAIRS_SHIFT) & QT_AUX_DPAIRS_MASK);
+                        if ((ctl & (QT_DESC | QT_SRC_GLOBAL | QT_MULV | QT_END)) == QT_DESC) {
+                            desc = k;
+                            continue;
+                        }
+                        if (ctl & (QT_TILE | QT_STOP)) continue;  // a piece that goes on in the next tile keeps its descriptor
+                        if ((ctl & QT_SRC_GLOBAL) && !(r.aux & QT_AUX_SLOT) && desc != NO_DESC) {
+                            QTRec& d = out[desc];
+                            const uint32_t pctl = d.w[4], ng = (pctl >> 2) & 7u, nf = (pctl >> QT_FOREIGN_SHIFT) & 7u;
+                            const uint32_t ref = (r.aux & REF_COL_MASK) | ((ctl & QT_NEXT) ? REF_NEXT : 0u);
+                            uint32_t slot = 4;
+                            for (uint32_t q = ng; q < ng + nf; q++)
+                                if (d.w[q] == ref) slot = q;  // the same cell twice in one piece: one slot
+                            if (slot == 4 && ng + nf < 4) {
+                                slot = ng + nf;
+                                d.w[slot] = ref;
+                                d.w[4] = pctl + (1u << QT_FOREIGN_SHIFT);
+                                Q.n_direct_loads++;
+                            }
+                            if (slot < 4) {
+                                r.aux = QT_AUX_SLOT | slot;
+                                if (Q.n_direct_loads) Q.n_direct_loads--;
+                            }
+                        }
+                        if (ctl & QT_END) desc = NO_DESC;
+                    }
+                }
                 Q.recs.resize(stream_first);
                 rec_c_begin.resize(stream_first);
                 rec_c_end.resize(stream_first);
