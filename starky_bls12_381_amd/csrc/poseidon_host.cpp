@@ -9,7 +9,7 @@
 //    lanes in the full rounds, scalar for element 0 in the partial rounds.
 //  * MDS: the 32-bit halves are stored twice in a row (lo[24], hi[24]), so the circulant's input rotated by i is an
 //    UNALIGNED LOAD at offset i -- no shuffles; 12 x (vpmuludq by a broadcast coefficient + add) per half.
-//  * partial rounds three at a time (poseidon_merged.h): per triple two dot products with a small-integer row and ONE dense
+//  * partial rounds four at a time (poseidon_merged.h): per merge three dot products with a small-integer row and ONE dense
 //    12 x 12 layer instead of three circulant layers -- a shorter dependency chain per round, which is what a sequential
 //    sponge is bound by (2.05 -> 1.86 us per permutation on the GPU box).
 // An earlier auto-vectorised AVX2 variant of the plain loop was slower than scalar (2.74 us) and was dropped.
@@ -239,36 +239,41 @@ AVX512_TARGET inline void mds(V12& s) { mds_t<false>(s, 0); }
 AVX512_TARGET inline void mds(V12& s) { mds_bcast(s); }
 #endif
 
-// ---- partial rounds three at a time (poseidon_merged.h).  The two intermediate element-0 values are dot products of the
-// state with one small-integer row (a multiply per half-vector and a horizontal add), the state after the third round is
-// ONE dense 12 x 12 layer: out = sum_j (column j of N3) * ut[j], twelve broadcast-multiply-adds per half like the
-// circulant layer.  Shorter dependency chain per round (the challenger's 36.8 K permutations are one sequential chain)
-// and two dense layers less per triple.
+// ---- partial rounds FOUR at a time (poseidon_merged.h; round 6 -- three at a time before).  The three intermediate element-0 values are
+// dot products of the state with one small-integer row (a multiply per half-vector and a horizontal add), the state after the fourth
+// round is ONE dense 12 x 12 layer: out = sum_j (column j of N4) * ut[j], twelve broadcast-multiply-adds per half like the circulant
+// layer.  Shorter dependency chain per round (the challenger's 36.8 K permutations are one sequential chain) and three dense layers
+// less per merge.  N4's entries are below 2^29 and a row of it with its x-coefficients sums to less than 0.83 * 2^32
+// (PoseidonMergedFours::sums_fit), so every 64-bit lane sum of (32-bit half) x (entry) below stays under 2^64.
 struct alignas(64) MergedVectors {   // each vector as 16 words: rows 0..7 (zmm), rows 8..11 (ymm), 4 unused
-    uint64_t n3[12][16];  // column j of N3
-    uint64_t r1[16], r2[16], r3[16], b2[16], b3[16], k3[POSEIDON_MERGED_TRIPLES][16];
-    gl_t k1[POSEIDON_MERGED_TRIPLES], k2[POSEIDON_MERGED_TRIPLES];
+    uint64_t n4[12][16];  // column j of N4
+    uint64_t r1[16], r2[16], r3[16], r4[16], b2[16], b3[16], b4[16], k4[POSEIDON_MERGED_FOURS][16];
+    gl_t k1[POSEIDON_MERGED_FOURS], k2[POSEIDON_MERGED_FOURS], k3[POSEIDON_MERGED_FOURS];
     uint64_t m00;
 };
 
 const MergedVectors& merged_vectors() {
     static const MergedVectors V = [] {
-        static PoseidonMergedTables P;
-        build_poseidon_merged_tables(P);
+        static PoseidonMergedFours P;
+        build_poseidon_merged_fours(P);
+        if (!P.sums_fit) abort();  // the constants are fixed: cannot happen
         MergedVectors v = {};
         for (int j = 0; j < 12; j++)
-            for (int i = 0; i < 12; i++) v.n3[j][i] = P.N3[i][j];
+            for (int i = 0; i < 12; i++) v.n4[j][i] = P.N4[i][j];
         for (int i = 0; i < 12; i++) {
             v.r1[i] = P.M[0][i];
             v.r2[i] = P.N2[0][i];
             v.r3[i] = P.N3[0][i];
-            v.b2[i] = P.N2[i][0];
-            v.b3[i] = P.M[i][0];
+            v.r4[i] = P.N4[0][i];
+            v.b2[i] = P.N3[i][0];
+            v.b3[i] = P.N2[i][0];
+            v.b4[i] = P.M[i][0];
         }
-        for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++) {
-            for (int i = 0; i < 12; i++) v.k3[t][i] = P.k3[t][i];
+        for (int t = 0; t < POSEIDON_MERGED_FOURS; t++) {
+            for (int i = 0; i < 12; i++) v.k4[t][i] = P.k4[t][i];
             v.k1[t] = P.k1[t];
             v.k2[t] = P.k2[t];
+            v.k3[t] = P.k3[t];
         }
         v.m00 = P.M[0][0];
         return v;
@@ -276,7 +281,7 @@ const MergedVectors& merged_vectors() {
     return V;
 }
 
-// (sum over the 12 lanes of lo * row) + (sum of hi * row) * 2^32 as an integer (the sums stay below 2^48, the value below 2^81)
+// (sum over the 12 lanes of lo * row) + (sum of hi * row) * 2^32 as an integer (each sum below 0.83 * 2^64, the value below 2^97)
 AVX512_TARGET inline unsigned __int128 dot_row(__m512i alo, __m512i ahi, __m256i blo, __m256i bhi, __m512i ra, __m256i rb) {
     const uint64_t L = (uint64_t)_mm512_reduce_add_epi64(_mm512_mul_epu32(alo, ra)) +
                        (uint64_t)_mm512_reduce_add_epi64(_mm512_zextsi256_si512(_mm256_mul_epu32(blo, rb)));
@@ -285,15 +290,16 @@ AVX512_TARGET inline unsigned __int128 dot_row(__m512i alo, __m512i ahi, __m256i
     return (unsigned __int128)L + ((unsigned __int128)H << 32);
 }
 
-// s: the state at the start of a partial round (constants added); on return the state three rounds later (constants added).
-// The three S-boxes are ONE dependent chain (x1 -> y1 -> x2 -> y2 -> x3), and a sequential sponge is bound by it: everything
+// s: the state at the start of a partial round (constants added); on return the state four rounds later (constants added).
+// The four S-boxes are ONE dependent chain (x1 -> y1 -> x2 -> y2 -> x3 -> y3 -> x4), and a sequential sponge is bound by it: everything
 // that does not depend on them -- the dot products and the dense layer over elements 1 .. 11 -- is computed from the state
-// with element 0 zeroed, beside the chain; each link then costs one scalar multiply-add and a reduction
-// (y1 = P1 + M00 x1 + k1, y2 = P2 + N2_00 x1 + M00 x2 + k2), and x1, x2, x3 enter the dense layer as three last terms.
-// e0: element 0 of the state as a scalar, in and out -- the next triple's S-box input is row 0 of the dense layer, formed here as
-// one more scalar link (P3 + N3_00 x1 + N2_00 x2 + M00 x3) instead of waiting for the vector layer, its fold and reduction and a
-// move back to a general register: the chain from triple to triple never leaves the scalar unit.  Lane 0 of s.a is not read.
-AVX512_TARGET inline void partial3(V12& s, const MergedVectors& V, int t, gl_t& e0) {
+// with element 0 zeroed, beside the chain; each link then costs a few scalar multiply-adds and a reduction
+// (y1 = P1 + M00 x1 + k1, y2 = P2 + N2_00 x1 + M00 x2 + k2, y3 = P3 + N3_00 x1 + N2_00 x2 + M00 x3 + k3), and x1 .. x4 enter the dense layer
+// as four last terms.
+// e0: element 0 of the state as a scalar, in and out -- the next merge's S-box input is row 0 of the dense layer, formed here as
+// one more scalar link (P4 + N4_00 x1 + N3_00 x2 + N2_00 x3 + M00 x4) instead of waiting for the vector layer, its fold and reduction and a
+// move back to a general register: the chain from merge to merge never leaves the scalar unit.  Lane 0 of s.a is not read.
+AVX512_TARGET inline void partial4(V12& s, const MergedVectors& V, int t, gl_t& e0) {
     const __m512i m32 = _mm512_set1_epi64((long long)EPS);
     const __m256i m32h = _mm256_set1_epi64x((long long)EPS);
     const gl_t x1 = sbox_nc(e0);  // the chain starts at once
@@ -302,8 +308,9 @@ AVX512_TARGET inline void partial3(V12& s, const MergedVectors& V, int t, gl_t& 
     const __m256i blo = _mm256_and_si256(s.b, m32h), bhi = _mm256_srli_epi64(s.b, 32);
     const unsigned __int128 P1 = dot_row(alo, ahi, blo, bhi, MV_A(V.r1), MV_B(V.r1)) + V.k1[t];
     const unsigned __int128 P2 = dot_row(alo, ahi, blo, bhi, MV_A(V.r2), MV_B(V.r2)) + V.k2[t];
-    const unsigned __int128 P3 = dot_row(alo, ahi, blo, bhi, MV_A(V.r3), MV_B(V.r3)) + V.k3[t][0];
-    // the dense layer over elements 1 .. 11: out = N3 ut + N2[:,0] x2 + M[:,0] x3 + k3, column 0 of N3 (times x1) added below
+    const unsigned __int128 P3 = dot_row(alo, ahi, blo, bhi, MV_A(V.r3), MV_B(V.r3)) + V.k3[t];
+    const unsigned __int128 P4 = dot_row(alo, ahi, blo, bhi, MV_A(V.r4), MV_B(V.r4)) + V.k4[t][0];
+    // the dense layer over elements 1 .. 11: out = N4 ut + N3[:,0] x2 + N2[:,0] x3 + M[:,0] x4 + k4, column 0 of N4 (times x1) added below
     alignas(64) uint64_t lo[12], hi[12];
     _mm512_store_si512((void*)lo, alo);
     _mm256_store_si256((__m256i*)(lo + 8), blo);
@@ -314,8 +321,8 @@ AVX512_TARGET inline void partial3(V12& s, const MergedVectors& V, int t, gl_t& 
     for (int j = 1; j < 12; j++) {
         const __m512i l8 = _mm512_set1_epi64((long long)lo[j]), h8 = _mm512_set1_epi64((long long)hi[j]);
         const __m256i l4 = _mm256_set1_epi64x((long long)lo[j]), h4 = _mm256_set1_epi64x((long long)hi[j]);
-        const __m512i ca = MV_A(V.n3[j]);
-        const __m256i cb = MV_B(V.n3[j]);
+        const __m512i ca = MV_A(V.n4[j]);
+        const __m256i cb = MV_B(V.n4[j]);
         La = _mm512_add_epi64(La, _mm512_mul_epu32(l8, ca));
         Ha = _mm512_add_epi64(Ha, _mm512_mul_epu32(h8, ca));
         Lb = _mm256_add_epi64(Lb, _mm256_mul_epu32(l4, cb));
@@ -329,28 +336,32 @@ AVX512_TARGET inline void partial3(V12& s, const MergedVectors& V, int t, gl_t& 
         Lb = _mm256_add_epi64(Lb, _mm256_mul_epu32(_mm256_set1_epi64x(xl), MV_B(col)));                                                  \
         Hb = _mm256_add_epi64(Hb, _mm256_mul_epu32(_mm256_set1_epi64x(xh), MV_B(col)));                                                  \
     }
-    ADD_TERM(x1, V.n3[0]);
-    // the chain: entries of M, N2 are < 2^21, so every sum below is < 2^81 + 2 * 2^85
+    ADD_TERM(x1, V.n4[0]);
+    // the chain: entries of M .. N4 are < 2^29, so every sum below is < 2^97 + 4 * 2^93: the high word stays far below 2^64
     const unsigned __int128 v1 = P1 + (unsigned __int128)V.r1[0] * x1;
     const gl_t x2 = sbox_nc(reduce128_nc((uint64_t)(v1 >> 64), (uint64_t)v1));
     ADD_TERM(x2, V.b2);
     const unsigned __int128 v2 = P2 + (unsigned __int128)V.r2[0] * x1 + (unsigned __int128)V.m00 * x2;
     const gl_t x3 = sbox_nc(reduce128_nc((uint64_t)(v2 >> 64), (uint64_t)v2));
-    const unsigned __int128 v3 = P3 + (unsigned __int128)V.r3[0] * x1 + (unsigned __int128)V.r2[0] * x2 + (unsigned __int128)V.m00 * x3;
-    e0 = reduce128_nc((uint64_t)(v3 >> 64), (uint64_t)v3);
     ADD_TERM(x3, V.b3);
+    const unsigned __int128 v3 = P3 + (unsigned __int128)V.r3[0] * x1 + (unsigned __int128)V.r2[0] * x2 + (unsigned __int128)V.m00 * x3;
+    const gl_t x4 = sbox_nc(reduce128_nc((uint64_t)(v3 >> 64), (uint64_t)v3));
+    const unsigned __int128 v4 = P4 + (unsigned __int128)V.r4[0] * x1 + (unsigned __int128)V.r3[0] * x2 + (unsigned __int128)V.r2[0] * x3 +
+                                 (unsigned __int128)V.m00 * x4;
+    e0 = reduce128_nc((uint64_t)(v4 >> 64), (uint64_t)v4);
+    ADD_TERM(x4, V.b4);
 #undef ADD_TERM
-    {  // value = L + H * 2^32 (L, H < 2^58), then + k3 (canonical)
+    {  // value = L + H * 2^32 (L, H < 0.83 * 2^64), then + k4 (canonical)
         const __m512i l = _mm512_add_epi64(La, _mm512_slli_epi64(Ha, 32));
         const __m512i h = _mm512_mask_add_epi64(_mm512_srli_epi64(Ha, 32), _mm512_cmplt_epu64_mask(l, La), _mm512_srli_epi64(Ha, 32),
                                                 _mm512_set1_epi64(1));
-        s.a = add_8(reduce128_8(h, l), MV_A(V.k3[t]));
+        s.a = add_8(reduce128_8(h, l), MV_A(V.k4[t]));
     }
     {
         const __m256i l = _mm256_add_epi64(Lb, _mm256_slli_epi64(Hb, 32));
         const __m256i h = _mm256_mask_add_epi64(_mm256_srli_epi64(Hb, 32), _mm256_cmplt_epu64_mask(l, Lb), _mm256_srli_epi64(Hb, 32),
                                                 _mm256_set1_epi64x(1));
-        s.b = add_4(reduce128_4(h, l), MV_B(V.k3[t]));
+        s.b = add_4(reduce128_4(h, l), MV_B(V.k4[t]));
     }
 }
 
@@ -365,14 +376,19 @@ AVX512_TARGET void permute_avx512(gl_t* st) {
         s.b = sbox_4(add_4(s.b, _mm256_loadu_si256((const __m256i*)(RC + rc + 8))));
         mds(s);
     }
-    // partial rounds: 7 triples, then the 22nd alone
+    // partial rounds: five merges of four, then the 21st and 22nd alone
     const MergedVectors& V = merged_vectors();
     s.a = add_8(s.a, _mm512_loadu_si512((const void*)(RC + rc)));
     s.b = add_4(s.b, _mm256_loadu_si256((const __m256i*)(RC + rc + 8)));
     gl_t e0 = (gl_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(s.a));
-    for (int t = 0; t < POSEIDON_MERGED_TRIPLES; t++) partial3(s, V, t, e0);
-    rc += 12 * 3 * POSEIDON_MERGED_TRIPLES;  // the constants of this round are already in s
-    {
+    for (int t = 0; t < POSEIDON_MERGED_FOURS; t++) partial4(s, V, t, e0);
+    rc += 12 * 4 * POSEIDON_MERGED_FOURS;  // the constants of this round are already in s
+    for (int single = 0; single < 2; single++) {
+        if (single) {  // the first of the two left this round's constants to be added
+            s.a = add_8(s.a, _mm512_loadu_si512((const void*)(RC + rc)));
+            s.b = add_4(s.b, _mm256_loadu_si256((const __m256i*)(RC + rc + 8)));
+            e0 = (gl_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(s.a));
+        }
         const gl_t x0 = sbox_nc(e0);  // element 0, scalar
         s.a = _mm512_maskz_mov_epi64(0xFE, s.a);  // the vector part does not wait for x0
         mds_t<true>(s, x0);
