@@ -111,7 +111,7 @@ L24 mul_wide(const L12& x, const L12& y) {  // mul_fp_without_reduction, native.
 // limbs -- six divisor limbs, one hardware 128 / 64 division per quotient limb -- and only as many quotient limbs as x has above p's
 // length: the reduce gadget's operands (twelve or thirteen 32-bit limbs: quotient below 16) and the subtraction's p + a - b take one
 // step, a product of two field elements seven.  Round 5 ran the 32-bit form over all thirteen positions whatever x was: a third of a
-// FinalExp recording (tools: build/prof, gprof).
+// FinalExp recording (tools/experiments/recording_cpu_probe.cpp).
 void div_rem_modulus(const L24& x, L12& div, L12& rem) {
     constexpr int n = 6, s = 3;  // p's top 64-bit limb 0x1a0111ea397fe69a has three leading zeros
     static const uint64_t V[n] = {  // p << 3

@@ -22,7 +22,7 @@ namespace starkhip {
 
 // The word vectors of finished logs, kept for the next recording.  A FinalExp recording writes 142 MB of records into vectors that grow
 // by doubling -- 100 000 page faults and as many pages unmapped again when the log is freed: 0.25 s of kernel time beside 0.41 s of
-// recording (build/prof, getrusage), every time, because the allocator hands blocks of this size straight back to the system.  A log
+// recording (tools/experiments/recording_cpu_probe.cpp), every time, because the allocator hands blocks of this size straight back to the system.  A log
 // returns its vectors here instead (capacity kept, at most TRACE_LOG_POOL_BYTES in all) and a new log takes the largest one.
 struct TraceLogWordPool {
     static constexpr size_t TRACE_LOG_POOL_BYTES = (size_t)3 << 30;
