@@ -147,8 +147,11 @@ int starkhip_prove_columns(void* ctx, starkhip_air_t air, const starkhip_config_
  * hashes commitments of <= 4096 leaves in the row form -- 16 lanes per leaf, the shortest chain per leaf --, those of >= 32 768 leaves in
  * the pair form -- two lanes per leaf, one 256-register wave per SIMD -- and the ones between in the quad form; 1 = quad always; 2 = row always;
  * 3 = lane form, one lane per leaf: what a pool with five or more big contexts uses for groups of big commitments, slower than the pair form for
- * one commitment alone; 4 = pair always; same digests; a pool's commitments always go through its scheduler).  Unknown
- * name or value out of range: STARKHIP_ERR_BAD_SHAPE. */
+ * one commitment alone; 4 = pair always; same digests; a pool's commitments always go through its scheduler),
+ * "lde_impl" (1 = 8192-row traces through lde_columns_v2_kernel instead of the wave-resident kernel; same bytes), "zeta_on_coset"
+ * (TESTS ONLY: k + 1 substitutes zeta = 7 w_n^k for the transcript's challenge, a point of the coset the trace values are kept on -- the
+ * branch a real transcript takes with probability 2^-115; the result is compared with the oracle under the same substitution and is not a
+ * proof the verifier accepts; 0 = off).  Unknown name or value out of range: STARKHIP_ERR_BAD_SHAPE. */
 int starkhip_set_option(void* ctx, const char* name, long value);
 
 /* --- compact traces: on-device trace expansion -----------------------------------------------
